@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Build the REAL reference native module into oracle/_ref/ (test infrastructure only).
+
+Compiles, from the sources WHERE THEY LIE under /root/reference (nothing is copied
+into this repo), exactly the one extension the reference's own setup.py declares
+(reference setup.py:82-116):
+
+    Extension("pgl.graph_kernel",
+              sources = pgl/graph_kernel.pyx + metis/GKlib/*.c + metis/*.c + metis/libmetis/*.c,
+              include_dirs = metis/include, metis/GKlib, metis/libmetis,
+              language = "c++", extra_compile_args = ["-std=c++11"])
+
+Outputs (all git-ignored, but they DO travel to the GPU box with gpurun):
+    oracle/_ref/graph_kernel.cpp            (Cython-generated, scratch)
+    oracle/_ref/obj/*.o                     (scratch)
+    oracle/_ref/ref_graph_kernel.<abi>.so   (the importable module, name `graph_kernel`)
+
+The module is loaded standalone by oracle/ref_native.py (importing `pgl` itself is
+impossible here: pgl/__init__.py imports paddle, which is not installed).
+
+This is the *integer / index* oracle: build_index, metis_partition, map_edges,
+map_nodes, slice_by_index are the reference's own compiled code.
+"""
+import glob
+import os
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("PGL_REFERENCE_ROOT", "/root/reference")
+OUT = os.path.join(HERE, "_ref")
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+        raise RuntimeError("command failed: %s" % cmd[0])
+
+
+def so_path():
+    return os.path.join(OUT, "graph_kernel" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build(force=False, jobs=None):
+    """Returns the path of the built module, or None when /root/reference is absent
+    (the GPU box): callers then use whatever prebuilt .so travelled with the snapshot."""
+    target = so_path()
+    pyx = os.path.join(REF, "pgl", "graph_kernel.pyx")
+    if not os.path.exists(pyx):
+        return target if os.path.exists(target) else None
+    if os.path.exists(target) and not force and \
+            os.path.getmtime(target) >= os.path.getmtime(pyx):
+        return target
+
+    import numpy as np
+    os.makedirs(os.path.join(OUT, "obj"), exist_ok=True)
+    metis = os.path.join(REF, "pgl", "third_party", "metis")
+    incs = [os.path.join(metis, "include"), os.path.join(metis, "GKlib"),
+            os.path.join(metis, "libmetis"), os.path.join(REF, "pgl"),
+            np.get_include(), sysconfig.get_paths()["include"]]
+    inc_flags = ["-I" + i for i in incs]
+
+    # 1. cython: pyx (read in place) -> C++ in oracle/_ref
+    gen_cpp = os.path.join(OUT, "graph_kernel.cpp")
+    _run([sys.executable, "-m", "cython", "--cplus", "-3", pyx, "-o", gen_cpp])
+
+    # 2. compile METIS + GKlib C sources in place (setup.py:82-91 source list)
+    c_srcs = sorted(glob.glob(os.path.join(metis, "GKlib", "*.c")) +
+                    glob.glob(os.path.join(metis, "*.c")) +
+                    glob.glob(os.path.join(metis, "libmetis", "*.c")))
+    jobs = jobs or os.cpu_count() or 4
+    objs = []
+
+    def cc(src):
+        tag = os.path.relpath(src, metis).replace(os.sep, "_")
+        obj = os.path.join(OUT, "obj", tag[:-2] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < os.path.getmtime(src):
+            # setup.py builds these as C++ (language="c++", -std=c++11); METIS is plain C
+            # and g++ -x c++ rejects some of its idioms only as warnings; use the same
+            # front end the reference uses (distutils compiles .c files with the C compiler).
+            _run(["gcc", "-O2", "-fPIC", "-w", "-c", src, "-o", obj] + inc_flags)
+        return obj
+
+    with ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(cc, c_srcs))
+
+    gen_obj = os.path.join(OUT, "obj", "graph_kernel.o")
+    _run(["g++", "-O2", "-fPIC", "-w", "-std=c++11", "-c", gen_cpp, "-o", gen_obj] + inc_flags)
+
+    # 3. link
+    _run(["g++", "-shared", "-o", target, gen_obj] + objs + ["-lm"])
+    return target
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv)
+    print(p if p else "reference not present and no prebuilt module")

@@ -1,0 +1,221 @@
+"""Pins the oracle (oracle/ref_ops.{c,py}) against every golden vector the reference's own tests
+hold for the hot path, against the reference's own compiled
+graph_kernel.pyx (oracle/_ref) for index work, and against independent scipy / torch-CPU
+formulations for the ops no reference test pins (mean/max/min, send_uv, mul).  CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import golden_vectors as G
+import ref_ops as R
+
+
+def _src_dst(e):
+    return e[:, 0].copy(), e[:, 1].copy()
+
+
+@pytest.mark.parametrize("impl", [R.np_send_u_recv, R.c_send_u_recv])
+@pytest.mark.parametrize("dtype", [np.int64, np.float32, np.float64, np.int32])
+def test_g1_send_recv_sum(impl, dtype):
+    s, d = _src_dst(G.G1_EDGES)
+    out = impl(G.G1_X.astype(dtype), s, d, "sum")
+    assert out.dtype == dtype
+    assert np.array_equal(out, G.G1_OUT.astype(dtype))
+
+
+def test_g1_send_then_recv():
+    s, d = _src_dst(G.G1_EDGES)
+    x = G.G1_X.astype(np.float32)
+    msg = x[s]
+    assert np.array_equal(msg, G.G1_MSG.astype(np.float32))
+    out = R.np_recv(lambda m, seg: R.c_segment(m["h"], seg, "sum"), {"h": msg}, G.G1_EDGES, G.G1_N)
+    assert np.array_equal(out, G.G1_OUT.astype(np.float32))
+
+
+@pytest.mark.parametrize("impl", [R.np_send_ue_recv, R.c_send_ue_recv])
+def test_g2_send_ue_recv_add_sum(impl):
+    s, d = _src_dst(G.G1_EDGES)
+    out = impl(G.G1_X.astype(np.float32), G.G2_EFEAT.astype(np.float32), s, d, "add", "sum")
+    assert np.array_equal(out, G.G2_OUT.astype(np.float32))
+
+
+@pytest.mark.parametrize("impl", [R.np_segment_softmax, R.c_segment_softmax])
+def test_g3_segment_softmax(impl):
+    out = impl(G.G3_DATA, G.G3_IDS)
+    np.testing.assert_allclose(out, G.G3_OUT, rtol=0, atol=1e-6)   # reference: decimal=5
+    big = impl(G.G3_DATA_BIG, G.G3_IDS)
+    assert np.isfinite(big).all()
+    np.testing.assert_allclose(big, G.G3_OUT_BIG, rtol=0, atol=1e-6)
+
+
+def test_g4_edge_softmax_exact_and_edge_order():
+    by_dst = R.np_edge_softmax(G.G4_EDGES, G.G4_N, G.G4_LOGITS.reshape(-1, 1), "dst").reshape(-1)
+    by_src = R.np_edge_softmax(G.G4_EDGES, G.G4_N, G.G4_LOGITS.reshape(-1, 1), "src").reshape(-1)
+    assert np.array_equal(by_dst, G.G4_BY_DST)      # exact fp32 equality, as the reference asserts
+    assert np.array_equal(by_src, G.G4_BY_SRC)
+
+
+@pytest.mark.parametrize("impl", [R.np_build_index, R.c_build_index])
+def test_g5_degree(impl):
+    s, d = _src_dst(G.G5_EDGES)
+    assert np.array_equal(impl(d, s, G.G5_N)[0], G.G5_INDEG)
+    assert np.array_equal(impl(s, d, G.G5_N)[0], G.G5_OUTDEG)
+
+
+@pytest.mark.parametrize("impl", [R.np_build_index, R.c_build_index])
+def test_g6_neighbours(impl):
+    s, d = _src_dst(G.G6_EDGES)
+    _, sv, _, _, ip = impl(d, s, G.G6_N)
+    assert [set(sv[ip[i]:ip[i + 1]].tolist()) for i in range(G.G6_N)] == G.G6_PRED
+    _, sv, _, _, ip = impl(s, d, G.G6_N)
+    assert [set(sv[ip[i]:ip[i + 1]].tolist()) for i in range(G.G6_N)] == G.G6_SUCC
+
+
+@pytest.mark.parametrize("impl", [R.np_segment, R.c_segment])
+@pytest.mark.parametrize("op", ["sum", "mean", "min", "max"])
+def test_g7_segment_docstrings(impl, op):
+    assert np.array_equal(impl(G.G7_DATA, G.G7_IDS, op), G.G7[op])
+
+
+@pytest.mark.parametrize("impl", [R.np_build_index, R.c_build_index])
+def test_g8_build_index(impl):
+    s, d = _src_dst(G.G1_EDGES)
+    deg, sv, su, se, ip = impl(d, s, G.G1_N)
+    for got, key in ((deg, "degree"), (sv, "sorted_v"), (su, "sorted_u"), (se, "sorted_eid"), (ip, "indptr")):
+        assert got.dtype == np.int64 and np.array_equal(got, G.G8[key]), key
+
+
+def test_g8_live_reference(ref_native):
+    s, d = _src_dst(G.G1_EDGES)
+    got = ref_native.build_index(d, s, G.G1_N)
+    for a, key in zip(got, ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr")):
+        assert np.array_equal(a, G.G8[key]), key
+
+
+def test_g9_bipartite():
+    s, d = _src_dst(G.G9_EDGES)
+    out = R.c_send_u_recv(G.G9_SRC_X, s, d, "sum", out_size=G.G9_DST_N)
+    assert np.array_equal(out, G.G9_SEND_RECV)
+    msg = G.G9_DST_X[d]
+    assert np.array_equal(msg, G.G9_DST_MSG)
+    out = R.np_recv(lambda m, seg: R.c_segment(m["h"], seg, "sum"), {"h": msg}, G.G9_EDGES,
+                    G.G9_SRC_N, mode="src")
+    assert np.array_equal(out, G.G9_RECV_SRC)
+
+
+def test_g10_scatter_add():
+    # scatter(mode='add') == send_u_recv(sum) of the updates into a row-initialised output
+    out = G.G10_X.copy()
+    np.add.at(out, G.G10_IDX, G.G10_UPD)
+    assert np.array_equal(out, G.G10_OUT)
+    agg = R.c_send_u_recv(G.G10_UPD, np.arange(2), G.G10_IDX, "sum", out_size=2)
+    assert np.array_equal(G.G10_X + agg, G.G10_OUT)
+
+
+def test_g11_send_gathers():
+    s, d = _src_dst(G.G11_EDGES)
+    assert np.array_equal(G.G11_NFEAT[s], G.G11_SRC)
+    assert np.array_equal(G.G11_NFEAT[d], G.G11_DST)
+
+
+# ------------------------------------------------------------------------------------------------
+# restatement (C) == reference's own compiled code (index work) on random graphs, bit-exact
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (7, 0, 1), (10, 50, 2), (1000, 20000, 3), (50000, 400000, 4)])
+def test_build_index_matches_reference_native(ref_native, n, e, seed):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, n, e).astype(np.int64)
+    v = rng.integers(0, n, e).astype(np.int64)
+    ref = ref_native.build_index(u, v, n)
+    for impl in (R.c_build_index, R.np_build_index):
+        got = impl(u, v, n)
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b)
+    uniq, inv = R.c_unique_segment(ref[2])
+    u2, i2 = R.np_unique_segment(ref[2])
+    assert np.array_equal(uniq, u2) and np.array_equal(inv, i2)
+
+
+# ------------------------------------------------------------------------------------------------
+# ops with no reference golden vector: C port == numpy formulation == independent scipy / torch
+# ------------------------------------------------------------------------------------------------
+def _rand_graph(n, e, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, n, e).astype(np.int64), rng.integers(0, n, e).astype(np.int64), rng
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_send_u_recv_cross_check(op, dtype):
+    n, e, d = 300, 4000, 24
+    src, dst, rng = _rand_graph(n, e, 11)
+    dst[dst % 7 == 0] = 3          # leaves rows with id%7==0 (except 3 -> not multiple) empty: zero rows
+    x = rng.standard_normal((n, d)).astype(dtype)
+    a = R.c_send_u_recv(x, src, dst, op)
+    b = R.np_send_u_recv(x, src, dst, op)
+    tol = 1e-5 if dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+    red = {"sum": "sum", "mean": "mean", "max": "amax", "min": "amin"}[op]
+    t = torch.zeros(n, d, dtype=torch.from_numpy(x).dtype)
+    t = t.scatter_reduce(0, torch.from_numpy(dst)[:, None].expand(-1, d), torch.from_numpy(x[src]), red,
+                         include_self=False)
+    np.testing.assert_allclose(a, t.numpy(), rtol=tol, atol=tol)
+    empty = np.setdiff1d(np.arange(n), dst)
+    assert len(empty) > 0 and (a[empty] == 0).all()
+    if op == "sum":
+        A = sp.csr_matrix((np.ones(e), (dst, src)), shape=(n, n))
+        np.testing.assert_allclose(a, (A @ x.astype(np.float64)).astype(dtype), rtol=tol * 10, atol=tol * 10)
+
+
+def test_send_u_recv_out_size():
+    src = np.array([0, 1, 2], np.int64); dst = np.array([1, 1, 0], np.int64)
+    x = np.arange(12, dtype=np.float32).reshape(3, 4)
+    assert R.c_send_u_recv(x, src, dst, "sum", out_size=2).shape == (2, 4)
+    assert R.c_send_u_recv(x, src, dst, "sum", out_size=7).shape == (7, 4)
+    assert R.c_send_u_recv(x, src, dst, "sum", out_size=0).shape == (3, 4)    # <=0: ignored
+    assert R.c_send_u_recv(x, src, dst, "sum", out_size=-1).shape == (3, 4)
+
+
+@pytest.mark.parametrize("mop", ["add", "sub", "mul", "div"])
+@pytest.mark.parametrize("rop", ["sum", "mean", "max", "min"])
+def test_send_ue_recv_cross_check(mop, rop):
+    n, e, h, dd = 120, 900, 4, 8
+    src, dst, rng = _rand_graph(n, e, 5)
+    x = rng.standard_normal((n, h, dd)).astype(np.float32)
+    y = (rng.standard_normal((e, h, 1)) + 3.0).astype(np.float32)
+    a = R.c_send_ue_recv(x, y, src, dst, mop, rop)
+    b = R.np_send_ue_recv(x, y, src, dst, mop, rop)
+    assert a.shape == (n, h, dd)
+    np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("mop", ["add", "sub", "mul", "div"])
+def test_send_uv_cross_check(mop):
+    n, e, h = 90, 700, 8
+    src, dst, rng = _rand_graph(n, e, 6)
+    x = rng.standard_normal((n, h)).astype(np.float32)
+    y = (rng.standard_normal((n, h)) + 3.0).astype(np.float32)
+    np.testing.assert_array_equal(R.c_send_uv(x, y, src, dst, mop), R.np_send_uv(x, y, src, dst, mop))
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "max", "min"])
+def test_segment_cross_check(op):
+    rng = np.random.default_rng(9)
+    ids = np.sort(rng.integers(0, 200, 3000)).astype(np.int64)
+    data = rng.standard_normal((3000, 6)).astype(np.float32)
+    a = R.c_segment(data, ids, op); b = R.np_segment(data, ids, op)
+    assert a.shape[0] == ids[-1] + 1
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
+    sm = R.c_segment_softmax(data, ids)
+    np.testing.assert_allclose(sm, R.np_segment_softmax(data, ids), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(R.c_segment(sm, ids, "sum")[np.unique(ids)], 1.0, rtol=1e-5)
+
+
+def test_csr_omp_equals_serial():
+    n, e, d = 2000, 30000, 16
+    src, dst, rng = _rand_graph(n, e, 12)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    _, sv, _, _, ip = R.c_build_index(dst, src, n)
+    np.testing.assert_allclose(R.c_csr_spmm_sum_omp(x, ip, sv), R.c_send_u_recv(x, src, dst, "sum"),
+                               rtol=1e-5, atol=1e-5)
