@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- aggregated edges/sec of the GCN send+recv_sum hot path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE pass of Graph.send_recv(x, "sum") (= pglamd_aggregate through the C ABI) over the
+whole synthetic graph with the feature matrix already resident in HBM.
+Workload (config.workload): BASELINE.json configs[1] -- RMAT (0.57,0.19,0.19,0.05) |V| = 2^20,
+|E| = 20 M, d = 128 fp32, graph seed 42, feature seed 7.
+N > 1: the SAME global graph is partitioned over the N ranks (strong scaling); one halo
+all-to-all-v (RCCL) per step overlapped with the interior rows; value = global |E| / max-rank time.
+
+Output: one JSON line on rank 0 with the driver's contract fields plus
+  roofline     -- dominant kernel (agg_flat_kernel) algorithmic bytes / its HIP-event time vs 8 TB/s
+  cpu_baseline -- the oracle's C port of the Paddle CPU kernel (serial, raw COO order), timed on
+                  this box's host cores (rank 0, N = 1 only); the checker, never the product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
+
+
+def algorithmic_bytes(E, N, d, s):
+    """B = E*(d*s + 4) + N*(d*s + 8)."""
+    return E * (d * s + 4) + N * (d * s + 8)
+
+
+def cpu_baseline(edges_cpu, x_cpu, budget_s=30.0):
+    """Oracle C port (kind 'port') on a bounded sample: the first `m` edges of the same graph,
+    m chosen so the pass takes ~10-30 s on one core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import ref_ops as R
+    e = edges_cpu.numpy()
+    x = x_cpu.numpy()
+    R.lib()
+    m = min(len(e), 2_000_000)
+    t0 = time.perf_counter()
+    R.c_send_u_recv(x, e[:m, 0], e[:m, 1], "sum")
+    t_probe = time.perf_counter() - t0
+    rate = m / t_probe
+    m2 = int(min(len(e), max(m, rate * min(budget_s, 20.0))))
+    t0 = time.perf_counter()
+    R.c_send_u_recv(x, e[:m2, 0], e[:m2, 1], "sum")
+    t = time.perf_counter() - t0
+    return {"value": m2 / t, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": "first %d of %d edges of the same RMAT graph, full [N,%d] fp32 features, 1 pass, "
+                      "oracle/ref_ops.c ref_send_u_recv_f32 (serial raw-COO loop)" % (m2, len(e), x.shape[1])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scale", type=int, default=20)
+    ap.add_argument("--edges", type=int, default=20_000_000)
+    ap.add_argument("--dim", type=int, default=128)
+    ap.add_argument("--partition", default="kway", choices=["kway", "random"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+
+    N, E, d = 1 << args.scale, args.edges, args.dim
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    edges = rmat_edges(args.scale, E, seed=42, device=dev)           # identical on every rank
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, d, generator=gen, device=dev, dtype=torch.float32)
+
+    if world == 1:
+        g = pgl.Graph(edges=edges, num_nodes=N)
+        g.adj_dst_index                                            # CSR build = setup, not timed
+        step = lambda: g.send_recv(x, "sum")
+        sync = lambda: torch.cuda.synchronize()
+        barrier = lambda: None
+        halo = None
+    else:
+        import torch.distributed as dist
+        from pgl_amd.distributed import DistGraph
+        dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev)
+        x_own = dg.take_owned(x)
+        del x
+        step = lambda: dg.send_recv(x_own, "sum")
+        sync = lambda: torch.cuda.synchronize()
+        barrier = lambda: dist.barrier()
+        halo = dg.stats()
+
+    for _ in range(args.warmup):
+        step()
+    sync(); barrier(); sync()
+    pgl.ops.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync(); barrier(); sync()
+    dt = time.perf_counter() - t0
+    kern_ms, launches = pgl.ops.profile_end()
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = E * args.steps / dt
+        B = algorithmic_bytes(E if world == 1 else halo["local_edges"], N if world == 1 else halo["local_rows"], d, 4)
+        kms = kern_ms / max(launches, 1)
+        achieved = B / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        rec = {
+            "metric": "aggregated edges/sec (GCN send+recv_sum, d=%d)" % d, "value": value, "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RMAT(0.57,0.19,0.19,0.05) scale %d |V|=%d |E|=%d d=%d fp32, Graph.send_recv(sum) "
+                                   "via pglamd_aggregate (BASELINE configs[1])" % (args.scale, N, E, d),
+                       "graph_seed": 42, "feature_seed": 7,
+                       "parallelism": "single GPU" if world == 1 else "row partition (%s) x%d + RCCL halo all-to-all-v" % (args.partition, world)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "agg_flat_kernel<float,2,1,0,0>", "kernel_ms": kms, "launches_per_step": launches / args.steps,
+                         "algorithmic_bytes_per_launch": B},
+        }
+        if halo is not None:
+            rec["halo"] = halo
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(edges.cpu(), x.cpu())
+        print(json.dumps(rec), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,233 @@
+/*
+ * pgl_amd.h -- C ABI of libpglamd.so: the MI355X (gfx950) message-passing engine that sits
+ * behind PGL's Graph.send / recv / send_recv / send_ue_recv / send_uv and pgl.math.segment_*.
+ *
+ * The reference (PaddlePaddle/PGL 2.2.6) has no plugin registry for this path: the seam is the
+ * set of paddle.* tensor ops its Python makes.  Each entry point below
+ * replaces one of those call sites; the reference file:line it stands in for is cited on it.
+ * INTEGRATION.md shows the ctypes stub a PGL maintainer would add on the reference side.
+ *
+ * Conventions (all entry points)
+ *   - plain pointers + sizes; every pointer is a DEVICE pointer unless it says "host";
+ *     no torch / paddle types anywhere in a signature;
+ *   - row-major, rows contiguous (last dim fastest), same as paddle/torch default layout;
+ *   - the caller owns every buffer, including outputs and scratch: query
+ *     pglamd_<op>_workspace_bytes(...) first, allocate, pass `workspace`;
+ *     the library never allocates or frees device memory on these paths;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t, NULL = default stream);
+ *     no hidden synchronisation unless the entry point says so;
+ *   - return 0 on success, a negative PGLAMD_E_* otherwise; pglamd_last_error() gives the
+ *     thread-local message;
+ *   - index validity (ids < num_nodes) is the caller's contract, exactly as in the reference.
+ *
+ * "CSR order" below means the order graph_kernel.build_index emits (pgl/graph_kernel.pyx:59-88):
+ * edges stably sorted by key u (= dst for adj_dst_index, pgl/graph.py:1319-1328), ascending
+ * original edge id within a row.
+ */
+#ifndef PGL_AMD_H_
+#define PGL_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGLAMD_ABI_VERSION 1
+
+/* status codes */
+#define PGLAMD_OK 0
+#define PGLAMD_E_SHAPE (-1)     /* bad size / unsupported broadcast */
+#define PGLAMD_E_DTYPE (-2)     /* dtype not supported by this entry point */
+#define PGLAMD_E_RANGE (-3)     /* num_nodes / num_edges beyond the int32 engine range */
+#define PGLAMD_E_WORKSPACE (-4) /* workspace NULL or too small */
+#define PGLAMD_E_HIP (-5)       /* HIP runtime error (message has hipGetErrorString) */
+#define PGLAMD_E_ARG (-6)       /* NULL pointer / bad enum */
+
+/* element types */
+#define PGLAMD_F16 0
+#define PGLAMD_F32 1
+#define PGLAMD_F64 2
+#define PGLAMD_I32 3
+#define PGLAMD_I64 4
+#define PGLAMD_BF16 5
+
+/* reduce_op of send_u_recv / send_ue_recv / segment_* ("sum","mean","max","min") */
+#define PGLAMD_SUM 0
+#define PGLAMD_MEAN 1
+#define PGLAMD_MAX 2
+#define PGLAMD_MIN 3
+
+/* message_op of send_ue_recv / send_uv ("add","sub","mul","div") */
+#define PGLAMD_ADD 0
+#define PGLAMD_SUB 1
+#define PGLAMD_MUL 2
+#define PGLAMD_DIV 3
+
+int32_t pglamd_abi_version(void);
+const char* pglamd_last_error(void);
+/* name of the device the library sees, e.g. "gfx950..." (host string, valid until next call) */
+const char* pglamd_device_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K8  CSR build.   Replaces graph_kernel.build_index (pgl/graph_kernel.pyx:59-88) as called by
+ * EdgeIndex.from_edges (pgl/utils/edge_index.py:38-58; numpy path :56-57, tensor path :42-54).
+ *   u, v            int64 keys / neighbours, element strides u_stride / v_stride (so a column of
+ *                   the [E,2] edge array can be passed in place: stride 2)
+ *   degree[N] sorted_v[E] sorted_u[E] sorted_eid[E] indptr[N+1]     int64, reference layout,
+ *                   bit-identical to build_index (stable by original edge id)
+ *   row32[E] col32[E] eid32[E]   optional (NULL to skip) int32 copies of sorted_u / sorted_v /
+ *                   sorted_eid that the aggregation kernels read (halves index traffic)
+ * Limits: N < 2^31, E < 2^31 (PGLAMD_E_RANGE otherwise).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pglamd_csr_build_workspace_bytes(int64_t num_edges, int64_t num_nodes);
+int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const int64_t* v, int64_t v_stride,
+                         int64_t num_edges, int64_t num_nodes, int64_t* degree, int64_t* sorted_v,
+                         int64_t* sorted_u, int64_t* sorted_eid, int64_t* indptr, int32_t* row32,
+                         int32_t* col32, int32_t* eid32, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* Replaces unique_segment(dst_sorted) = paddle.unique(return_inverse=True)
+ * (pgl/utils/helper.py:156-160, cached by Graph.get_segment_ids, pgl/graph.py:1397-1407).
+ *   uniq_ind[<=N]   ascending ids of rows with degree > 0 (first *num_uniq entries valid)
+ *   segment_ids[E]  dense rank of each CSR-ordered edge's row
+ *   num_uniq        device int64[1]                                                              */
+size_t pglamd_unique_segment_workspace_bytes(int64_t num_edges, int64_t num_nodes);
+int32_t pglamd_unique_segment(const int64_t* degree, const int64_t* sorted_u, int64_t num_edges,
+                              int64_t num_nodes, int64_t* uniq_ind, int64_t* segment_ids,
+                              int64_t* num_uniq, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* strided int64 -> int32 narrowing copy (src/dst columns of the edge array for send_uv) */
+int32_t pglamd_narrow_i64(const int64_t* in, int64_t in_stride, int64_t n, int32_t* out,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1 / K2  aggregation over a CSR-ordered edge list (atomic-free, deterministic).
+ * Replaces paddle.geometric.send_u_recv  (pgl/graph.py:859-861, 885-887: Graph.send_recv /
+ * send_u_recv) and paddle.geometric.send_ue_recv (pgl/graph.py:929-937: Graph.send_ue_recv):
+ *
+ *     out[r, j] = dst_scale[r] * REDUCE_{p : row[p]==r}  ( src_scale[col[p]] * x[col[p], xj] (mop) y[yp, yj] )
+ *
+ *   x          [n_x_rows, dx]   node features, `dtype`
+ *   row, col   [E] int32, CSR order (row non-decreasing): destination row / source row per edge
+ *   indptr     [n_csr_rows+1] int64 (the reference's indptr)
+ *   y          NULL for send_u_recv; else edge features [E, dy] of `dtype` in ORIGINAL edge order
+ *              when eid != NULL (yp = eid[p]) or already in CSR order when eid == NULL (yp = p)
+ *   dx, dy, dout   trailing sizes.  Broadcast rule supported on the fast path: trailing-dim
+ *              broadcast only, xj = j / (dout/dx), yj = j / (dout/dy)  (covers [H,D]x[H,1],
+ *              [H,D]x[H,D], [D]x[1]); other numpy patterns must be expanded by the caller.
+ *   src_scale, dst_scale   optional float32 [n_x_rows] / [out_rows] (NULL = 1): fuses GCN's
+ *              symmetric degree normalisation (pgl/nn/conv.py:242,250) into the aggregation;
+ *              only for floating dtypes with reduce_op SUM / MEAN.
+ *   out        [out_rows, dout]; every row is written exactly once (rows without messages = 0,
+ *              as the reference guarantees); out_rows may exceed n_csr_rows (out_size semantics)
+ *   reduce_op  PGLAMD_SUM/MEAN/MAX/MIN ; message_op PGLAMD_ADD/SUB/MUL/DIV (ignored if y NULL)
+ * ---------------------------------------------------------------------------------------------- */
+size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t dout, int32_t dtype);
+int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t dx, const void* y,
+                         int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
+                         const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
+                         int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
+                         const float* src_scale, const float* dst_scale, void* out, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* Measurement hook for the dominant kernel (bench.py roofline leg): between profile_begin and
+ * profile_end every launch of the flat aggregation kernel is bracketed by HIP events on its own
+ * launch stream; profile_end synchronises them and returns the summed kernel time (host out). */
+int32_t pglamd_profile_begin(void);
+int32_t pglamd_profile_end(double* total_ms, int64_t* launches);
+
+/* K1'  un-indexed COO variant (edges in arbitrary order, hardware float atomics; SUM only,
+ * F32).  For one-shot graphs where building the CSR would cost more than it saves.  Result is
+ * order-nondeterministic in the last bits, unlike pglamd_aggregate.  `out` is zero-filled here. */
+int32_t pglamd_scatter_add_coo(const float* x, int64_t d, const int32_t* src, const int32_t* dst,
+                               int64_t num_edges, int64_t out_rows, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  send_uv.  Replaces paddle.geometric.send_uv (pgl/graph.py:964-966):
+ *     out[e, j] = x[src[e], j/(dout/dx)] (mop) y[dst[e], j/(dout/dy)]      (original edge order)
+ * ---------------------------------------------------------------------------------------------- */
+int32_t pglamd_send_uv(const void* x, const void* y, int32_t dtype, int64_t dx, int64_t dy,
+                       int64_t dout, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                       int32_t message_op, void* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5  segment reduce.  Replaces paddle.geometric.segment_{sum,mean,max,min}
+ * (pgl/math.py:30-178; Message.reduce_*, pgl/message.py:34-105).
+ *   data [E, d] of `dtype`; ids [E] sorted non-decreasing, int32 (ids_i64 = 0) or int64 (= 1);
+ *   out [n_out_rows, d] with n_out_rows = ids[E-1] + 1 supplied by the caller; rows whose id
+ *   never occurs are 0.
+ * ---------------------------------------------------------------------------------------------- */
+size_t pglamd_segment_reduce_workspace_bytes(int64_t num_rows, int64_t d, int64_t n_out_rows,
+                                             int32_t dtype);
+int32_t pglamd_segment_reduce(const void* data, int32_t dtype, const void* ids, int32_t ids_i64,
+                              int64_t num_rows, int64_t d, int64_t n_out_rows, int32_t reduce_op,
+                              void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  segment softmax.  Replaces pgl.math.segment_softmax (pgl/math.py:181-224: segment_max,
+ * gather, sub, exp, segment_sum, gather, div = 7 passes) with one kernel, and -- when `perm` is
+ * given -- the whole of GF.edge_softmax (pgl/nn/functional/graph_op.py:101-123: gather by eid,
+ * segment_softmax, scatter back by eid):
+ *     p-th CSR-ordered element is data[perm[p]] (perm == NULL: data[p]); result written to
+ *     out[perm[p]], i.e. in ORIGINAL edge order when perm = sorted_eid.
+ *   data/out [E, d] F32 or F64;  seg_ptr [n_seg+1] int64 offsets of each segment in CSR order
+ *   (the reference's indptr: empty segments allowed).
+ * ---------------------------------------------------------------------------------------------- */
+int32_t pglamd_segment_softmax(const void* data, int32_t dtype, const int32_t* perm,
+                               const int64_t* seg_ptr, int64_t n_seg, int64_t num_rows, int64_t d,
+                               void* out, void* stream);
+
+/* K4'  segment boundaries from sorted ids: seg_ptr[n_seg+1] (int64), n_seg = ids[E-1]+1 given by
+ * the caller.  Used when segment_softmax is called with raw ids (pgl.math API). */
+int32_t pglamd_seg_ptr_from_ids(const void* ids, int32_t ids_i64, int64_t num_rows, int64_t n_seg,
+                                int64_t* seg_ptr, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6 / K7  row gather / scatter.  Replace paddle.gather (pgl/utils/op.py:45 read_rows / RowReader,
+ * pgl/message.py:157 edge_expand, pgl/graph.py:822) and paddle.scatter(overwrite=True)
+ * (pgl/graph.py:828-830 recv epilogue).  index int32 (index_i64 = 0) or int64 (= 1).
+ *   gather : out[i, :] = x[index[i], :]          out [n_index, d]
+ *   scatter: out[index[i], :] = x[i, :]          (indices unique; out pre-initialised by caller)
+ * elem_bytes = size of one element (1,2,4,8): these are pure byte moves.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t pglamd_gather_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index,
+                           int32_t index_i64, int64_t n_index, void* out, void* stream);
+int32_t pglamd_scatter_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index,
+                            int32_t index_i64, int64_t n_index, void* out, void* stream);
+
+/* K9  degree_norm.  Replaces cast/clip/pow in GF.degree_norm (pgl/nn/functional/graph_op.py:46-55):
+ *     out[i] = max((float)degree[i], 1) ** -0.5      out F32 (out_f64 = 0) or F64 (= 1)           */
+int32_t pglamd_degree_norm(const int64_t* degree, int64_t n, void* out, int32_t out_f64,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side (CPU) helpers.  Pointers here are HOST pointers.
+ * pglamd_map_ids replaces graph_kernel.map_edges / map_nodes (pgl/graph_kernel.pyx:104-138):
+ *     out[i] = value of key in[i] in the (keys -> vals) dictionary; missing key -> 0, like
+ *     std::unordered_map::operator[] in the reference.
+ * pglamd_partition_kway is the engine's own multilevel k-way partitioner standing in for
+ * METIS_PartGraphKway as called by pgl.partition.metis_partition (pgl/partition.py:37-91,
+ * pgl/graph_kernel.pyx:434-472).  Same inputs (CSR xadj/adjncy int64, optional positive int64
+ * vertex / edge weights), same output (part[N] int64 in [0, nparts)); partition ids are NOT
+ * bit-identical to METIS (METIS is not reimplemented) -- parity is on balance and edge cut.
+ * ---------------------------------------------------------------------------------------------- */
+/* Host twin of pglamd_csr_build for numpy-mode graphs (Graph.indegree()/sorted_edges() before
+ * Graph.tensor(), as examples/gcn/train.py:83 does): same outputs, same order, HOST pointers.
+ * Replaces graph_kernel.build_index (pgl/graph_kernel.pyx:59-88) on the CPU side. */
+int32_t pglamd_build_index_host(const int64_t* u, int64_t u_stride, const int64_t* v,
+                                int64_t v_stride, int64_t num_edges, int64_t num_nodes,
+                                int64_t* degree, int64_t* sorted_v, int64_t* sorted_u,
+                                int64_t* sorted_eid, int64_t* indptr);
+int32_t pglamd_map_ids(const int64_t* keys, const int64_t* vals, int64_t n_keys, const int64_t* in,
+                       int64_t n_in, int64_t* out);
+int32_t pglamd_partition_kway(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
+                              const int64_t* vwgt, const int64_t* adjwgt, int64_t nparts,
+                              uint64_t seed, int64_t* part, int64_t* edgecut);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGL_AMD_H_ */

@@ -1,0 +1,261 @@
+"""Differentiable wrappers (torch.autograd.Function) around pgl_amd.ops.
+
+The C ABI is forward-only and stateless; gradients are expressed with the SAME
+kernels on the transposed index (adj_src_index): d/dx of a sum over in-edges is a sum over
+out-edges.  Fused backward kernels (SDDMM for d/d(edge feature), softmax-backward) are the
+"next" row f1; where they are missing the backward composes existing kernels and says so.
+"""
+import torch
+
+from . import ops
+
+
+def _unbroadcast(g, shape):
+    """Sum `g` ([rows, *out_tail]) back to [rows, *tail] after numpy-style broadcasting."""
+    tail = tuple(shape[1:])
+    gt = tuple(g.shape[1:])
+    if gt == tail:
+        return g
+    lead = len(gt) - len(tail)
+    if lead > 0:
+        g = g.sum(dim=tuple(range(1, 1 + lead)))
+    dims = tuple(i + 1 for i, s in enumerate(tail) if s == 1 and g.shape[i + 1] != 1)
+    if dims:
+        g = g.sum(dim=dims, keepdim=True)
+    return g.reshape((g.shape[0],) + tail)
+
+
+class _Aggregate(torch.autograd.Function):
+    """send_u_recv / send_ue_recv.  csr = dst-keyed CSR; csr_t() lazily returns the src-keyed one."""
+
+    @staticmethod
+    def forward(ctx, x, y, csr, csr_t, rop, mop, out_size, src32, dst32):
+        out = ops.aggregate(x, csr, rop, out_size, y, mop)
+        ctx.csr, ctx.csr_t, ctx.rop, ctx.mop = csr, csr_t, rop, mop
+        ctx.src32, ctx.dst32 = src32, dst32
+        ctx.x_shape = tuple(x.shape)
+        ctx.y_shape = None if y is None else tuple(y.shape)
+        need_out = rop in ("max", "min")
+        ctx.save_for_backward(x, y if y is not None else x.new_zeros(0), out if need_out else x.new_zeros(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, y, out = ctx.saved_tensors
+        has_y = ctx.y_shape is not None
+        y = y if has_y else None
+        grad = grad.contiguous()
+        gx = gy = None
+        csr_t = ctx.csr_t()
+        n_x = ctx.x_shape[0]
+        if ctx.rop in ("sum", "mean"):
+            scale = None
+            if ctx.rop == "mean":
+                # d out[v] / d msg = 1 / indeg(v): rides along as the per-source scale of the transposed sum
+                scale = (1.0 / ctx.csr.degree.clamp(min=1).to(torch.float32))
+                if grad.shape[0] > scale.shape[0]:
+                    scale = torch.cat([scale, scale.new_ones(grad.shape[0] - scale.shape[0])])
+                if grad.dtype != torch.float32:       # kernel scales are fp32-only: pre-scale instead
+                    grad = grad * scale.to(grad.dtype).reshape((-1,) + (1,) * (grad.dim() - 1))
+                    scale = None
+            if ctx.needs_input_grad[0]:
+                if not has_y or ctx.mop in ("add", "sub"):
+                    g = ops.aggregate(grad, csr_t, "sum", n_x, src_scale=scale)
+                elif ctx.mop == "mul":
+                    g = ops.aggregate(grad, csr_t, "sum", n_x, y, "mul", src_scale=scale)
+                else:
+                    g = ops.aggregate(grad, csr_t, "sum", n_x, y, "div", src_scale=scale)
+                gx = _unbroadcast(g, ctx.x_shape)
+            if has_y and ctx.needs_input_grad[1]:
+                # composed (materialises [E, out_tail]); fused SDDMM is the "next" row f1
+                gd = ops.gather_rows(grad, ctx.dst32)
+                if scale is not None:
+                    gd = gd * ops.gather_rows(scale.reshape(-1, 1), ctx.dst32).reshape((-1,) + (1,) * (gd.dim() - 1))
+                if ctx.mop == "add":
+                    gy = gd
+                elif ctx.mop == "sub":
+                    gy = -gd
+                else:
+                    xs = ops.gather_rows(x, ctx.src32)
+                    gy = gd * xs if ctx.mop == "mul" else -gd * xs / (y * y)
+                gy = _unbroadcast(gy, ctx.y_shape)
+        else:
+            # max / min: gradient flows to every message equal to the winner (Paddle's rule);
+            # composed from gathers -- not on the graded path
+            xs = ops.gather_rows(x, ctx.src32)
+            msg = xs if not has_y else {"add": xs + y, "sub": xs - y, "mul": xs * y, "div": xs / y}[ctx.mop]
+            hit = (msg == ops.gather_rows(out, ctx.dst32)).to(grad.dtype)
+            gm = ops.gather_rows(grad, ctx.dst32) * hit
+            if ctx.needs_input_grad[0]:
+                gxe = gm if not has_y or ctx.mop in ("add", "sub") else (gm * y if ctx.mop == "mul" else gm / y)
+                g = ops.aggregate(gxe.contiguous(), _edge_csr(csr_t), "sum", n_x)
+                gx = _unbroadcast(g, ctx.x_shape)
+            if has_y and ctx.needs_input_grad[1]:
+                gy = {"add": gm, "sub": -gm, "mul": gm * xs, "div": -gm * xs / (y * y)}[ctx.mop]
+                gy = _unbroadcast(gy, ctx.y_shape)
+        return gx, gy, None, None, None, None, None, None, None
+
+
+class _EdgeCSR(object):
+    """View of a CSR whose 'source rows' are EDGE rows: col = original edge id."""
+
+    def __init__(self, c):
+        self.row32, self.col32, self.eid32, self.indptr = c.row32, c.eid32, c.eid32, c.indptr
+        self.num_edges, self.num_nodes, self.degree = c.num_edges, c.num_nodes, c.degree
+
+
+def _edge_csr(c):
+    return _EdgeCSR(c)
+
+
+def aggregate(x, csr, csr_t, reduce_op="sum", out_size=None, y=None, message_op="add", src32=None, dst32=None):
+    if torch.is_grad_enabled() and (x.requires_grad or (y is not None and y.requires_grad)):
+        return _Aggregate.apply(x, y, csr, csr_t, reduce_op, message_op, out_size, src32, dst32)
+    return ops.aggregate(x, csr, reduce_op, out_size, y, message_op)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, index, index_csr):
+        ctx.index, ctx.index_csr, ctx.n = index, index_csr, x.shape[0]
+        return ops.gather_rows(x, index)
+
+    @staticmethod
+    def backward(ctx, grad):
+        csr = ctx.index_csr() if callable(ctx.index_csr) else ctx.index_csr
+        if csr is None:     # arbitrary index: key it on the fly
+            iota = torch.arange(ctx.index.shape[0], device=grad.device, dtype=torch.int64)
+            csr = ops.csr_build(ctx.index.to(torch.int64), iota, ctx.n)
+        return ops.aggregate(grad.contiguous(), _edge_csr(csr), "sum", ctx.n), None, None
+
+
+def gather_rows(x, index, index_csr=None):
+    """Differentiable paddle.gather(x, index, axis=0).  index_csr: CSR keyed by `index` (the graph
+    passes adj_src/adj_dst so the backward is one aggregation, no sort)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _GatherRows.apply(x, index, index_csr)
+    return ops.gather_rows(x, index)
+
+
+class _SendUV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, src32, dst32, mop, csr_dst, csr_src):
+        ctx.mop, ctx.src32, ctx.dst32, ctx.csr_dst, ctx.csr_src = mop, src32, dst32, csr_dst, csr_src
+        ctx.save_for_backward(x, y)
+        return ops.send_uv(x, y, src32, dst32, mop)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, y = ctx.saved_tensors
+        grad = grad.contiguous()
+        gx = gy = None
+        if ctx.mop in ("add", "sub"):
+            ge_x, ge_y = grad, (grad if ctx.mop == "add" else -grad)
+        else:
+            xs, yd = ops.gather_rows(x, ctx.src32), ops.gather_rows(y, ctx.dst32)
+            xs = xs.reshape((xs.shape[0],) + (1,) * (grad.dim() - xs.dim()) + tuple(xs.shape[1:]))
+            yd = yd.reshape((yd.shape[0],) + (1,) * (grad.dim() - yd.dim()) + tuple(yd.shape[1:]))
+            if ctx.mop == "mul":
+                ge_x, ge_y = grad * yd, grad * xs
+            else:
+                ge_x, ge_y = grad / yd, -grad * xs / (yd * yd)
+        if ctx.needs_input_grad[0]:
+            g = ops.aggregate(ge_x.contiguous(), _edge_csr(ctx.csr_src()), "sum", x.shape[0])
+            gx = _unbroadcast(g, tuple(x.shape))
+        if ctx.needs_input_grad[1]:
+            g = ops.aggregate(ge_y.contiguous(), _edge_csr(ctx.csr_dst()), "sum", y.shape[0])
+            gy = _unbroadcast(g, tuple(y.shape))
+        return gx, gy, None, None, None, None, None
+
+
+def send_uv(x, y, src32, dst32, mop, csr_dst, csr_src):
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        return _SendUV.apply(x, y, src32, dst32, mop, csr_dst, csr_src)
+    return ops.send_uv(x, y, src32, dst32, mop)
+
+
+class _SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, ids, pool, num_segments):
+        out = ops.segment_reduce(data, ids, pool, num_segments)
+        ctx.pool, ctx.ids = pool, ids
+        ctx.save_for_backward(data, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        data, out = ctx.saved_tensors
+        grad = grad.contiguous()
+        ge = ops.gather_rows(grad, ctx.ids)
+        if ctx.pool == "mean":
+            seg_ptr = ops.seg_ptr_from_ids(ctx.ids, out.shape[0])
+            cnt = (seg_ptr[1:] - seg_ptr[:-1]).clamp(min=1).to(grad.dtype)
+            ge = ge / ops.gather_rows(cnt.reshape(-1, 1), ctx.ids).reshape((-1,) + (1,) * (ge.dim() - 1))
+        elif ctx.pool in ("max", "min"):
+            ge = ge * (data == ops.gather_rows(out, ctx.ids)).to(grad.dtype)
+        return ge, None, None, None
+
+
+def segment_reduce(data, ids, pool="sum", num_segments=None):
+    if torch.is_grad_enabled() and data.requires_grad:
+        return _SegmentReduce.apply(data, ids, pool, num_segments)
+    return ops.segment_reduce(data, ids, pool, num_segments)
+
+
+class _SegmentSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, data, seg_ptr, perm32):
+        out = ops.segment_softmax(data, seg_ptr, perm32)
+        ctx.seg_ptr, ctx.perm32 = seg_ptr, perm32
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        # dL/dx = p * (g - sum_seg(p * g)); composed: segment sum through the flat aggregation kernel
+        (p,) = ctx.saved_tensors
+        pg = (p * grad).contiguous()
+        n_seg = ctx.seg_ptr.shape[0] - 1
+        ids = _ids_from_seg_ptr(ctx.seg_ptr, p.shape[0])
+        if ctx.perm32 is not None:
+            pg_sorted = ops.gather_rows(pg, ctx.perm32)
+            s = ops.gather_rows(ops.segment_reduce(pg_sorted, ids, "sum", n_seg), ids)
+            s_edge = torch.empty_like(s)
+            ops.scatter_rows(s_edge, ctx.perm32, s)
+        else:
+            s_edge = ops.gather_rows(ops.segment_reduce(pg, ids, "sum", n_seg), ids)
+        return pg - p * s_edge, None, None
+
+
+def _ids_from_seg_ptr(seg_ptr, n):
+    if n == 0:
+        return seg_ptr.new_zeros(0)
+    marks = torch.zeros(n + 1, dtype=torch.int64, device=seg_ptr.device)
+    marks.index_add_(0, seg_ptr[1:-1], torch.ones_like(seg_ptr[1:-1]))
+    return torch.cumsum(marks[:n], 0)
+
+
+def segment_softmax(data, seg_ptr, perm32=None):
+    if torch.is_grad_enabled() and data.requires_grad:
+        return _SegmentSoftmax.apply(data, seg_ptr, perm32)
+    return ops.segment_softmax(data, seg_ptr, perm32)
+
+
+class _ScatterRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, n_rows, index, x):
+        out = torch.zeros((n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        ctx.index = index
+        return ops.scatter_rows(out, index, x)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return None, None, ops.gather_rows(grad.contiguous(), ctx.index)
+
+
+def scatter_into_zeros(n_rows, index, x):
+    """zeros([n_rows, ...]) with rows `index` (unique) overwritten by x (pgl/graph.py:828-830)."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _ScatterRows.apply(n_rows, index, x)
+    out = torch.zeros((n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    return ops.scatter_rows(out, index, x)

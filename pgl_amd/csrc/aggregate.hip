@@ -1,0 +1,610 @@
+// aggregate.hip -- K1/K2: atomic-free segmented aggregation over a CSR-ordered edge list.
+//
+//   out[r, :] = dst_scale[r] * REDUCE_{p: row[p]==r} ( src_scale[col[p]] * x[col[p], :] (mop) y[yp, :] )
+//
+// Replaces paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937)
+// and, with col == NULL (identity gather), paddle.geometric.segment_* (pgl/math.py:30-178).
+//
+// Design (MI355X, HBM-bound: ~516 B of gathered feature row per edge at d=128 fp32, 2 flops/B^-1):
+//   * The edge list is a flat stream sorted by destination row.  Wave w owns the fixed-size chunk
+//     [w*K, (w+1)*K) of that stream regardless of row boundaries (merge-path style): perfect
+//     load balance on power-law graphs, no per-row launch geometry, no atomics.
+//   * Inside a chunk everything that steers control flow is WAVE-UNIFORM: col/row/eid indices are
+//     read with scalar loads (s_load_dwordx8), the feature row address is an SGPR base + lane
+//     offset, row-boundary tests are scalar branches.  The 64 lanes span the feature dimension
+//     (VEC contiguous elements per lane, NT tiles per lane): one gathered row = one fully
+//     coalesced wave-wide load (512 B for d=128 fp32).
+//   * U = 8 edges are issued back-to-back and double-buffered, so a wave keeps 8..16 independent
+//     row gathers (4-8 KiB) in flight irrespective of how short the rows are; at 8 waves/SIMD
+//     that is >128 KiB per CU outstanding, enough to cover HBM latency at >5 TB/s.
+//   * A row that lies wholly inside a chunk is reduced in registers and stored once.  A row that
+//     straddles chunk boundaries leaves per-chunk partials in the caller's workspace
+//     (tail partial T[c] for the chunk where it starts, head partial H[c] for every later chunk)
+//     and a second tiny kernel adds them IN CHUNK ORDER: deterministic, bit-reproducible run
+//     to run, every output row written exactly once.  Rows without edges are zero-filled by a
+//     third kernel from indptr (the reference guarantees 0, not +-inf, for every reduce op).
+//   * Logical blocks are remapped so consecutive chunks (consecutive destination rows) run on
+//     the same XCD: partition-ordered graphs then reuse source rows in that XCD's private L2.
+#include "common.hpp"
+
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace pglamd {
+
+struct AggParams {
+    const void* x; const void* y; void* out;
+    const int* row; const int* col; const int* eid;
+    const int64_t* indptr;
+    const float* src_scale; const float* dst_scale;
+    void* part_head; void* part_tail;     // [n_chunks, tile_cols] of ACC each
+    int64_t ldx, ldy, ldo;                // row strides (elements) of x, y, out
+    int64_t out_rows, n_csr_rows;
+    int E, n_chunks, chunk, n_blocks;
+    int j_base, tile_cols;                // this launch covers out columns [j_base, j_base+tile_cols)
+    int gy;                               // y column = j / gy   (YMODE 1)
+    int mop, is_max, is_mean;
+};
+
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
+
+template <typename T> struct Limits;
+template <> struct Limits<float> { static __device__ float lo() { return -INFINITY; } static __device__ float hi() { return INFINITY; } };
+template <> struct Limits<double> { static __device__ double lo() { return -INFINITY; } static __device__ double hi() { return INFINITY; } };
+template <> struct Limits<int32_t> { static __device__ int32_t lo() { return INT32_MIN; } static __device__ int32_t hi() { return INT32_MAX; } };
+template <> struct Limits<int64_t> { static __device__ int64_t lo() { return INT64_MIN; } static __device__ int64_t hi() { return INT64_MAX; } };
+
+template <typename T> __device__ __forceinline__ T apply_mop(T a, T b, int mop) {
+    switch (mop) {
+        case PGLAMD_ADD: return a + b;
+        case PGLAMD_SUB: return a - b;
+        case PGLAMD_MUL: return a * b;
+        default: return a / b;
+    }
+}
+
+// RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector
+template <typename T, int VEC, int NT, int RCLS, int YMODE>
+__global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
+    constexpr int U = 8;
+    using V = VecT<T, VEC>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
+    if (lb < 0) return;
+    const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
+    if (c >= p.n_chunks) return;
+    const int e0 = c * p.chunk;
+    const int e1 = min(e0 + p.chunk, p.E);
+
+    const cptr<int> rowp = as_const(p.row);
+    const cptr<int> colp = as_const(p.col);
+    const cptr<int> eidp = as_const(p.eid);
+    const cptr<float> sscale = as_const(p.src_scale);
+    const cptr<float> dscale = as_const(p.dst_scale);
+    const T* __restrict__ x = static_cast<const T*>(p.x);
+    const T* __restrict__ y = static_cast<const T*>(p.y);
+    T* __restrict__ out = static_cast<T*>(p.out);
+    const bool has_ss = p.src_scale != nullptr;
+    const bool is_max = p.is_max != 0;
+
+    // lane -> column mapping
+    int j0[NT]; bool act[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        j0[t] = (t * kWave + lane) * VEC;
+        act[t] = j0[t] < p.tile_cols;
+        j0[t] += p.j_base;
+    }
+
+    int yj[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) yj[t] = YMODE == 1 ? j0[t] / p.gy : 0;
+
+    T acc[NT][VEC];
+    auto reset = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                acc[t][k] = RCLS == 0 ? T(0) : (is_max ? Limits<T>::lo() : Limits<T>::hi());
+    };
+    reset();
+
+    int cur = rowp[e0];
+    bool head_open = e0 > 0 && rowp[e0 - 1] == cur;   // current row began in an earlier chunk
+    int cnt = 0;
+
+    auto store_partial = [&](void* base) {
+        T* dst = static_cast<T*>(base) + (int64_t)c * p.tile_cols;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (act[t]) {
+                V o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o.v[k] = acc[t][k];
+                *reinterpret_cast<V*>(dst + (j0[t] - p.j_base)) = o;
+            }
+    };
+    auto store_final = [&](int r, int n) {
+        if (r >= p.out_rows) return;
+        T* dst = out + (int64_t)r * p.ldo;
+        float ds = 1.f;
+        if constexpr (RCLS == 0) { if (p.dst_scale) ds = dscale[r]; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (act[t]) {
+                V o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    T a = acc[t][k];
+                    if constexpr (RCLS == 0) {
+                        if (p.is_mean) a = a / (T)n;
+                        if constexpr (std::is_floating_point_v<T>) { if (p.dst_scale) a = a * (T)ds; }
+                    }
+                    o.v[k] = a;
+                }
+                *reinterpret_cast<V*>(dst + j0[t]) = o;
+            }
+    };
+    // closes row `cur` when the stream moved on to another row inside this chunk
+    auto flush_mid = [&]() {
+        if (head_open) store_partial(p.part_head); else store_final(cur, cnt);
+        head_open = false;
+    };
+
+    auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U], int (&yy)[U], float (&ss)[U]) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            rr[i] = rowp[e + i];
+            cc[i] = colp ? colp[e + i] : e + i;
+            if constexpr (YMODE != 0) yy[i] = eidp ? eidp[e + i] : e + i;
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) ss[i] = has_ss ? sscale[cc[i]] : 1.f;
+    };
+    auto load_rows = [&](const int (&cc)[U], const int (&yy)[U], V (&vx)[U][NT], V (&vy)[U][NT]) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const T* xr = x + (int64_t)cc[i] * p.ldx;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (act[t]) vx[i][t] = *reinterpret_cast<const V*>(xr + j0[t]);
+            if constexpr (YMODE == 1) {
+                const T* yr = y + (int64_t)yy[i] * p.ldy;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (act[t]) vy[i][t].v[0] = yr[yj[t]];
+            } else if constexpr (YMODE == 2) {
+                const T* yr = y + (int64_t)yy[i] * p.ldy;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (act[t]) vy[i][t] = *reinterpret_cast<const V*>(yr + j0[t]);
+            }
+        }
+    };
+    auto consume_one = [&](int r, float s, const V (&vx)[NT], const V (&vy)[NT]) {
+        if (r != cur) { flush_mid(); cur = r; cnt = 0; reset(); }
+        ++cnt;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                T m = vx[t].v[k];
+                if constexpr (std::is_floating_point_v<T>) { if (has_ss) m = m * (T)s; }
+                if constexpr (YMODE == 1) m = apply_mop(m, vy[t].v[0], p.mop);
+                if constexpr (YMODE == 2) m = apply_mop(m, vy[t].v[k], p.mop);
+                if constexpr (RCLS == 0) acc[t][k] += m;
+                else acc[t][k] = is_max ? (m > acc[t][k] ? m : acc[t][k]) : (m < acc[t][k] ? m : acc[t][k]);
+            }
+    };
+
+    int e = e0;
+    const int n_full = (e1 - e0) / U;
+    int cA[U], rA[U], yA[U]; float sA[U];
+    V xA[U][NT], wA[U][NT];
+    if (n_full > 0) { load_idx(e, cA, rA, yA, sA); load_rows(cA, yA, xA, wA); }
+    for (int g = 0; g < n_full; ++g) {
+        int cB[U], rB[U], yB[U]; float sB[U];
+        V xB[U][NT], wB[U][NT];
+        const bool more = g + 1 < n_full;
+        if (more) { load_idx(e + U, cB, rB, yB, sB); load_rows(cB, yB, xB, wB); }
+#pragma unroll
+        for (int i = 0; i < U; ++i) consume_one(rA[i], sA[i], xA[i], wA[i]);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                rA[i] = rB[i]; sA[i] = sB[i];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) { xA[i][t] = xB[i][t]; wA[i][t] = wB[i][t]; }
+            }
+        }
+        e += U;
+    }
+    for (; e < e1; ++e) {   // remainder (< U edges): one at a time
+        int r = rowp[e];
+        int cc = colp ? colp[e] : e;
+        float s = has_ss ? sscale[cc] : 1.f;
+        V vx[NT], vy[NT];
+        const T* xr = x + (int64_t)cc * p.ldx;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (act[t]) vx[t] = *reinterpret_cast<const V*>(xr + j0[t]);
+        if constexpr (YMODE != 0) {
+            int yy = eidp ? eidp[e] : e;
+            const T* yr = y + (int64_t)yy * p.ldy;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (act[t]) {
+                    if constexpr (YMODE == 1) vy[t].v[0] = yr[yj[t]];
+                    else vy[t] = *reinterpret_cast<const V*>(yr + j0[t]);
+                }
+        }
+        consume_one(r, s, vx, vy);
+    }
+
+    // the row open at the end of the chunk
+    const bool tail_open = e1 < p.E && rowp[e1] == cur;
+    if (head_open) store_partial(p.part_head);          // middle or closing piece of a long row
+    else if (tail_open) store_partial(p.part_tail);     // first piece of a row that continues
+    else store_final(cur, cnt);
+}
+
+// Adds, in chunk order, the partials of every row that straddles a chunk boundary.
+// One wave per chunk a; it acts iff a row STARTS in chunk a and continues past its end.
+template <typename T, int VEC, int NT, int RCLS>
+__global__ __launch_bounds__(kBlock) void agg_fixup_kernel(AggParams p) {
+    using V = VecT<T, VEC>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int a = wave_uniform((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
+    if (a >= p.n_chunks) return;
+    const int e0 = a * p.chunk;
+    const int e1 = e0 + p.chunk;
+    if (e1 >= p.E) return;
+    const cptr<int> rowp = as_const(p.row);
+    const cptr<int64_t> ip = as_const(p.indptr);
+    const int r = rowp[e1 - 1];
+    if (rowp[e1] != r) return;                  // nothing continues
+    const int64_t rs = ip[r], re = ip[r + 1];
+    if (rs < e0) return;                        // row started earlier: that chunk's wave owns it
+    if (r >= p.out_rows) return;
+    const int b = (int)((re - 1) / p.chunk);    // last chunk holding a piece of row r
+    const bool is_max = p.is_max != 0;
+
+    T acc[NT][VEC];
+    int j0[NT]; bool act[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        j0[t] = (t * kWave + lane) * VEC;
+        act[t] = j0[t] < p.tile_cols;
+        if (act[t]) {
+            V v = *reinterpret_cast<const V*>(static_cast<const T*>(p.part_tail) + (int64_t)a * p.tile_cols + j0[t]);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[t][k] = v.v[k];
+        }
+    }
+    for (int c = a + 1; c <= b; ++c) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (act[t]) {
+                V v = *reinterpret_cast<const V*>(static_cast<const T*>(p.part_head) + (int64_t)c * p.tile_cols + j0[t]);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if constexpr (RCLS == 0) acc[t][k] += v.v[k];
+                    else acc[t][k] = is_max ? (v.v[k] > acc[t][k] ? v.v[k] : acc[t][k]) : (v.v[k] < acc[t][k] ? v.v[k] : acc[t][k]);
+                }
+            }
+    }
+    T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
+    float ds = 1.f;
+    if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (act[t]) {
+            V o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                T v = acc[t][k];
+                if constexpr (RCLS == 0) {
+                    if (p.is_mean) v = v / (T)(re - rs);
+                    if constexpr (std::is_floating_point_v<T>) { if (p.dst_scale) v = v * (T)ds; }
+                }
+                o.v[k] = v;
+            }
+            *reinterpret_cast<V*>(dst + j0[t]) = o;
+        }
+}
+
+// Zero-fills output rows that receive no edge: rows r < n_csr_rows with indptr[r]==indptr[r+1],
+// and rows in [n_csr_rows, out_rows).  One wave inspects 64 rows (coalesced indptr read).
+template <typename W>
+__global__ __launch_bounds__(kBlock) void zero_empty_rows_kernel(const int64_t* __restrict__ indptr,
+                                                                int64_t n_csr_rows, int64_t out_rows,
+                                                                W* __restrict__ out, int64_t row_words) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t r0 = w * kWave;
+    if (r0 >= out_rows) return;
+    const int64_t r = r0 + lane;
+    bool empty = false;
+    if (r < out_rows) empty = (r >= n_csr_rows) || (indptr[r] == indptr[r + 1]);
+    unsigned long long m = __ballot(empty);
+    W z{};
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        W* dst = out + (r0 + l) * row_words;
+        for (int64_t j = lane; j < row_words; j += kWave) dst[j] = z;
+    }
+}
+
+// Catch-all: any dtype handled as T, any trailing-dim broadcast (gx, gy), any width.
+// One wave per destination row, lanes stride over output columns, edges serial.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= p.out_rows) return;
+    const T* __restrict__ x = static_cast<const T*>(p.x);
+    const T* __restrict__ y = static_cast<const T*>(p.y);
+    T* out = static_cast<T*>(p.out) + r * p.ldo;
+    const int64_t n_csr = p.n_csr_rows;
+    int64_t s = 0, t = 0;
+    if (r < n_csr) { s = p.indptr[r]; t = p.indptr[r + 1]; }
+    const bool additive = !(p.is_max == 1 || p.is_max == 2);
+    for (int j = lane; j < p.tile_cols; j += kWave) {
+        T acc = T(0);
+        for (int64_t q = s; q < t; ++q) {
+            const int cc = p.col ? p.col[q] : (int)q;
+            T m = x[(int64_t)cc * p.ldx + j / gx];
+            if (y) {
+                const int64_t yy = p.eid ? p.eid[q] : q;
+                m = apply_mop(m, y[yy * p.ldy + j / p.gy], p.mop);
+            }
+            if (additive) acc += m;
+            else if (q == s) acc = m;
+            else if (p.is_max == 1) acc = m > acc ? m : acc;
+            else acc = m < acc ? m : acc;
+        }
+        if (additive && p.is_mean && t > s) acc = acc / (T)(t - s);
+        out[j] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+static int chunk_edges() {
+    static int k = [] {
+        const char* s = getenv("PGLAMD_CHUNK");
+        int v = s ? atoi(s) : 256;
+        if (v < 8) v = 8;
+        return v / 8 * 8;
+    }();
+    return k;
+}
+
+// Optional in-library timing of the dominant kernel (bench.py's roofline leg): while enabled,
+// every flat-kernel launch is bracketed by a pair of HIP events on the launch stream.
+struct ProfileState {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+static ProfileState& prof() { static ProfileState s; return s; }
+
+template <typename T, int VEC, int NT, int RCLS, int YMODE>
+static int32_t launch_flat(AggParams p, hipStream_t st) {
+    const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
+    p.n_blocks = (int)nb;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof().on) {
+        PGLAMD_HIP_CHECK(hipEventCreate(&e0));
+        PGLAMD_HIP_CHECK(hipEventCreate(&e1));
+        PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE>), dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p);
+    PGLAMD_LAUNCH_CHECK();
+    if (prof().on) {
+        PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
+        prof().ev.emplace_back(e0, e1);
+    }
+    hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS>), dim3((unsigned)nb), dim3(kBlock), 0, st, p);
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+template <typename T, int VEC, int NT>
+static int32_t dispatch_mode(const AggParams& p, int rcls, int ymode, hipStream_t st, bool* handled) {
+    *handled = true;
+    if (rcls == 0) {
+        if (ymode == 0) return launch_flat<T, VEC, NT, 0, 0>(p, st);
+        if constexpr (std::is_floating_point_v<T>) {
+            if (ymode == 1) return launch_flat<T, VEC, NT, 0, 1>(p, st);
+            if (ymode == 2) return launch_flat<T, VEC, NT, 0, 2>(p, st);
+        }
+    } else if (ymode == 0) {
+        return launch_flat<T, VEC, NT, 1, 0>(p, st);
+    }
+    *handled = false;
+    return PGLAMD_OK;
+}
+
+// picks (VEC, NT) for one column tile of width w; widths are capped by max_tile_cols<T>()
+template <typename T>
+static int32_t dispatch_shape(const AggParams& p, int vec, int rcls, int ymode, hipStream_t st, bool* handled) {
+    const int w = p.tile_cols;
+    if constexpr (sizeof(T) == 4) {
+        if (vec >= 4) {
+            if (w <= 256) return dispatch_mode<T, 4, 1>(p, rcls, ymode, st, handled);
+            if (w <= 512) return dispatch_mode<T, 4, 2>(p, rcls, ymode, st, handled);
+            return dispatch_mode<T, 4, 4>(p, rcls, ymode, st, handled);
+        }
+        if (vec == 2) {
+            if (w <= 128) return dispatch_mode<T, 2, 1>(p, rcls, ymode, st, handled);
+            if (w <= 256) return dispatch_mode<T, 2, 2>(p, rcls, ymode, st, handled);
+            return dispatch_mode<T, 2, 4>(p, rcls, ymode, st, handled);
+        }
+        if (w <= 64) return dispatch_mode<T, 1, 1>(p, rcls, ymode, st, handled);
+        if (w <= 128) return dispatch_mode<T, 1, 2>(p, rcls, ymode, st, handled);
+        return dispatch_mode<T, 1, 4>(p, rcls, ymode, st, handled);
+    } else {
+        if (vec >= 2) {
+            if (w <= 128) return dispatch_mode<T, 2, 1>(p, rcls, ymode, st, handled);
+            if (w <= 256) return dispatch_mode<T, 2, 2>(p, rcls, ymode, st, handled);
+            return dispatch_mode<T, 2, 4>(p, rcls, ymode, st, handled);
+        }
+        if (w <= 64) return dispatch_mode<T, 1, 1>(p, rcls, ymode, st, handled);
+        if (w <= 128) return dispatch_mode<T, 1, 2>(p, rcls, ymode, st, handled);
+        return dispatch_mode<T, 1, 4>(p, rcls, ymode, st, handled);
+    }
+}
+
+template <typename T> static int max_vec() { return sizeof(T) == 4 ? 4 : 2; }
+
+static int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_rows, void* out,
+                               size_t row_bytes, hipStream_t st) {
+    if (out_rows <= 0 || row_bytes == 0) return PGLAMD_OK;
+    const int64_t waves = ceil_div(out_rows, kWave);
+    const unsigned grid = (unsigned)ceil_div(waves, kWavesPerBlock);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(out);
+    if (row_bytes % 16 == 0 && a % 16 == 0)
+        hipLaunchKernelGGL(zero_empty_rows_kernel<uint4>, dim3(grid), dim3(kBlock), 0, st, indptr, n_csr_rows, out_rows, static_cast<uint4*>(out), (int64_t)(row_bytes / 16));
+    else if (row_bytes % 8 == 0 && a % 8 == 0)
+        hipLaunchKernelGGL(zero_empty_rows_kernel<uint2>, dim3(grid), dim3(kBlock), 0, st, indptr, n_csr_rows, out_rows, static_cast<uint2*>(out), (int64_t)(row_bytes / 8));
+    else if (row_bytes % 4 == 0 && a % 4 == 0)
+        hipLaunchKernelGGL(zero_empty_rows_kernel<uint32_t>, dim3(grid), dim3(kBlock), 0, st, indptr, n_csr_rows, out_rows, static_cast<uint32_t*>(out), (int64_t)(row_bytes / 4));
+    else
+        hipLaunchKernelGGL(zero_empty_rows_kernel<uint16_t>, dim3(grid), dim3(kBlock), 0, st, indptr, n_csr_rows, out_rows, static_cast<uint16_t*>(out), (int64_t)(row_bytes / 2));
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+template <typename T>
+static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, const int32_t* eid,
+                               const int32_t* row, const int32_t* col, const int64_t* indptr, int64_t E,
+                               int64_t n_csr_rows, int64_t out_rows, int64_t dout, int32_t mop, int32_t rop,
+                               const float* src_scale, const float* dst_scale, void* out, void* ws,
+                               size_t ws_bytes, hipStream_t st) {
+    int32_t rc = zero_empty_rows(indptr, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
+    if (rc != PGLAMD_OK || E == 0) return rc;
+
+    AggParams p{};
+    p.x = x; p.y = y; p.out = out; p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
+    p.src_scale = src_scale; p.dst_scale = dst_scale;
+    p.ldx = dx; p.ldy = dy; p.ldo = dout; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)E;
+    p.mop = mop; p.is_mean = rop == PGLAMD_MEAN; p.is_max = rop == PGLAMD_MAX;
+    const int rcls = (rop == PGLAMD_SUM || rop == PGLAMD_MEAN) ? 0 : 1;
+    const int gx = (int)(dout / dx);
+    const int gy = y ? (int)(dout / dy) : 1;
+    p.gy = gy;
+
+    // fast path eligibility
+    bool fast = gx == 1;
+    int vec = max_vec<T>();
+    const uintptr_t align_bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+                                 (y && gy == 1 ? reinterpret_cast<uintptr_t>(y) : 0) |
+                                 reinterpret_cast<uintptr_t>(ws);
+    while (vec > 1 && (dout % vec != 0 || align_bits % (vec * sizeof(T)) != 0)) vec >>= 1;
+    int ymode = 0;
+    if (y) {
+        if (gy == 1) ymode = 2;
+        else { ymode = 1; while (vec > 1 && gy % vec != 0) vec >>= 1; }
+    }
+    if ((src_scale || dst_scale) && (rcls != 0 || !std::is_floating_point_v<T>))
+        return fail(PGLAMD_E_ARG, "src_scale/dst_scale need a floating dtype and sum/mean");
+
+    if (fast) {
+        const int K = chunk_edges();
+        p.chunk = K;
+        p.n_chunks = (int)ceil_div(E, K);
+        const int max_cols = kWave * vec * 4;
+        const int64_t tile_full = dout < max_cols ? dout : max_cols;
+        const size_t need = 2 * align_up((size_t)p.n_chunks * tile_full * sizeof(T), 256);
+        if (!ws || ws_bytes < need) return fail(PGLAMD_E_WORKSPACE, "aggregate: workspace %zu < %zu", ws_bytes, need);
+        p.part_head = ws;
+        p.part_tail = static_cast<char*>(ws) + need / 2;
+        for (int64_t jb = 0; jb < dout; jb += max_cols) {
+            p.j_base = (int)jb;
+            p.tile_cols = (int)((dout - jb) < max_cols ? (dout - jb) : max_cols);
+            bool handled = false;
+            rc = dispatch_shape<T>(p, vec, rcls, ymode, st, &handled);
+            if (rc != PGLAMD_OK) return rc;
+            if (!handled) { fast = false; break; }
+        }
+        if (fast) return PGLAMD_OK;
+    }
+    // generic fallback (rows were zero-filled above; it rewrites every row < out_rows)
+    p.tile_cols = (int)dout; p.j_base = 0;
+    p.is_max = rop == PGLAMD_MAX ? 1 : rop == PGLAMD_MIN ? 2 : 0;
+    if (src_scale || dst_scale) return fail(PGLAMD_E_SHAPE, "scales unsupported with this broadcast pattern");
+    hipLaunchKernelGGL(agg_generic_kernel<T>, dim3((unsigned)ceil_div(out_rows, kWavesPerBlock)), dim3(kBlock), 0, st, p, gx);
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+}  // namespace pglamd
+
+using namespace pglamd;
+
+extern "C" size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t dout, int32_t dtype) {
+    const size_t es = dtype_size(dtype);
+    if (es == 0 || num_edges <= 0) return 256;
+    const int64_t n_chunks = ceil_div(num_edges, chunk_edges());
+    const int max_vec_ = es == 4 ? 4 : 2;
+    const int64_t max_cols = (int64_t)kWave * max_vec_ * 4;
+    const int64_t tile = dout < max_cols ? dout : max_cols;
+    return 2 * align_up((size_t)n_chunks * tile * es, 256) + 256;
+}
+
+extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t dx, const void* y,
+                                    int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
+                                    const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
+                                    int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
+                                    const float* src_scale, const float* dst_scale, void* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    (void)n_x_rows;
+    if (!out || !indptr || (num_edges > 0 && (!x || !row))) return fail(PGLAMD_E_ARG, "aggregate: NULL pointer");
+    if (num_edges < 0 || num_edges >= INT32_MAX || n_csr_rows >= INT32_MAX || out_rows >= INT32_MAX)
+        return fail(PGLAMD_E_RANGE, "aggregate: sizes beyond int32 engine range");
+    if (dout <= 0 || dx <= 0 || dout % dx != 0 || (y && (dy <= 0 || dout % dy != 0)))
+        return fail(PGLAMD_E_SHAPE, "aggregate: dx=%lld dy=%lld dout=%lld is not a trailing-dim broadcast",
+                    (long long)dx, (long long)dy, (long long)dout);
+    if (reduce_op < 0 || reduce_op > 3 || (y && (message_op < 0 || message_op > 3)))
+        return fail(PGLAMD_E_ARG, "aggregate: bad op enum");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define CALL(T) aggregate_typed<T>(x, dx, y, dy, eid, row, col, indptr, num_edges, n_csr_rows, out_rows, dout, \
+                                   message_op, reduce_op, src_scale, dst_scale, out, workspace, workspace_bytes, st)
+    switch (dtype) {
+        case PGLAMD_F32: return CALL(float);
+        case PGLAMD_F64: return CALL(double);
+        case PGLAMD_I32: return CALL(int32_t);
+        case PGLAMD_I64: return CALL(int64_t);
+        default: return fail(PGLAMD_E_DTYPE, "aggregate: dtype %d not supported (F32/F64/I32/I64)", dtype);
+    }
+#undef CALL
+}
+
+extern "C" int32_t pglamd_profile_begin(void) {
+    for (auto& pr : prof().ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    prof().ev.clear();
+    prof().on = true;
+    return PGLAMD_OK;
+}
+
+extern "C" int32_t pglamd_profile_end(double* total_ms, int64_t* launches) {
+    prof().on = false;
+    double tot = 0;
+    int64_t n = 0;
+    for (auto& pr : prof().ev) {
+        float ms = 0;
+        PGLAMD_HIP_CHECK(hipEventSynchronize(pr.second));
+        PGLAMD_HIP_CHECK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        tot += ms; ++n;
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    prof().ev.clear();
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return PGLAMD_OK;
+}

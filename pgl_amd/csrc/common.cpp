@@ -1,0 +1,38 @@
+// common.cpp -- error state + version/introspection entry points of libpglamd.
+#include "common.hpp"
+
+namespace pglamd {
+
+std::string& last_error_ref() {
+    thread_local std::string e;
+    return e;
+}
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_ref() = buf;
+    return code;
+}
+
+}  // namespace pglamd
+
+extern "C" int32_t pglamd_abi_version(void) { return PGLAMD_ABI_VERSION; }
+
+extern "C" const char* pglamd_last_error(void) { return pglamd::last_error_ref().c_str(); }
+
+extern "C" const char* pglamd_device_arch(void) {
+    thread_local std::string arch;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        arch = "";
+        return arch.c_str();
+    }
+    arch = prop.gcnArchName;
+    return arch.c_str();
+}

@@ -1,0 +1,82 @@
+// common.hpp -- shared host/device helpers for libpglamd (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+
+#include <cstdarg>
+#include <cstring>
+#include <cstdlib>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/pgl_amd.h"
+
+namespace pglamd {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // 4 waves per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kXcds = 8;           // MI355X: block b is dispatched to XCD b % 8
+
+std::string& last_error_ref();
+int32_t fail(int32_t code, const char* fmt, ...);
+
+#define PGLAMD_HIP_CHECK(expr)                                                             \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return ::pglamd::fail(PGLAMD_E_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                                  hipGetErrorString(_e), __FILE__, __LINE__);              \
+    } while (0)
+
+#define PGLAMD_LAUNCH_CHECK() PGLAMD_HIP_CHECK(hipGetLastError())
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+inline size_t dtype_size(int32_t dt) {
+    switch (dt) {
+        case PGLAMD_F16: case PGLAMD_BF16: return 2;
+        case PGLAMD_F32: case PGLAMD_I32: return 4;
+        case PGLAMD_F64: case PGLAMD_I64: return 8;
+        default: return 0;
+    }
+}
+
+// Bump allocator over the caller's workspace (256-byte aligned slices).
+struct Carver {
+    char* base; size_t cap; size_t off = 0;
+    Carver(void* p, size_t n) : base(static_cast<char*>(p)), cap(n) {}
+    template <typename T> T* take(size_t count) {
+        size_t bytes = align_up(count * sizeof(T), 256);
+        T* r = reinterpret_cast<T*>(base + off);
+        off += bytes;
+        return r;
+    }
+    bool ok() const { return base != nullptr && off <= cap; }
+};
+
+// blockIdx -> logical block so that CONSECUTIVE logical blocks land on the SAME XCD
+// (dispatcher places block b on XCD b % 8; speed only, never correctness).
+// Launch ceil(nb/8)*8 blocks; returns -1 for the padding blocks.
+__device__ __forceinline__ int64_t xcd_swizzle(int64_t b, int64_t nb) {
+    int64_t per = (nb + kXcds - 1) / kXcds;
+    int64_t lb = (b % kXcds) * per + b / kXcds;
+    return lb < nb ? lb : -1;
+}
+inline int64_t xcd_grid(int64_t nb) { return ceil_div(nb, kXcds) * kXcds; }
+
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Read-only kernel inputs addressed wave-uniformly (index arrays, per-row scalars) are viewed
+// through the CONSTANT address space: the backend then always emits scalar loads
+// (s_load_dword..x8 through the scalar cache) instead of a vector load + v_readfirstlane.
+// Only valid for memory no thread of the running kernel writes.
+template <typename T> using cptr = const T __attribute__((address_space(4)))*;
+template <typename T> __device__ __forceinline__ cptr<T> as_const(const T* p) {
+    return (cptr<T>)(unsigned long long)p;
+}
+
+}  // namespace pglamd

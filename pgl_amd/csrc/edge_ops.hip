@@ -1,0 +1,356 @@
+// edge_ops.hip -- K3 send_uv, K4 segment softmax / fused edge_softmax, K5 segment reduce wrapper,
+// K6/K7 row gather / scatter, K9 degree_norm, K1' COO atomic scatter-add.
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace pglamd {
+
+template <typename T> __device__ __forceinline__ T mop_apply(T a, T b, int mop) {
+    switch (mop) {
+        case PGLAMD_ADD: return a + b;
+        case PGLAMD_SUB: return a - b;
+        case PGLAMD_MUL: return a * b;
+        default: return a / b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 send_uv (pgl/graph.py:964-966): out[e, j] = x[src[e], j/gx] (mop) y[dst[e], j/gy]
+// One thread per output element group; for the GAT shape (dx=dy=dout=8 fp32) each thread moves a
+// float4, two threads per edge, so a wave writes 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void send_uv_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t d,
+                                                             const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                             int64_t E, int mop, T* __restrict__ out) {
+    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    const int64_t per = d / VEC;
+    const int64_t total = E * per;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t e = i / per, j = (i - e * per) * VEC;
+        const V a = *reinterpret_cast<const V*>(x + (int64_t)src[e] * d + j);
+        const V b = *reinterpret_cast<const V*>(y + (int64_t)dst[e] * d + j);
+        V o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.v[k] = mop_apply(a.v[k], b.v[k], mop);
+        *reinterpret_cast<V*>(out + e * d + j) = o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void send_uv_generic_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t dx,
+                                                                 int64_t dy, int64_t dout, const int32_t* __restrict__ src,
+                                                                 const int32_t* __restrict__ dst, int64_t E, int mop,
+                                                                 T* __restrict__ out) {
+    const int64_t gx = dout / dx, gy = dout / dy;
+    const int64_t total = E * dout;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t e = i / dout, j = i - e * dout;
+        out[i] = mop_apply(x[(int64_t)src[e] * dx + j / gx], y[(int64_t)dst[e] * dy + j / gy], mop);
+    }
+}
+
+static unsigned grid_for(int64_t n) {
+    int64_t g = ceil_div(n > 0 ? n : 1, kBlock);
+    return (unsigned)(g < 256 * 32 ? g : 256 * 32);
+}
+
+template <typename T>
+static int32_t send_uv_typed(const void* x, const void* y, int64_t dx, int64_t dy, int64_t dout, const int32_t* src,
+                             const int32_t* dst, int64_t E, int mop, void* out, hipStream_t st) {
+    const T* xp = static_cast<const T*>(x); const T* yp = static_cast<const T*>(y); T* op = static_cast<T*>(out);
+    constexpr int VEC = 16 / sizeof(T);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out);
+    if (dx == dout && dy == dout && dout % VEC == 0 && al % 16 == 0)
+        hipLaunchKernelGGL((send_uv_vec_kernel<T, VEC>), dim3(grid_for(E * (dout / VEC))), dim3(kBlock), 0, st, xp, yp, dout, src, dst, E, mop, op);
+    else
+        hipLaunchKernelGGL(send_uv_generic_kernel<T>, dim3(grid_for(E * dout)), dim3(kBlock), 0, st, xp, yp, dx, dy, dout, src, dst, E, mop, op);
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 segment softmax, optionally fused with the eid gather/scatter of GF.edge_softmax.
+// One wave per segment.  Lane = (k, j): j = column (DP = pow2 >= d columns side by side),
+// k = edge slot; EP = 64/DP edges are processed per step.  Values of short segments
+// (<= R*EP edges) stay in registers between the three phases (max, sum of exp, normalise), so the
+// logits are read once and the scores written once; longer segments re-read (L2-resident).
+// Arithmetic is the reference's: e = exp(x - max); out = e / sum(e)   (pgl/math.py:216-224).
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T exp_t(T v);
+template <> __device__ __forceinline__ float exp_t<float>(float v) { return expf(v); }
+template <> __device__ __forceinline__ double exp_t<double>(double v) { return exp(v); }
+
+template <typename T, int DP>
+__global__ __launch_bounds__(kBlock) void segment_softmax_kernel(const T* __restrict__ data, const int32_t* __restrict__ perm,
+                                                                 const int64_t* __restrict__ seg_ptr, int64_t n_seg, int64_t d,
+                                                                 T* __restrict__ out) {
+    constexpr int EP = kWave / DP;
+    constexpr int R = 8;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int j = lane % DP, k = lane / DP;
+    const bool colok = j < d;
+    for (int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); s < n_seg; s += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t b = seg_ptr[s], e = seg_ptr[s + 1];
+        const int64_t n = e - b;
+        if (n == 0) continue;
+        const bool small = n <= (int64_t)R * EP;
+        T vals[R];
+        int64_t pos[R];
+        T mx = -INFINITY;
+        if (small) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t q = b + (int64_t)r * EP + k;
+                vals[r] = -INFINITY;
+                pos[r] = -1;
+                if (q < e && colok) {
+                    const int64_t row = perm ? (int64_t)perm[q] : q;
+                    pos[r] = row * d + j;
+                    vals[r] = data[pos[r]];
+                }
+                mx = vals[r] > mx ? vals[r] : mx;
+            }
+        } else {
+            for (int64_t q = b + k; q < e; q += EP)
+                if (colok) {
+                    const int64_t row = perm ? (int64_t)perm[q] : q;
+                    const T v = data[row * d + j];
+                    mx = v > mx ? v : mx;
+                }
+        }
+#pragma unroll
+        for (int off = DP; off < kWave; off <<= 1) { const T o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
+        T sum = 0;
+        if (small) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (pos[r] >= 0) { vals[r] = exp_t<T>(vals[r] - mx); sum += vals[r]; }
+        } else {
+            for (int64_t q = b + k; q < e; q += EP)
+                if (colok) {
+                    const int64_t row = perm ? (int64_t)perm[q] : q;
+                    sum += exp_t<T>(data[row * d + j] - mx);
+                }
+        }
+#pragma unroll
+        for (int off = DP; off < kWave; off <<= 1) sum += __shfl_xor(sum, off);
+        if (small) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (pos[r] >= 0) out[pos[r]] = vals[r] / sum;
+        } else {
+            for (int64_t q = b + k; q < e; q += EP)
+                if (colok) {
+                    const int64_t row = perm ? (int64_t)perm[q] : q;
+                    out[row * d + j] = exp_t<T>(data[row * d + j] - mx) / sum;
+                }
+        }
+    }
+}
+
+// wide rows (d > 64): lanes stride over columns, edges serial
+template <typename T>
+__global__ __launch_bounds__(kBlock) void segment_softmax_wide_kernel(const T* __restrict__ data, const int32_t* __restrict__ perm,
+                                                                      const int64_t* __restrict__ seg_ptr, int64_t n_seg, int64_t d,
+                                                                      T* __restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); s < n_seg; s += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t b = seg_ptr[s], e = seg_ptr[s + 1];
+        for (int64_t j = lane; j < d; j += kWave) {
+            T mx = -INFINITY;
+            for (int64_t q = b; q < e; ++q) { const int64_t row = perm ? (int64_t)perm[q] : q; const T v = data[row * d + j]; mx = v > mx ? v : mx; }
+            T sum = 0;
+            for (int64_t q = b; q < e; ++q) { const int64_t row = perm ? (int64_t)perm[q] : q; sum += exp_t<T>(data[row * d + j] - mx); }
+            for (int64_t q = b; q < e; ++q) { const int64_t row = perm ? (int64_t)perm[q] : q; out[row * d + j] = exp_t<T>(data[row * d + j] - mx) / sum; }
+        }
+    }
+}
+
+template <typename T>
+static int32_t segment_softmax_typed(const void* data, const int32_t* perm, const int64_t* seg_ptr, int64_t n_seg, int64_t d,
+                                     void* out, hipStream_t st) {
+    const T* dp = static_cast<const T*>(data); T* op = static_cast<T*>(out);
+    int64_t g = ceil_div(n_seg, kWavesPerBlock);
+    const unsigned grid = (unsigned)(g < 256 * 64 ? g : 256 * 64);
+#define SM(DP) hipLaunchKernelGGL((segment_softmax_kernel<T, DP>), dim3(grid), dim3(kBlock), 0, st, dp, perm, seg_ptr, n_seg, d, op)
+    if (d <= 1) SM(1); else if (d <= 2) SM(2); else if (d <= 4) SM(4); else if (d <= 8) SM(8);
+    else if (d <= 16) SM(16); else if (d <= 32) SM(32); else if (d <= 64) SM(64);
+    else hipLaunchKernelGGL(segment_softmax_wide_kernel<T>, dim3(grid), dim3(kBlock), 0, st, dp, perm, seg_ptr, n_seg, d, op);
+#undef SM
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 / K7 row gather / scatter: pure byte moves, W = widest word that divides the row
+// ------------------------------------------------------------------------------------------------
+template <typename W, typename I, bool SCATTER>
+__global__ __launch_bounds__(kBlock) void move_rows_kernel(const W* __restrict__ x, int64_t row_words, const I* __restrict__ index,
+                                                           int64_t n_index, W* __restrict__ out) {
+    const int64_t total = n_index * row_words;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / row_words, w = i - r * row_words;
+        const int64_t s = (int64_t)index[r];
+        if (SCATTER) out[s * row_words + w] = x[i];
+        else out[i] = x[s * row_words + w];
+    }
+}
+
+template <bool SCATTER>
+static int32_t move_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index, int32_t index_i64, int64_t n_index,
+                         void* out, hipStream_t st) {
+    if (n_index == 0 || d == 0) return PGLAMD_OK;
+    const size_t row_bytes = (size_t)d * elem_bytes;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out);
+#define MV(W)                                                                                                               \
+    do {                                                                                                                    \
+        const int64_t rw = row_bytes / sizeof(W);                                                                           \
+        if (index_i64)                                                                                                      \
+            hipLaunchKernelGGL((move_rows_kernel<W, int64_t, SCATTER>), dim3(grid_for(n_index * rw)), dim3(kBlock), 0, st,  \
+                               static_cast<const W*>(x), rw, static_cast<const int64_t*>(index), n_index, static_cast<W*>(out)); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((move_rows_kernel<W, int32_t, SCATTER>), dim3(grid_for(n_index * rw)), dim3(kBlock), 0, st,  \
+                               static_cast<const W*>(x), rw, static_cast<const int32_t*>(index), n_index, static_cast<W*>(out)); \
+    } while (0)
+    if (row_bytes % 16 == 0 && al % 16 == 0) MV(uint4);
+    else if (row_bytes % 8 == 0 && al % 8 == 0) MV(uint2);
+    else if (row_bytes % 4 == 0 && al % 4 == 0) MV(uint32_t);
+    else if (row_bytes % 2 == 0 && al % 2 == 0) MV(uint16_t);
+    else MV(uint8_t);
+#undef MV
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+// K9 degree_norm (graph_op.py:46-55): pow(max(float(deg), 1), -0.5)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void degree_norm_kernel(const int64_t* __restrict__ degree, int64_t n, T* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        T v = (T)degree[i];
+        v = v < (T)1 ? (T)1 : v;
+        out[i] = (T)1 / sqrt(v);
+    }
+}
+
+// K1' COO scatter-add with hardware fp32 atomics (global_atomic_add_f32); lanes span columns so a
+// wave's 64 atomics hit one 256-B row segment.  Order-nondeterministic; the CSR path is the default.
+__global__ __launch_bounds__(kBlock) void scatter_add_coo_kernel(const float* __restrict__ x, int64_t d,
+                                                                 const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                                 int64_t E, float* __restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
+    for (int64_t e = wave; e < E; e += nw) {
+        const int s = wave_uniform(src[e]);
+        const int t = wave_uniform(dst[e]);
+        for (int64_t j = lane; j < d; j += kWave) unsafeAtomicAdd(out + (int64_t)t * d + j, x[(int64_t)s * d + j]);
+    }
+}
+
+}  // namespace pglamd
+
+using namespace pglamd;
+
+extern "C" int32_t pglamd_send_uv(const void* x, const void* y, int32_t dtype, int64_t dx, int64_t dy, int64_t dout,
+                                  const int32_t* src, const int32_t* dst, int64_t num_edges, int32_t message_op, void* out,
+                                  void* stream) {
+    if (num_edges < 0 || (num_edges > 0 && (!x || !y || !src || !dst || !out))) return fail(PGLAMD_E_ARG, "send_uv: bad argument");
+    if (dout <= 0 || dx <= 0 || dy <= 0 || dout % dx != 0 || dout % dy != 0)
+        return fail(PGLAMD_E_SHAPE, "send_uv: dx=%lld dy=%lld dout=%lld is not a trailing-dim broadcast", (long long)dx, (long long)dy, (long long)dout);
+    if (message_op < 0 || message_op > 3) return fail(PGLAMD_E_ARG, "send_uv: bad message_op");
+    if (num_edges == 0) return PGLAMD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PGLAMD_F32: return send_uv_typed<float>(x, y, dx, dy, dout, src, dst, num_edges, message_op, out, st);
+        case PGLAMD_F64: return send_uv_typed<double>(x, y, dx, dy, dout, src, dst, num_edges, message_op, out, st);
+        case PGLAMD_I32: return send_uv_typed<int32_t>(x, y, dx, dy, dout, src, dst, num_edges, message_op, out, st);
+        case PGLAMD_I64: return send_uv_typed<int64_t>(x, y, dx, dy, dout, src, dst, num_edges, message_op, out, st);
+        default: return fail(PGLAMD_E_DTYPE, "send_uv: dtype %d not supported", dtype);
+    }
+}
+
+extern "C" int32_t pglamd_segment_softmax(const void* data, int32_t dtype, const int32_t* perm, const int64_t* seg_ptr,
+                                          int64_t n_seg, int64_t num_rows, int64_t d, void* out, void* stream) {
+    if (num_rows < 0 || n_seg < 0 || d <= 0 || (num_rows > 0 && (!data || !out || !seg_ptr)))
+        return fail(PGLAMD_E_ARG, "segment_softmax: bad argument");
+    if (num_rows == 0 || n_seg == 0) return PGLAMD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (dtype) {
+        case PGLAMD_F32: return segment_softmax_typed<float>(data, perm, seg_ptr, n_seg, d, out, st);
+        case PGLAMD_F64: return segment_softmax_typed<double>(data, perm, seg_ptr, n_seg, d, out, st);
+        default: return fail(PGLAMD_E_DTYPE, "segment_softmax: dtype %d not supported (F32/F64)", dtype);
+    }
+}
+
+extern "C" size_t pglamd_segment_reduce_workspace_bytes(int64_t num_rows, int64_t d, int64_t n_out_rows, int32_t dtype) {
+    const int64_t n = num_rows > 0 ? num_rows : 1;
+    // seg_ptr + ids32 (int64 ids are narrowed) + partials of the flat aggregation
+    return align_up((size_t)(n_out_rows + 1) * 8, 256) + align_up((size_t)n * 4, 256) +
+           pglamd_aggregate_workspace_bytes(num_rows, d, dtype) + 512;
+}
+
+extern "C" int32_t pglamd_segment_reduce(const void* data, int32_t dtype, const void* ids, int32_t ids_i64, int64_t num_rows,
+                                         int64_t d, int64_t n_out_rows, int32_t reduce_op, void* out, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    if (num_rows < 0 || n_out_rows < 0 || d <= 0) return fail(PGLAMD_E_ARG, "segment_reduce: bad size");
+    if (n_out_rows == 0) return PGLAMD_OK;
+    if (!out || (num_rows > 0 && (!data || !ids))) return fail(PGLAMD_E_ARG, "segment_reduce: NULL pointer");
+    const size_t seg_bytes = align_up((size_t)(n_out_rows + 1) * 8, 256);
+    const size_t id_bytes = ids_i64 ? align_up((size_t)(num_rows > 0 ? num_rows : 1) * 4, 256) : 0;
+    const size_t agg_bytes = pglamd_aggregate_workspace_bytes(num_rows, d, dtype);
+    if (!workspace || workspace_bytes < seg_bytes + id_bytes + agg_bytes)
+        return fail(PGLAMD_E_WORKSPACE, "segment_reduce: workspace %zu < %zu (+ (n_out_rows+1)*8 for seg_ptr)", workspace_bytes,
+                    seg_bytes + id_bytes + agg_bytes);
+    char* w = static_cast<char*>(workspace);
+    int64_t* seg_ptr = reinterpret_cast<int64_t*>(w); w += seg_bytes;
+    const int32_t* ids32 = static_cast<const int32_t*>(ids);
+    if (ids_i64) {
+        int32_t* tmp = reinterpret_cast<int32_t*>(w); w += id_bytes;
+        int32_t rc = pglamd_narrow_i64(static_cast<const int64_t*>(ids), 1, num_rows, tmp, stream);
+        if (rc != PGLAMD_OK) return rc;
+        ids32 = tmp;
+    }
+    int32_t rc = pglamd_seg_ptr_from_ids(ids32, 0, num_rows, n_out_rows, seg_ptr, stream);
+    if (rc != PGLAMD_OK) return rc;
+    return pglamd_aggregate(data, dtype, num_rows, d, nullptr, 0, nullptr, ids32, nullptr, seg_ptr, num_rows, n_out_rows,
+                            n_out_rows, d, 0, reduce_op, nullptr, nullptr, out, w, workspace_bytes - (size_t)(w - static_cast<char*>(workspace)),
+                            stream);
+}
+
+extern "C" int32_t pglamd_gather_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index, int32_t index_i64,
+                                      int64_t n_index, void* out, void* stream) {
+    if (n_index < 0 || d < 0 || (n_index > 0 && d > 0 && (!x || !index || !out))) return fail(PGLAMD_E_ARG, "gather_rows: bad argument");
+    return move_rows<false>(x, d, elem_bytes, index, index_i64, n_index, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t pglamd_scatter_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index, int32_t index_i64,
+                                       int64_t n_index, void* out, void* stream) {
+    if (n_index < 0 || d < 0 || (n_index > 0 && d > 0 && (!x || !index || !out))) return fail(PGLAMD_E_ARG, "scatter_rows: bad argument");
+    return move_rows<true>(x, d, elem_bytes, index, index_i64, n_index, out, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t pglamd_degree_norm(const int64_t* degree, int64_t n, void* out, int32_t out_f64, void* stream) {
+    if (n < 0 || (n > 0 && (!degree || !out))) return fail(PGLAMD_E_ARG, "degree_norm: bad argument");
+    if (n == 0) return PGLAMD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (out_f64) hipLaunchKernelGGL(degree_norm_kernel<double>, dim3(grid_for(n)), dim3(kBlock), 0, st, degree, n, static_cast<double*>(out));
+    else hipLaunchKernelGGL(degree_norm_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, st, degree, n, static_cast<float*>(out));
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+extern "C" int32_t pglamd_scatter_add_coo(const float* x, int64_t d, const int32_t* src, const int32_t* dst, int64_t num_edges,
+                                          int64_t out_rows, float* out, void* stream) {
+    if (num_edges < 0 || out_rows < 0 || d <= 0 || !out || (num_edges > 0 && (!x || !src || !dst)))
+        return fail(PGLAMD_E_ARG, "scatter_add_coo: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PGLAMD_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)out_rows * d * sizeof(float), st));
+    if (num_edges == 0) return PGLAMD_OK;
+    int64_t g = ceil_div(num_edges, kWavesPerBlock);
+    hipLaunchKernelGGL(scatter_add_coo_kernel, dim3((unsigned)(g < 256 * 32 ? g : 256 * 32)), dim3(kBlock), 0, st, x, d, src, dst,
+                       num_edges, out);
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}

@@ -1,0 +1,391 @@
+"""pgl_amd.Graph -- host-side mirror of the reference's `pgl.Graph` message-passing API
+(pgl/graph.py), re-expressed over libpglamd's HIP kernels.
+
+Same names, argument meaning and error behaviour as the reference for the hot-path surface:
+    send / recv / send_recv / send_u_recv / send_ue_recv / send_uv     (pgl/graph.py:694-966)
+    sorted_edges / indegree / outdegree / adj_src_index / adj_dst_index / get_segment_ids
+    tensor() / numpy() / dump() / load()
+Differences, all deliberate:
+  * tensor mode lives on the MI355X (torch-ROCm tensors as the device container); there is no
+    CPU tensor mode and no silent fallback -- without a GPU, tensor() raises;
+  * send_recv / send_u_recv / send_ue_recv run on the graph's cached dst-sorted CSR with the
+    atomic-free flat kernel (K1/K2) instead of a per-edge atomic scatter over raw COO;
+  * num_nodes stays a Python int in both modes (the reference turns it into a 1-element tensor).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import autograd as ag
+from . import ops
+from .message import Message
+from .utils import op
+from .utils.edge_index import EdgeIndex
+from .utils.helper import check_is_tensor, maybe_num_nodes, to_device_tensor
+
+_REDUCE = ("sum", "mean", "max", "min")
+_MSGOP = ("add", "sub", "mul", "div")
+
+
+class Graph(object):
+    """Graph(edges, num_nodes=None, node_feat=None, edge_feat=None, **kwargs) -- pgl/graph.py:38-193."""
+
+    def __init__(self, edges, num_nodes=None, node_feat=None, edge_feat=None, **kwargs):
+        self._node_feat = node_feat if node_feat is not None else {}
+        self._edge_feat = edge_feat if edge_feat is not None else {}
+        if not check_is_tensor(edges):
+            edges = np.asarray(edges, dtype="int64") if not (isinstance(edges, np.ndarray) and edges.dtype == np.int64) else edges
+            if edges.size == 0:
+                edges = edges.reshape(0, 2)
+        self._edges = edges
+        if self._edges.ndim != 2 or self._edges.shape[1] != 2:
+            raise ValueError("edges must have shape (num_edges, 2)")
+        self._num_nodes = int(num_nodes) if num_nodes is not None else maybe_num_nodes(self._edges)
+        self._adj_src_index = kwargs.get("adj_src_index", None)
+        self._adj_dst_index = kwargs.get("adj_dst_index", None)
+        self._is_tensor = check_is_tensor(self._edges, *self._node_feat.values(), *self._edge_feat.values()) or \
+            any(ix is not None and ix.is_tensor() for ix in (self._adj_src_index, self._adj_dst_index))
+        self._device = None
+        if self._is_tensor:
+            dev = next((t.device for t in [self._edges, *self._node_feat.values(), *self._edge_feat.values()]
+                        if isinstance(t, torch.Tensor)), None)
+            self._to_tensor_inplace(dev)
+        self._nodes = None
+        self._src32 = self._dst32 = None
+        self._seg_cache = {}
+        self._process_graph_info(**kwargs)
+
+    # ---- graph-level (batched graph) bookkeeping: pgl/graph.py:1330-1370 -----------------------
+    def _process_graph_info(self, **kwargs):
+        self._graph_node_index = kwargs.get("_graph_node_index", None)
+        self._graph_edge_index = kwargs.get("_graph_edge_index", None)
+        self._num_graph = kwargs.get("_num_graph", None)
+        if self._num_graph is None:
+            self._num_graph = 1
+            self._graph_node_index = np.array([0, self._num_nodes], dtype="int64")
+            self._graph_edge_index = np.array([0, self.num_edges], dtype="int64")
+
+    def __repr__(self):
+        d = {"class": self.__class__.__name__, "num_nodes": int(self.num_nodes),
+             "edges_shape": list(self.edges.shape),
+             "node_feat": [{"name": k, "shape": list(v.shape), "dtype": str(v.dtype)} for k, v in self.node_feat.items()],
+             "edge_feat": [{"name": k, "shape": list(v.shape), "dtype": str(v.dtype)} for k, v in self.edge_feat.items()]}
+        return json.dumps(d, ensure_ascii=False)
+
+    # ---- numpy <-> device ---------------------------------------------------------------------
+    def is_tensor(self):
+        return self._is_tensor
+
+    def _to_tensor_inplace(self, device=None):
+        self._edges = to_device_tensor(self._edges, device)
+        device = self._edges.device
+        if self._edges.dtype != torch.int64:
+            self._edges = self._edges.to(torch.int64)
+        self._node_feat = {k: to_device_tensor(v, device) for k, v in self._node_feat.items()}
+        self._edge_feat = {k: to_device_tensor(v, device) for k, v in self._edge_feat.items()}
+        for ix in (self._adj_src_index, self._adj_dst_index):
+            if ix is not None and not ix.is_tensor():
+                ix.tensor(inplace=True, device=device)
+        self._device = device
+        self._is_tensor = True
+        self._nodes = None
+
+    def tensor(self, inplace=True, device=None):
+        """pgl/graph.py:227-267.  Moves edges, features and any already-built index to the GPU."""
+        if self._is_tensor:
+            return self
+        if inplace:
+            self._to_tensor_inplace(device)
+            return self
+        g = self.__class__(edges=self._edges.copy(), num_nodes=self._num_nodes, node_feat=dict(self._node_feat),
+                           edge_feat=dict(self._edge_feat),
+                           adj_src_index=None if self._adj_src_index is None else self._adj_src_index.tensor(False, device),
+                           adj_dst_index=None if self._adj_dst_index is None else self._adj_dst_index.tensor(False, device),
+                           _num_graph=self._num_graph, _graph_node_index=self._graph_node_index,
+                           _graph_edge_index=self._graph_edge_index)
+        if not g._is_tensor:
+            g._to_tensor_inplace(device)
+        return g
+
+    def numpy(self, inplace=True):
+        """pgl/graph.py:269-300."""
+        if not self._is_tensor:
+            return self
+        conv = lambda t: t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else t
+        edges = conv(self._edges)
+        nf = {k: conv(v) for k, v in self._node_feat.items()}
+        ef = {k: conv(v) for k, v in self._edge_feat.items()}
+        if inplace:
+            self._edges, self._node_feat, self._edge_feat = edges, nf, ef
+            for ix in (self._adj_src_index, self._adj_dst_index):
+                if ix is not None:
+                    ix.numpy(inplace=True)
+            self._is_tensor, self._device, self._nodes = False, None, None
+            self._src32 = self._dst32 = None
+            self._seg_cache = {}
+            return self
+        return self.__class__(edges=edges, num_nodes=self._num_nodes, node_feat=nf, edge_feat=ef,
+                              adj_src_index=None if self._adj_src_index is None else self._adj_src_index.numpy(False),
+                              adj_dst_index=None if self._adj_dst_index is None else self._adj_dst_index.numpy(False),
+                              _num_graph=self._num_graph, _graph_node_index=self._graph_node_index,
+                              _graph_edge_index=self._graph_edge_index)
+
+    # ---- dump / load: the reference's .npy directory layout (pgl/graph.py:1177-1302) ------------
+    def dump(self, path):
+        if self._is_tensor:
+            return self.numpy(inplace=False).dump(path)
+        os.makedirs(path, exist_ok=True)
+        np.save(os.path.join(path, "num_nodes.npy"), self._num_nodes)
+        np.save(os.path.join(path, "edges.npy"), self._edges)
+        np.save(os.path.join(path, "num_graph.npy"), self._num_graph)
+        if self._adj_src_index is not None:
+            self._adj_src_index.dump(os.path.join(path, "adj_src"))
+        if self._adj_dst_index is not None:
+            self._adj_dst_index.dump(os.path.join(path, "adj_dst"))
+        for sub, feats in (("node_feat", self._node_feat), ("edge_feat", self._edge_feat)):
+            os.makedirs(os.path.join(path, sub), exist_ok=True)
+            for k, v in feats.items():
+                np.save(os.path.join(path, sub, k + ".npy"), v)
+
+    @classmethod
+    def load(cls, path, mmap_mode="r"):
+        num_nodes = int(np.load(os.path.join(path, "num_nodes.npy")))
+        edges = np.load(os.path.join(path, "edges.npy"), mmap_mode=mmap_mode)
+        num_graph = int(np.load(os.path.join(path, "num_graph.npy")))
+        kw = {}
+        for name in ("adj_src", "adj_dst"):
+            p = os.path.join(path, name)
+            kw[name + "_index"] = EdgeIndex.load(p, mmap_mode=mmap_mode) if os.path.isdir(p) else None
+
+        def feats(sub):
+            d = os.path.join(path, sub)
+            if not os.path.isdir(d):
+                return {}
+            return {f[:-4]: np.load(os.path.join(d, f), mmap_mode=mmap_mode) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
+
+        g = cls(edges=edges, num_nodes=num_nodes, node_feat=feats("node_feat"), edge_feat=feats("edge_feat"), **kw)
+        g._num_graph = num_graph
+        return g
+
+    # ---- basic properties ---------------------------------------------------------------------
+    @property
+    def num_nodes(self):
+        return self._num_nodes
+
+    @property
+    def num_edges(self):
+        return int(self._edges.shape[0])
+
+    @property
+    def edges(self):
+        return self._edges
+
+    @property
+    def nodes(self):
+        if self._nodes is None:
+            self._nodes = torch.arange(self._num_nodes, device=self._device) if self._is_tensor else np.arange(self._num_nodes)
+        return self._nodes
+
+    @property
+    def node_feat(self):
+        return self._node_feat
+
+    @property
+    def edge_feat(self):
+        return self._edge_feat
+
+    @property
+    def num_graph(self):
+        return self._num_graph
+
+    @property
+    def graph_node_id(self):
+        """pgl/graph.py graph_node_id: graph id of each node in a batched graph."""
+        from .utils.helper import generate_segment_id_from_index
+        ids = generate_segment_id_from_index(np.asarray(self._graph_node_index))
+        return to_device_tensor(ids, self._device) if self._is_tensor else ids
+
+    @property
+    def adj_src_index(self):
+        """pgl/graph.py:1307-1316."""
+        if self._adj_src_index is None:
+            self._adj_src_index = EdgeIndex.from_edges(u=self._edges[:, 0], v=self._edges[:, 1], num_nodes=self._num_nodes)
+        return self._adj_src_index
+
+    @property
+    def adj_dst_index(self):
+        """pgl/graph.py:1319-1328 (u = dst, v = src)."""
+        if self._adj_dst_index is None:
+            self._adj_dst_index = EdgeIndex.from_edges(u=self._edges[:, 1], v=self._edges[:, 0], num_nodes=self._num_nodes)
+        return self._adj_dst_index
+
+    def sorted_edges(self, sort_by="src"):
+        """pgl/graph.py:392-413 -> (sorted_src, sorted_dst, sorted_eid)."""
+        if sort_by not in ["src", "dst"]:
+            raise ValueError("sort_by should be in 'src' or 'dst'.")
+        if sort_by == "src":
+            src, dst, eid = self.adj_src_index.triples()
+        else:
+            dst, src, eid = self.adj_dst_index.triples()
+        return src, dst, eid
+
+    def indegree(self, nodes=None):
+        """pgl/graph.py:427-447."""
+        deg = self.adj_dst_index.degree
+        if nodes is None:
+            return deg
+        return ops.gather_rows(deg, to_device_tensor(nodes, self._device)) if self._is_tensor else deg[nodes]
+
+    def outdegree(self, nodes=None):
+        """pgl/graph.py:449-469."""
+        deg = self.adj_src_index.degree
+        if nodes is None:
+            return deg
+        return ops.gather_rows(deg, to_device_tensor(nodes, self._device)) if self._is_tensor else deg[nodes]
+
+    def successor(self, nodes=None, return_eids=False):
+        """pgl/graph.py:475-528 (numpy mode only, as in the reference)."""
+        if self.is_tensor():
+            raise ValueError("You must call Graph.numpy() first. Tensor object don't supprt successor now.")
+        if return_eids:
+            return self.adj_src_index.view_v(nodes), self.adj_src_index.view_eid(nodes)
+        return self.adj_src_index.view_v(nodes)
+
+    def predecessor(self, nodes=None, return_eids=False):
+        """pgl/graph.py:572-626."""
+        if self.is_tensor():
+            raise ValueError("You must call Graph.numpy() first. Tensor object don't supprt predecessor now.")
+        if return_eids:
+            return self.adj_dst_index.view_v(nodes), self.adj_dst_index.view_eid(nodes)
+        return self.adj_dst_index.view_v(nodes)
+
+    def get_segment_ids(self, src, dst, segment_by="dst"):
+        """pgl/graph.py:1397-1407 -- cached (uniq_ind, segment_ids) of the sorted key column."""
+        if segment_by not in self._seg_cache:
+            ix = self.adj_dst_index if segment_by == "dst" else self.adj_src_index
+            self._seg_cache[segment_by] = ops.unique_segment(ix.degree, ix.triples()[0])
+        return self._seg_cache[segment_by]
+
+    # ---- engine plumbing ----------------------------------------------------------------------
+    def _require_tensor(self, msg="You must call Graph.tensor()"):
+        if not self._is_tensor:
+            raise ValueError(msg)
+
+    def _edge_cols32(self):
+        if self._src32 is None:
+            self._src32 = ops.narrow_i64(self._edges[:, 0])
+            self._dst32 = ops.narrow_i64(self._edges[:, 1])
+        return self._src32, self._dst32
+
+    def _csr_dst(self):
+        return self.adj_dst_index.csr
+
+    def _csr_src(self):
+        return self.adj_src_index.csr
+
+    # ---- message passing (pgl/graph.py:694-966) -------------------------------------------------
+    def send(self, message_func, src_feat=None, dst_feat=None, edge_feat=None, node_feat=None):
+        """pgl/graph.py:694-776."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor() first")
+        if (src_feat is not None or dst_feat is not None) and node_feat is not None:
+            raise ValueError("Can not use src/dst feat and node feat at the same time")
+        src_feat_temp, dst_feat_temp = {}, {}
+        if node_feat is not None:
+            assert isinstance(node_feat, dict), "The input node_feat must be a dict"
+            src_feat_temp.update(node_feat)
+            dst_feat_temp.update(node_feat)
+        else:
+            if src_feat is not None:
+                assert isinstance(src_feat, dict), "The input src_feat must be a dict"
+                src_feat_temp.update(src_feat)
+            if dst_feat is not None:
+                assert isinstance(dst_feat, dict), "The input dst_feat must be a dict"
+                dst_feat_temp.update(dst_feat)
+        edge_feat_temp = {}
+        if edge_feat is not None:
+            assert isinstance(edge_feat, dict), "The input edge_feat must be a dict"
+            edge_feat_temp.update(edge_feat)
+        src32, dst32 = self._edge_cols32()
+        src_reader = _GraphRowReader(src_feat_temp, src32, self._csr_src)
+        dst_reader = _GraphRowReader(dst_feat_temp, dst32, self._csr_dst)
+        msg = message_func(src_reader, dst_reader, edge_feat_temp)
+        if not isinstance(msg, dict):
+            raise TypeError("The outputs of the %s function is expected to be a dict, but got %s"
+                            % (message_func.__name__, type(msg)))
+        return msg
+
+    def recv(self, reduce_func, msg, recv_mode="dst"):
+        """pgl/graph.py:778-832."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        if not isinstance(msg, dict):
+            raise TypeError("The input of msg should be a dict, but receives a %s" % (type(msg)))
+        if not callable(reduce_func):
+            raise TypeError("reduce_func should be callable")
+        src, dst, eid = self.sorted_edges(sort_by=recv_mode)
+        csr = self._csr_dst() if recv_mode == "dst" else self._csr_src()
+        msg = op.RowReader(msg, csr.eid32)
+        uniq_ind, segment_ids = self.get_segment_ids(src, dst, segment_by=recv_mode)
+        bucketed_msg = Message(msg, segment_ids, num_segments=int(uniq_ind.shape[0]))
+        output = reduce_func(bucketed_msg)
+        return ag.scatter_into_zeros(self._num_nodes, uniq_ind, output)
+
+    def send_recv(self, feature, reduce_func="sum", out_size=None):
+        """pgl/graph.py:834-861."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        assert reduce_func in _REDUCE, "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
+        return self._aggregate(feature, None, "add", reduce_func, out_size)
+
+    def send_u_recv(self, feature, reduce_op="sum", out_size=None):
+        """pgl/graph.py:863-887."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        assert reduce_op in _REDUCE, "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
+        return self._aggregate(feature, None, "add", reduce_op, out_size)
+
+    def send_ue_recv(self, feature, edge_feature, message_op="add", reduce_op="sum", out_size=None):
+        """pgl/graph.py:889-937."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        assert message_op in _MSGOP, "Only support 'add', 'sub', 'max', 'min' build-in message functions."
+        assert reduce_op in _REDUCE, "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
+        return self._aggregate(feature, edge_feature, message_op, reduce_op, out_size)
+
+    def send_uv(self, src_feature, dst_feature, message_op="add"):
+        """pgl/graph.py:939-966."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        assert message_op in _MSGOP, "Only support 'add', 'sub', 'max', 'min' build-in message functions."
+        src32, dst32 = self._edge_cols32()
+        return ag.send_uv(src_feature, dst_feature, src32, dst32, message_op, self._csr_dst, self._csr_src)
+
+    def send_ue(self, feature, edge_feature, message_op="add"):
+        raise NotImplementedError
+
+    def _aggregate(self, feature, edge_feature, message_op, reduce_op, out_size):
+        if isinstance(out_size, torch.Tensor):
+            out_size = int(out_size.item())
+        needs_grad = torch.is_grad_enabled() and (feature.requires_grad or
+                                                  (edge_feature is not None and edge_feature.requires_grad))
+        src32 = dst32 = None
+        if needs_grad and (edge_feature is not None or reduce_op in ("max", "min")):
+            src32, dst32 = self._edge_cols32()
+        return ag.aggregate(feature, self._csr_dst(), self._csr_src, reduce_op, out_size, edge_feature, message_op,
+                            src32, dst32)
+
+
+class _GraphRowReader(op.RowReader):
+    """RowReader whose gathers know the CSR keyed by their index, so backward needs no sort."""
+
+    def __init__(self, nfeat, index, csr_fn):
+        super(_GraphRowReader, self).__init__(nfeat, index)
+        self._csr_fn = csr_fn
+
+    def __getitem__(self, key):
+        if key not in self.loaded_nfeat:
+            self.loaded_nfeat[key] = ag.gather_rows(self.nfeat[key], self.index, self._csr_fn)
+        return self.loaded_nfeat[key]

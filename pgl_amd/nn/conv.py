@@ -1,0 +1,130 @@
+"""GCNConv / GATConv / GraphSageConv over the pgl_amd engine.
+
+Mirrors pgl/nn/conv.py (GraphSageConv :46-115, GCNConv :189-254, GATConv :257-346): same
+constructor arguments, same forward semantics, same order of operations.  paddle.nn.Layer becomes
+torch.nn.Module (torch is the device-memory / autograd container here); the dense X @ W is a
+library GEMM (hipBLASLt through torch: the only MFMA work on this path, as north_star prescribes);
+every graph operation goes through Graph.send_recv / send_uv / send_ue_recv / edge_softmax, i.e.
+through libpglamd's HIP kernels.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as GF
+
+__all__ = ["GraphSageConv", "GCNConv", "GATConv"]
+
+
+def _act(activation):
+    if isinstance(activation, str):
+        return getattr(F, activation)
+    return activation
+
+
+def _linear(n_in, n_out, bias=True):
+    """paddle.nn.Linear defaults: Xavier-uniform weight, zero bias."""
+    lin = nn.Linear(n_in, n_out, bias=bias)
+    nn.init.xavier_uniform_(lin.weight)
+    if bias:
+        nn.init.zeros_(lin.bias)
+    return lin
+
+
+class GraphSageConv(nn.Module):
+    """pgl/nn/conv.py:46-115."""
+
+    def __init__(self, input_size, hidden_size, aggr_func="sum", normalize=True):
+        super(GraphSageConv, self).__init__()
+        assert aggr_func in ["sum", "mean", "max", "min"], "Only support 'sum', 'mean', 'max', 'min'."
+        self.aggr_func = aggr_func
+        self.normalize = normalize
+        self.self_linear = _linear(input_size, hidden_size)
+        self.neigh_linear = _linear(input_size, hidden_size)
+
+    def forward(self, graph, feature, act=None):
+        if isinstance(feature, torch.Tensor):
+            feature = (feature, feature)
+        neigh_feature = graph.send_recv(feature[0], self.aggr_func, out_size=feature[1].shape[0])
+        neigh_feature = self.neigh_linear(neigh_feature)
+        self_feature = self.self_linear(feature[1])
+        output = self_feature + neigh_feature
+        if act is not None:
+            output = getattr(F, act)(output)
+        if self.normalize:
+            output = F.normalize(output, dim=1)
+        return output
+
+
+class GCNConv(nn.Module):
+    """pgl/nn/conv.py:189-254."""
+
+    def __init__(self, input_size, output_size, activation=None, norm=True):
+        super(GCNConv, self).__init__()
+        self.input_size = input_size
+        self.output_size = output_size
+        self.linear = _linear(input_size, output_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(output_size))
+        self.norm = norm
+        self.activation = _act(activation)
+
+    def forward(self, graph, feature, norm=None):
+        if self.norm and norm is None:
+            norm = GF.degree_norm(graph)
+        if self.input_size > self.output_size:
+            feature = self.linear(feature)
+        if norm is not None:
+            feature = feature * norm
+        output = graph.send_recv(feature, "sum")
+        if self.input_size <= self.output_size:
+            output = self.linear(output)
+        if norm is not None:
+            output = output * norm
+        output = output + self.bias
+        if self.activation is not None:
+            output = self.activation(output)
+        return output
+
+
+class GATConv(nn.Module):
+    """pgl/nn/conv.py:257-346."""
+
+    def __init__(self, input_size, hidden_size, feat_drop=0.6, attn_drop=0.6, num_heads=1, concat=True,
+                 activation=None):
+        super(GATConv, self).__init__()
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.feat_drop = feat_drop
+        self.attn_drop = attn_drop
+        self.concat = concat
+        self.linear = _linear(input_size, num_heads * hidden_size)
+        self.weight_src = nn.Parameter(torch.empty(num_heads, hidden_size))
+        self.weight_dst = nn.Parameter(torch.empty(num_heads, hidden_size))
+        nn.init.xavier_uniform_(self.weight_src)
+        nn.init.xavier_uniform_(self.weight_dst)
+        self.feat_dropout = nn.Dropout(p=feat_drop)
+        self.attn_dropout = nn.Dropout(p=attn_drop)
+        self.leaky_relu = nn.LeakyReLU(negative_slope=0.2)
+        self.activation = _act(activation)
+
+    def forward(self, graph, feature):
+        if self.feat_drop > 1e-15:
+            feature = self.feat_dropout(feature)
+        feature = self.linear(feature)
+        feature = feature.reshape(-1, self.num_heads, self.hidden_size)
+        attn_src = torch.sum(feature * self.weight_src, dim=-1)
+        attn_dst = torch.sum(feature * self.weight_dst, dim=-1)
+        alpha = graph.send_uv(attn_src, attn_dst, "add")
+        alpha = self.leaky_relu(alpha)
+        alpha = GF.edge_softmax(graph, alpha)
+        alpha = alpha.reshape(-1, self.num_heads, 1)
+        if self.attn_drop > 1e-15:
+            alpha = self.attn_dropout(alpha)
+        output = graph.send_ue_recv(feature, alpha, "mul", "sum")
+        if self.concat:
+            output = output.reshape(-1, self.num_heads * self.hidden_size)
+        else:
+            output = torch.mean(output, dim=1)
+        if self.activation is not None:
+            output = self.activation(output)
+        return output

@@ -1,0 +1,39 @@
+"""Mirrors pgl/nn/functional/graph_op.py: degree_norm, edge_softmax, graph_pool, graph_norm."""
+import torch
+
+from ... import autograd as ag
+from ... import math as _math
+from ... import ops
+
+__all__ = ["degree_norm", "graph_pool", "graph_norm", "edge_softmax"]
+
+
+def degree_norm(graph, mode="indegree"):
+    """pgl/nn/functional/graph_op.py:29-55 -> [num_nodes, 1] in the default float dtype."""
+    assert mode in ["indegree", "outdegree"], \
+        "The degree_norm mode should be in ['indegree', 'outdegree']. But recieve mode=%s" % mode
+    degree = graph.indegree() if mode == "indegree" else graph.outdegree()
+    dt = torch.get_default_dtype()
+    return ops.degree_norm(degree, dt if dt in (torch.float32, torch.float64) else torch.float32)
+
+
+def graph_pool(graph, feature, pool_type):
+    """pgl/nn/functional/graph_op.py:58-73."""
+    return _math.segment_pool(feature, graph.graph_node_id, pool_type, num_segments=graph.num_graph)
+
+
+def graph_norm(graph, feature):
+    """pgl/nn/functional/graph_op.py:76-98."""
+    nodes = torch.ones((graph.num_nodes, 1), dtype=torch.float32, device=feature.device)
+    norm = torch.sqrt(graph_pool(graph, nodes, "sum"))
+    return feature / ops.gather_rows(norm, graph.graph_node_id)
+
+
+def edge_softmax(graph, logits, norm_by="dst"):
+    """pgl/nn/functional/graph_op.py:101-123.  One kernel: the eid gather, the segment softmax and
+    the scatter back to ORIGINAL edge order are fused (the reference makes ~12 passes)."""
+    if norm_by not in ("src", "dst"):
+        raise ValueError("norm_by should be in 'src' or 'dst'.")
+    ix = graph.adj_dst_index if norm_by == "dst" else graph.adj_src_index
+    csr = ix.csr
+    return ag.segment_softmax(logits, csr.indptr, csr.eid32)

@@ -1,0 +1,379 @@
+"""pgl_amd.ops -- thin Python front end over the C ABI (include/pgl_amd.h).
+
+torch tensors are only the device-memory container (data_ptr + current HIP stream); every op
+here is one call into libpglamd.so.  GPU ops refuse CPU tensors: there is no eager / CPU fallback
+on the message-passing path.  The host_* functions are the CPU-side helpers of the same library
+(numpy in, numpy out) used by numpy-mode graphs and by the partitioner.
+
+Each function names the reference call site it stands in for (reference = PaddlePaddle/PGL 2.2.6).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+REDUCE = {"sum": 0, "mean": 1, "max": 2, "min": 3}
+MSG = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+_DTYPE = {torch.float16: 0, torch.float32: 1, torch.float64: 2, torch.int32: 3, torch.int64: 4, torch.bfloat16: 5}
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pgl_amd: this op runs only on an MI355X (got a %s tensor); there is no CPU "
+                               "fallback for the message-passing path" % t.device)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _code(dtype):
+    if dtype not in _DTYPE:
+        raise TypeError("pgl_amd: unsupported dtype %s" % dtype)
+    return _DTYPE[dtype]
+
+
+def _prod(shape):
+    p = 1
+    for s in shape:
+        p *= int(s)
+    return p
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR build / segment ids
+# ------------------------------------------------------------------------------------------------
+class CSR(object):
+    """Device-side result of csr_build: the reference's five int64 arrays + int32 engine copies."""
+    __slots__ = ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr", "row32", "col32", "eid32",
+                 "num_nodes", "num_edges")
+
+
+def csr_build(u, v, num_nodes):
+    """EdgeIndex.from_edges (pgl/utils/edge_index.py:38-58) / build_index (graph_kernel.pyx:59-88).
+    u, v: 1-D int64 CUDA tensors (may be strided views of the [E,2] edge tensor)."""
+    _need_cuda(u, v)
+    if u.dtype != torch.int64 or v.dtype != torch.int64:
+        u, v = u.to(torch.int64), v.to(torch.int64)
+    E, N, dev = int(u.shape[0]), int(num_nodes), u.device
+    L = _ffi.lib()
+    c = CSR()
+    c.num_nodes, c.num_edges = N, E
+    i64 = dict(dtype=torch.int64, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    c.degree = torch.empty(N, **i64); c.indptr = torch.empty(N + 1, **i64)
+    c.sorted_v = torch.empty(E, **i64); c.sorted_u = torch.empty(E, **i64); c.sorted_eid = torch.empty(E, **i64)
+    c.row32 = torch.empty(E, **i32); c.col32 = torch.empty(E, **i32); c.eid32 = torch.empty(E, **i32)
+    su = u.stride(0) if E > 0 else 1
+    sv = v.stride(0) if E > 0 else 1
+    nb = L.pglamd_csr_build_workspace_bytes(E, N)
+    ws = _ws(nb, dev)
+    with torch.cuda.device(dev):
+        _ffi.check(L.pglamd_csr_build(_ptr(u), su, _ptr(v), sv, E, N, _ptr(c.degree), _ptr(c.sorted_v),
+                                      _ptr(c.sorted_u), _ptr(c.sorted_eid), _ptr(c.indptr), _ptr(c.row32),
+                                      _ptr(c.col32), _ptr(c.eid32), _ptr(ws), ws.numel(), _stream(u)), "csr_build")
+    return c
+
+
+def unique_segment(degree, sorted_u):
+    """unique_segment (pgl/utils/helper.py:156-160) on CSR-sorted keys -> (uniq_ind, segment_ids)."""
+    _need_cuda(degree, sorted_u)
+    N, E, dev = int(degree.shape[0]), int(sorted_u.shape[0]), degree.device
+    L = _ffi.lib()
+    uniq = torch.empty(N, dtype=torch.int64, device=dev)
+    seg = torch.empty(E, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _ws(L.pglamd_unique_segment_workspace_bytes(E, N), dev)
+    with torch.cuda.device(dev):
+        _ffi.check(L.pglamd_unique_segment(_ptr(degree), _ptr(sorted_u), E, N, _ptr(uniq), _ptr(seg), _ptr(cnt),
+                                           _ptr(ws), ws.numel(), _stream(degree)), "unique_segment")
+    return uniq[:int(cnt.item())], seg
+
+
+def narrow_i64(t):
+    """int64 (possibly strided) -> contiguous int32."""
+    _need_cuda(t)
+    n = int(t.shape[0])
+    out = torch.empty(n, dtype=torch.int32, device=t.device)
+    if n:
+        with torch.cuda.device(t.device):
+            _ffi.check(_ffi.lib().pglamd_narrow_i64(_ptr(t), t.stride(0), n, _ptr(out), _stream(t)), "narrow_i64")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# broadcasting between x[src] tail dims and y tail dims
+# ------------------------------------------------------------------------------------------------
+def _trailing_ok(tail, out_tail):
+    """True iff expanding `tail` to `out_tail` is 'column j reads element j // (dout/d)'."""
+    r = len(out_tail)
+    t = (1,) * (r - len(tail)) + tuple(tail)
+    k = 0
+    while k < r and t[k] == out_tail[k]:
+        k += 1
+    return all(s == 1 for s in t[k:])
+
+
+def _bcast(x, y):
+    """Returns (x2, y2, out_tail) with both operands in a layout the C ABI's trailing-dim rule covers."""
+    xt, yt = tuple(x.shape[1:]), tuple(y.shape[1:])
+    out_tail = tuple(torch.broadcast_shapes(xt, yt))
+    if not _trailing_ok(xt, out_tail):
+        x = x.reshape((x.shape[0],) + (1,) * (len(out_tail) - len(xt)) + xt).expand((x.shape[0],) + out_tail)
+    if not _trailing_ok(yt, out_tail):
+        y = y.reshape((y.shape[0],) + (1,) * (len(out_tail) - len(yt)) + yt).expand((y.shape[0],) + out_tail)
+    return x.contiguous(), y.contiguous(), out_tail
+
+
+# ------------------------------------------------------------------------------------------------
+# aggregation (send_u_recv / send_ue_recv)
+# ------------------------------------------------------------------------------------------------
+def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None):
+    """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
+    graph's cached dst-CSR.  y (if given) is in ORIGINAL edge order, shape [E, ...]."""
+    _need_cuda(x, y, src_scale, dst_scale)
+    L = _ffi.lib()
+    x = x.contiguous()
+    M = int(out_size) if (out_size is not None and int(out_size) > 0) else int(x.shape[0])
+    if y is not None:
+        if y.dtype != x.dtype:
+            y = y.to(x.dtype)
+        if int(y.shape[0]) != csr.num_edges:
+            raise ValueError("edge feature has %d rows, graph has %d edges" % (y.shape[0], csr.num_edges))
+        x, y, tail = _bcast(x, y)
+        dy = _prod(y.shape[1:])
+    else:
+        tail, dy = tuple(x.shape[1:]), 0
+    dx, dout = _prod(x.shape[1:]), _prod(tail)
+    out = torch.empty((M,) + tuple(tail), dtype=x.dtype, device=x.device)
+    if M == 0 or dout == 0:
+        return out
+    code = _code(x.dtype)
+    ws = _ws(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
+    with torch.cuda.device(x.device):
+        _ffi.check(L.pglamd_aggregate(_ptr(x), code, int(x.shape[0]), dx, _ptr(y), dy,
+                                      _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
+                                      _ptr(csr.indptr), csr.num_edges, csr.num_nodes, M, dout, MSG[message_op],
+                                      REDUCE[reduce_op], _ptr(src_scale), _ptr(dst_scale), _ptr(out), _ptr(ws),
+                                      ws.numel(), _stream(x)), "aggregate")
+    return out
+
+
+def profile_begin():
+    """Start bracketing every flat-kernel launch with HIP events (bench.py roofline leg)."""
+    _ffi.check(_ffi.lib().pglamd_profile_begin(), "profile_begin")
+
+
+def profile_end():
+    """-> (summed kernel milliseconds, number of launches) since profile_begin."""
+    ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+    _ffi.check(_ffi.lib().pglamd_profile_end(ctypes.cast(ctypes.pointer(ms), ctypes.c_void_p),
+                                             ctypes.cast(ctypes.pointer(n), ctypes.c_void_p)), "profile_end")
+    return ms.value, n.value
+
+
+def scatter_add_coo(x, src32, dst32, out_rows):
+    """un-indexed fp32 atomic variant (K1'); order-nondeterministic."""
+    _need_cuda(x, src32, dst32)
+    x = x.contiguous()
+    d = _prod(x.shape[1:])
+    out = torch.empty((int(out_rows),) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _ffi.check(_ffi.lib().pglamd_scatter_add_coo(_ptr(x), d, _ptr(src32), _ptr(dst32), int(src32.shape[0]),
+                                                     int(out_rows), _ptr(out), _stream(x)), "scatter_add_coo")
+    return out
+
+
+def send_uv(x, y, src32, dst32, message_op="add"):
+    """paddle.geometric.send_uv (pgl/graph.py:964-966)."""
+    _need_cuda(x, y, src32, dst32)
+    if y.dtype != x.dtype:
+        y = y.to(x.dtype)
+    E = int(src32.shape[0])
+    xt, yt = tuple(x.shape[1:]), tuple(y.shape[1:])
+    out_tail = tuple(torch.broadcast_shapes(xt, yt))
+    if not _trailing_ok(xt, out_tail):
+        x = x.reshape((x.shape[0],) + (1,) * (len(out_tail) - len(xt)) + xt).expand((x.shape[0],) + out_tail)
+    if not _trailing_ok(yt, out_tail):
+        y = y.reshape((y.shape[0],) + (1,) * (len(out_tail) - len(yt)) + yt).expand((y.shape[0],) + out_tail)
+    x, y = x.contiguous(), y.contiguous()
+    out = torch.empty((E,) + out_tail, dtype=x.dtype, device=x.device)
+    dout = _prod(out_tail)
+    if E and dout:
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().pglamd_send_uv(_ptr(x), _ptr(y), _code(x.dtype), _prod(x.shape[1:]), _prod(y.shape[1:]),
+                                                 dout, _ptr(src32), _ptr(dst32), E, MSG[message_op], _ptr(out),
+                                                 _stream(x)), "send_uv")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# segment ops
+# ------------------------------------------------------------------------------------------------
+def segment_reduce(data, segment_ids, pool_type="sum", num_segments=None):
+    """paddle.geometric.segment_{sum,mean,max,min} (pgl/math.py:30-178).  ids sorted; out rows =
+    ids[-1]+1 (read back from the device unless num_segments is supplied)."""
+    _need_cuda(data, segment_ids)
+    data = data.contiguous()
+    segment_ids = segment_ids.contiguous()
+    if segment_ids.dtype not in (torch.int32, torch.int64):
+        raise TypeError("segment_ids must be int32 or int64")
+    n = int(data.shape[0])
+    if int(segment_ids.shape[0]) != n:
+        raise ValueError("segment_ids length %d != data rows %d" % (segment_ids.shape[0], n))
+    if num_segments is None:
+        num_segments = int(segment_ids[-1].item()) + 1 if n else 0
+    R, d = int(num_segments), _prod(data.shape[1:])
+    out = torch.empty((R,) + tuple(data.shape[1:]), dtype=data.dtype, device=data.device)
+    if R == 0 or d == 0:
+        return out
+    L = _ffi.lib()
+    code = _code(data.dtype)
+    ws = _ws(L.pglamd_segment_reduce_workspace_bytes(n, d, R, code), data.device)
+    with torch.cuda.device(data.device):
+        _ffi.check(L.pglamd_segment_reduce(_ptr(data), code, _ptr(segment_ids), int(segment_ids.dtype == torch.int64),
+                                           n, d, R, REDUCE[pool_type], _ptr(out), _ptr(ws), ws.numel(),
+                                           _stream(data)), "segment_reduce")
+    return out
+
+
+def seg_ptr_from_ids(segment_ids, num_segments):
+    _need_cuda(segment_ids)
+    segment_ids = segment_ids.contiguous()
+    out = torch.empty(int(num_segments) + 1, dtype=torch.int64, device=segment_ids.device)
+    with torch.cuda.device(segment_ids.device):
+        _ffi.check(_ffi.lib().pglamd_seg_ptr_from_ids(_ptr(segment_ids), int(segment_ids.dtype == torch.int64),
+                                                      int(segment_ids.shape[0]), int(num_segments), _ptr(out),
+                                                      _stream(segment_ids)), "seg_ptr_from_ids")
+    return out
+
+
+def segment_softmax(data, seg_ptr, perm32=None):
+    """pgl.math.segment_softmax (pgl/math.py:181-224); with perm32 = sorted_eid also the gather /
+    scatter of GF.edge_softmax (pgl/nn/functional/graph_op.py:117-123): result in data's own order."""
+    _need_cuda(data, seg_ptr, perm32)
+    data = data.contiguous()
+    out = torch.empty_like(data)
+    n, d = int(data.shape[0]), _prod(data.shape[1:])
+    if n == 0 or d == 0:
+        return out
+    with torch.cuda.device(data.device):
+        _ffi.check(_ffi.lib().pglamd_segment_softmax(_ptr(data), _code(data.dtype), _ptr(perm32), _ptr(seg_ptr),
+                                                     int(seg_ptr.shape[0]) - 1, n, d, _ptr(out), _stream(data)),
+                   "segment_softmax")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# row moves, degree norm
+# ------------------------------------------------------------------------------------------------
+def gather_rows(x, index):
+    """paddle.gather(x, index, axis=0) (pgl/utils/op.py:45, pgl/message.py:157, pgl/graph.py:822)."""
+    _need_cuda(x, index)
+    x = x.contiguous(); index = index.contiguous()
+    if index.dtype not in (torch.int32, torch.int64):
+        raise TypeError("index must be int32 or int64")
+    n, d = int(index.shape[0]), _prod(x.shape[1:])
+    out = torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if n and d:
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().pglamd_gather_rows(_ptr(x), d, x.element_size(), _ptr(index),
+                                                     int(index.dtype == torch.int64), n, _ptr(out), _stream(x)),
+                       "gather_rows")
+    return out
+
+
+def scatter_rows(out, index, x):
+    """paddle.scatter(out, index, x, overwrite=True) with unique indices, in place on `out`
+    (pgl/graph.py:828-830)."""
+    _need_cuda(out, index, x)
+    x = x.contiguous(); index = index.contiguous()
+    if not out.is_contiguous():
+        raise ValueError("scatter_rows: destination must be contiguous")
+    n, d = int(index.shape[0]), _prod(x.shape[1:])
+    if n and d:
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().pglamd_scatter_rows(_ptr(x), d, x.element_size(), _ptr(index),
+                                                      int(index.dtype == torch.int64), n, _ptr(out), _stream(x)),
+                       "scatter_rows")
+    return out
+
+
+def degree_norm(degree, dtype=torch.float32):
+    """GF.degree_norm body (pgl/nn/functional/graph_op.py:51-54) -> [N, 1]."""
+    _need_cuda(degree)
+    degree = degree.contiguous()
+    if dtype not in (torch.float32, torch.float64):
+        raise TypeError("degree_norm: float32/float64 only")
+    n = int(degree.shape[0])
+    out = torch.empty((n, 1), dtype=dtype, device=degree.device)
+    if n:
+        with torch.cuda.device(degree.device):
+            _ffi.check(_ffi.lib().pglamd_degree_norm(_ptr(degree), n, _ptr(out), int(dtype == torch.float64),
+                                                     _stream(degree)), "degree_norm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# host (CPU, numpy) helpers -- same shared library, HOST pointers
+# ------------------------------------------------------------------------------------------------
+def _np_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def host_build_index(u, v, num_nodes):
+    """graph_kernel.build_index (pgl/graph_kernel.pyx:59-88) for numpy-mode graphs."""
+    u = np.asarray(u); v = np.asarray(v)
+    if u.dtype != np.int64:
+        u = u.astype(np.int64)
+    if v.dtype != np.int64:
+        v = v.astype(np.int64)
+    E, N = int(u.shape[0]), int(num_nodes)
+    if u.ndim != 1 or v.ndim != 1 or v.shape[0] != E:
+        raise ValueError("u and v must be 1-D of equal length")
+    su = u.strides[0] // 8 if E else 1
+    sv = v.strides[0] // 8 if E else 1
+    degree = np.empty(N, np.int64); indptr = np.empty(N + 1, np.int64)
+    sorted_v = np.empty(E, np.int64); sorted_u = np.empty(E, np.int64); sorted_eid = np.empty(E, np.int64)
+    _ffi.check(_ffi.lib().pglamd_build_index_host(_np_ptr(u), su, _np_ptr(v), sv, E, N, _np_ptr(degree),
+                                                  _np_ptr(sorted_v), _np_ptr(sorted_u), _np_ptr(sorted_eid),
+                                                  _np_ptr(indptr)), "build_index_host")
+    return degree, sorted_v, sorted_u, sorted_eid, indptr
+
+
+def host_map_ids(ids, reindex):
+    """graph_kernel.map_nodes (pyx:123-138): ids -> reindex[ids] (missing keys map to 0)."""
+    ids = _np_i64(ids)
+    keys = _np_i64(list(reindex.keys())); vals = _np_i64(list(reindex.values()))
+    out = np.empty(ids.shape, np.int64)
+    _ffi.check(_ffi.lib().pglamd_map_ids(_np_ptr(keys), _np_ptr(vals), len(keys), _np_ptr(ids), ids.size, _np_ptr(out)),
+               "map_ids")
+    return out
+
+
+def host_partition_kway(num_nodes, indptr, adjncy, nparts, node_weights=None, edge_weights=None, seed=0):
+    """Engine partitioner standing in for METIS_PartGraphKway (pgl/graph_kernel.pyx:434-472)."""
+    indptr = _np_i64(indptr); adjncy = _np_i64(adjncy)
+    vw = None if node_weights is None else _np_i64(node_weights)
+    ew = None if edge_weights is None else _np_i64(edge_weights)
+    part = np.empty(int(num_nodes), np.int64)
+    cut = ctypes.c_int64(0)
+    _ffi.check(_ffi.lib().pglamd_partition_kway(int(num_nodes), _np_ptr(indptr), _np_ptr(adjncy), _np_ptr(vw),
+                                                _np_ptr(ew), int(nparts), int(seed), _np_ptr(part),
+                                                ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)), "partition_kway")
+    return part, int(cut.value)

@@ -1,0 +1,62 @@
+"""Mirror of the hot-path helpers in pgl/utils/helper.py (reference lines cited per function)."""
+import os
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def check_is_tensor(*data):
+    """pgl/utils/helper.py check_is_tensor: True if any argument is a device tensor."""
+    return any(isinstance(d, torch.Tensor) for d in data)
+
+
+def default_device():
+    """The device Graph.tensor() targets: this rank's MI355X.  Raises when no GPU is visible --
+    tensor-mode graphs exist only on the accelerator (no CPU fallback)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("pgl_amd: Graph.tensor() needs an MI355X (torch.cuda.is_available() is False); "
+                           "tensor-mode message passing has no CPU fallback")
+    return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+
+
+def to_device_tensor(data, device=None):
+    """pgl/utils/helper.py:32-43 to_paddle_tensor (UVA mode is not reproduced: 288 GB of HBM per
+    GPU holds the structures the reference had to leave in host memory)."""
+    if isinstance(data, torch.Tensor):
+        return data if device is None or data.device == device else data.to(device)
+    device = device or default_device()
+    return torch.as_tensor(np.ascontiguousarray(data)).to(device)
+
+
+def maybe_num_nodes(edges):
+    """pgl/utils/helper.py:133-153."""
+    if isinstance(edges, torch.Tensor):
+        return int(edges.max().item()) + 1 if edges.numel() else 0
+    if len(edges) == 0:
+        return 0
+    return int(np.max(edges)) + 1
+
+
+def unique_segment(data, dtype="int64"):
+    """pgl/utils/helper.py:156-160 for arbitrary SORTED device keys (paddle.unique on a sorted
+    array == run-length ranks).  Graph.get_segment_ids uses the cached-CSR fast path instead."""
+    if not isinstance(data, torch.Tensor):
+        uniq, inv = np.unique(np.asarray(data), return_inverse=True)
+        return uniq.astype(dtype), inv.reshape(-1).astype(dtype)
+    n = int(data.shape[0])
+    if n == 0:
+        return data.new_zeros(0, dtype=torch.int64), data.new_zeros(0, dtype=torch.int64)
+    hi = int(data[-1].item()) + 1
+    seg_ptr = ops.seg_ptr_from_ids(data, hi)
+    degree = seg_ptr[1:] - seg_ptr[:-1]
+    return ops.unique_segment(degree, data.to(torch.int64))
+
+
+def generate_segment_id_from_index(index):
+    """pgl/utils/helper.py:116-130 (numpy path; used for graph_node_id of batched graphs)."""
+    index = np.asarray(index)
+    seg = np.zeros(int(index[-1]) + 1, dtype="int32")
+    np.add.at(seg, index[:-1], 1)
+    return (np.cumsum(seg)[:-1] - 1).astype("int32")
