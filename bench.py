@@ -143,8 +143,9 @@ def main():
                        "parallelism": "single GPU" if world == 1 else "row partition (%s) x%d + RCCL halo all-to-all-v" % (args.partition, world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "agg_flat_kernel<float,2,1,0,0>", "kernel_ms": kms, "launches_per_step": launches / args.steps,
-                         "algorithmic_bytes_per_launch": B},
+                         "kernel": pgl.ops.profile_last_kernel(), "kernel_ms": kms, "launches_per_step": launches / args.steps,
+                         "algorithmic_bytes_per_launch": B,
+                         "compulsory_bytes_per_launch": E * 4 + N * (2 * d * 4 + 8) if world == 1 else None},
         }
         if halo is not None:
             rec["halo"] = halo

@@ -138,6 +138,8 @@ int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t
  * launch stream; profile_end synchronises them and returns the summed kernel time (host out). */
 int32_t pglamd_profile_begin(void);
 int32_t pglamd_profile_end(double* total_ms, int64_t* launches);
+/* name + template arguments of the flat kernel the last pglamd_aggregate call launched (host string) */
+const char* pglamd_profile_last_kernel(void);
 
 /* K1'  un-indexed COO variant (edges in arbitrary order, hardware float atomics; SUM only,
  * F32).  For one-shot graphs where building the CSR would cost more than it saves.  Result is

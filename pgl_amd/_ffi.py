@@ -29,6 +29,7 @@ _SIGNATURES = {
                                   c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_profile_begin": (c_i32, []),
     "pglamd_profile_end": (c_i32, [c_vp, c_vp]),
+    "pglamd_profile_last_kernel": (ctypes.c_char_p, []),
     "pglamd_scatter_add_coo": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     "pglamd_send_uv": (c_i32, [c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "pglamd_segment_reduce_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i32]),

@@ -27,6 +27,7 @@
 //     the same XCD: partition-ordered graphs then reuse source rows in that XCD's private L2.
 #include "common.hpp"
 
+#include <string>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -42,9 +43,11 @@ struct AggParams {
     int64_t ldx, ldy, ldo;                // row strides (elements) of x, y, out
     int64_t out_rows, n_csr_rows;
     int E, n_chunks, chunk, n_blocks;
+    int n_grid_chunks;                    // blocks [0, n_grid_chunks) walk edge chunks, the rest zero-fill
     int j_base, tile_cols;                // this launch covers out columns [j_base, j_base+tile_cols)
     int gy;                               // y column = j / gy   (YMODE 1)
     int mop, is_max, is_mean;
+    int zvec;                             // vector width the zero-fill role may use (1, 2, 4)
 };
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
@@ -64,6 +67,33 @@ template <typename T> __device__ __forceinline__ T apply_mop(T a, T b, int mop) 
     }
 }
 
+// Zero-fills the columns [j_base, j_base+tile_cols) of output rows that receive no edge: rows
+// r < n_csr_rows with indptr[r]==indptr[r+1], and rows in [n_csr_rows, out_rows).  One wave
+// inspects 64 rows (coalesced indptr read) and clears the empty ones, lanes across the columns.
+template <typename T>
+__device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t zb, int lane) {
+    const int64_t w = zb * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t r0 = w * kWave;
+    if (r0 >= p.out_rows) return;
+    const int64_t r = r0 + lane;
+    bool empty = false;
+    if (r < p.out_rows) empty = (r >= p.n_csr_rows) || (p.indptr[r] == p.indptr[r + 1]);
+    unsigned long long m = __ballot(empty);
+    T* out = static_cast<T*>(p.out) + p.j_base;
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        T* dst = out + (r0 + l) * p.ldo;
+        if (p.zvec == 4) {
+            for (int j = lane * 4; j < p.tile_cols; j += kWave * 4) *reinterpret_cast<VecT<T, 4>*>(dst + j) = VecT<T, 4>{};
+        } else if (p.zvec == 2) {
+            for (int j = lane * 2; j < p.tile_cols; j += kWave * 2) *reinterpret_cast<VecT<T, 2>*>(dst + j) = VecT<T, 2>{};
+        } else {
+            for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = T(0);
+        }
+    }
+}
+
 // RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector
 template <typename T, int VEC, int NT, int RCLS, int YMODE>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
@@ -71,6 +101,10 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     using V = VecT<T, VEC>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
+    if ((int)blockIdx.x >= p.n_grid_chunks) {   // trailing blocks: zero-fill rows that receive no edge
+        zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
+        return;
+    }
     const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
     if (lb < 0) return;
     const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
@@ -251,14 +285,18 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     else store_final(cur, cnt);
 }
 
-// Adds, in chunk order, the partials of every row that straddles a chunk boundary.
-// One wave per chunk a; it acts iff a row STARTS in chunk a and continues past its end.
+// Adds the partials of every row that straddles a chunk boundary, in a FIXED order (bit-reproducible).
+// One 256-thread block per chunk a; it acts iff a row STARTS in chunk a and continues past its end.
+// Wave w of the block sums the partials a+1+w, a+1+w+4, ... (8 independent loads in flight), then the
+// four wave sums are combined through LDS in wave order.  Hub rows of power-law graphs leave hundreds
+// of partials, so this must not be one serial dependent chain.
 template <typename T, int VEC, int NT, int RCLS>
 __global__ __launch_bounds__(kBlock) void agg_fixup_kernel(AggParams p) {
     using V = VecT<T, VEC>;
+    __shared__ T red[kWavesPerBlock][NT * kWave * VEC];
     const int lane = threadIdx.x & (kWave - 1);
-    const int a = wave_uniform((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
-    if (a >= p.n_chunks) return;
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    const int a = (int)blockIdx.x;
     const int e0 = a * p.chunk;
     const int e1 = e0 + p.chunk;
     if (e1 >= p.E) return;
@@ -267,35 +305,75 @@ __global__ __launch_bounds__(kBlock) void agg_fixup_kernel(AggParams p) {
     const int r = rowp[e1 - 1];
     if (rowp[e1] != r) return;                  // nothing continues
     const int64_t rs = ip[r], re = ip[r + 1];
-    if (rs < e0) return;                        // row started earlier: that chunk's wave owns it
+    if (rs < e0) return;                        // row started earlier: that chunk's block owns it
     if (r >= p.out_rows) return;
     const int b = (int)((re - 1) / p.chunk);    // last chunk holding a piece of row r
     const bool is_max = p.is_max != 0;
+    const T* __restrict__ ph = static_cast<const T*>(p.part_head);
 
+    auto comb = [&](T x, T y) -> T {
+        if constexpr (RCLS == 0) return x + y;
+        else return is_max ? (y > x ? y : x) : (y < x ? y : x);
+    };
     T acc[NT][VEC];
     int j0[NT]; bool act[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         j0[t] = (t * kWave + lane) * VEC;
         act[t] = j0[t] < p.tile_cols;
-        if (act[t]) {
-            V v = *reinterpret_cast<const V*>(static_cast<const T*>(p.part_tail) + (int64_t)a * p.tile_cols + j0[t]);
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[t][k] = v.v[k];
-        }
+        for (int k = 0; k < VEC; ++k) acc[t][k] = RCLS == 0 ? T(0) : (is_max ? Limits<T>::lo() : Limits<T>::hi());
     }
-    for (int c = a + 1; c <= b; ++c) {
+    bool any = false;
+    constexpr int UF = 8;
+    int c = a + 1 + wib;
+    for (; c + (UF - 1) * kWavesPerBlock <= b; c += UF * kWavesPerBlock) {
+        V v[UF][NT];
+#pragma unroll
+        for (int u = 0; u < UF; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (act[t]) v[u][t] = *reinterpret_cast<const V*>(ph + (int64_t)(c + u * kWavesPerBlock) * p.tile_cols + j0[t]);
+#pragma unroll
+        for (int u = 0; u < UF; ++u)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (act[t]) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v[u][t].v[k]);
+                }
+        any = true;
+    }
+    for (; c <= b; c += kWavesPerBlock) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (act[t]) {
-                V v = *reinterpret_cast<const V*>(static_cast<const T*>(p.part_head) + (int64_t)c * p.tile_cols + j0[t]);
+                const V v = *reinterpret_cast<const V*>(ph + (int64_t)c * p.tile_cols + j0[t]);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if constexpr (RCLS == 0) acc[t][k] += v.v[k];
-                    else acc[t][k] = is_max ? (v.v[k] > acc[t][k] ? v.v[k] : acc[t][k]) : (v.v[k] < acc[t][k] ? v.v[k] : acc[t][k]);
-                }
+                for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v.v[k]);
             }
+        any = true;
     }
+    (void)any;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) red[wib][(t * kWave + lane) * VEC + k] = acc[t][k];
+    __syncthreads();
+    if (wib != 0) return;
+    // wave 0: tail partial of chunk a first, then the four wave sums in wave order
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (act[t]) {
+            const V v = *reinterpret_cast<const V*>(static_cast<const T*>(p.part_tail) + (int64_t)a * p.tile_cols + j0[t]);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                T s = v.v[k];
+#pragma unroll
+                for (int w = 0; w < kWavesPerBlock; ++w) s = comb(s, red[w][(t * kWave + lane) * VEC + k]);
+                acc[t][k] = s;
+            }
+        }
     T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
     float ds = 1.f;
     if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
@@ -389,27 +467,40 @@ static int chunk_edges() {
 // every flat-kernel launch is bracketed by a pair of HIP events on the launch stream.
 struct ProfileState {
     bool on = false;
+    std::string last_kernel;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 static ProfileState& prof() { static ProfileState s; return s; }
+template <typename T> static const char* type_name() {
+    return std::is_same_v<T, float> ? "float" : std::is_same_v<T, double> ? "double" : std::is_same_v<T, int32_t> ? "int" : "long";
+}
+template <typename T> static std::string kernel_name(int vec, int nt, int rcls, int ymode) {
+    char b[96];
+    snprintf(b, sizeof(b), "agg_flat_kernel<%s, %d, %d, %d, %d>", type_name<T>(), vec, nt, rcls, ymode);
+    return b;
+}
 
 template <typename T, int VEC, int NT, int RCLS, int YMODE>
 static int32_t launch_flat(AggParams p, hipStream_t st) {
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     p.n_blocks = (int)nb;
+    p.n_grid_chunks = (int)xcd_grid(nb);
+    const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
+    prof().last_kernel = kernel_name<T>(VEC, NT, RCLS, YMODE);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof().on) {
         PGLAMD_HIP_CHECK(hipEventCreate(&e0));
         PGLAMD_HIP_CHECK(hipEventCreate(&e1));
         PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE>), dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p);
+    hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (prof().on) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
         prof().ev.emplace_back(e0, e1);
     }
-    hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS>), dim3((unsigned)nb), dim3(kBlock), 0, st, p);
+    if (p.n_chunks > 1)
+        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS>), dim3((unsigned)(p.n_chunks - 1)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }
@@ -486,8 +577,8 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
                                int64_t n_csr_rows, int64_t out_rows, int64_t dout, int32_t mop, int32_t rop,
                                const float* src_scale, const float* dst_scale, void* out, void* ws,
                                size_t ws_bytes, hipStream_t st) {
-    int32_t rc = zero_empty_rows(indptr, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
-    if (rc != PGLAMD_OK || E == 0) return rc;
+    int32_t rc = PGLAMD_OK;
+    if (E == 0) return zero_empty_rows(indptr, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
 
     AggParams p{};
     p.x = x; p.y = y; p.out = out; p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
@@ -499,18 +590,34 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
     const int gy = y ? (int)(dout / dy) : 1;
     p.gy = gy;
 
-    // fast path eligibility
+    // fast path eligibility + lane geometry: VEC elements per lane.  Candidates are limited by
+    // divisibility / pointer alignment; among them take the one that needs the fewest 64-lane
+    // tiles and, for equal tiles, keeps the most lanes busy (d=128 fp32 -> VEC 2: 64 x 8 B).
     bool fast = gx == 1;
-    int vec = max_vec<T>();
+    int vmax = max_vec<T>();
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
                                  (y && gy == 1 ? reinterpret_cast<uintptr_t>(y) : 0) |
                                  reinterpret_cast<uintptr_t>(ws);
-    while (vec > 1 && (dout % vec != 0 || align_bits % (vec * sizeof(T)) != 0)) vec >>= 1;
+    while (vmax > 1 && (dout % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0)) vmax >>= 1;
     int ymode = 0;
     if (y) {
         if (gy == 1) ymode = 2;
-        else { ymode = 1; while (vec > 1 && gy % vec != 0) vec >>= 1; }
+        else { ymode = 1; while (vmax > 1 && gy % vmax != 0) vmax >>= 1; }
     }
+    int vec = vmax;
+    {
+        int64_t best_tiles = -1, best_lanes = -1;
+        for (int v = vmax; v >= 1; v >>= 1) {
+            const int64_t lanes = dout / v, tiles = ceil_div(lanes, kWave);
+            const int64_t busy = lanes < kWave ? lanes : kWave;
+            if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && busy > best_lanes)) {
+                best_tiles = tiles; best_lanes = busy; vec = v;
+            }
+        }
+        static const int forced = [] { const char* e = getenv("PGLAMD_VEC"); return e ? atoi(e) : 0; }();
+        if (forced >= 1 && forced <= vmax && (forced & (forced - 1)) == 0) vec = forced;
+    }
+    p.zvec = vec;
     if ((src_scale || dst_scale) && (rcls != 0 || !std::is_floating_point_v<T>))
         return fail(PGLAMD_E_ARG, "src_scale/dst_scale need a floating dtype and sum/mean");
 
@@ -534,7 +641,7 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
         }
         if (fast) return PGLAMD_OK;
     }
-    // generic fallback (rows were zero-filled above; it rewrites every row < out_rows)
+    // generic fallback: rewrites every row < out_rows (rows without edges get 0)
     p.tile_cols = (int)dout; p.j_base = 0;
     p.is_max = rop == PGLAMD_MAX ? 1 : rop == PGLAMD_MIN ? 2 : 0;
     if (src_scale || dst_scale) return fail(PGLAMD_E_SHAPE, "scales unsupported with this broadcast pattern");
@@ -608,3 +715,5 @@ extern "C" int32_t pglamd_profile_end(double* total_ms, int64_t* launches) {
     if (launches) *launches = n;
     return PGLAMD_OK;
 }
+
+extern "C" const char* pglamd_profile_last_kernel(void) { return prof().last_kernel.c_str(); }

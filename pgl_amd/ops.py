@@ -183,6 +183,10 @@ def profile_end():
     return ms.value, n.value
 
 
+def profile_last_kernel():
+    return _ffi.lib().pglamd_profile_last_kernel().decode()
+
+
 def scatter_add_coo(x, src32, dst32, out_rows):
     """un-indexed fp32 atomic variant (K1'); order-nondeterministic."""
     _need_cuda(x, src32, dst32)
