@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--partition", default="kway", choices=["kway", "random"])
+    ap.add_argument("--partition", default="auto", choices=["auto", "kway", "random"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -140,7 +140,7 @@ def main():
             "config": {"workload": "RMAT(0.57,0.19,0.19,0.05) scale %d |V|=%d |E|=%d d=%d fp32, Graph.send_recv(sum) "
                                    "via pglamd_aggregate (BASELINE configs[1])" % (args.scale, N, E, d),
                        "graph_seed": 42, "feature_seed": 7,
-                       "parallelism": "single GPU" if world == 1 else "row partition (%s) x%d + RCCL halo all-to-all-v" % (args.partition, world)},
+                       "parallelism": "single GPU" if world == 1 else "row partition (%s) x%d + RCCL halo all-to-all-v" % (halo["partition"], world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": pgl.ops.profile_last_kernel(), "kernel_ms": kms, "launches_per_step": launches / args.steps,

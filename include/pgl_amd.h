@@ -124,14 +124,18 @@ int32_t pglamd_narrow_i64(const int64_t* in, int64_t in_stride, int64_t n, int32
  *   out        [out_rows, dout]; every row is written exactly once (rows without messages = 0,
  *              as the reference guarantees); out_rows may exceed n_csr_rows (out_size semantics)
  *   reduce_op  PGLAMD_SUM/MEAN/MAX/MIN ; message_op PGLAMD_ADD/SUB/MUL/DIV (ignored if y NULL)
+ *   accumulate 0: out is overwritten (rows without edges = 0).  1: rows that receive edges are
+ *              combined (+ / max / min) with their existing contents, other rows are untouched --
+ *              used to add the halo-source edges after the local-source edges of a partitioned
+ *              graph (still deterministic: the two launches are ordered on the stream); not with MEAN.
  * ---------------------------------------------------------------------------------------------- */
 size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t dout, int32_t dtype);
 int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t dx, const void* y,
                          int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
                          const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
                          int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
-                         const float* src_scale, const float* dst_scale, void* out, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         const float* src_scale, const float* dst_scale, int32_t accumulate, void* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement hook for the dominant kernel (bench.py roofline leg): between profile_begin and
  * profile_end every launch of the flat aggregation kernel is bracketed by HIP events on its own

@@ -26,7 +26,7 @@ _SIGNATURES = {
     "pglamd_narrow_i64": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
     "pglamd_aggregate_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "pglamd_aggregate": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
-                                  c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                  c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_profile_begin": (c_i32, []),
     "pglamd_profile_end": (c_i32, [c_vp, c_vp]),
     "pglamd_profile_last_kernel": (ctypes.c_char_p, []),

@@ -48,6 +48,7 @@ struct AggParams {
     int gy;                               // y column = j / gy   (YMODE 1)
     int mop, is_max, is_mean;
     int zvec;                             // vector width the zero-fill role may use (1, 2, 4)
+    int accumulate;                       // 1: combine with the existing out row instead of overwriting
 };
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
@@ -178,6 +179,14 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                         if constexpr (std::is_floating_point_v<T>) { if (p.dst_scale) a = a * (T)ds; }
                     }
                     o.v[k] = a;
+                }
+                if (p.accumulate) {
+                    const V old = *reinterpret_cast<const V*>(dst + j0[t]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        if constexpr (RCLS == 0) o.v[k] = old.v[k] + o.v[k];
+                        else o.v[k] = is_max ? (o.v[k] > old.v[k] ? o.v[k] : old.v[k]) : (o.v[k] < old.v[k] ? o.v[k] : old.v[k]);
+                    }
                 }
                 *reinterpret_cast<V*>(dst + j0[t]) = o;
             }
@@ -390,6 +399,11 @@ __global__ __launch_bounds__(kBlock) void agg_fixup_kernel(AggParams p) {
                 }
                 o.v[k] = v;
             }
+            if (p.accumulate) {
+                const V old = *reinterpret_cast<const V*>(dst + j0[t]);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o.v[k] = comb(old.v[k], o.v[k]);
+            }
             *reinterpret_cast<V*>(dst + j0[t]) = o;
         }
 }
@@ -446,7 +460,11 @@ __global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx
             else acc = m < acc ? m : acc;
         }
         if (additive && p.is_mean && t > s) acc = acc / (T)(t - s);
-        out[j] = acc;
+        if (p.accumulate) {
+            if (t > s) out[j] = additive ? out[j] + acc : (p.is_max == 1 ? (acc > out[j] ? acc : out[j]) : (acc < out[j] ? acc : out[j]));
+        } else {
+            out[j] = acc;
+        }
     }
 }
 
@@ -485,7 +503,7 @@ static int32_t launch_flat(AggParams p, hipStream_t st) {
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
-    const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
+    const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     prof().last_kernel = kernel_name<T>(VEC, NT, RCLS, YMODE);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof().on) {
@@ -575,16 +593,18 @@ template <typename T>
 static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, const int32_t* eid,
                                const int32_t* row, const int32_t* col, const int64_t* indptr, int64_t E,
                                int64_t n_csr_rows, int64_t out_rows, int64_t dout, int32_t mop, int32_t rop,
-                               const float* src_scale, const float* dst_scale, void* out, void* ws,
+                               const float* src_scale, const float* dst_scale, int accumulate, void* out, void* ws,
                                size_t ws_bytes, hipStream_t st) {
     int32_t rc = PGLAMD_OK;
-    if (E == 0) return zero_empty_rows(indptr, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
+    if (accumulate && rop == PGLAMD_MEAN)
+        return fail(PGLAMD_E_ARG, "aggregate: accumulate with MEAN is undefined (use SUM with dst_scale = 1/degree)");
+    if (E == 0) return accumulate ? PGLAMD_OK : zero_empty_rows(indptr, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
 
     AggParams p{};
     p.x = x; p.y = y; p.out = out; p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
     p.src_scale = src_scale; p.dst_scale = dst_scale;
     p.ldx = dx; p.ldy = dy; p.ldo = dout; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)E;
-    p.mop = mop; p.is_mean = rop == PGLAMD_MEAN; p.is_max = rop == PGLAMD_MAX;
+    p.mop = mop; p.is_mean = rop == PGLAMD_MEAN; p.is_max = rop == PGLAMD_MAX; p.accumulate = accumulate;
     const int rcls = (rop == PGLAMD_SUM || rop == PGLAMD_MEAN) ? 0 : 1;
     const int gx = (int)(dout / dx);
     const int gy = y ? (int)(dout / dy) : 1;
@@ -668,8 +688,8 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
                                     int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
                                     const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
                                     int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
-                                    const float* src_scale, const float* dst_scale, void* out, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    const float* src_scale, const float* dst_scale, int32_t accumulate, void* out,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
     (void)n_x_rows;
     if (!out || !indptr || (num_edges > 0 && (!x || !row))) return fail(PGLAMD_E_ARG, "aggregate: NULL pointer");
     if (num_edges < 0 || num_edges >= INT32_MAX || n_csr_rows >= INT32_MAX || out_rows >= INT32_MAX)
@@ -681,7 +701,7 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
         return fail(PGLAMD_E_ARG, "aggregate: bad op enum");
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define CALL(T) aggregate_typed<T>(x, dx, y, dy, eid, row, col, indptr, num_edges, n_csr_rows, out_rows, dout, \
-                                   message_op, reduce_op, src_scale, dst_scale, out, workspace, workspace_bytes, st)
+                                   message_op, reduce_op, src_scale, dst_scale, accumulate, out, workspace, workspace_bytes, st)
     switch (dtype) {
         case PGLAMD_F32: return CALL(float);
         case PGLAMD_F64: return CALL(double);

@@ -315,7 +315,7 @@ extern "C" int32_t pglamd_segment_reduce(const void* data, int32_t dtype, const 
     int32_t rc = pglamd_seg_ptr_from_ids(ids32, 0, num_rows, n_out_rows, seg_ptr, stream);
     if (rc != PGLAMD_OK) return rc;
     return pglamd_aggregate(data, dtype, num_rows, d, nullptr, 0, nullptr, ids32, nullptr, seg_ptr, num_rows, n_out_rows,
-                            n_out_rows, d, 0, reduce_op, nullptr, nullptr, out, w, workspace_bytes - (size_t)(w - static_cast<char*>(workspace)),
+                            n_out_rows, d, 0, reduce_op, nullptr, nullptr, 0, out, w, workspace_bytes - (size_t)(w - static_cast<char*>(workspace)),
                             stream);
 }
 

@@ -9,8 +9,8 @@
 // linked here; the partitioner below is a from-scratch implementation of the same published
 // scheme (Karypis & Kumar multilevel k-way: heavy-edge matching coarsening, greedy graph-growing
 // initial partition, greedy boundary k-way refinement with a balance constraint).  Its output is
-// therefore not bit-identical to METIS; tests compare balance and edge cut against the real METIS
-// (oracle/_ref) instead.  Partitioning is one-off setup work on the host, not the accelerated path.
+// therefore not bit-identical to METIS; the test-suite compares balance and edge cut against the real
+// METIS (built from the reference tree as test infrastructure only).  Partitioning is one-off host setup.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>

@@ -139,7 +139,8 @@ def _bcast(x, y):
 # ------------------------------------------------------------------------------------------------
 # aggregation (send_u_recv / send_ue_recv)
 # ------------------------------------------------------------------------------------------------
-def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None):
+def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None,
+              out=None, accumulate=False):
     """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
     graph's cached dst-CSR.  y (if given) is in ORIGINAL edge order, shape [E, ...]."""
     _need_cuda(x, y, src_scale, dst_scale)
@@ -156,7 +157,13 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     else:
         tail, dy = tuple(x.shape[1:]), 0
     dx, dout = _prod(x.shape[1:]), _prod(tail)
-    out = torch.empty((M,) + tuple(tail), dtype=x.dtype, device=x.device)
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an existing `out`")
+        out = torch.empty((M,) + tuple(tail), dtype=x.dtype, device=x.device)
+    else:
+        if tuple(out.shape) != (M,) + tuple(tail) or out.dtype != x.dtype or not out.is_contiguous():
+            raise ValueError("out must be a contiguous %s tensor of dtype %s" % ((M,) + tuple(tail), x.dtype))
     if M == 0 or dout == 0:
         return out
     code = _code(x.dtype)
@@ -165,7 +172,7 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
         _ffi.check(L.pglamd_aggregate(_ptr(x), code, int(x.shape[0]), dx, _ptr(y), dy,
                                       _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
                                       _ptr(csr.indptr), csr.num_edges, csr.num_nodes, M, dout, MSG[message_op],
-                                      REDUCE[reduce_op], _ptr(src_scale), _ptr(dst_scale), _ptr(out), _ptr(ws),
+                                      REDUCE[reduce_op], _ptr(src_scale), _ptr(dst_scale), int(bool(accumulate)), _ptr(out), _ptr(ws),
                                       ws.numel(), _stream(x)), "aggregate")
     return out
 

@@ -458,3 +458,42 @@ def test_full_size_gat_path_properties(pgl, rmat20):
     sub = e[sel]
     want = R.np_send_ue_recv(host(x).reshape(-1, h, 16), host(alpha)[sel].reshape(-1, h, 1), sub[:, 0], sub[:, 1], "mul", "sum")
     close(host(out)[rows], want[rows], scale=np.abs(want[rows]).max(), rtol=5e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# partitioned multi-GPU data flow with the HIP kernels (exchange simulated in-process: the GPU box
+# has one device; the RCCL all-to-all itself is covered by the gloo tests + the driver's 8-GPU run)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("op", ["sum", "mean", "max", "min"])
+def test_distgraph_compute_path_matches_single_gpu(pgl, world, op):
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    n, e, d = 6000, 90000, 128
+    edges, rng = rand_graph(n, e, 300 + world, hub=8000)
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    et = dev(edges)
+    want = pgl.Graph(edges=et, num_nodes=n).send_recv(x, op)
+    part = pgl.partition.random_partition(pgl.Graph(edges=edges, num_nodes=n), world)
+    dgs = [DistGraph(HaloPlan(et, n, part, r, world)) for r in range(world)]
+    packs = [dg.pack(dg.take_owned(x)) for dg in dgs]
+    full = torch.zeros_like(want)
+    for r, dg in enumerate(dgs):
+        recv = []
+        for q, dq in enumerate(dgs):
+            so = np.concatenate([[0], np.cumsum(dq.plan.send_splits)])
+            recv.append(packs[q][so[r]:so[r + 1]])
+        recv = torch.cat(recv, 0)
+        assert recv.shape[0] == dg.plan.n_halo
+        full[dg.plan.own_global] = dg.aggregate_with_halo(dg.take_owned(x), recv, op)
+    close(host(full), host(want), scale=float(want.abs().max()))
+
+
+def test_distgraph_world1_is_plain_graph(pgl):
+    from pgl_amd.distributed import DistGraph
+    n, e = 3000, 40000
+    edges, rng = rand_graph(n, e, 77)
+    x = dev(rng.standard_normal((n, 64)).astype(np.float32))
+    dg = DistGraph.from_global(dev(edges), n, 0, 1)
+    out = dg.send_recv(dg.take_owned(x), "sum")
+    want = pgl.Graph(edges=dev(edges), num_nodes=n).send_recv(x, "sum")
+    assert torch.equal(out, want[dg.plan.own_global])
