@@ -174,17 +174,44 @@ int32_t pglamd_segment_reduce(const void* data, int32_t dtype, const void* ids, 
 
 /* ------------------------------------------------------------------------------------------------
  * K4  segment softmax.  Replaces pgl.math.segment_softmax (pgl/math.py:181-224: segment_max,
- * gather, sub, exp, segment_sum, gather, div = 7 passes) with one kernel, and -- when `perm` is
- * given -- the whole of GF.edge_softmax (pgl/nn/functional/graph_op.py:101-123: gather by eid,
- * segment_softmax, scatter back by eid):
- *     p-th CSR-ordered element is data[perm[p]] (perm == NULL: data[p]); result written to
- *     out[perm[p]], i.e. in ORIGINAL edge order when perm = sorted_eid.
- *   data/out [E, d] F32 or F64;  seg_ptr [n_seg+1] int64 offsets of each segment in CSR order
- *   (the reference's indptr: empty segments allowed).
+ * gather, sub, exp, segment_sum, gather, div) and -- with perm32 = sorted_eid -- the whole of
+ * GF.edge_softmax (pgl/nn/functional/graph_op.py:101-123: gather by eid, segment_softmax,
+ * scatter back by eid): data and out are only ever addressed in the data's OWN order.
+ *   data/out        [num_rows, d] F32 or F64 (out != data)
+ *   row32           [num_rows] segment id of the p-th element in SEGMENT-SORTED order (non-decreasing)
+ *   perm32          [num_rows] position in `data` of the p-th sorted element, or NULL if data is
+ *                   already sorted by segment (pgl.math.segment_softmax)
+ *   seg_of_elem32   [num_rows] segment id of data row i (== row32 when perm32 is NULL; the dst
+ *                   column of the edge list for edge_softmax by dst)
+ *   seg_ptr         [n_seg+1] int64 offsets of each segment in sorted order (the reference's indptr)
+ * Arithmetic is the reference's: e = exp(x - max_seg); out = e / sum_seg(e).  Deterministic.
  * ---------------------------------------------------------------------------------------------- */
-int32_t pglamd_segment_softmax(const void* data, int32_t dtype, const int32_t* perm,
-                               const int64_t* seg_ptr, int64_t n_seg, int64_t num_rows, int64_t d,
-                               void* out, void* stream);
+size_t pglamd_segment_softmax_workspace_bytes(int64_t num_rows, int64_t d, int64_t n_seg, int32_t dtype);
+int32_t pglamd_segment_softmax(const void* data, int32_t dtype, int64_t num_rows, int64_t d,
+                               const int32_t* row32, const int32_t* perm32,
+                               const int32_t* seg_of_elem32, const int64_t* seg_ptr, int64_t n_seg,
+                               void* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3+K4+K2 fused: the attention aggregation of GATConv (pgl/nn/conv.py:331-339) in ONE pass over
+ * the dst-sorted edges, with an online softmax per (row, head):
+ *     out[v,h,:] = sum_{e=(u->v)} softmax_v( leaky_relu(attn_src[u,h] + attn_dst[v,h], slope) ) * feature[u,h,:]
+ * == send_uv("add") -> leaky_relu -> edge_softmax(by dst) -> send_ue_recv("mul","sum") of the
+ * reference, without materialising any [E,H] tensor.  F32.  heads*head_dim <= 256.
+ *   feature [N, heads, head_dim], attn_src/attn_dst [N, heads]; row/col/indptr: dst-sorted CSR
+ *   out [out_rows, heads, head_dim] (rows without in-edges = 0)
+ *   row_max,row_sum  optional [out_rows, heads]: the softmax statistics (max logit, sum of
+ *                    exp(logit - max)) from which a backward pass can recompute alpha per edge.
+ * Deterministic (no atomics).  Softmax sums are accumulated with rescaling, so alpha differs from
+ * the reference's two-pass evaluation only by fp32 rounding (tests: <= 1e-5 relative on out).
+ * ---------------------------------------------------------------------------------------------- */
+size_t pglamd_gat_aggregate_workspace_bytes(int64_t num_edges, int64_t heads, int64_t head_dim);
+int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const float* attn_dst,
+                             int64_t heads, int64_t head_dim, float negative_slope,
+                             const int32_t* row, const int32_t* col, const int64_t* indptr,
+                             int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, float* out,
+                             float* row_max, float* row_sum, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* K4'  segment boundaries from sorted ids: seg_ptr[n_seg+1] (int64), n_seg = ids[E-1]+1 given by
  * the caller.  Used when segment_softmax is called with raw ids (pgl.math API). */

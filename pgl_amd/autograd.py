@@ -29,9 +29,10 @@ class _Aggregate(torch.autograd.Function):
     """send_u_recv / send_ue_recv.  csr = dst-keyed CSR; csr_t() lazily returns the src-keyed one."""
 
     @staticmethod
-    def forward(ctx, x, y, csr, csr_t, rop, mop, out_size, src32, dst32):
-        out = ops.aggregate(x, csr, rop, out_size, y, mop)
+    def forward(ctx, x, y, csr, csr_t, rop, mop, out_size, src32, dst32, src_scale=None, dst_scale=None):
+        out = ops.aggregate(x, csr, rop, out_size, y, mop, src_scale, dst_scale)
         ctx.csr, ctx.csr_t, ctx.rop, ctx.mop = csr, csr_t, rop, mop
+        ctx.scales = (src_scale, dst_scale)
         ctx.src32, ctx.dst32 = src32, dst32
         ctx.x_shape = tuple(x.shape)
         ctx.y_shape = None if y is None else tuple(y.shape)
@@ -48,6 +49,10 @@ class _Aggregate(torch.autograd.Function):
         gx = gy = None
         csr_t = ctx.csr_t()
         n_x = ctx.x_shape[0]
+        if ctx.scales[0] is not None or ctx.scales[1] is not None:
+            # out = ds * A (ss * x)  =>  dx = ss * A^T (ds * g): the two fused scales swap roles
+            g = ops.aggregate(grad, csr_t, "sum", n_x, src_scale=ctx.scales[1], dst_scale=ctx.scales[0])
+            return (g,) + (None,) * 10
         if ctx.rop in ("sum", "mean"):
             scale = None
             if ctx.rop == "mean":
@@ -93,7 +98,7 @@ class _Aggregate(torch.autograd.Function):
             if has_y and ctx.needs_input_grad[1]:
                 gy = {"add": gm, "sub": -gm, "mul": gm * xs, "div": -gm * xs / (y * y)}[ctx.mop]
                 gy = _unbroadcast(gy, ctx.y_shape)
-        return gx, gy, None, None, None, None, None, None, None
+        return gx, gy, None, None, None, None, None, None, None, None, None
 
 
 class _EdgeCSR(object):
@@ -108,10 +113,12 @@ def _edge_csr(c):
     return _EdgeCSR(c)
 
 
-def aggregate(x, csr, csr_t, reduce_op="sum", out_size=None, y=None, message_op="add", src32=None, dst32=None):
+def aggregate(x, csr, csr_t, reduce_op="sum", out_size=None, y=None, message_op="add", src32=None, dst32=None,
+              src_scale=None, dst_scale=None):
+    """src_scale / dst_scale ([N] fp32, no gradient): fused row scalings, only with y=None and sum."""
     if torch.is_grad_enabled() and (x.requires_grad or (y is not None and y.requires_grad)):
-        return _Aggregate.apply(x, y, csr, csr_t, reduce_op, message_op, out_size, src32, dst32)
-    return ops.aggregate(x, csr, reduce_op, out_size, y, message_op)
+        return _Aggregate.apply(x, y, csr, csr_t, reduce_op, message_op, out_size, src32, dst32, src_scale, dst_scale)
+    return ops.aggregate(x, csr, reduce_op, out_size, y, message_op, src_scale, dst_scale)
 
 
 class _GatherRows(torch.autograd.Function):
@@ -202,43 +209,37 @@ def segment_reduce(data, ids, pool="sum", num_segments=None):
     return ops.segment_reduce(data, ids, pool, num_segments)
 
 
+class _SegView2CSR(object):
+    """Adapter: lets ops.aggregate run a segment reduction described by an ops.SegView."""
+
+    def __init__(self, v, n_elem):
+        self.row32, self.col32, self.eid32, self.indptr = v.row32, v.perm32, v.perm32, v.seg_ptr
+        self.num_edges, self.num_nodes = n_elem, int(v.seg_ptr.shape[0]) - 1
+
+
 class _SegmentSoftmax(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, data, seg_ptr, perm32):
-        out = ops.segment_softmax(data, seg_ptr, perm32)
-        ctx.seg_ptr, ctx.perm32 = seg_ptr, perm32
+    def forward(ctx, data, view):
+        out = ops.segment_softmax(data, view)
+        ctx.view = view
         ctx.save_for_backward(out)
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        # dL/dx = p * (g - sum_seg(p * g)); composed: segment sum through the flat aggregation kernel
+        # dL/dx = p * (g - sum_seg(p * g)): the segment sum runs through the flat aggregation kernel
         (p,) = ctx.saved_tensors
+        v = ctx.view
         pg = (p * grad).contiguous()
-        n_seg = ctx.seg_ptr.shape[0] - 1
-        ids = _ids_from_seg_ptr(ctx.seg_ptr, p.shape[0])
-        if ctx.perm32 is not None:
-            pg_sorted = ops.gather_rows(pg, ctx.perm32)
-            s = ops.gather_rows(ops.segment_reduce(pg_sorted, ids, "sum", n_seg), ids)
-            s_edge = torch.empty_like(s)
-            ops.scatter_rows(s_edge, ctx.perm32, s)
-        else:
-            s_edge = ops.gather_rows(ops.segment_reduce(pg, ids, "sum", n_seg), ids)
-        return pg - p * s_edge, None, None
+        n_seg = int(v.seg_ptr.shape[0]) - 1
+        s = ops.aggregate(pg, _SegView2CSR(v, int(p.shape[0])), "sum", n_seg)
+        return pg - p * ops.gather_rows(s, v.elem_seg32), None
 
 
-def _ids_from_seg_ptr(seg_ptr, n):
-    if n == 0:
-        return seg_ptr.new_zeros(0)
-    marks = torch.zeros(n + 1, dtype=torch.int64, device=seg_ptr.device)
-    marks.index_add_(0, seg_ptr[1:-1], torch.ones_like(seg_ptr[1:-1]))
-    return torch.cumsum(marks[:n], 0)
-
-
-def segment_softmax(data, seg_ptr, perm32=None):
+def segment_softmax(data, view):
     if torch.is_grad_enabled() and data.requires_grad:
-        return _SegmentSoftmax.apply(data, seg_ptr, perm32)
-    return ops.segment_softmax(data, seg_ptr, perm32)
+        return _SegmentSoftmax.apply(data, view)
+    return ops.segment_softmax(data, view)
 
 
 class _ScatterRows(torch.autograd.Function):

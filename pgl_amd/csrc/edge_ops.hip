@@ -71,114 +71,45 @@ static int32_t send_uv_typed(const void* x, const void* y, int64_t dx, int64_t d
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4 segment softmax, optionally fused with the eid gather/scatter of GF.edge_softmax.
-// One wave per segment.  Lane = (k, j): j = column (DP = pow2 >= d columns side by side),
-// k = edge slot; EP = 64/DP edges are processed per step.  Values of short segments
-// (<= R*EP edges) stay in registers between the three phases (max, sum of exp, normalise), so the
-// logits are read once and the scores written once; longer segments re-read (L2-resident).
-// Arithmetic is the reference's: e = exp(x - max); out = e / sum(e)   (pgl/math.py:216-224).
+// K4 segment softmax / edge_softmax.  Load-balanced and deterministic on power-law graphs:
+//   m = segment max   -> flat aggregation kernel (K1, reduce = max, gather through `perm`)
+//   e = exp(x - m[seg])      -> softmax_exp_kernel, element-parallel in the data's own order
+//   s = segment sum of e     -> flat aggregation kernel (reduce = sum)
+//   out = e / s[seg]         -> softmax_div_kernel (in place on out)
+// Same arithmetic as the reference (pgl/math.py:216-224: e = exp(x - max); e / sum(e)).  With
+// perm = sorted_eid and seg = dst the eid gather and the scatter back to original edge order of
+// GF.edge_softmax (graph_op.py:117-123) disappear: data is only ever touched in its own order.
 // ------------------------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T exp_t(T v);
 template <> __device__ __forceinline__ float exp_t<float>(float v) { return expf(v); }
 template <> __device__ __forceinline__ double exp_t<double>(double v) { return exp(v); }
 
-template <typename T, int DP>
-__global__ __launch_bounds__(kBlock) void segment_softmax_kernel(const T* __restrict__ data, const int32_t* __restrict__ perm,
-                                                                 const int64_t* __restrict__ seg_ptr, int64_t n_seg, int64_t d,
-                                                                 T* __restrict__ out) {
-    constexpr int EP = kWave / DP;
-    constexpr int R = 8;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int j = lane % DP, k = lane / DP;
-    const bool colok = j < d;
-    for (int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); s < n_seg; s += (int64_t)gridDim.x * kWavesPerBlock) {
-        const int64_t b = seg_ptr[s], e = seg_ptr[s + 1];
-        const int64_t n = e - b;
-        if (n == 0) continue;
-        const bool small = n <= (int64_t)R * EP;
-        T vals[R];
-        int64_t pos[R];
-        T mx = -INFINITY;
-        if (small) {
+template <typename T, int VEC, bool DIV>
+__global__ __launch_bounds__(kBlock) void softmax_elem_kernel(const T* x, const T* __restrict__ stat,
+                                                              const int32_t* __restrict__ seg, int64_t n, int64_t d,
+                                                              T* out) {   // x may alias out (in-place divide)
+    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    const int64_t per = d / VEC;
+    const int64_t total = n * per;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t e = i / per, j = (i - e * per) * VEC;
+        const V a = *reinterpret_cast<const V*>(x + e * d + j);
+        const V b = *reinterpret_cast<const V*>(stat + (int64_t)seg[e] * d + j);
+        V o;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t q = b + (int64_t)r * EP + k;
-                vals[r] = -INFINITY;
-                pos[r] = -1;
-                if (q < e && colok) {
-                    const int64_t row = perm ? (int64_t)perm[q] : q;
-                    pos[r] = row * d + j;
-                    vals[r] = data[pos[r]];
-                }
-                mx = vals[r] > mx ? vals[r] : mx;
-            }
-        } else {
-            for (int64_t q = b + k; q < e; q += EP)
-                if (colok) {
-                    const int64_t row = perm ? (int64_t)perm[q] : q;
-                    const T v = data[row * d + j];
-                    mx = v > mx ? v : mx;
-                }
-        }
-#pragma unroll
-        for (int off = DP; off < kWave; off <<= 1) { const T o = __shfl_xor(mx, off); mx = o > mx ? o : mx; }
-        T sum = 0;
-        if (small) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (pos[r] >= 0) { vals[r] = exp_t<T>(vals[r] - mx); sum += vals[r]; }
-        } else {
-            for (int64_t q = b + k; q < e; q += EP)
-                if (colok) {
-                    const int64_t row = perm ? (int64_t)perm[q] : q;
-                    sum += exp_t<T>(data[row * d + j] - mx);
-                }
-        }
-#pragma unroll
-        for (int off = DP; off < kWave; off <<= 1) sum += __shfl_xor(sum, off);
-        if (small) {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                if (pos[r] >= 0) out[pos[r]] = vals[r] / sum;
-        } else {
-            for (int64_t q = b + k; q < e; q += EP)
-                if (colok) {
-                    const int64_t row = perm ? (int64_t)perm[q] : q;
-                    out[row * d + j] = exp_t<T>(data[row * d + j] - mx) / sum;
-                }
-        }
+        for (int k = 0; k < VEC; ++k) o.v[k] = DIV ? a.v[k] / b.v[k] : exp_t<T>(a.v[k] - b.v[k]);
+        *reinterpret_cast<V*>(out + e * d + j) = o;
     }
 }
 
-// wide rows (d > 64): lanes stride over columns, edges serial
-template <typename T>
-__global__ __launch_bounds__(kBlock) void segment_softmax_wide_kernel(const T* __restrict__ data, const int32_t* __restrict__ perm,
-                                                                      const int64_t* __restrict__ seg_ptr, int64_t n_seg, int64_t d,
-                                                                      T* __restrict__ out) {
-    const int lane = threadIdx.x & (kWave - 1);
-    for (int64_t s = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); s < n_seg; s += (int64_t)gridDim.x * kWavesPerBlock) {
-        const int64_t b = seg_ptr[s], e = seg_ptr[s + 1];
-        for (int64_t j = lane; j < d; j += kWave) {
-            T mx = -INFINITY;
-            for (int64_t q = b; q < e; ++q) { const int64_t row = perm ? (int64_t)perm[q] : q; const T v = data[row * d + j]; mx = v > mx ? v : mx; }
-            T sum = 0;
-            for (int64_t q = b; q < e; ++q) { const int64_t row = perm ? (int64_t)perm[q] : q; sum += exp_t<T>(data[row * d + j] - mx); }
-            for (int64_t q = b; q < e; ++q) { const int64_t row = perm ? (int64_t)perm[q] : q; out[row * d + j] = exp_t<T>(data[row * d + j] - mx) / sum; }
-        }
-    }
-}
-
-template <typename T>
-static int32_t segment_softmax_typed(const void* data, const int32_t* perm, const int64_t* seg_ptr, int64_t n_seg, int64_t d,
-                                     void* out, hipStream_t st) {
-    const T* dp = static_cast<const T*>(data); T* op = static_cast<T*>(out);
-    int64_t g = ceil_div(n_seg, kWavesPerBlock);
-    const unsigned grid = (unsigned)(g < 256 * 64 ? g : 256 * 64);
-#define SM(DP) hipLaunchKernelGGL((segment_softmax_kernel<T, DP>), dim3(grid), dim3(kBlock), 0, st, dp, perm, seg_ptr, n_seg, d, op)
-    if (d <= 1) SM(1); else if (d <= 2) SM(2); else if (d <= 4) SM(4); else if (d <= 8) SM(8);
-    else if (d <= 16) SM(16); else if (d <= 32) SM(32); else if (d <= 64) SM(64);
-    else hipLaunchKernelGGL(segment_softmax_wide_kernel<T>, dim3(grid), dim3(kBlock), 0, st, dp, perm, seg_ptr, n_seg, d, op);
-#undef SM
+template <typename T, bool DIV>
+static int32_t softmax_elem(const T* x, const T* stat, const int32_t* seg, int64_t n, int64_t d, T* out, hipStream_t st) {
+    constexpr int VMAX = 16 / sizeof(T);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(stat) | reinterpret_cast<uintptr_t>(out);
+    if (d % VMAX == 0 && al % 16 == 0)
+        hipLaunchKernelGGL((softmax_elem_kernel<T, VMAX, DIV>), dim3(grid_for(n * (d / VMAX))), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
+    else
+        hipLaunchKernelGGL((softmax_elem_kernel<T, 1, DIV>), dim3(grid_for(n * d)), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }
@@ -271,17 +202,38 @@ extern "C" int32_t pglamd_send_uv(const void* x, const void* y, int32_t dtype, i
     }
 }
 
-extern "C" int32_t pglamd_segment_softmax(const void* data, int32_t dtype, const int32_t* perm, const int64_t* seg_ptr,
-                                          int64_t n_seg, int64_t num_rows, int64_t d, void* out, void* stream) {
-    if (num_rows < 0 || n_seg < 0 || d <= 0 || (num_rows > 0 && (!data || !out || !seg_ptr)))
-        return fail(PGLAMD_E_ARG, "segment_softmax: bad argument");
+extern "C" size_t pglamd_segment_softmax_workspace_bytes(int64_t num_rows, int64_t d, int64_t n_seg, int32_t dtype) {
+    const size_t es = dtype_size(dtype);
+    return 2 * align_up((size_t)(n_seg > 0 ? n_seg : 1) * d * es, 256) + pglamd_aggregate_workspace_bytes(num_rows, d, dtype) + 256;
+}
+
+extern "C" int32_t pglamd_segment_softmax(const void* data, int32_t dtype, int64_t num_rows, int64_t d, const int32_t* row32,
+                                          const int32_t* perm32, const int32_t* seg_of_elem32, const int64_t* seg_ptr,
+                                          int64_t n_seg, void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (num_rows < 0 || n_seg < 0 || d <= 0) return fail(PGLAMD_E_ARG, "segment_softmax: bad size");
     if (num_rows == 0 || n_seg == 0) return PGLAMD_OK;
+    if (!data || !out || !seg_ptr || !row32 || !seg_of_elem32) return fail(PGLAMD_E_ARG, "segment_softmax: NULL pointer");
+    if (dtype != PGLAMD_F32 && dtype != PGLAMD_F64) return fail(PGLAMD_E_DTYPE, "segment_softmax: dtype %d not supported (F32/F64)", dtype);
+    if (!workspace || workspace_bytes < pglamd_segment_softmax_workspace_bytes(num_rows, d, n_seg, dtype))
+        return fail(PGLAMD_E_WORKSPACE, "segment_softmax: workspace too small");
+    const size_t es = dtype_size(dtype);
+    const size_t stat_bytes = align_up((size_t)n_seg * d * es, 256);
+    char* w = static_cast<char*>(workspace);
+    void* mx = w; void* sm = w + stat_bytes;
+    void* aw = w + 2 * stat_bytes;
+    const size_t aw_bytes = workspace_bytes - 2 * stat_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (dtype) {
-        case PGLAMD_F32: return segment_softmax_typed<float>(data, perm, seg_ptr, n_seg, d, out, st);
-        case PGLAMD_F64: return segment_softmax_typed<double>(data, perm, seg_ptr, n_seg, d, out, st);
-        default: return fail(PGLAMD_E_DTYPE, "segment_softmax: dtype %d not supported (F32/F64)", dtype);
-    }
+    int32_t rc = pglamd_aggregate(data, dtype, num_rows, d, nullptr, 0, nullptr, row32, perm32, seg_ptr, num_rows, n_seg, n_seg, d,
+                                  0, PGLAMD_MAX, nullptr, nullptr, 0, mx, aw, aw_bytes, stream);
+    if (rc != PGLAMD_OK) return rc;
+    if (dtype == PGLAMD_F32) rc = softmax_elem<float, false>((const float*)data, (const float*)mx, seg_of_elem32, num_rows, d, (float*)out, st);
+    else rc = softmax_elem<double, false>((const double*)data, (const double*)mx, seg_of_elem32, num_rows, d, (double*)out, st);
+    if (rc != PGLAMD_OK) return rc;
+    rc = pglamd_aggregate(out, dtype, num_rows, d, nullptr, 0, nullptr, row32, perm32, seg_ptr, num_rows, n_seg, n_seg, d, 0,
+                          PGLAMD_SUM, nullptr, nullptr, 0, sm, aw, aw_bytes, stream);
+    if (rc != PGLAMD_OK) return rc;
+    if (dtype == PGLAMD_F32) return softmax_elem<float, true>((const float*)out, (const float*)sm, seg_of_elem32, num_rows, d, (float*)out, st);
+    return softmax_elem<double, true>((const double*)out, (const double*)sm, seg_of_elem32, num_rows, d, (double*)out, st);
 }
 
 extern "C" size_t pglamd_segment_reduce_workspace_bytes(int64_t num_rows, int64_t d, int64_t n_out_rows, int32_t dtype) {

@@ -366,6 +366,22 @@ class Graph(object):
     def send_ue(self, feature, edge_feature, message_op="add"):
         raise NotImplementedError
 
+    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None):
+        """out[v] = dst_scale[v] * sum_{u->v} src_scale[u] * feature[u] in ONE kernel: GCN's symmetric
+        normalisation (pgl/nn/conv.py:242-250) fused into the aggregation (engine extension, fp32)."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        ss = None if src_scale is None else src_scale.reshape(-1).contiguous()
+        ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()
+        return ag.aggregate(feature, self._csr_dst(), self._csr_src, "sum", None, None, "add", None, None, ss, ds)
+
+    def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2):
+        """send_uv(add) -> leaky_relu -> edge_softmax -> send_ue_recv(mul, sum) of GATConv
+        (pgl/nn/conv.py:331-339) fused into one pass (engine extension; forward only, fp32)."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        return ops.gat_aggregate(feature, attn_src, attn_dst, self._csr_dst(), negative_slope)
+
     def _aggregate(self, feature, edge_feature, message_op, reduce_op, out_size):
         if isinstance(out_size, torch.Tensor):
             out_size = int(out_size.item())

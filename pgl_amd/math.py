@@ -3,6 +3,8 @@ are graph-pooling helpers outside the message-passing path and are not provided)
 
 `num_segments` is an optional extension: when the caller knows ids[-1]+1 it avoids a device sync.
 """
+import torch
+
 from . import autograd as ag
 from . import ops
 
@@ -38,8 +40,9 @@ def segment_max(data, segment_ids, name=None, num_segments=None):
 
 
 def segment_softmax(data, segment_ids, num_segments=None):
-    """pgl/math.py:181-224: one fused kernel instead of max / gather / sub / exp / sum / gather / div."""
+    """pgl/math.py:181-224: max / exp / sum / div as four balanced launches instead of 7 tensor ops."""
     if num_segments is None:
         num_segments = int(segment_ids[-1].item()) + 1 if int(segment_ids.shape[0]) else 0
     seg_ptr = ops.seg_ptr_from_ids(segment_ids, num_segments)
-    return ag.segment_softmax(data, seg_ptr, None)
+    ids32 = segment_ids if segment_ids.dtype == torch.int32 else ops.narrow_i64(segment_ids)
+    return ag.segment_softmax(data, ops.SegView(seg_ptr, ids32, ids32, None))

@@ -73,13 +73,20 @@ class GCNConv(nn.Module):
             norm = GF.degree_norm(graph)
         if self.input_size > self.output_size:
             feature = self.linear(feature)
-        if norm is not None:
-            feature = feature * norm
-        output = graph.send_recv(feature, "sum")
-        if self.input_size <= self.output_size:
-            output = self.linear(output)
-        if norm is not None:
-            output = output * norm
+        fuse = norm is not None and feature.dtype == torch.float32 and norm.dtype == torch.float32 \
+            and norm.numel() == feature.shape[0] and hasattr(graph, "send_recv_scaled")
+        if fuse and self.input_size > self.output_size:
+            # same arithmetic as the three reference steps, one pass over the edges:
+            # (feature * norm) -> send_recv(sum) -> (* norm)
+            output = graph.send_recv_scaled(feature, norm, norm)
+        else:
+            if norm is not None and not fuse:
+                feature = feature * norm
+            output = graph.send_recv_scaled(feature, norm, None) if fuse else graph.send_recv(feature, "sum")
+            if self.input_size <= self.output_size:
+                output = self.linear(output)
+            if norm is not None:
+                output = output * norm
         output = output + self.bias
         if self.activation is not None:
             output = self.activation(output)
@@ -114,6 +121,19 @@ class GATConv(nn.Module):
         feature = feature.reshape(-1, self.num_heads, self.hidden_size)
         attn_src = torch.sum(feature * self.weight_src, dim=-1)
         attn_dst = torch.sum(feature * self.weight_dst, dim=-1)
+        no_attn_drop = self.attn_drop <= 1e-15 or not self.training
+        needs_grad = torch.is_grad_enabled() and (feature.requires_grad or attn_src.requires_grad)
+        if (no_attn_drop and not needs_grad and feature.dtype == torch.float32 and hasattr(graph, "gat_aggregate")
+                and self.num_heads * self.hidden_size <= 256):
+            # inference fast path: the four graph ops below fused into one pass over the edges
+            output = graph.gat_aggregate(feature, attn_src, attn_dst, 0.2)
+            if self.concat:
+                output = output.reshape(-1, self.num_heads * self.hidden_size)
+            else:
+                output = torch.mean(output, dim=1)
+            if self.activation is not None:
+                output = self.activation(output)
+            return output
         alpha = graph.send_uv(attn_src, attn_dst, "add")
         alpha = self.leaky_relu(alpha)
         alpha = GF.edge_softmax(graph, alpha)

@@ -36,4 +36,5 @@ def edge_softmax(graph, logits, norm_by="dst"):
         raise ValueError("norm_by should be in 'src' or 'dst'.")
     ix = graph.adj_dst_index if norm_by == "dst" else graph.adj_src_index
     csr = ix.csr
-    return ag.segment_softmax(logits, csr.indptr, csr.eid32)
+    src32, dst32 = graph._edge_cols32()
+    return ag.segment_softmax(logits, ops.SegView(csr.indptr, csr.row32, dst32 if norm_by == "dst" else src32, csr.eid32))

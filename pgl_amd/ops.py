@@ -270,20 +270,61 @@ def seg_ptr_from_ids(segment_ids, num_segments):
     return out
 
 
-def segment_softmax(data, seg_ptr, perm32=None):
-    """pgl.math.segment_softmax (pgl/math.py:181-224); with perm32 = sorted_eid also the gather /
+class SegView(object):
+    """Index view a segment softmax needs: seg_ptr [n_seg+1] int64, row32 (sorted-order segment ids),
+    elem_seg32 (segment id of each data row in the data's own order), perm32 (sorted position ->
+    data row, None when the data is already sorted)."""
+    __slots__ = ("seg_ptr", "row32", "elem_seg32", "perm32")
+
+    def __init__(self, seg_ptr, row32, elem_seg32, perm32=None):
+        self.seg_ptr, self.row32, self.elem_seg32, self.perm32 = seg_ptr, row32, elem_seg32, perm32
+
+
+def segment_softmax(data, view):
+    """pgl.math.segment_softmax (pgl/math.py:181-224); with view.perm32 = sorted_eid also the gather /
     scatter of GF.edge_softmax (pgl/nn/functional/graph_op.py:117-123): result in data's own order."""
-    _need_cuda(data, seg_ptr, perm32)
+    _need_cuda(data, view.seg_ptr, view.row32, view.elem_seg32, view.perm32)
     data = data.contiguous()
     out = torch.empty_like(data)
     n, d = int(data.shape[0]), _prod(data.shape[1:])
-    if n == 0 or d == 0:
+    n_seg = int(view.seg_ptr.shape[0]) - 1
+    if n == 0 or d == 0 or n_seg == 0:
         return out
+    L = _ffi.lib()
+    code = _code(data.dtype)
+    ws = _ws(L.pglamd_segment_softmax_workspace_bytes(n, d, n_seg, code), data.device)
     with torch.cuda.device(data.device):
-        _ffi.check(_ffi.lib().pglamd_segment_softmax(_ptr(data), _code(data.dtype), _ptr(perm32), _ptr(seg_ptr),
-                                                     int(seg_ptr.shape[0]) - 1, n, d, _ptr(out), _stream(data)),
-                   "segment_softmax")
+        _ffi.check(L.pglamd_segment_softmax(_ptr(data), code, n, d, _ptr(view.row32), _ptr(view.perm32),
+                                            _ptr(view.elem_seg32), _ptr(view.seg_ptr), n_seg, _ptr(out), _ptr(ws),
+                                            ws.numel(), _stream(data)), "segment_softmax")
     return out
+
+
+def gat_aggregate(feature, attn_src, attn_dst, csr, negative_slope=0.2, out_size=None, return_stats=False):
+    """Fused send_uv(add) -> leaky_relu -> edge_softmax(dst) -> send_ue_recv(mul, sum) of GATConv
+    (pgl/nn/conv.py:331-339) in one pass over the edges.  feature [N,H,D] fp32, attn_* [N,H]."""
+    _need_cuda(feature, attn_src, attn_dst)
+    if feature.dtype != torch.float32 or feature.dim() != 3:
+        raise TypeError("gat_aggregate: feature must be float32 [N, heads, head_dim]")
+    feature = feature.contiguous()
+    attn_src = attn_src.to(torch.float32).contiguous(); attn_dst = attn_dst.to(torch.float32).contiguous()
+    n, H, D = (int(v) for v in feature.shape)
+    if tuple(attn_src.shape) != (n, H) or attn_dst.shape[1] != H:
+        raise ValueError("gat_aggregate: attn_src/attn_dst must be [N, heads]")
+    M = int(out_size) if (out_size is not None and int(out_size) > 0) else n
+    out = torch.empty((M, H, D), dtype=torch.float32, device=feature.device)
+    mx = sm = None
+    if return_stats:
+        mx = torch.empty((M, H), dtype=torch.float32, device=feature.device)
+        sm = torch.empty((M, H), dtype=torch.float32, device=feature.device)
+    L = _ffi.lib()
+    ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), feature.device)
+    with torch.cuda.device(feature.device):
+        _ffi.check(L.pglamd_gat_aggregate(_ptr(feature), _ptr(attn_src), _ptr(attn_dst), H, D, float(negative_slope),
+                                          _ptr(csr.row32), _ptr(csr.col32), _ptr(csr.indptr), csr.num_edges,
+                                          csr.num_nodes, M, _ptr(out), _ptr(mx), _ptr(sm), _ptr(ws), ws.numel(),
+                                          _stream(feature)), "gat_aggregate")
+    return (out, mx, sm) if return_stats else out
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Per-op timings at the BASELINE sizes (not the driver's bench): CSR build, the GAT trio, segment ops.
+Prints one line per op: ms, algorithmic GB, GB/s, fraction of 8 TB/s."""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import pgl_amd as pgl
+from pgl_amd.utils.rmat import rmat_edges
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scale", type=int, default=20); ap.add_argument("--edges", type=int, default=20_000_000)
+ap.add_argument("--iters", type=int, default=20)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+N, E, H, D = 1 << args.scale, args.edges, 8, 16
+edges = rmat_edges(args.scale, E, seed=42, device=dev)
+gen = torch.Generator(device=dev); gen.manual_seed(7)
+x = torch.randn(N, H * D, generator=gen, device=dev)
+
+
+def timeit(fn, iters=args.iters, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def report(name, ms, gbytes):
+    print("%-34s %8.3f ms  %7.2f GB alg  %8.1f GB/s  frac %.3f" % (name, ms, gbytes, gbytes / ms * 1e3, gbytes / ms * 1e3 / 8000))
+
+
+ms = timeit(lambda: pgl.ops.csr_build(edges[:, 1], edges[:, 0], N), iters=5)
+report("csr_build (K8)", ms, (E * (16 + 12 + 24) + N * 16) / 1e9)       # reads u,v int64; writes 3 int32 + 3 int64 + N*2 int64
+g = pgl.Graph(edges=edges, num_nodes=N)
+csr = g.adj_dst_index.csr; g.adj_src_index
+ms = timeit(lambda: pgl.ops.unique_segment(csr.degree, csr.sorted_u), iters=5)
+report("unique_segment", ms, (E * 16 + N * 24) / 1e9)
+ms = timeit(lambda: g.send_recv(x, "sum")); report("send_recv sum d=128", ms, (E * 516 + N * 520) / 1e9)
+ms = timeit(lambda: g.send_recv(x, "mean")); report("send_recv mean d=128", ms, (E * 516 + N * 520) / 1e9)
+ms = timeit(lambda: g.send_recv(x, "max")); report("send_recv max d=128", ms, (E * 516 + N * 520) / 1e9)
+x64 = x[:, :64].contiguous(); x256 = torch.cat([x, x], 1)
+ms = timeit(lambda: g.send_recv(x64, "sum")); report("send_recv sum d=64", ms, (E * 260 + N * 264) / 1e9)
+ms = timeit(lambda: g.send_recv(x256, "sum")); report("send_recv sum d=256", ms, (E * 1028 + N * 1032) / 1e9)
+a_s = torch.randn(N, H, generator=gen, device=dev); a_d = torch.randn(N, H, generator=gen, device=dev)
+ms = timeit(lambda: g.send_uv(a_s, a_d, "add")); report("send_uv [N,8]+[N,8] (K3)", ms, E * (32 + 32 + 32 + 8) / 1e9)
+alpha = torch.nn.functional.leaky_relu(g.send_uv(a_s, a_d, "add"), 0.2)
+ms = timeit(lambda: pgl.nn.functional.edge_softmax(g, alpha)); report("edge_softmax [E,8] (K4)", ms, E * (32 + 32 + 4) / 1e9)
+sm = pgl.nn.functional.edge_softmax(g, alpha).reshape(-1, H, 1)
+xf = x.reshape(N, H, D)
+ms = timeit(lambda: g.send_ue_recv(xf, sm, "mul", "sum")); report("send_ue_recv mul,sum (K2)", ms, (E * (512 + 32 + 8) + N * 520) / 1e9)
+_, seg = g.get_segment_ids(None, None, "dst"); nseg = int(g.get_segment_ids(None, None, "dst")[0].shape[0])
+msg = torch.randn(E, 32, generator=gen, device=dev)
+ms = timeit(lambda: pgl.ops.segment_reduce(msg, seg, "sum", nseg)); report("segment_sum [E,32] (K5)", ms, (E * (128 + 8) + nseg * 128) / 1e9)
+ms = timeit(lambda: pgl.ops.gather_rows(x, csr.col32)[:1], iters=3); report("gather_rows [E,128] (K6)", ms, E * (512 + 512 + 4) / 1e9)
+ms = timeit(lambda: pgl.ops.gat_aggregate(xf, a_s, a_d, csr, 0.2)); report("gat_aggregate fused (K3+K4+K2)", ms, (E * 620 + N * 552) / 1e9)
+gat = pgl.nn.GATConv(128, D, feat_drop=0.0, attn_drop=0.0, num_heads=H).to(dev)
+with torch.no_grad():
+    ms = timeit(lambda: gat(g, x), iters=10); report("GATConv forward (fused inference)", ms, (E * 620 + N * 552) / 1e9)
+gcn = pgl.nn.GCNConv(128, 128).to(dev)
+with torch.no_grad():
+    ms = timeit(lambda: gcn(g, x), iters=10); report("GCNConv forward", ms, (E * 516 + N * 520) / 1e9)
