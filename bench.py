@@ -112,7 +112,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync(); barrier(); sync()
-    pgl.ops.profile_begin()
+    if not os.environ.get("PGLAMD_BENCH_NOPROF"):
+        pgl.ops.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -40,6 +40,8 @@ struct AggParams {
     const int64_t* indptr;
     const float* src_scale; const float* dst_scale;
     void* part_head; void* part_tail;     // [n_chunks, tile_cols] of ACC each
+    int* long_count; int* long_list;      // [2] counters + work list of split-row fix-up tasks (workspace)
+    int* long_list2;                      // second-level list: rows with more than kFixShort partials
     int64_t ldx, ldy, ldo;                // row strides (elements) of x, y, out
     int64_t out_rows, n_csr_rows;
     int E, n_chunks, chunk, n_blocks;
@@ -49,6 +51,7 @@ struct AggParams {
     int mop, is_max, is_mean;
     int zvec;                             // vector width the zero-fill role may use (1, 2, 4)
     int accumulate;                       // 1: combine with the existing out row instead of overwriting
+    int align;                            // 1: never split rows of <= chunk edges (chunk_cut)
 };
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
@@ -110,11 +113,11 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     if (lb < 0) return;
     const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
     if (c >= p.n_chunks) return;
-    const int e0 = c * p.chunk;
-    const int e1 = min(e0 + p.chunk, p.E);
-
     const cptr<int> rowp = as_const(p.row);
     const cptr<int> colp = as_const(p.col);
+    const int e0 = p.align ? chunk_cut(rowp, as_const(p.indptr), c * p.chunk, p.chunk, p.E) : c * p.chunk;
+    const int e1 = p.align ? chunk_cut(rowp, as_const(p.indptr), c * p.chunk + p.chunk, p.chunk, p.E) : min(c * p.chunk + p.chunk, p.E);
+    if (e0 >= e1) return;
     const cptr<int> eidp = as_const(p.eid);
     const cptr<float> sscale = as_const(p.src_scale);
     const cptr<float> dscale = as_const(p.dst_scale);
@@ -290,122 +293,176 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     // the row open at the end of the chunk
     const bool tail_open = e1 < p.E && rowp[e1] == cur;
     if (head_open) store_partial(p.part_head);          // middle or closing piece of a long row
-    else if (tail_open) store_partial(p.part_tail);     // first piece of a row that continues
+    else if (tail_open) {                               // first piece of a LONG row that continues:
+        store_partial(p.part_tail);                     // this chunk owns its fix-up task
+        if (lane == 0) p.long_list[atomicAdd(p.long_count, 1)] = c;
+    }
     else store_final(cur, cnt);
 }
 
-// Adds the partials of every row that straddles a chunk boundary, in a FIXED order (bit-reproducible).
-// One 256-thread block per chunk a; it acts iff a row STARTS in chunk a and continues past its end.
-// Wave w of the block sums the partials a+1+w, a+1+w+4, ... (8 independent loads in flight), then the
-// four wave sums are combined through LDS in wave order.  Hub rows of power-law graphs leave hundreds
-// of partials, so this must not be one serial dependent chain.
-template <typename T, int VEC, int NT, int RCLS>
-__global__ __launch_bounds__(kBlock) void agg_fixup_kernel(AggParams p) {
+// ------------------------------------------------------------------------------------------------
+// Fix-up: only rows LONGER than a chunk are ever split (chunk_cut), so only hub rows leave partials:
+// the row's value is T[a] (+) H[a+1] (+) ... (+) H[b] with a = the chunk where it starts.  The flat
+// kernel appends `a` to a work list when it writes T[a].
+//   pass 1 (LONG = false): one WAVE per listed task (grid-stride over the list).  Rows with <= 16
+//          partials (degree <= 17 chunks: almost all of them) are finished here, their loads issued
+//          in two batches of 8; longer ones go to a second list.
+//   pass 2 (LONG = true): a few 1024-thread blocks walk the second list; the 16 waves of a block split
+//          one row's partial list (8 loads in flight each) and combine through LDS in wave order, so
+//          a 10^5-edge hub is not one serial dependent chain.
+// List order is arbitrary; every row's own combination order is fixed => bit-reproducible.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFixShort = 16;
+constexpr int kFixWaves = 16;
+constexpr int kFixGridShort = 2048;
+constexpr int kFixGridLong = 512;
+
+template <typename T, int VEC, int NT, int RCLS, bool LONG>
+__global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_kernel(AggParams p) {
     using V = VecT<T, VEC>;
-    __shared__ T red[kWavesPerBlock][NT * kWave * VEC];
+    constexpr int NW = LONG ? kFixWaves : 1;
+    __shared__ T red[LONG ? kFixWaves : 1][LONG ? NT * kWave * VEC : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
-    const int a = (int)blockIdx.x;
-    const int e0 = a * p.chunk;
-    const int e1 = e0 + p.chunk;
-    if (e1 >= p.E) return;
     const cptr<int> rowp = as_const(p.row);
     const cptr<int64_t> ip = as_const(p.indptr);
-    const int r = rowp[e1 - 1];
-    if (rowp[e1] != r) return;                  // nothing continues
-    const int64_t rs = ip[r], re = ip[r + 1];
-    if (rs < e0) return;                        // row started earlier: that chunk's block owns it
-    if (r >= p.out_rows) return;
-    const int b = (int)((re - 1) / p.chunk);    // last chunk holding a piece of row r
     const bool is_max = p.is_max != 0;
     const T* __restrict__ ph = static_cast<const T*>(p.part_head);
-
+    const T* __restrict__ pt = static_cast<const T*>(p.part_tail);
     auto comb = [&](T x, T y) -> T {
         if constexpr (RCLS == 0) return x + y;
         else return is_max ? (y > x ? y : x) : (y < x ? y : x);
     };
-    T acc[NT][VEC];
     int j0[NT]; bool act[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        j0[t] = (t * kWave + lane) * VEC;
-        act[t] = j0[t] < p.tile_cols;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[t][k] = RCLS == 0 ? T(0) : (is_max ? Limits<T>::lo() : Limits<T>::hi());
-    }
-    bool any = false;
-    constexpr int UF = 8;
-    int c = a + 1 + wib;
-    for (; c + (UF - 1) * kWavesPerBlock <= b; c += UF * kWavesPerBlock) {
-        V v[UF][NT];
-#pragma unroll
-        for (int u = 0; u < UF; ++u)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (act[t]) v[u][t] = *reinterpret_cast<const V*>(ph + (int64_t)(c + u * kWavesPerBlock) * p.tile_cols + j0[t]);
-#pragma unroll
-        for (int u = 0; u < UF; ++u)
+    for (int t = 0; t < NT; ++t) { j0[t] = (t * kWave + lane) * VEC; act[t] = j0[t] < p.tile_cols; }
+
+    const int* list = LONG ? p.long_list2 : p.long_list;
+    const int n_tasks = LONG ? p.long_count[1] : p.long_count[0];
+    const int first = LONG ? (int)blockIdx.x : (int)blockIdx.x * kWavesPerBlock + wib;
+    const int stride = LONG ? (int)gridDim.x : (int)gridDim.x * kWavesPerBlock;
+    for (int t_id = first; t_id < n_tasks; t_id += stride) {
+        const int a = wave_uniform(list[t_id]);
+        const int e1 = (a + 1) * p.chunk;
+        const int r = rowp[e1 - 1];
+        const int64_t rs = ip[r], re = ip[r + 1];
+        const int b = (int)((re - 1) / p.chunk);        // last chunk holding a piece of row r
+        if constexpr (!LONG) {
+            if (b - a > kFixShort) {                    // hub row: defer to the block-parallel pass
+                if (lane == 0) p.long_list2[atomicAdd(p.long_count + 1, 1)] = a;
+                continue;
+            }
+        }
+        T acc[NT][VEC];
+        if constexpr (!LONG) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (act[t]) {
+                    const V tv = *reinterpret_cast<const V*>(pt + (int64_t)a * p.tile_cols + j0[t]);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v[u][t].v[k]);
+                    for (int k = 0; k < VEC; ++k) acc[t][k] = tv.v[k];
                 }
-        any = true;
-    }
-    for (; c <= b; c += kWavesPerBlock) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int c0 = a + 1 + half * 8;
+                if (c0 > b) break;
+                V v[8][NT];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + u <= b) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (act[t]) v[u][t] = *reinterpret_cast<const V*>(ph + (int64_t)(c0 + u) * p.tile_cols + j0[t]);
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (c0 + u <= b) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            if (act[t]) {
+#pragma unroll
+                                for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v[u][t].v[k]);
+                            }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[t][k] = RCLS == 0 ? T(0) : (is_max ? Limits<T>::lo() : Limits<T>::hi());
+            constexpr int UF = 8;
+            int c = a + 1 + wib;
+            for (; c + (UF - 1) * NW <= b; c += UF * NW) {
+                V v[UF][NT];
+#pragma unroll
+                for (int u = 0; u < UF; ++u)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (act[t]) v[u][t] = *reinterpret_cast<const V*>(ph + (int64_t)(c + u * NW) * p.tile_cols + j0[t]);
+#pragma unroll
+                for (int u = 0; u < UF; ++u)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        if (act[t]) {
+#pragma unroll
+                            for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v[u][t].v[k]);
+                        }
+            }
+            for (; c <= b; c += NW) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (act[t]) {
+                        const V v = *reinterpret_cast<const V*>(ph + (int64_t)c * p.tile_cols + j0[t]);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v.v[k]);
+                    }
+            }
+            __syncthreads();                            // previous task's readers are done with `red`
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) red[wib][(t * kWave + lane) * VEC + k] = acc[t][k];
+            __syncthreads();
+            if (wib != 0) continue;
+            // wave 0: tail partial of chunk a first, then the wave results in wave order
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (act[t]) {
+                    const V tv = *reinterpret_cast<const V*>(pt + (int64_t)a * p.tile_cols + j0[t]);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        T sv = tv.v[k];
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) sv = comb(sv, red[w][(t * kWave + lane) * VEC + k]);
+                        acc[t][k] = sv;
+                    }
+                }
+        }
+        if (r >= p.out_rows) continue;
+        T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
+        float ds = 1.f;
+        if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (act[t]) {
-                const V v = *reinterpret_cast<const V*>(ph + (int64_t)c * p.tile_cols + j0[t]);
+                V o;
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v.v[k]);
-            }
-        any = true;
-    }
-    (void)any;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) red[wib][(t * kWave + lane) * VEC + k] = acc[t][k];
-    __syncthreads();
-    if (wib != 0) return;
-    // wave 0: tail partial of chunk a first, then the four wave sums in wave order
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        if (act[t]) {
-            const V v = *reinterpret_cast<const V*>(static_cast<const T*>(p.part_tail) + (int64_t)a * p.tile_cols + j0[t]);
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                T s = v.v[k];
-#pragma unroll
-                for (int w = 0; w < kWavesPerBlock; ++w) s = comb(s, red[w][(t * kWave + lane) * VEC + k]);
-                acc[t][k] = s;
-            }
-        }
-    T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
-    float ds = 1.f;
-    if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-        if (act[t]) {
-            V o;
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                T v = acc[t][k];
-                if constexpr (RCLS == 0) {
-                    if (p.is_mean) v = v / (T)(re - rs);
-                    if constexpr (std::is_floating_point_v<T>) { if (p.dst_scale) v = v * (T)ds; }
+                for (int k = 0; k < VEC; ++k) {
+                    T v = acc[t][k];
+                    if constexpr (RCLS == 0) {
+                        if (p.is_mean) v = v / (T)(re - rs);
+                        if constexpr (std::is_floating_point_v<T>) { if (p.dst_scale) v = v * (T)ds; }
+                    }
+                    o.v[k] = v;
                 }
-                o.v[k] = v;
-            }
-            if (p.accumulate) {
-                const V old = *reinterpret_cast<const V*>(dst + j0[t]);
+                if (p.accumulate) {
+                    const V old = *reinterpret_cast<const V*>(dst + j0[t]);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) o.v[k] = comb(old.v[k], o.v[k]);
+                    for (int k = 0; k < VEC; ++k) o.v[k] = comb(old.v[k], o.v[k]);
+                }
+                *reinterpret_cast<V*>(dst + j0[t]) = o;
             }
-            *reinterpret_cast<V*>(dst + j0[t]) = o;
-        }
+    }
 }
 
 // Zero-fills output rows that receive no edge: rows r < n_csr_rows with indptr[r]==indptr[r+1],
@@ -505,6 +562,7 @@ static int32_t launch_flat(AggParams p, hipStream_t st) {
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     prof().last_kernel = kernel_name<T>(VEC, NT, RCLS, YMODE);
+    if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof().on) {
         PGLAMD_HIP_CHECK(hipEventCreate(&e0));
@@ -517,8 +575,11 @@ static int32_t launch_flat(AggParams p, hipStream_t st) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
         prof().ev.emplace_back(e0, e1);
     }
-    if (p.n_chunks > 1)
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS>), dim3((unsigned)(p.n_chunks - 1)), dim3(kBlock), 0, st, p);
+    if (p.n_chunks > 1) {
+        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), dim3(kFixGridShort), dim3(kBlock), 0, st, p);
+        PGLAMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), dim3(kFixGridLong), dim3(kFixWaves * kWave), 0, st, p);
+    }
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }
@@ -638,6 +699,7 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
         if (forced >= 1 && forced <= vmax && (forced & (forced - 1)) == 0) vec = forced;
     }
     p.zvec = vec;
+    { static const int al = [] { const char* e = getenv("PGLAMD_ALIGN"); return e ? atoi(e) : 1; }(); p.align = al; }
     if ((src_scale || dst_scale) && (rcls != 0 || !std::is_floating_point_v<T>))
         return fail(PGLAMD_E_ARG, "src_scale/dst_scale need a floating dtype and sum/mean");
 
@@ -647,10 +709,15 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
         p.n_chunks = (int)ceil_div(E, K);
         const int max_cols = kWave * vec * 4;
         const int64_t tile_full = dout < max_cols ? dout : max_cols;
-        const size_t need = 2 * align_up((size_t)p.n_chunks * tile_full * sizeof(T), 256);
+        const size_t half = align_up((size_t)p.n_chunks * tile_full * sizeof(T), 256);
+        const size_t lst = align_up((size_t)(p.n_chunks + 64) * sizeof(int), 256);
+        const size_t need = 2 * half + 2 * lst;
         if (!ws || ws_bytes < need) return fail(PGLAMD_E_WORKSPACE, "aggregate: workspace %zu < %zu", ws_bytes, need);
         p.part_head = ws;
-        p.part_tail = static_cast<char*>(ws) + need / 2;
+        p.part_tail = static_cast<char*>(ws) + half;
+        p.long_count = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half);
+        p.long_list = p.long_count + 64;
+        p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half + lst);
         for (int64_t jb = 0; jb < dout; jb += max_cols) {
             p.j_base = (int)jb;
             p.tile_cols = (int)((dout - jb) < max_cols ? (dout - jb) : max_cols);
@@ -681,7 +748,7 @@ extern "C" size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t do
     const int max_vec_ = es == 4 ? 4 : 2;
     const int64_t max_cols = (int64_t)kWave * max_vec_ * 4;
     const int64_t tile = dout < max_cols ? dout : max_cols;
-    return 2 * align_up((size_t)n_chunks * tile * es, 256) + 256;
+    return 2 * align_up((size_t)n_chunks * tile * es, 256) + 2 * align_up((size_t)(n_chunks + 64) * sizeof(int), 256) + 256;
 }
 
 extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t dx, const void* y,

@@ -79,4 +79,18 @@ template <typename T> __device__ __forceinline__ cptr<T> as_const(const T* p) {
     return (cptr<T>)(unsigned long long)p;
 }
 
+// Edge range [e0, e1) of chunk c of a dst-sorted edge stream cut on the grid c*K.  A row with <= K
+// edges is never split: it belongs wholly to the chunk in which it STARTS (so a chunk walks between
+// 0 and 2K-1 edges).  Only rows longer than K are cut at grid positions; those leave partials.
+__device__ __forceinline__ int chunk_cut(cptr<int> rowp, cptr<int64_t> ip, int pos, int K, int E) {
+    if (pos <= 0) return 0;
+    if (pos >= E) return E;
+    const int r = rowp[pos];
+    const int64_t rs = ip[r];
+    if (rs == pos) return pos;                 // grid position is a row start
+    const int64_t re = ip[r + 1];
+    if (re - rs > K) return pos;               // long row: cut here
+    return (int)re;                            // short row started in an earlier chunk: skip past it
+}
+
 }  // namespace pglamd

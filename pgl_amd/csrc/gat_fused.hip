@@ -21,6 +21,7 @@ struct GatParams {
     float* row_max; float* row_sum;              // optional [out_rows, H] softmax statistics (NULL to skip)
     const int* row; const int* col; const int64_t* indptr;
     float* part_head; float* part_tail;          // [n_chunks, 3, d]: acc | m | s (m, s replicated per column)
+    int* long_count; int* long_list; int* long_list2;   // [2] counters + two-level fix-up work lists
     int64_t out_rows, n_csr_rows;
     int E, n_chunks, chunk, n_blocks, n_grid_chunks;
     int d, H, D;
@@ -59,10 +60,11 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     if (lb < 0) return;
     const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
     if (c >= p.n_chunks) return;
-    const int e0 = c * p.chunk;
-    const int e1 = min(e0 + p.chunk, p.E);
     const cptr<int> rowp = as_const(p.row);
     const cptr<int> colp = as_const(p.col);
+    const int e0 = chunk_cut(rowp, as_const(p.indptr), c * p.chunk, p.chunk, p.E);
+    const int e1 = chunk_cut(rowp, as_const(p.indptr), c * p.chunk + p.chunk, p.chunk, p.E);
+    if (e0 >= e1) return;
     const float* __restrict__ x = p.x;
     const float* __restrict__ asrc = p.a_src;
     const float slope = p.slope;
@@ -160,73 +162,102 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     }
     const bool tail_open = e1 < p.E && rowp[e1] == cur;
     if (head_open) store_partial(p.part_head);
-    else if (tail_open) store_partial(p.part_tail);
-    else store_final(cur);
+    else if (tail_open) {
+        store_partial(p.part_tail);
+        if (lane == 0) p.long_list[atomicAdd(p.long_count, 1)] = c;
+    } else store_final(cur);
 }
 
-// merges the (acc, m, s) partials of a row that straddles chunk boundaries; one block per chunk a,
-// acting iff a row starts in chunk a and continues.  4 waves split the list, LDS combine in wave order.
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void gat_fixup_kernel(GatParams p) {
+// merges the (acc, m, s) partials of the rows longer than a chunk (only those are split), from the
+// work list the flat kernel filled.  Pass 1 (LONG = false): one wave per task, rows with <= 16
+// partials are merged right there, longer ones go to a second list.  Pass 2 (LONG = true): 1024-thread
+// blocks, 16 waves split one hub row's partial list, LDS combine in wave order.  The softmax merge is
+// associative; every row's own merge order is fixed => bit-reproducible.
+constexpr int kGatFixShort = 16;
+constexpr int kGatFixWaves = 16;
+constexpr int kGatFixGridShort = 2048;
+constexpr int kGatFixGridLong = 512;
+
+template <int VEC, bool LONG>
+__global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixup_kernel(GatParams p) {
     using V = FV<VEC>;
-    __shared__ float red[kWavesPerBlock][3][kWave * VEC];
+    constexpr int NW = LONG ? kGatFixWaves : 1;
+    __shared__ float red[LONG ? kGatFixWaves : 1][3][LONG ? kWave * VEC : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
-    const int a = (int)blockIdx.x;
-    const int e0 = a * p.chunk, e1 = e0 + p.chunk;
-    if (e1 >= p.E) return;
     const cptr<int> rowp = as_const(p.row);
     const cptr<int64_t> ip = as_const(p.indptr);
-    const int r = rowp[e1 - 1];
-    if (rowp[e1] != r) return;
-    const int64_t rs = ip[r], re = ip[r + 1];
-    if (rs < e0 || r >= p.out_rows) return;
-    const int b = (int)((re - 1) / p.chunk);
     const int j0 = lane * VEC;
     const bool act = j0 < p.d;
-
-    float m = -INFINITY, s = 0.f, acc[VEC];
+    const int* list = LONG ? p.long_list2 : p.long_list;
+    const int n_tasks = LONG ? p.long_count[1] : p.long_count[0];
+    const int first = LONG ? (int)blockIdx.x : (int)blockIdx.x * kWavesPerBlock + wib;
+    const int stride = LONG ? (int)gridDim.x : (int)gridDim.x * kWavesPerBlock;
+    for (int t_id = first; t_id < n_tasks; t_id += stride) {
+        const int a = wave_uniform(list[t_id]);
+        const int e1 = (a + 1) * p.chunk;
+        const int r = rowp[e1 - 1];
+        const int64_t re = ip[r + 1];
+        const int b = (int)((re - 1) / p.chunk);
+        if constexpr (!LONG) {
+            if (b - a > kGatFixShort) {
+                if (lane == 0) p.long_list2[atomicAdd(p.long_count + 1, 1)] = a;
+                continue;
+            }
+        }
+        float m = -INFINITY, s = 0.f, acc[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    auto merge = [&](const float* base) {
-        const V va = *reinterpret_cast<const V*>(base + j0);
-        const float m2 = base[p.d + j0], s2 = base[2 * p.d + j0];
-        const float mn = fmaxf(m, m2);
-        const float c1 = expf(m - mn), c2 = expf(m2 - mn);
-        s = s * c1 + s2 * c2;
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        auto merge_vals = [&](const V& va, float m2, float s2) {
+            const float mn = fmaxf(m, m2);
+            const float c1 = expf(m - mn), c2 = expf(m2 - mn);
+            s = s * c1 + s2 * c2;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * c1 + va.v[k] * c2;
-        m = mn;
-    };
-    if (act)
-        for (int c = a + 1 + wib; c <= b; c += kWavesPerBlock) merge(p.part_head + (int64_t)c * 3 * p.d);
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * c1 + va.v[k] * c2;
+            m = mn;
+        };
+        auto merge = [&](const float* base) {
+            merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], base[2 * p.d + j0]);
+        };
+        if constexpr (!LONG) {
+            if (act) {
+                merge(p.part_tail + (int64_t)a * 3 * p.d);
+#pragma unroll 4
+                for (int c = a + 1; c <= b; ++c) merge(p.part_head + (int64_t)c * 3 * p.d);
+            }
+        } else {
+            if (act)
+                for (int c = a + 1 + wib; c <= b; c += NW) merge(p.part_head + (int64_t)c * 3 * p.d);
+            __syncthreads();
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) red[wib][0][lane * VEC + k] = acc[k];
-    red[wib][1][lane * VEC] = m; red[wib][2][lane * VEC] = s;
-    __syncthreads();
-    if (wib != 0 || !act) return;
-    // wave 0: tail partial of chunk a first, then the wave sums in wave order
-    m = -INFINITY; s = 0.f;
+            for (int k = 0; k < VEC; ++k) red[wib][0][lane * VEC + k] = acc[k];
+            red[wib][1][lane * VEC] = m; red[wib][2][lane * VEC] = s;
+            __syncthreads();
+            if (wib != 0) continue;
+            // wave 0: tail partial of chunk a first, then the wave results in wave order
+            m = -INFINITY; s = 0.f;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-    merge(p.part_tail + (int64_t)a * 3 * p.d);
+            for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+            if (act) {
+                merge(p.part_tail + (int64_t)a * 3 * p.d);
+                for (int w = 0; w < NW; ++w) {
+                    const float s2 = red[w][2][lane * VEC];
+                    if (s2 == 0.f) continue;                     // that wave had no partial
+                    V va;
 #pragma unroll
-    for (int w = 0; w < kWavesPerBlock; ++w) {
-        const float m2 = red[w][1][lane * VEC], s2 = red[w][2][lane * VEC];
-        if (s2 == 0.f && m2 == -INFINITY) continue;          // that wave had no partial
-        const float mn = fmaxf(m, m2);
-        const float c1 = expf(m - mn), c2 = expf(m2 - mn);
-        s = s * c1 + s2 * c2;
+                    for (int k = 0; k < VEC; ++k) va.v[k] = red[w][0][lane * VEC + k];
+                    merge_vals(va, red[w][1][lane * VEC], s2);
+                }
+            }
+        }
+        if (!act || r >= p.out_rows) continue;
+        V o;
+        const float inv = 1.f / s;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * c1 + red[w][0][lane * VEC + k] * c2;
-        m = mn;
+        for (int k = 0; k < VEC; ++k) o.v[k] = acc[k] * inv;
+        *reinterpret_cast<V*>(p.out + (int64_t)r * p.d + j0) = o;
+        if (p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + j0 / p.D] = m; p.row_sum[(int64_t)r * p.H + j0 / p.D] = s; }
     }
-    V o;
-    const float inv = 1.f / s;
-#pragma unroll
-    for (int k = 0; k < VEC; ++k) o.v[k] = acc[k] * inv;
-    *reinterpret_cast<V*>(p.out + (int64_t)r * p.d + j0) = o;
-    if (p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + j0 / p.D] = m; p.row_sum[(int64_t)r * p.H + j0 / p.D] = s; }
 }
 
 static int gat_chunk_edges() {
@@ -245,10 +276,13 @@ static int32_t launch_gat(GatParams p, hipStream_t st) {
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
+    if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipLaunchKernelGGL(gat_flat_kernel<VEC>, dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (p.n_chunks > 1) {
-        hipLaunchKernelGGL(gat_fixup_kernel<VEC>, dim3((unsigned)(p.n_chunks - 1)), dim3(kBlock), 0, st, p);
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, false>), dim3(kGatFixGridShort), dim3(kBlock), 0, st, p);
+        PGLAMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, true>), dim3(kGatFixGridLong), dim3(kGatFixWaves * kWave), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
     }
     return PGLAMD_OK;
@@ -261,7 +295,8 @@ using namespace pglamd;
 extern "C" size_t pglamd_gat_aggregate_workspace_bytes(int64_t num_edges, int64_t heads, int64_t head_dim) {
     if (num_edges <= 0) return 256;
     const int64_t n_chunks = ceil_div(num_edges, gat_chunk_edges());
-    return 2 * align_up((size_t)n_chunks * 3 * heads * head_dim * sizeof(float), 256) + 256;
+    return 2 * align_up((size_t)n_chunks * 3 * heads * head_dim * sizeof(float), 256) +
+           2 * align_up((size_t)(n_chunks + 64) * sizeof(int), 256) + 256;
 }
 
 extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const float* attn_dst, int64_t heads,
@@ -302,6 +337,9 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
     const size_t half = align_up((size_t)p.n_chunks * 3 * d * sizeof(float), 256);
     p.part_head = static_cast<float*>(workspace);
     p.part_tail = reinterpret_cast<float*>(static_cast<char*>(workspace) + half);
+    p.long_count = reinterpret_cast<int*>(static_cast<char*>(workspace) + 2 * half);
+    p.long_list = p.long_count + 64;
+    p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(workspace) + 2 * half + align_up((size_t)(p.n_chunks + 64) * sizeof(int), 256));
     switch (vec) {
         case 1: return launch_gat<1>(p, st);
         case 2: return launch_gat<2>(p, st);
