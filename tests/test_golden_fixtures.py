@@ -1,0 +1,67 @@
+"""Committed golden fixtures (tests/golden/*.npz, produced by the REFERENCE's compiled native code via
+tests/golden/make_golden.py) checked against (a) the oracle restatement and the engine's host-side
+code on CPU, (b) the HIP CSR build on the GPU.  These do not need /root/reference at run time."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import ref_ops as R
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BUILD = sorted(glob.glob(os.path.join(GOLD, "build_index_*.npz")))
+KEYS = ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr")
+
+
+def test_fixtures_present():
+    assert len(BUILD) >= 6 and os.path.exists(os.path.join(GOLD, "map_ids.npz"))
+    assert len(glob.glob(os.path.join(GOLD, "metis_k*.npz"))) == 3
+
+
+@pytest.mark.parametrize("path", BUILD, ids=[os.path.basename(p)[12:-4] for p in BUILD])
+def test_oracle_and_host_build_index_match_reference_fixture(path):
+    import pgl_amd
+    z = np.load(path)
+    e, n = z["edges"], int(z["num_nodes"])
+    for tag, (u, v) in (("dst", (e[:, 1], e[:, 0])), ("src", (e[:, 0], e[:, 1]))):
+        for impl in (R.c_build_index, R.np_build_index, pgl_amd.ops.host_build_index):
+            got = impl(u, v, n)
+            for g, k in zip(got, KEYS):
+                assert np.array_equal(g, z[tag + "_" + k]), (impl.__name__, tag, k)
+
+
+def test_map_ids_fixture():
+    import pgl_amd
+    z = np.load(os.path.join(GOLD, "map_ids.npz"))
+    reindex = dict(zip(z["keys"].tolist(), z["vals"].tolist()))
+    assert np.array_equal(pgl_amd.ops.host_map_ids(z["nodes"], reindex), z["mapped_nodes"])
+    assert np.array_equal(pgl_amd.ops.host_map_ids(z["edges"].reshape(-1), reindex).reshape(-1, 2), z["mapped_edges"])
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_partitioner_vs_metis_fixture(k):
+    import pgl_amd
+    z = np.load(os.path.join(GOLD, "metis_k%d.npz" % k))
+    e, n = z["edges"], int(z["num_nodes"])
+    g = pgl_amd.Graph(edges=e, num_nodes=n)
+    with pytest.warns(UserWarning):
+        part = pgl_amd.partition.metis_partition(g, k)
+    cut = int((part[e[:, 0]] != part[e[:, 1]]).sum())
+    assert np.bincount(part, minlength=k).max() <= 1.10 * n / k
+    assert cut <= 1.5 * int(z["cut"]) + 50, (cut, int(z["cut"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", BUILD, ids=[os.path.basename(p)[12:-4] for p in BUILD])
+def test_hip_csr_build_matches_reference_fixture(path):
+    import torch
+    import pgl_amd
+    z = np.load(path)
+    e, n = torch.as_tensor(z["edges"]).cuda(), int(z["num_nodes"])
+    for tag, (u, v) in (("dst", (e[:, 1], e[:, 0])), ("src", (e[:, 0], e[:, 1]))):
+        c = pgl_amd.ops.csr_build(u, v, n)
+        for k in KEYS:
+            assert np.array_equal(getattr(c, k).cpu().numpy(), z[tag + "_" + k]), (tag, k)
+        assert np.array_equal(c.row32.cpu().numpy(), z[tag + "_sorted_u"])
+        assert np.array_equal(c.col32.cpu().numpy(), z[tag + "_sorted_v"])
