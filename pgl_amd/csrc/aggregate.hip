@@ -56,6 +56,17 @@ struct AggParams {
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
 
+// storage type T -> accumulator type A: 16-bit floats are accumulated (and their partials kept) in fp32
+template <typename T> struct AccT { using type = T; };
+template <> struct AccT<__half> { using type = float; };
+template <> struct AccT<__hip_bfloat16> { using type = float; };
+template <typename T> __device__ __forceinline__ typename AccT<T>::type to_acc(T v) { return v; }
+template <> __device__ __forceinline__ float to_acc<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float to_acc<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_acc(typename AccT<T>::type v) { return v; }
+template <> __device__ __forceinline__ __half from_acc<__half>(float v) { return __float2half(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 from_acc<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
 template <typename T> struct Limits;
 template <> struct Limits<float> { static __device__ float lo() { return -INFINITY; } static __device__ float hi() { return INFINITY; } };
 template <> struct Limits<double> { static __device__ double lo() { return -INFINITY; } static __device__ double hi() { return INFINITY; } };
@@ -93,16 +104,18 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
         } else if (p.zvec == 2) {
             for (int j = lane * 2; j < p.tile_cols; j += kWave * 2) *reinterpret_cast<VecT<T, 2>*>(dst + j) = VecT<T, 2>{};
         } else {
-            for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = T(0);
+            for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = from_acc<T>(typename AccT<T>::type(0));
         }
     }
 }
 
 // RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector
-template <typename T, int VEC, int NT, int RCLS, int YMODE>
+template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     constexpr int U = 8;
     using V = VecT<T, VEC>;
+    using A = typename AccT<T>::type;
+    using VA = VecT<A, VEC>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
     if ((int)blockIdx.x >= p.n_grid_chunks) {   // trailing blocks: zero-fill rows that receive no edge
@@ -120,11 +133,9 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     if (e0 >= e1) return;
     const cptr<int> eidp = as_const(p.eid);
     const cptr<float> sscale = as_const(p.src_scale);
-    const cptr<float> dscale = as_const(p.dst_scale);
     const T* __restrict__ x = static_cast<const T*>(p.x);
     const T* __restrict__ y = static_cast<const T*>(p.y);
-    T* __restrict__ out = static_cast<T*>(p.out);
-    const bool has_ss = p.src_scale != nullptr;
+    constexpr bool has_ss = SS;       // per-source scale compiled in only where asked for (keeps 16 SGPRs free otherwise)
     const bool is_max = p.is_max != 0;
 
     // lane -> column mapping
@@ -140,13 +151,13 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) yj[t] = YMODE == 1 ? j0[t] / p.gy : 0;
 
-    T acc[NT][VEC];
+    A acc[NT][VEC];
     auto reset = [&]() {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int k = 0; k < VEC; ++k)
-                acc[t][k] = RCLS == 0 ? T(0) : (is_max ? Limits<T>::lo() : Limits<T>::hi());
+                acc[t][k] = RCLS == 0 ? A(0) : (is_max ? Limits<A>::lo() : Limits<A>::hi());
     };
     reset();
 
@@ -154,49 +165,68 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     bool head_open = e0 > 0 && rowp[e0 - 1] == cur;   // current row began in an earlier chunk
     int cnt = 0;
 
-    auto store_partial = [&](void* base) {
-        T* dst = static_cast<T*>(base) + (int64_t)c * p.tile_cols;
+    // Everything a row store needs (output base, strides, scales, flags) is re-read from the kernarg
+    // segment AT THE STORE through an opaque pointer, instead of living in ~25 SGPRs across the hot
+    // loop: stores happen once per row, the freed SGPRs buy one more resident workgroup per CU.
+    const cptr<AggParams> kargs = (cptr<AggParams>)__builtin_amdgcn_kernarg_segment_ptr();
+    auto cold = [&]() -> cptr<AggParams> {
+        cptr<AggParams> q = kargs;
+        asm volatile("" : "+s"(q));      // defeats hoisting of the field loads out of the store path
+        return q;
+    };
+    auto store_partial = [&](bool head) {
+        const cptr<AggParams> q = cold();
+        A* dst = static_cast<A*>(head ? q->part_head : q->part_tail) + (int64_t)c * q->tile_cols;
+        const int jb = q->j_base;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (act[t]) {
-                V o;
+                VA o;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = acc[t][k];
-                *reinterpret_cast<V*>(dst + (j0[t] - p.j_base)) = o;
+                *reinterpret_cast<VA*>(dst + (j0[t] - jb)) = o;
             }
+        if (!head && lane == 0) q->long_list[atomicAdd(q->long_count, 1)] = c;   // this chunk owns the row's fix-up
     };
     auto store_final = [&](int r, int n) {
-        if (r >= p.out_rows) return;
-        T* dst = out + (int64_t)r * p.ldo;
+        const cptr<AggParams> q = cold();
+        if (r >= q->out_rows) return;
+        T* dst = static_cast<T*>(q->out) + (int64_t)r * q->ldo;
+        const float* dsp = q->dst_scale;
+        const bool is_mean = q->is_mean != 0, accumulate = q->accumulate != 0;
         float ds = 1.f;
-        if constexpr (RCLS == 0) { if (p.dst_scale) ds = dscale[r]; }
+        if constexpr (RCLS == 0) { if (dsp) ds = as_const(dsp)[r]; }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (act[t]) {
-                V o;
+                A ov[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    T a = acc[t][k];
+                    A a = acc[t][k];
                     if constexpr (RCLS == 0) {
-                        if (p.is_mean) a = a / (T)n;
-                        if constexpr (std::is_floating_point_v<T>) { if (p.dst_scale) a = a * (T)ds; }
+                        if (is_mean) a = a / (A)n;
+                        if constexpr (std::is_floating_point_v<A>) { if (dsp) a = a * (A)ds; }
                     }
-                    o.v[k] = a;
+                    ov[k] = a;
                 }
-                if (p.accumulate) {
+                if (accumulate) {
                     const V old = *reinterpret_cast<const V*>(dst + j0[t]);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        if constexpr (RCLS == 0) o.v[k] = old.v[k] + o.v[k];
-                        else o.v[k] = is_max ? (o.v[k] > old.v[k] ? o.v[k] : old.v[k]) : (o.v[k] < old.v[k] ? o.v[k] : old.v[k]);
+                        const A ol = to_acc<T>(old.v[k]);
+                        if constexpr (RCLS == 0) ov[k] = ol + ov[k];
+                        else ov[k] = is_max ? (ov[k] > ol ? ov[k] : ol) : (ov[k] < ol ? ov[k] : ol);
                     }
                 }
+                V o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
                 *reinterpret_cast<V*>(dst + j0[t]) = o;
             }
     };
     // closes row `cur` when the stream moved on to another row inside this chunk
     auto flush_mid = [&]() {
-        if (head_open) store_partial(p.part_head); else store_final(cur, cnt);
+        if (head_open) store_partial(true); else store_final(cur, cnt);
         head_open = false;
     };
 
@@ -237,10 +267,10 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
-                T m = vx[t].v[k];
-                if constexpr (std::is_floating_point_v<T>) { if (has_ss) m = m * (T)s; }
-                if constexpr (YMODE == 1) m = apply_mop(m, vy[t].v[0], p.mop);
-                if constexpr (YMODE == 2) m = apply_mop(m, vy[t].v[k], p.mop);
+                A m = to_acc<T>(vx[t].v[k]);
+                if constexpr (std::is_floating_point_v<A>) { if (has_ss) m = m * (A)s; }
+                if constexpr (YMODE == 1) m = apply_mop(m, to_acc<T>(vy[t].v[0]), p.mop);
+                if constexpr (YMODE == 2) m = apply_mop(m, to_acc<T>(vy[t].v[k]), p.mop);
                 if constexpr (RCLS == 0) acc[t][k] += m;
                 else acc[t][k] = is_max ? (m > acc[t][k] ? m : acc[t][k]) : (m < acc[t][k] ? m : acc[t][k]);
             }
@@ -292,11 +322,8 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
 
     // the row open at the end of the chunk
     const bool tail_open = e1 < p.E && rowp[e1] == cur;
-    if (head_open) store_partial(p.part_head);          // middle or closing piece of a long row
-    else if (tail_open) {                               // first piece of a LONG row that continues:
-        store_partial(p.part_tail);                     // this chunk owns its fix-up task
-        if (lane == 0) p.long_list[atomicAdd(p.long_count, 1)] = c;
-    }
+    if (head_open) store_partial(true);                 // middle or closing piece of a long row
+    else if (tail_open) store_partial(false);           // first piece of a LONG row that continues
     else store_final(cur, cnt);
 }
 
@@ -319,17 +346,19 @@ constexpr int kFixGridLong = 512;
 
 template <typename T, int VEC, int NT, int RCLS, bool LONG>
 __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_kernel(AggParams p) {
-    using V = VecT<T, VEC>;
+    using A = typename AccT<T>::type;
+    using V = VecT<A, VEC>;     // partials are stored in the accumulator type
+    using VO = VecT<T, VEC>;
     constexpr int NW = LONG ? kFixWaves : 1;
-    __shared__ T red[LONG ? kFixWaves : 1][LONG ? NT * kWave * VEC : 1];
+    __shared__ A red[LONG ? kFixWaves : 1][LONG ? NT * kWave * VEC : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
     const cptr<int> rowp = as_const(p.row);
     const cptr<int64_t> ip = as_const(p.indptr);
     const bool is_max = p.is_max != 0;
-    const T* __restrict__ ph = static_cast<const T*>(p.part_head);
-    const T* __restrict__ pt = static_cast<const T*>(p.part_tail);
-    auto comb = [&](T x, T y) -> T {
+    const A* __restrict__ ph = static_cast<const A*>(p.part_head);
+    const A* __restrict__ pt = static_cast<const A*>(p.part_tail);
+    auto comb = [&](A x, A y) -> A {
         if constexpr (RCLS == 0) return x + y;
         else return is_max ? (y > x ? y : x) : (y < x ? y : x);
     };
@@ -353,7 +382,7 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
                 continue;
             }
         }
-        T acc[NT][VEC];
+        A acc[NT][VEC];
         if constexpr (!LONG) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
@@ -389,7 +418,7 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[t][k] = RCLS == 0 ? T(0) : (is_max ? Limits<T>::lo() : Limits<T>::hi());
+                for (int k = 0; k < VEC; ++k) acc[t][k] = RCLS == 0 ? A(0) : (is_max ? Limits<A>::lo() : Limits<A>::hi());
             constexpr int UF = 8;
             int c = a + 1 + wib;
             for (; c + (UF - 1) * NW <= b; c += UF * NW) {
@@ -431,7 +460,7 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
                     const V tv = *reinterpret_cast<const V*>(pt + (int64_t)a * p.tile_cols + j0[t]);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) {
-                        T sv = tv.v[k];
+                        A sv = tv.v[k];
 #pragma unroll
                         for (int w = 0; w < NW; ++w) sv = comb(sv, red[w][(t * kWave + lane) * VEC + k]);
                         acc[t][k] = sv;
@@ -445,22 +474,25 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (act[t]) {
-                V o;
+                A ov[VEC];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    T v = acc[t][k];
+                    A v = acc[t][k];
                     if constexpr (RCLS == 0) {
-                        if (p.is_mean) v = v / (T)(re - rs);
-                        if constexpr (std::is_floating_point_v<T>) { if (p.dst_scale) v = v * (T)ds; }
+                        if (p.is_mean) v = v / (A)(re - rs);
+                        if constexpr (std::is_floating_point_v<A>) { if (p.dst_scale) v = v * (A)ds; }
                     }
-                    o.v[k] = v;
+                    ov[k] = v;
                 }
                 if (p.accumulate) {
-                    const V old = *reinterpret_cast<const V*>(dst + j0[t]);
+                    const VO old = *reinterpret_cast<const VO*>(dst + j0[t]);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) o.v[k] = comb(old.v[k], o.v[k]);
+                    for (int k = 0; k < VEC; ++k) ov[k] = comb(to_acc<T>(old.v[k]), ov[k]);
                 }
-                *reinterpret_cast<V*>(dst + j0[t]) = o;
+                VO o;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
+                *reinterpret_cast<VO*>(dst + j0[t]) = o;
             }
     }
 }
@@ -492,6 +524,7 @@ __global__ __launch_bounds__(kBlock) void zero_empty_rows_kernel(const int64_t* 
 // One wave per destination row, lanes stride over output columns, edges serial.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx) {
+    using A = typename AccT<T>::type;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= p.out_rows) return;
@@ -503,24 +536,25 @@ __global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx
     if (r < n_csr) { s = p.indptr[r]; t = p.indptr[r + 1]; }
     const bool additive = !(p.is_max == 1 || p.is_max == 2);
     for (int j = lane; j < p.tile_cols; j += kWave) {
-        T acc = T(0);
+        A acc = A(0);
         for (int64_t q = s; q < t; ++q) {
             const int cc = p.col ? p.col[q] : (int)q;
-            T m = x[(int64_t)cc * p.ldx + j / gx];
+            A m = to_acc<T>(x[(int64_t)cc * p.ldx + j / gx]);
             if (y) {
                 const int64_t yy = p.eid ? p.eid[q] : q;
-                m = apply_mop(m, y[yy * p.ldy + j / p.gy], p.mop);
+                m = apply_mop(m, to_acc<T>(y[yy * p.ldy + j / p.gy]), p.mop);
             }
             if (additive) acc += m;
             else if (q == s) acc = m;
             else if (p.is_max == 1) acc = m > acc ? m : acc;
             else acc = m < acc ? m : acc;
         }
-        if (additive && p.is_mean && t > s) acc = acc / (T)(t - s);
+        if (additive && p.is_mean && t > s) acc = acc / (A)(t - s);
         if (p.accumulate) {
-            if (t > s) out[j] = additive ? out[j] + acc : (p.is_max == 1 ? (acc > out[j] ? acc : out[j]) : (acc < out[j] ? acc : out[j]));
+            const A ol = to_acc<T>(out[j]);
+            if (t > s) out[j] = from_acc<T>(additive ? ol + acc : (p.is_max == 1 ? (acc > ol ? acc : ol) : (acc < ol ? acc : ol)));
         } else {
-            out[j] = acc;
+            out[j] = from_acc<T>(acc);
         }
     }
 }
@@ -547,7 +581,8 @@ struct ProfileState {
 };
 static ProfileState& prof() { static ProfileState s; return s; }
 template <typename T> static const char* type_name() {
-    return std::is_same_v<T, float> ? "float" : std::is_same_v<T, double> ? "double" : std::is_same_v<T, int32_t> ? "int" : "long";
+    return std::is_same_v<T, float> ? "float" : std::is_same_v<T, double> ? "double" : std::is_same_v<T, int32_t> ? "int" :
+           std::is_same_v<T, int64_t> ? "long" : std::is_same_v<T, __half> ? "__half" : "__hip_bfloat16";
 }
 template <typename T> static std::string kernel_name(int vec, int nt, int rcls, int ymode) {
     char b[96];
@@ -569,7 +604,15 @@ static int32_t launch_flat(AggParams p, hipStream_t st) {
         PGLAMD_HIP_CHECK(hipEventCreate(&e1));
         PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    constexpr bool can_scale = RCLS == 0 && std::is_floating_point_v<typename AccT<T>::type>;
+    if constexpr (can_scale) {
+        if (p.src_scale)
+            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+        else
+            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    }
     PGLAMD_LAUNCH_CHECK();
     if (prof().on) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
@@ -589,7 +632,7 @@ static int32_t dispatch_mode(const AggParams& p, int rcls, int ymode, hipStream_
     *handled = true;
     if (rcls == 0) {
         if (ymode == 0) return launch_flat<T, VEC, NT, 0, 0>(p, st);
-        if constexpr (std::is_floating_point_v<T>) {
+        if constexpr (std::is_floating_point_v<T>) {      // fp32 / fp64 only: 16-bit and integer operands take the generic path
             if (ymode == 1) return launch_flat<T, VEC, NT, 0, 1>(p, st);
             if (ymode == 2) return launch_flat<T, VEC, NT, 0, 2>(p, st);
         }
@@ -604,7 +647,25 @@ static int32_t dispatch_mode(const AggParams& p, int rcls, int ymode, hipStream_
 template <typename T>
 static int32_t dispatch_shape(const AggParams& p, int vec, int rcls, int ymode, hipStream_t st, bool* handled) {
     const int w = p.tile_cols;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 2) {
+        if (vec >= 8) {
+            if (w <= 512) return dispatch_mode<T, 8, 1>(p, rcls, ymode, st, handled);
+            return dispatch_mode<T, 8, 2>(p, rcls, ymode, st, handled);
+        }
+        if (vec == 4) {
+            if (w <= 256) return dispatch_mode<T, 4, 1>(p, rcls, ymode, st, handled);
+            if (w <= 512) return dispatch_mode<T, 4, 2>(p, rcls, ymode, st, handled);
+            return dispatch_mode<T, 4, 4>(p, rcls, ymode, st, handled);
+        }
+        if (vec == 2) {
+            if (w <= 128) return dispatch_mode<T, 2, 1>(p, rcls, ymode, st, handled);
+            if (w <= 256) return dispatch_mode<T, 2, 2>(p, rcls, ymode, st, handled);
+            return dispatch_mode<T, 2, 4>(p, rcls, ymode, st, handled);
+        }
+        if (w <= 64) return dispatch_mode<T, 1, 1>(p, rcls, ymode, st, handled);
+        if (w <= 128) return dispatch_mode<T, 1, 2>(p, rcls, ymode, st, handled);
+        return dispatch_mode<T, 1, 4>(p, rcls, ymode, st, handled);
+    } else if constexpr (sizeof(T) == 4) {
         if (vec >= 4) {
             if (w <= 256) return dispatch_mode<T, 4, 1>(p, rcls, ymode, st, handled);
             if (w <= 512) return dispatch_mode<T, 4, 2>(p, rcls, ymode, st, handled);
@@ -630,7 +691,9 @@ static int32_t dispatch_shape(const AggParams& p, int vec, int rcls, int ymode, 
     }
 }
 
-template <typename T> static int max_vec() { return sizeof(T) == 4 ? 4 : 2; }
+template <typename T> static int max_vec() { return sizeof(T) == 2 ? 8 : sizeof(T) == 4 ? 4 : 2; }
+// columns one launch covers: 64 lanes x VEC x NT(max)
+template <typename T> static int max_tiles(int vec) { return (sizeof(T) == 2 && vec == 8) ? 2 : 4; }
 
 static int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_rows, void* out,
                                size_t row_bytes, hipStream_t st) {
@@ -698,18 +761,18 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
         static const int forced = [] { const char* e = getenv("PGLAMD_VEC"); return e ? atoi(e) : 0; }();
         if (forced >= 1 && forced <= vmax && (forced & (forced - 1)) == 0) vec = forced;
     }
-    p.zvec = vec;
+    p.zvec = vec > 4 ? 4 : vec;
     { static const int al = [] { const char* e = getenv("PGLAMD_ALIGN"); return e ? atoi(e) : 1; }(); p.align = al; }
-    if ((src_scale || dst_scale) && (rcls != 0 || !std::is_floating_point_v<T>))
+    if ((src_scale || dst_scale) && (rcls != 0 || !std::is_floating_point_v<typename AccT<T>::type>))
         return fail(PGLAMD_E_ARG, "src_scale/dst_scale need a floating dtype and sum/mean");
 
     if (fast) {
         const int K = chunk_edges();
         p.chunk = K;
         p.n_chunks = (int)ceil_div(E, K);
-        const int max_cols = kWave * vec * 4;
+        const int max_cols = kWave * vec * max_tiles<T>(vec);
         const int64_t tile_full = dout < max_cols ? dout : max_cols;
-        const size_t half = align_up((size_t)p.n_chunks * tile_full * sizeof(T), 256);
+        const size_t half = align_up((size_t)p.n_chunks * tile_full * sizeof(typename AccT<T>::type), 256);
         const size_t lst = align_up((size_t)(p.n_chunks + 64) * sizeof(int), 256);
         const size_t need = 2 * half + 2 * lst;
         if (!ws || ws_bytes < need) return fail(PGLAMD_E_WORKSPACE, "aggregate: workspace %zu < %zu", ws_bytes, need);
@@ -742,12 +805,12 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
 using namespace pglamd;
 
 extern "C" size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t dout, int32_t dtype) {
-    const size_t es = dtype_size(dtype);
+    size_t es = dtype_size(dtype);
     if (es == 0 || num_edges <= 0) return 256;
     const int64_t n_chunks = ceil_div(num_edges, chunk_edges());
-    const int max_vec_ = es == 4 ? 4 : 2;
-    const int64_t max_cols = (int64_t)kWave * max_vec_ * 4;
+    const int64_t max_cols = 1024;                      // widest tile any (VEC, NT) pair covers
     const int64_t tile = dout < max_cols ? dout : max_cols;
+    if (es == 2) es = 4;                                // 16-bit floats keep fp32 partials
     return 2 * align_up((size_t)n_chunks * tile * es, 256) + 2 * align_up((size_t)(n_chunks + 64) * sizeof(int), 256) + 256;
 }
 
@@ -774,7 +837,9 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
         case PGLAMD_F64: return CALL(double);
         case PGLAMD_I32: return CALL(int32_t);
         case PGLAMD_I64: return CALL(int64_t);
-        default: return fail(PGLAMD_E_DTYPE, "aggregate: dtype %d not supported (F32/F64/I32/I64)", dtype);
+        case PGLAMD_F16: return CALL(__half);
+        case PGLAMD_BF16: return CALL(__hip_bfloat16);
+        default: return fail(PGLAMD_E_DTYPE, "aggregate: dtype %d not supported", dtype);
     }
 #undef CALL
 }

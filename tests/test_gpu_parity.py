@@ -568,3 +568,25 @@ def test_gatconv_eval_uses_fused_path_and_matches_training_path(pgl):
         fused = gat(g, x)
     unfused = gat(g, x.clone().requires_grad_(True))            # needs grad -> unfused composite
     close(host(fused), host(unfused.detach()), scale=float(unfused.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# 16-bit feature storage, fp32 accumulation (BASELINE config 5: "fp16 features")
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("op", ["sum", "mean", "max"])
+@pytest.mark.parametrize("d", [128, 64, 100, 7, 1024])
+def test_send_recv_16bit_storage_fp32_accumulate(pgl, tdt, op, d):
+    n, e = 3000, 45000
+    edges, rng = rand_graph(n, e, 600 + d, hub=4000)
+    x32 = rng.standard_normal((n, d)).astype(np.float32)
+    xt = torch.from_numpy(x32).to(tdt).cuda()
+    xq = xt.float().cpu().numpy()                       # the values the kernel actually reads
+    want = torch.from_numpy(R.c_send_u_recv(xq, edges[:, 0], edges[:, 1], op)).to(tdt).float().numpy()
+    got = pgl.Graph(edges=edges, num_nodes=n).tensor().send_recv(xt, op)
+    assert got.dtype == tdt
+    eps = 2.0 ** -10 if tdt == torch.float16 else 2.0 ** -7         # one ulp of the storage type (+ fp32 reassociation)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want, rtol=eps, atol=eps * np.abs(want).max() * 0.05)
+    empty = np.setdiff1d(np.arange(n), edges[:, 1])
+    if len(empty):
+        assert float(got[torch.from_numpy(empty).cuda()].float().abs().max()) == 0.0
