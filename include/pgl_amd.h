@@ -206,12 +206,34 @@ int32_t pglamd_segment_softmax(const void* data, int32_t dtype, int64_t num_rows
  * the reference's two-pass evaluation only by fp32 rounding (tests: <= 1e-5 relative on out).
  * ---------------------------------------------------------------------------------------------- */
 size_t pglamd_gat_aggregate_workspace_bytes(int64_t num_edges, int64_t heads, int64_t head_dim);
+/* drop_p in [0,1): attention dropout applied to alpha (pgl/nn/conv.py:337-338) as a counter-based
+ * hash of (seed, original edge id, head); needs eid (dst-sorted sorted_eid) when drop_p > 0. */
 int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const float* attn_dst,
-                             int64_t heads, int64_t head_dim, float negative_slope,
-                             const int32_t* row, const int32_t* col, const int64_t* indptr,
-                             int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, float* out,
-                             float* row_max, float* row_sum, void* workspace, size_t workspace_bytes,
-                             void* stream);
+                             int64_t heads, int64_t head_dim, float negative_slope, float drop_p,
+                             uint32_t seed, const int32_t* row, const int32_t* col,
+                             const int32_t* eid, const int64_t* indptr, int64_t num_edges,
+                             int64_t n_csr_rows, int64_t out_rows, float* out, float* row_max,
+                             float* row_sum, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of pglamd_gat_aggregate (row "next" f1: fused backward), alpha recomputed per edge from
+ * the forward's statistics, nothing of size [E,H,D] is materialised:
+ *   grad_feature[u,h,:] = sum_{e=(u->v)} drop_e alpha_e grad_out[v,h,:]          (src-sorted walk)
+ *   grad_pre[e,h]       = d loss / d (attn_src[u,h] + attn_dst[v,h])  in ORIGINAL edge order;
+ *                         grad attn_src / attn_dst are its segment sums by src / dst, which the
+ *                         caller takes with two pglamd_aggregate calls (x = grad_pre, col = eid).
+ *   t [N,H]             = sum_d grad_out[v,h,d] * out[v,h,d], supplied by the caller.
+ *   dst_* / src_*       the dst-sorted and src-sorted CSRs (int32 row / col / eid, int64 indptr).
+ * Workspace: pglamd_gat_aggregate_workspace_bytes.  Same shape limits as the forward, and
+ * head_dim / VEC must be a power of two (per-head dot products are shuffle reductions). */
+int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const float* attn_src,
+                            const float* attn_dst, const float* row_max, const float* row_sum,
+                            const float* t, int64_t heads, int64_t head_dim, float negative_slope,
+                            float drop_p, uint32_t seed, const int32_t* dst_row,
+                            const int32_t* dst_col, const int32_t* dst_eid, const int32_t* src_row,
+                            const int32_t* src_col, const int32_t* src_eid,
+                            const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
+                            float* grad_feature, float* grad_pre, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* K4'  segment boundaries from sorted ids: seg_ptr[n_seg+1] (int64), n_seg = ids[E-1]+1 given by
  * the caller.  Used when segment_softmax is called with raw ids (pgl.math API). */

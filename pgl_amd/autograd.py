@@ -242,6 +242,31 @@ def segment_softmax(data, view):
     return ops.segment_softmax(data, view)
 
 
+class _GatAttention(torch.autograd.Function):
+    """Fused GAT attention aggregation (forward: one pass, online softmax; backward: alpha recomputed
+    from the saved per-row statistics).  Attention dropout is regenerated from (seed, edge id, head)."""
+
+    @staticmethod
+    def forward(ctx, feature, attn_src, attn_dst, csr_dst, csr_src_fn, slope, drop_p, seed):
+        out, mx, sm = ops.gat_aggregate(feature, attn_src, attn_dst, csr_dst, slope, None, True, drop_p, seed)
+        ctx.csr_dst, ctx.csr_src_fn, ctx.slope, ctx.drop_p, ctx.seed = csr_dst, csr_src_fn, slope, drop_p, seed
+        ctx.save_for_backward(feature, attn_src, attn_dst, out, mx, sm)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        feature, a_s, a_d, out, mx, sm = ctx.saved_tensors
+        gf, gs, gd = ops.gat_backward(grad, feature, out, a_s, a_d, mx, sm, ctx.csr_dst, ctx.csr_src_fn(), ctx.slope,
+                                      ctx.drop_p, ctx.seed)
+        return gf, gs, gd, None, None, None, None, None
+
+
+def gat_attention(feature, attn_src, attn_dst, csr_dst, csr_src_fn, slope=0.2, drop_p=0.0, seed=0):
+    if torch.is_grad_enabled() and (feature.requires_grad or attn_src.requires_grad or attn_dst.requires_grad):
+        return _GatAttention.apply(feature, attn_src, attn_dst, csr_dst, csr_src_fn, slope, drop_p, seed)
+    return ops.gat_aggregate(feature, attn_src, attn_dst, csr_dst, slope, None, False, drop_p, seed)
+
+
 class _ScatterRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n_rows, index, x):

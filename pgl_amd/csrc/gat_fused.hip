@@ -1,38 +1,66 @@
-// gat_fused.hip -- K3+K4+K2 in ONE pass over the edges: the whole attention aggregation of GATConv
-// (pgl/nn/conv.py:331-339):
-//     alpha = send_uv(a_src, a_dst, "add") ; leaky_relu ; edge_softmax (by dst) ; send_ue_recv(f, alpha, "mul", "sum")
-// i.e.  out[v, h, :] = sum_{e=(u->v)} softmax_v( leaky(a_src[u,h] + a_dst[v,h]) ) * f[u, h, :]
+// gat_fused.hip -- the whole attention aggregation of GATConv (pgl/nn/conv.py:331-339), forward AND
+// backward, without ever materialising an [E,H] tensor:
+//     alpha = send_uv(a_src, a_dst, "add") ; leaky_relu ; edge_softmax(by dst) ; dropout ;
+//     out   = send_ue_recv(f, alpha, "mul", "sum")
+// i.e.  out[v,h,:] = sum_{e=(u->v)} drop_e * softmax_v( leaky(a_src[u,h] + a_dst[v,h]) ) * f[u,h,:]
 //
-// The reference materialises four [E,H] tensors and makes ~14 passes over them.  Here
-// the logits never exist in memory: each wave walks its fixed-size chunk of the dst-sorted edge
-// stream (same geometry as agg_flat_kernel) carrying an ONLINE softmax state per lane
-// (running max m, running sum s, running weighted row acc; flash-attention style rescaling), so
-// HBM traffic is one gather of f[u] (H*D*4 B) + a_src[u] (H*4 B) + 8 B of index per edge and one
-// write of the output row: the byte count of a plain SpMM + 6 %.
-// Rows that straddle chunk boundaries leave (acc, m, s) partials that a second kernel merges in a
-// fixed order with the associative softmax merge  (m, s, a) + (m', s', a') =
-// (M = max(m, m'), s e^{m-M} + s' e^{m'-M}, a e^{m-M} + a' e^{m'-M}):  atomic-free, bit-reproducible.
+// The reference materialises four [E,H] tensors and makes ~14 passes over them.
+//
+// FORWARD (gat_flat_kernel<VEC, 0>): each wave walks its chunk of the dst-sorted edge stream (same
+//   geometry as agg_flat_kernel: scalar index loads, lanes across the H*D columns, 8 edges in
+//   flight, double buffered) carrying an ONLINE softmax state per lane (running max m, running sum
+//   s, running weighted row acc -- flash-attention style rescaling).  HBM traffic = one gather of
+//   f[u] (H*D*4 B) + a_src[u] (H*4 B) + 8 B of index per edge + one output row: a plain SpMM + 6 %.
+//   The per-row statistics (m, s) are optionally written out ([N,H] each): they are all a backward
+//   pass needs to recompute alpha_e = exp(leaky(a_src[u]+a_dst[v]) - m[v]) / s[v] on the fly.
+// BACKWARD
+//   d f[u]      = sum_{e=(u->v)} drop_e alpha_e g[v]          gat_flat_kernel<VEC, 1> over the SRC-sorted
+//                                                              stream, alpha recomputed per edge
+//   d logit_e   = alpha_e (drop_e <g[v], f[u]>_h - t[v,h]),   t[v,h] = <g[v,h,:], out[v,h,:]>
+//   d pre_e     = d logit_e * (pre_e > 0 ? 1 : slope)          gat_bwd_edge_kernel (dst-sorted stream),
+//                 written to [E,H] in ORIGINAL edge order; d a_src / d a_dst are its segment sums by
+//                 src / dst (two small pglamd_aggregate calls made by the caller).
+// Attention dropout is a counter-based hash of (seed, original edge id, head): forward and both
+// backward kernels regenerate the same mask, nothing is stored.
+// Rows longer than a chunk leave partials merged in a fixed order by gat_fixup_kernel (associative
+// softmax merge, or plain sums for the backward): atomic-free, bit-reproducible.
 #include "common.hpp"
 
 namespace pglamd {
 
 struct GatParams {
-    const float* x; const float* a_src; const float* a_dst; float* out;
-    float* row_max; float* row_sum;              // optional [out_rows, H] softmax statistics (NULL to skip)
-    const int* row; const int* col; const int64_t* indptr;
-    float* part_head; float* part_tail;          // [n_chunks, 3, d]: acc | m | s (m, s replicated per column)
-    int* long_count; int* long_list; int* long_list2;   // [2] counters + two-level fix-up work lists
+    const float* x;                 // gathered by col: f (forward) or g = dL/dout (backward-feature)
+    const float* p_col;             // per-col scalar [*,H]: a_src (forward) / a_dst (backward-feature)
+    const float* p_row;             // per-row scalar [*,H]: a_dst (forward) / a_src (backward-feature)
+    const float* stat_m; const float* stat_s;   // backward: softmax statistics of the dst node [N,H]
+    float* out;
+    float* row_max; float* row_sum;             // forward: optional statistics output [out_rows,H]
+    const int* row; const int* col; const int* eid; const int64_t* indptr;
+    float* part_head; float* part_tail;         // [n_chunks, 3, d]: acc | m | s (forward) ; [n_chunks, d] (backward)
+    int* long_count; int* long_list; int* long_list2;
     int64_t out_rows, n_csr_rows;
     int E, n_chunks, chunk, n_blocks, n_grid_chunks;
     int d, H, D;
-    float slope;
+    float slope, drop_p, drop_scale;
+    unsigned seed;
+    // backward-edge only
+    const float* f; const float* g; const float* t; float* dpre;
 };
 
 template <int VEC> struct alignas(4 * VEC) FV { float v[VEC]; };
 
-template <int VEC>
+// keep-mask of attention dropout: stateless hash of (seed, original edge id, head) -> [0,1)
+__device__ __forceinline__ float drop_factor(unsigned seed, int eid, int head, float p, float scale) {
+    unsigned h = seed ^ ((unsigned)eid * 0x9E3779B1u) ^ ((unsigned)head * 0x85EBCA77u + 0xC2B2AE3Du);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return ((h >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
+}
+
+// MODE 0: forward (online softmax).  MODE 1: backward w.r.t. features (additive, alpha recomputed).
+template <int VEC, int MODE, bool DROP>
 __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     constexpr int U = 8;
+    constexpr int PW = MODE == 0 ? 3 : 1;               // floats per column in a partial
     using V = FV<VEC>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
@@ -40,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     const bool act = j0 < p.d;
     const int head = act ? j0 / p.D : 0;
 
-    if ((int)blockIdx.x >= p.n_grid_chunks) {           // zero-fill role: rows with no in-edge
+    if ((int)blockIdx.x >= p.n_grid_chunks) {           // zero-fill role: rows that receive no edge
         const int64_t w = ((int64_t)blockIdx.x - p.n_grid_chunks) * kWavesPerBlock + wib;
         const int64_t r0 = w * kWave;
         if (r0 >= p.out_rows) return;
@@ -52,7 +80,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             const int l = __builtin_ctzll(mk);
             mk &= mk - 1;
             if (act) *reinterpret_cast<V*>(p.out + (r0 + l) * p.d + j0) = V{};
-            if (p.row_max && lane < p.H) { p.row_max[(r0 + l) * p.H + lane] = 0.f; p.row_sum[(r0 + l) * p.H + lane] = 0.f; }
+            if (MODE == 0 && p.row_max && lane < p.H) { p.row_max[(r0 + l) * p.H + lane] = 0.f; p.row_sum[(r0 + l) * p.H + lane] = 0.f; }
         }
         return;
     }
@@ -62,126 +90,147 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     if (c >= p.n_chunks) return;
     const cptr<int> rowp = as_const(p.row);
     const cptr<int> colp = as_const(p.col);
+    const cptr<int> eidp = as_const(p.eid);
     const int e0 = chunk_cut(rowp, as_const(p.indptr), c * p.chunk, p.chunk, p.E);
     const int e1 = chunk_cut(rowp, as_const(p.indptr), c * p.chunk + p.chunk, p.chunk, p.E);
     if (e0 >= e1) return;
     const float* __restrict__ x = p.x;
-    const float* __restrict__ asrc = p.a_src;
+    const float* __restrict__ pcol = p.p_col;
+    const float* __restrict__ prow = p.p_row;
+    const float* __restrict__ sm = p.stat_m;
+    const float* __restrict__ ss = p.stat_s;
     const float slope = p.slope;
+    constexpr bool drop = DROP;
 
     float m = -INFINITY, s = 0.f, acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
     int cur = rowp[e0];
     bool head_open = e0 > 0 && rowp[e0 - 1] == cur;
-    const float* __restrict__ adst = p.a_dst;
 
-    auto store_partial = [&](float* base) {
-        if (!act) return;
-        float* dst = base + (int64_t)c * 3 * p.d;
-        V o;
+    auto store_partial = [&](bool headp) {
+        if (act) {
+            float* dst = (headp ? p.part_head : p.part_tail) + (int64_t)c * PW * p.d;
+            V o;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
-        *reinterpret_cast<V*>(dst + j0) = o;
+            for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
+            *reinterpret_cast<V*>(dst + j0) = o;
+            if constexpr (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o.v[k] = m;
-        *reinterpret_cast<V*>(dst + p.d + j0) = o;
+                for (int k = 0; k < VEC; ++k) o.v[k] = m;
+                *reinterpret_cast<V*>(dst + p.d + j0) = o;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o.v[k] = s;
-        *reinterpret_cast<V*>(dst + 2 * p.d + j0) = o;
+                for (int k = 0; k < VEC; ++k) o.v[k] = s;
+                *reinterpret_cast<V*>(dst + 2 * p.d + j0) = o;
+            }
+        }
+        if (!headp && lane == 0) p.long_list[atomicAdd(p.long_count, 1)] = c;
     };
     auto store_final = [&](int r) {
         if (r >= p.out_rows || !act) return;
         V o;
-        const float inv = 1.f / s;
+        const float inv = MODE == 0 ? 1.f / s : 1.f;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o.v[k] = acc[k] * inv;
         *reinterpret_cast<V*>(p.out + (int64_t)r * p.d + j0) = o;
-        if (p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + head] = m; p.row_sum[(int64_t)r * p.H + head] = s; }
+        if (MODE == 0 && p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + head] = m; p.row_sum[(int64_t)r * p.H + head] = s; }
     };
-    // a_dst[row] rides along with every edge of the batch (an L1/L2 hit after the first edge of a
-    // row) instead of being fetched on the row change, which would stall the wave once per row.
-    auto consume = [&](int r, float as_val, float ad, const V& xv) {
+    // per-row scalars ride along with every edge of the batch (an L1/L2 hit after the first edge of
+    // a row) instead of being fetched on the row change, which would stall the wave once per row.
+    auto consume = [&](int r, int ed, float vc, float vr, float vm, float vs, const V& xv) {
         if (r != cur) {
-            if (head_open) store_partial(p.part_head); else store_final(cur);
+            if (head_open) store_partial(true); else store_final(cur);
             head_open = false;
             cur = r;
             m = -INFINITY; s = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
         }
-        float l = as_val + ad;
+        float l = vc + vr;
         l = l > 0.f ? l : slope * l;
-        const float mn = fmaxf(m, l);
-        const float sc = expf(m - mn);          // m = -inf on the first edge of a row: e^{-inf} = 0
-        const float pe = expf(l - mn);
-        s = s * sc + pe;
+        const float df = drop ? drop_factor(p.seed, ed, head, p.drop_p, p.drop_scale) : 1.f;
+        if constexpr (MODE == 0) {
+            const float mn = fmaxf(m, l);
+            const float sc = expf(m - mn);          // m = -inf on the first edge of a row: e^{-inf} = 0
+            const float pe = expf(l - mn);
+            s = s * sc + pe;
+            const float w = pe * df;
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * sc + pe * xv.v[k];
-        m = mn;
-    };
-    auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U]) {
+            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * sc + w * xv.v[k];
+            m = mn;
+        } else {
+            const float w = expf(l - vm) / vs * df;  // alpha_e of the destination's softmax, recomputed
 #pragma unroll
-        for (int i = 0; i < U; ++i) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; }
+            for (int k = 0; k < VEC; ++k) acc[k] += w * xv.v[k];
+        }
     };
-    auto load_rows = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], float (&va)[U], float (&vd)[U]) {
+    auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U], int (&ee)[U]) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; ee[i] = drop ? eidp[e + i] : 0; }
+    };
+    auto load_rows = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], float (&vc)[U], float (&vr)[U], float (&vm)[U], float (&vs)[U]) {
 #pragma unroll
         for (int i = 0; i < U; ++i)
             if (act) {
                 vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc[i] * p.d + j0);
-                va[i] = asrc[(int64_t)cc[i] * p.H + head];
-                vd[i] = adst[(int64_t)rr[i] * p.H + head];
+                vc[i] = pcol[(int64_t)cc[i] * p.H + head];
+                vr[i] = prow[(int64_t)rr[i] * p.H + head];
+                if constexpr (MODE == 1) { vm[i] = sm[(int64_t)cc[i] * p.H + head]; vs[i] = ss[(int64_t)cc[i] * p.H + head]; }
             }
     };
 
     int e = e0;
     const int n_full = (e1 - e0) / U;
-    int cA[U], rA[U]; V xA[U]; float aA[U], dA[U];
-    if (n_full > 0) { load_idx(e, cA, rA); load_rows(cA, rA, xA, aA, dA); }
+    int cA[U], rA[U], eA[U]; V xA[U]; float vcA[U], vrA[U], vmA[U], vsA[U];
+    if (n_full > 0) { load_idx(e, cA, rA, eA); load_rows(cA, rA, xA, vcA, vrA, vmA, vsA); }
     for (int g = 0; g < n_full; ++g) {
-        int cB[U], rB[U]; V xB[U]; float aB[U], dB[U];
+        int cB[U], rB[U], eB[U]; V xB[U]; float vcB[U], vrB[U], vmB[U], vsB[U];
         const bool more = g + 1 < n_full;
-        if (more) { load_idx(e + U, cB, rB); load_rows(cB, rB, xB, aB, dB); }
+        if (more) { load_idx(e + U, cB, rB, eB); load_rows(cB, rB, xB, vcB, vrB, vmB, vsB); }
 #pragma unroll
-        for (int i = 0; i < U; ++i) consume(rA[i], aA[i], dA[i], xA[i]);
+        for (int i = 0; i < U; ++i) consume(rA[i], eA[i], vcA[i], vrA[i], vmA[i], vsA[i], xA[i]);
         if (more) {
 #pragma unroll
-            for (int i = 0; i < U; ++i) { rA[i] = rB[i]; xA[i] = xB[i]; aA[i] = aB[i]; dA[i] = dB[i]; }
+            for (int i = 0; i < U; ++i) {
+                rA[i] = rB[i]; eA[i] = eB[i]; xA[i] = xB[i]; vcA[i] = vcB[i]; vrA[i] = vrB[i];
+                if constexpr (MODE == 1) { vmA[i] = vmB[i]; vsA[i] = vsB[i]; }
+            }
         }
         e += U;
     }
     for (; e < e1; ++e) {
         const int r = rowp[e], cc = colp[e];
-        V xv{}; float av = 0.f, dv = 0.f;
+        const int ed = drop ? eidp[e] : 0;
+        V xv{}; float vc = 0.f, vr = 0.f, vm = 0.f, vs = 1.f;
         if (act) {
             xv = *reinterpret_cast<const V*>(x + (int64_t)cc * p.d + j0);
-            av = asrc[(int64_t)cc * p.H + head];
-            dv = adst[(int64_t)r * p.H + head];
+            vc = pcol[(int64_t)cc * p.H + head];
+            vr = prow[(int64_t)r * p.H + head];
+            if constexpr (MODE == 1) { vm = sm[(int64_t)cc * p.H + head]; vs = ss[(int64_t)cc * p.H + head]; }
         }
-        consume(r, av, dv, xv);
+        consume(r, ed, vc, vr, vm, vs, xv);
     }
     const bool tail_open = e1 < p.E && rowp[e1] == cur;
-    if (head_open) store_partial(p.part_head);
-    else if (tail_open) {
-        store_partial(p.part_tail);
-        if (lane == 0) p.long_list[atomicAdd(p.long_count, 1)] = c;
-    } else store_final(cur);
+    if (head_open) store_partial(true);
+    else if (tail_open) store_partial(false);
+    else store_final(cur);
 }
 
-// merges the (acc, m, s) partials of the rows longer than a chunk (only those are split), from the
-// work list the flat kernel filled.  Pass 1 (LONG = false): one wave per task, rows with <= 16
-// partials are merged right there, longer ones go to a second list.  Pass 2 (LONG = true): 1024-thread
-// blocks, 16 waves split one hub row's partial list, LDS combine in wave order.  The softmax merge is
-// associative; every row's own merge order is fixed => bit-reproducible.
+// merges the partials of the rows longer than a chunk (only those are split), from the work list
+// the flat kernel filled.  Pass 1 (LONG = false): one wave per task, rows with <= 16 partials are
+// merged right there, longer ones go to a second list.  Pass 2 (LONG = true): 1024-thread blocks, 16
+// waves split one hub row's partial list, LDS combine in wave order.  Every row's own merge order is
+// fixed => bit-reproducible.
 constexpr int kGatFixShort = 16;
 constexpr int kGatFixWaves = 16;
 constexpr int kGatFixGridShort = 2048;
 constexpr int kGatFixGridLong = 512;
 
-template <int VEC, bool LONG>
+template <int VEC, bool LONG, int MODE>
 __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixup_kernel(GatParams p) {
     using V = FV<VEC>;
     constexpr int NW = LONG ? kGatFixWaves : 1;
+    constexpr int PW = MODE == 0 ? 3 : 1;
     __shared__ float red[LONG ? kGatFixWaves : 1][3][LONG ? kWave * VEC : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
@@ -205,29 +254,36 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
                 continue;
             }
         }
-        float m = -INFINITY, s = 0.f, acc[VEC];
+        float m = MODE == 0 ? -INFINITY : 0.f, s = 0.f, acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
         auto merge_vals = [&](const V& va, float m2, float s2) {
-            const float mn = fmaxf(m, m2);
-            const float c1 = expf(m - mn), c2 = expf(m2 - mn);
-            s = s * c1 + s2 * c2;
+            if constexpr (MODE == 0) {
+                const float mn = fmaxf(m, m2);
+                const float c1 = expf(m - mn), c2 = expf(m2 - mn);
+                s = s * c1 + s2 * c2;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * c1 + va.v[k] * c2;
-            m = mn;
+                for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * c1 + va.v[k] * c2;
+                m = mn;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += va.v[k];
+                s = 1.f;
+            }
         };
         auto merge = [&](const float* base) {
-            merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], base[2 * p.d + j0]);
+            if constexpr (MODE == 0) merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], base[2 * p.d + j0]);
+            else merge_vals(*reinterpret_cast<const V*>(base + j0), 0.f, 1.f);
         };
         if constexpr (!LONG) {
             if (act) {
-                merge(p.part_tail + (int64_t)a * 3 * p.d);
+                merge(p.part_tail + (int64_t)a * PW * p.d);
 #pragma unroll 4
-                for (int c = a + 1; c <= b; ++c) merge(p.part_head + (int64_t)c * 3 * p.d);
+                for (int c = a + 1; c <= b; ++c) merge(p.part_head + (int64_t)c * PW * p.d);
             }
         } else {
             if (act)
-                for (int c = a + 1 + wib; c <= b; c += NW) merge(p.part_head + (int64_t)c * 3 * p.d);
+                for (int c = a + 1 + wib; c <= b; c += NW) merge(p.part_head + (int64_t)c * PW * p.d);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < VEC; ++k) red[wib][0][lane * VEC + k] = acc[k];
@@ -235,11 +291,11 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
             __syncthreads();
             if (wib != 0) continue;
             // wave 0: tail partial of chunk a first, then the wave results in wave order
-            m = -INFINITY; s = 0.f;
+            m = MODE == 0 ? -INFINITY : 0.f; s = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
             if (act) {
-                merge(p.part_tail + (int64_t)a * 3 * p.d);
+                merge(p.part_tail + (int64_t)a * PW * p.d);
                 for (int w = 0; w < NW; ++w) {
                     const float s2 = red[w][2][lane * VEC];
                     if (s2 == 0.f) continue;                     // that wave had no partial
@@ -252,11 +308,89 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
         }
         if (!act || r >= p.out_rows) continue;
         V o;
-        const float inv = 1.f / s;
+        const float inv = MODE == 0 ? 1.f / s : 1.f;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o.v[k] = acc[k] * inv;
         *reinterpret_cast<V*>(p.out + (int64_t)r * p.d + j0) = o;
-        if (p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + j0 / p.D] = m; p.row_sum[(int64_t)r * p.H + j0 / p.D] = s; }
+        if (MODE == 0 && p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + j0 / p.D] = m; p.row_sum[(int64_t)r * p.H + j0 / p.D] = s; }
+    }
+}
+
+// d pre_e for every edge (dst-sorted walk, result scattered to ORIGINAL edge order):
+//   alpha_e = exp(l_e - m[v]) / s[v],  l_e = leaky(pre_e),  pre_e = a_src[u] + a_dst[v]
+//   d pre_e = alpha_e * (drop_e * <g[v,h,:], f[u,h,:]> - t[v,h]) * (pre_e > 0 ? 1 : slope)
+// Lanes span the H*D columns; the per-head dot product is a xor-shuffle reduction over the D/VEC
+// lanes of a head (a power of two); lane 0 of each head writes dpre[eid, h].
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(GatParams p) {
+    constexpr int U = 8;
+    using V = FV<VEC>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    const int j0 = lane * VEC;
+    const bool act = j0 < p.d;
+    const int lph = p.D / VEC;                           // lanes per head (power of two)
+    const int head = act ? j0 / p.D : 0;
+    const bool writer = act && (lane % lph) == 0;
+    const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
+    if (lb < 0) return;
+    const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
+    if (c >= p.n_chunks) return;
+    const int e0 = c * p.chunk, e1 = min(e0 + p.chunk, p.E);
+    const cptr<int> rowp = as_const(p.row);
+    const cptr<int> colp = as_const(p.col);
+    const cptr<int> eidp = as_const(p.eid);
+    const bool drop = p.drop_p > 0.f;
+    int cur = -1;
+    V gv{}; float ad = 0.f, mv = 0.f, sv = 1.f, tv = 0.f;
+    auto row_change = [&](int r) {
+        cur = r;
+        if (act) {
+            gv = *reinterpret_cast<const V*>(p.g + (int64_t)r * p.d + j0);
+            ad = p.p_row[(int64_t)r * p.H + head];
+            mv = p.stat_m[(int64_t)r * p.H + head];
+            sv = p.stat_s[(int64_t)r * p.H + head];
+            tv = p.t[(int64_t)r * p.H + head];
+        }
+    };
+    auto consume = [&](int r, int ed, float as_val, const V& fv) {
+        if (r != cur) row_change(r);
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dot += gv.v[k] * fv.v[k];
+        for (int off = 1; off < lph; off <<= 1) dot += __shfl_xor(dot, off);
+        const float pre = as_val + ad;
+        const float l = pre > 0.f ? pre : p.slope * pre;
+        const float alpha = expf(l - mv) / sv;
+        const float df = drop ? drop_factor(p.seed, ed, head, p.drop_p, p.drop_scale) : 1.f;
+        const float dl = alpha * (df * dot - tv);
+        if (writer) p.dpre[(int64_t)ed * p.H + head] = pre > 0.f ? dl : p.slope * dl;
+    };
+    auto load_batch = [&](int e, int nb, int (&rr)[U], int (&ee)[U], V (&fx)[U], float (&av)[U]) {
+        int cc[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+            if (i < nb) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; ee[i] = eidp[e + i]; }
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+            if (i < nb && act) {
+                fx[i] = *reinterpret_cast<const V*>(p.f + (int64_t)cc[i] * p.d + j0);
+                av[i] = p.p_col[(int64_t)cc[i] * p.H + head];
+            }
+    };
+    int rA[U], eA[U]; V fA[U]; float aA[U];
+    int nA = min(U, e1 - e0);
+    load_batch(e0, nA, rA, eA, fA, aA);
+    for (int e = e0; e < e1; e += U) {
+        int rB[U], eB[U]; V fB[U]; float aB[U];
+        const int nB = max(0, min(U, e1 - (e + U)));
+        if (nB > 0) load_batch(e + U, nB, rB, eB, fB, aB);          // next batch in flight while this one is consumed
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+            if (i < nA) consume(rA[i], eA[i], aA[i], fA[i]);
+#pragma unroll
+        for (int i = 0; i < U; ++i) { rA[i] = rB[i]; eA[i] = eB[i]; fA[i] = fB[i]; aA[i] = aB[i]; }
+        nA = nB;
     }
 }
 
@@ -270,22 +404,48 @@ static int gat_chunk_edges() {
     return k;
 }
 
-template <int VEC>
+template <int VEC, int MODE>
 static int32_t launch_gat(GatParams p, hipStream_t st) {
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
-    hipLaunchKernelGGL(gat_flat_kernel<VEC>, dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    if (p.drop_p > 0.f)
+        hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    else
+        hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (p.n_chunks > 1) {
-        hipLaunchKernelGGL((gat_fixup_kernel<VEC, false>), dim3(kGatFixGridShort), dim3(kBlock), 0, st, p);
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, false, MODE>), dim3(kGatFixGridShort), dim3(kBlock), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gat_fixup_kernel<VEC, true>), dim3(kGatFixGridLong), dim3(kGatFixWaves * kWave), 0, st, p);
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, true, MODE>), dim3(kGatFixGridLong), dim3(kGatFixWaves * kWave), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
     }
     return PGLAMD_OK;
+}
+
+// lane geometry: one 64-lane tile covers all H*D columns, VEC elements of ONE head per lane
+static int gat_vec(int64_t heads, int64_t head_dim, const void* a, const void* b, const void* c, bool need_pow2) {
+    const int64_t d = heads * head_dim;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
+    for (int v = 1; v <= 4; v <<= 1) {
+        if (d % v || head_dim % v || d / v > kWave || al % (4 * v)) continue;
+        const int64_t lph = head_dim / v;
+        if (need_pow2 && (lph & (lph - 1))) continue;
+        return v;
+    }
+    return 0;
+}
+
+static void gat_setup_partials(GatParams& p, void* workspace, int pw) {
+    const size_t half = align_up((size_t)p.n_chunks * pw * p.d * sizeof(float), 256);
+    const size_t lst = align_up((size_t)(p.n_chunks + 64) * sizeof(int), 256);
+    p.part_head = static_cast<float*>(workspace);
+    p.part_tail = reinterpret_cast<float*>(static_cast<char*>(workspace) + half);
+    p.long_count = reinterpret_cast<int*>(static_cast<char*>(workspace) + 2 * half);
+    p.long_list = p.long_count + 64;
+    p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(workspace) + 2 * half + lst);
 }
 
 }  // namespace pglamd
@@ -300,13 +460,14 @@ extern "C" size_t pglamd_gat_aggregate_workspace_bytes(int64_t num_edges, int64_
 }
 
 extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const float* attn_dst, int64_t heads,
-                                        int64_t head_dim, float negative_slope, const int32_t* row, const int32_t* col,
-                                        const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows, int64_t out_rows,
-                                        float* out, float* row_max, float* row_sum, void* workspace, size_t workspace_bytes,
-                                        void* stream) {
+                                        int64_t head_dim, float negative_slope, float drop_p, uint32_t seed,
+                                        const int32_t* row, const int32_t* col, const int32_t* eid, const int64_t* indptr,
+                                        int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, float* out, float* row_max,
+                                        float* row_sum, void* workspace, size_t workspace_bytes, void* stream) {
     if (!out || !indptr || heads <= 0 || head_dim <= 0 || out_rows < 0 || (num_edges > 0 && (!feature || !attn_src || !attn_dst || !row || !col)))
         return fail(PGLAMD_E_ARG, "gat_aggregate: bad argument");
     if ((row_max == nullptr) != (row_sum == nullptr)) return fail(PGLAMD_E_ARG, "gat_aggregate: row_max/row_sum must both be given or both NULL");
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !eid)) return fail(PGLAMD_E_ARG, "gat_aggregate: dropout needs 0 <= p < 1 and eid");
     if (num_edges < 0 || num_edges >= INT32_MAX || out_rows >= INT32_MAX) return fail(PGLAMD_E_RANGE, "gat_aggregate: sizes beyond int32 engine range");
     const int64_t d = heads * head_dim;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -319,30 +480,79 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
         }
         return PGLAMD_OK;
     }
-    // lane geometry: one 64-lane tile must cover all H*D columns, VEC elements of ONE head per lane
-    int vec = 0;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(feature) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(workspace);
-    for (int v = 1; v <= 4; v <<= 1)
-        if (d % v == 0 && head_dim % v == 0 && d / v <= kWave && al % (4 * v) == 0) { vec = v; break; }
+    const int vec = gat_vec(heads, head_dim, feature, out, workspace, false);
     if (vec == 0 || heads > kWave)
         return fail(PGLAMD_E_SHAPE, "gat_aggregate: heads*head_dim = %lld does not fit one 64-lane tile (max 256 with head_dim %% 4 == 0)", (long long)d);
     if (!workspace || workspace_bytes < pglamd_gat_aggregate_workspace_bytes(num_edges, heads, head_dim))
         return fail(PGLAMD_E_WORKSPACE, "gat_aggregate: workspace too small");
     GatParams p{};
-    p.x = feature; p.a_src = attn_src; p.a_dst = attn_dst; p.out = out; p.row_max = row_max; p.row_sum = row_sum;
-    p.row = row; p.col = col; p.indptr = indptr;
+    p.x = feature; p.p_col = attn_src; p.p_row = attn_dst; p.out = out; p.row_max = row_max; p.row_sum = row_sum;
+    p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
     p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)num_edges;
     p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
     p.d = (int)d; p.H = (int)heads; p.D = (int)head_dim; p.slope = negative_slope;
-    const size_t half = align_up((size_t)p.n_chunks * 3 * d * sizeof(float), 256);
-    p.part_head = static_cast<float*>(workspace);
-    p.part_tail = reinterpret_cast<float*>(static_cast<char*>(workspace) + half);
-    p.long_count = reinterpret_cast<int*>(static_cast<char*>(workspace) + 2 * half);
-    p.long_list = p.long_count + 64;
-    p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(workspace) + 2 * half + align_up((size_t)(p.n_chunks + 64) * sizeof(int), 256));
+    p.drop_p = drop_p; p.drop_scale = 1.f / (1.f - drop_p); p.seed = seed;
+    gat_setup_partials(p, workspace, 3);
     switch (vec) {
-        case 1: return launch_gat<1>(p, st);
-        case 2: return launch_gat<2>(p, st);
-        default: return launch_gat<4>(p, st);
+        case 1: return launch_gat<1, 0>(p, st);
+        case 2: return launch_gat<2, 0>(p, st);
+        default: return launch_gat<4, 0>(p, st);
+    }
+}
+
+extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const float* attn_src,
+                                       const float* attn_dst, const float* row_max, const float* row_sum, const float* t,
+                                       int64_t heads, int64_t head_dim, float negative_slope, float drop_p, uint32_t seed,
+                                       const int32_t* dst_row, const int32_t* dst_col, const int32_t* dst_eid,
+                                       const int32_t* src_row, const int32_t* src_col, const int32_t* src_eid,
+                                       const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
+                                       float* grad_feature, float* grad_pre, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    if (heads <= 0 || head_dim <= 0 || num_nodes < 0 || num_edges < 0 || !grad_feature || (num_edges > 0 && (!grad_out || !feature ||
+        !attn_src || !attn_dst || !row_max || !row_sum || !t || !dst_row || !dst_col || !dst_eid || !src_row ||
+        !src_col || !src_eid || !src_indptr || !grad_pre)))
+        return fail(PGLAMD_E_ARG, "gat_backward: bad argument");
+    if (drop_p < 0.f || drop_p >= 1.f) return fail(PGLAMD_E_ARG, "gat_backward: dropout needs 0 <= p < 1");
+    if (num_edges >= INT32_MAX || num_nodes >= INT32_MAX) return fail(PGLAMD_E_RANGE, "gat_backward: sizes beyond int32 engine range");
+    const int64_t d = heads * head_dim;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (num_nodes == 0) return PGLAMD_OK;
+    if (num_edges == 0) {
+        PGLAMD_HIP_CHECK(hipMemsetAsync(grad_feature, 0, (size_t)num_nodes * d * sizeof(float), st));
+        return PGLAMD_OK;
+    }
+    const int vec = gat_vec(heads, head_dim, feature, grad_out, grad_feature, true);
+    if (vec == 0 || heads > kWave || reinterpret_cast<uintptr_t>(workspace) % 16)
+        return fail(PGLAMD_E_SHAPE, "gat_backward: heads*head_dim = %lld needs one 64-lane tile and head_dim/VEC a power of two", (long long)d);
+    if (!workspace || workspace_bytes < pglamd_gat_aggregate_workspace_bytes(num_edges, heads, head_dim))
+        return fail(PGLAMD_E_WORKSPACE, "gat_backward: workspace too small");
+    GatParams p{};
+    p.H = (int)heads; p.D = (int)head_dim; p.d = (int)d; p.slope = negative_slope;
+    p.drop_p = drop_p; p.drop_scale = 1.f / (1.f - drop_p); p.seed = seed;
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.stat_m = row_max; p.stat_s = row_sum;
+    // (1) d pre_e, dst-sorted walk
+    {
+        GatParams q = p;
+        q.row = dst_row; q.col = dst_col; q.eid = dst_eid;
+        q.f = feature; q.g = grad_out; q.t = t; q.dpre = grad_pre; q.p_col = attn_src; q.p_row = attn_dst;
+        const int64_t nb = ceil_div(q.n_chunks, kWavesPerBlock);
+        q.n_blocks = (int)nb;
+        switch (vec) {
+            case 1: hipLaunchKernelGGL(gat_bwd_edge_kernel<1>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, q); break;
+            case 2: hipLaunchKernelGGL(gat_bwd_edge_kernel<2>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, q); break;
+            default: hipLaunchKernelGGL(gat_bwd_edge_kernel<4>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, q); break;
+        }
+        PGLAMD_LAUNCH_CHECK();
+    }
+    // (2) d f[u] = sum over out-edges of alpha_e * g[v]: src-sorted walk, alpha recomputed
+    p.x = grad_out; p.p_col = attn_dst; p.p_row = attn_src; p.out = grad_feature;
+    p.row = src_row; p.col = src_col; p.eid = src_eid; p.indptr = src_indptr;
+    p.out_rows = num_nodes; p.n_csr_rows = num_nodes;
+    gat_setup_partials(p, workspace, 1);
+    switch (vec) {
+        case 1: return launch_gat<1, 1>(p, st);
+        case 2: return launch_gat<2, 1>(p, st);
+        default: return launch_gat<4, 1>(p, st);
     }
 }

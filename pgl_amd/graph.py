@@ -375,12 +375,12 @@ class Graph(object):
         ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()
         return ag.aggregate(feature, self._csr_dst(), self._csr_src, "sum", None, None, "add", None, None, ss, ds)
 
-    def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2):
-        """send_uv(add) -> leaky_relu -> edge_softmax -> send_ue_recv(mul, sum) of GATConv
-        (pgl/nn/conv.py:331-339) fused into one pass (engine extension; forward only, fp32)."""
+    def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2, attn_drop=0.0, seed=0):
+        """send_uv(add) -> leaky_relu -> edge_softmax -> dropout -> send_ue_recv(mul, sum) of GATConv
+        (pgl/nn/conv.py:331-339) fused into one pass, differentiable (engine extension; fp32)."""
         if not self._is_tensor:
             raise ValueError("You must call Graph.tensor()")
-        return ops.gat_aggregate(feature, attn_src, attn_dst, self._csr_dst(), negative_slope)
+        return ag.gat_attention(feature, attn_src, attn_dst, self._csr_dst(), self._csr_src, negative_slope, attn_drop, seed)
 
     def _aggregate(self, feature, edge_feature, message_op, reduce_op, out_size):
         if isinstance(out_size, torch.Tensor):

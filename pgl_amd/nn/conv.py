@@ -113,6 +113,7 @@ class GATConv(nn.Module):
         self.attn_dropout = nn.Dropout(p=attn_drop)
         self.leaky_relu = nn.LeakyReLU(negative_slope=0.2)
         self.activation = _act(activation)
+        self.fused = True      # False: compose send_uv / edge_softmax / send_ue_recv exactly as the reference does
 
     def forward(self, graph, feature):
         if self.feat_drop > 1e-15:
@@ -121,12 +122,16 @@ class GATConv(nn.Module):
         feature = feature.reshape(-1, self.num_heads, self.hidden_size)
         attn_src = torch.sum(feature * self.weight_src, dim=-1)
         attn_dst = torch.sum(feature * self.weight_dst, dim=-1)
-        no_attn_drop = self.attn_drop <= 1e-15 or not self.training
-        needs_grad = torch.is_grad_enabled() and (feature.requires_grad or attn_src.requires_grad)
-        if (no_attn_drop and not needs_grad and feature.dtype == torch.float32 and hasattr(graph, "gat_aggregate")
-                and self.num_heads * self.hidden_size <= 256):
-            # inference fast path: the four graph ops below fused into one pass over the edges
-            output = graph.gat_aggregate(feature, attn_src, attn_dst, 0.2)
+        D = self.hidden_size
+        vec = 4 if D % 4 == 0 else 2 if D % 2 == 0 else 1
+        fusable = (feature.dtype == torch.float32 and hasattr(graph, "gat_aggregate") and self.fused
+                   and self.num_heads * D <= 64 * vec and ((D // vec) & (D // vec - 1)) == 0)
+        if fusable:
+            # the four graph ops below as ONE pass over the edges (forward) and two (backward);
+            # attention dropout is drawn inside the kernel from (seed, edge id, head)
+            p = self.attn_drop if (self.training and self.attn_drop > 1e-15) else 0.0
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
+            output = graph.gat_aggregate(feature, attn_src, attn_dst, 0.2, p, seed)
             if self.concat:
                 output = output.reshape(-1, self.num_heads * self.hidden_size)
             else:

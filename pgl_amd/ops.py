@@ -300,8 +300,9 @@ def segment_softmax(data, view):
     return out
 
 
-def gat_aggregate(feature, attn_src, attn_dst, csr, negative_slope=0.2, out_size=None, return_stats=False):
-    """Fused send_uv(add) -> leaky_relu -> edge_softmax(dst) -> send_ue_recv(mul, sum) of GATConv
+def gat_aggregate(feature, attn_src, attn_dst, csr, negative_slope=0.2, out_size=None, return_stats=False,
+                  drop_p=0.0, seed=0):
+    """Fused send_uv(add) -> leaky_relu -> edge_softmax(dst) -> dropout -> send_ue_recv(mul, sum) of GATConv
     (pgl/nn/conv.py:331-339) in one pass over the edges.  feature [N,H,D] fp32, attn_* [N,H]."""
     _need_cuda(feature, attn_src, attn_dst)
     if feature.dtype != torch.float32 or feature.dim() != 3:
@@ -321,10 +322,38 @@ def gat_aggregate(feature, attn_src, attn_dst, csr, negative_slope=0.2, out_size
     ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), feature.device)
     with torch.cuda.device(feature.device):
         _ffi.check(L.pglamd_gat_aggregate(_ptr(feature), _ptr(attn_src), _ptr(attn_dst), H, D, float(negative_slope),
-                                          _ptr(csr.row32), _ptr(csr.col32), _ptr(csr.indptr), csr.num_edges,
-                                          csr.num_nodes, M, _ptr(out), _ptr(mx), _ptr(sm), _ptr(ws), ws.numel(),
-                                          _stream(feature)), "gat_aggregate")
+                                          float(drop_p), int(seed) & 0xFFFFFFFF, _ptr(csr.row32), _ptr(csr.col32),
+                                          _ptr(csr.eid32), _ptr(csr.indptr), csr.num_edges, csr.num_nodes, M, _ptr(out),
+                                          _ptr(mx), _ptr(sm), _ptr(ws), ws.numel(), _stream(feature)), "gat_aggregate")
     return (out, mx, sm) if return_stats else out
+
+
+def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, csr_dst, csr_src, negative_slope=0.2,
+                 drop_p=0.0, seed=0):
+    """Backward of gat_aggregate -> (grad_feature [N,H,D], grad_attn_src [N,H], grad_attn_dst [N,H])."""
+    _need_cuda(grad_out, feature, out)
+    grad_out = grad_out.contiguous(); feature = feature.contiguous()
+    n, H, D = (int(v) for v in feature.shape)
+    t = (grad_out * out).sum(-1).contiguous()                      # [N,H] row-local dot, elementwise plumbing
+    gf = torch.empty_like(feature)
+    gpre = torch.empty((csr_dst.num_edges, H), dtype=torch.float32, device=feature.device)
+    L = _ffi.lib()
+    ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr_dst.num_edges, H, D), feature.device)
+    with torch.cuda.device(feature.device):
+        _ffi.check(L.pglamd_gat_backward(_ptr(grad_out), _ptr(feature), _ptr(attn_src), _ptr(attn_dst), _ptr(row_max),
+                                         _ptr(row_sum), _ptr(t), H, D, float(negative_slope), float(drop_p),
+                                         int(seed) & 0xFFFFFFFF, _ptr(csr_dst.row32), _ptr(csr_dst.col32),
+                                         _ptr(csr_dst.eid32), _ptr(csr_src.row32), _ptr(csr_src.col32), _ptr(csr_src.eid32),
+                                         _ptr(csr_src.indptr), csr_dst.num_edges, n, _ptr(gf), _ptr(gpre), _ptr(ws),
+                                         ws.numel(), _stream(feature)), "gat_backward")
+
+    class _E(object):       # edge rows gathered through the original edge id
+        def __init__(self, c):
+            self.row32, self.col32, self.eid32, self.indptr = c.row32, c.eid32, c.eid32, c.indptr
+            self.num_edges, self.num_nodes = c.num_edges, c.num_nodes
+    g_src = aggregate(gpre, _E(csr_src), "sum", n)
+    g_dst = aggregate(gpre, _E(csr_dst), "sum", n)
+    return gf, g_src, g_dst
 
 
 # ------------------------------------------------------------------------------------------------

@@ -566,7 +566,8 @@ def test_gatconv_eval_uses_fused_path_and_matches_training_path(pgl):
     gat = pgl.nn.GATConv(64, 16, feat_drop=0.0, attn_drop=0.0, num_heads=8).cuda()
     with torch.no_grad():
         fused = gat(g, x)
-    unfused = gat(g, x.clone().requires_grad_(True))            # needs grad -> unfused composite
+    gat.fused = False
+    unfused = gat(g, x.clone().requires_grad_(True))            # the reference's four-op composition
     close(host(fused), host(unfused.detach()), scale=float(unfused.abs().max()))
 
 
@@ -603,3 +604,59 @@ def test_examples_train_on_synthetic_citation_graph(pgl, model):
     hist = mod.main(["--model", model, "--epochs", "40"])
     assert hist[-1][0] < 0.7 * hist[0][0]            # loss went down
     assert hist[-1][2] > 0.6                         # and the planted classes are learned (7-way chance = 0.14)
+
+
+@pytest.mark.parametrize("H,D", [(8, 16), (4, 8), (2, 32), (1, 64)])
+def test_gat_fused_backward_matches_unfused_autograd(pgl, H, D):
+    """d/d(feature, attn_src, attn_dst) of the fused kernel pair == autograd through the reference-style
+    composition send_uv -> leaky_relu -> edge_softmax -> send_ue_recv (same engine, unfused ops)."""
+    n, e = 2500, 40000
+    edges, rng = rand_graph(n, e, 700 + H, hub=6000)
+    edges[edges[:, 1] % 11 == 0, 1] = 3
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    f0 = rng.standard_normal((n, H, D)).astype(np.float32)
+    as0 = rng.standard_normal((n, H)).astype(np.float32); ad0 = rng.standard_normal((n, H)).astype(np.float32)
+    w = dev(rng.standard_normal((n, H, D)).astype(np.float32))
+    grads = []
+    for fused in (True, False):
+        f, a_s, a_d = (dev(v).requires_grad_(True) for v in (f0, as0, ad0))
+        if fused:
+            out = g.gat_aggregate(f, a_s, a_d, 0.2)
+        else:
+            al = torch.nn.functional.leaky_relu(g.send_uv(a_s, a_d, "add"), 0.2)
+            al = pgl.nn.functional.edge_softmax(g, al).reshape(-1, H, 1)
+            out = g.send_ue_recv(f, al, "mul", "sum")
+        (out * w).sum().backward()
+        grads.append([host(out.detach())] + [host(t.grad) for t in (f, a_s, a_d)])
+    for a, b, name in zip(grads[0], grads[1], ("out", "d_feature", "d_attn_src", "d_attn_dst")):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(b).max()), err_msg=name)
+
+
+def test_gat_fused_dropout_is_consistent_between_forward_and_backward(pgl):
+    """With attention dropout the in-kernel mask must be identical in forward and backward: check the
+    gradient against finite differences of the (deterministic for a fixed seed) forward."""
+    n, e, H, D = 300, 3000, 4, 8
+    edges, rng = rand_graph(n, e, 810)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    f = dev(rng.standard_normal((n, H, D)).astype(np.float32)).requires_grad_(True)
+    a_s = dev(rng.standard_normal((n, H)).astype(np.float32)).requires_grad_(True)
+    a_d = dev(rng.standard_normal((n, H)).astype(np.float32)).requires_grad_(True)
+    w = dev(rng.standard_normal((n, H, D)).astype(np.float32))
+    seed, p = 1234, 0.4
+    out = g.gat_aggregate(f, a_s, a_d, 0.2, p, seed)
+    assert torch.equal(out, g.gat_aggregate(f, a_s, a_d, 0.2, p, seed))            # same seed, same mask
+    assert not torch.equal(out, g.gat_aggregate(f, a_s, a_d, 0.2, p, seed + 1))
+    nodrop = g.gat_aggregate(f.detach(), a_s.detach(), a_d.detach(), 0.2)
+    assert 0.05 < float((out.detach() - nodrop).abs().mean() / nodrop.abs().mean()) < 2.0
+    (out * w).sum().backward()
+    loss = lambda ff, aa, dd: float((g.gat_aggregate(ff, aa, dd, 0.2, p, seed).double() * w.double()).sum())
+    eps = 1e-2
+    for t, gr in ((f, f.grad), (a_s, a_s.grad), (a_d, a_d.grad)):
+        for _ in range(6):
+            idx = tuple(int(rng.integers(0, s)) for s in t.shape)
+            base = t.detach().clone()
+            tp, tm = base.clone(), base.clone()
+            tp[idx] += eps; tm[idx] -= eps
+            args = lambda v: [v if t is x else x.detach() for x in (f, a_s, a_d)]
+            num = (loss(*args(tp)) - loss(*args(tm))) / (2 * eps)
+            assert abs(num - float(gr[idx])) <= 2e-2 * max(1.0, abs(num)), (idx, num, float(gr[idx]))
