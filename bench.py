@@ -35,6 +35,16 @@ def algorithmic_bytes(E, N, d, s):
     return E * (d * s + 4) + N * (d * s + 8)
 
 
+def measured_traffic(scale, edges, dim):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC profile of this exact
+    workload (profiles/r01/traffic.json: separate rocprofv3 --pmc passes, calibrated FETCH/WRITE), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+        return t["workloads"]["scale%d_e%d_d%d_f32" % (scale, edges, dim)]["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(edges_cpu, x_cpu, budget_s=30.0):
     """Oracle C port (kind 'port') on a bounded sample: the first `m` edges of the same graph,
     m chosen so the pass takes ~10-30 s on one core."""
@@ -143,7 +153,8 @@ def main():
                        "graph_seed": 42, "feature_seed": 7,
                        "parallelism": "single GPU" if world == 1 else "row partition (%s) x%d + RCCL halo all-to-all-v" % (halo["partition"], world)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.scale, E, d) if world == 1 else None,
                          "kernel": pgl.ops.profile_last_kernel(), "kernel_ms": kms, "launches_per_step": launches / args.steps,
                          "algorithmic_bytes_per_launch": B,
                          "compulsory_bytes_per_launch": E * 4 + N * (2 * d * 4 + 8) if world == 1 else None},
