@@ -235,6 +235,15 @@ int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const f
                             float* grad_feature, float* grad_pre, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* SDDMM over a sorted edge stream:  out[eid[p], h] = < x_by_col[col[p], h, :], y_by_row[row[p], h, :] >
+ * (eid NULL: out[p, h]).  With (row, col, eid) = the dst-sorted CSR, x = node features and
+ * y = the incoming gradient this is d loss / d edge_feature of Graph.send_ue_recv(x, e, "mul", "sum")
+ * for e of shape [E, H, 1] (pgl/graph.py:929-937 backward) without materialising [E,H,D].  F32,
+ * heads*head_dim <= 256, head_dim/VEC a power of two. */
+int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, int64_t heads, int64_t head_dim,
+                     const int32_t* row, const int32_t* col, const int32_t* eid, int64_t num_edges,
+                     float* out, void* stream);
+
 /* K4'  segment boundaries from sorted ids: seg_ptr[n_seg+1] (int64), n_seg = ids[E-1]+1 given by
  * the caller.  Used when segment_softmax is called with raw ids (pgl.math API). */
 int32_t pglamd_seg_ptr_from_ids(const void* ids, int32_t ids_i64, int64_t num_rows, int64_t n_seg,

@@ -71,8 +71,13 @@ class _Aggregate(torch.autograd.Function):
                 else:
                     g = ops.aggregate(grad, csr_t, "sum", n_x, y, "div", src_scale=scale)
                 gx = _unbroadcast(g, ctx.x_shape)
-            if has_y and ctx.needs_input_grad[1]:
-                # composed (materialises [E, out_tail]); fused SDDMM is the "next" row f1
+            if (has_y and ctx.needs_input_grad[1] and ctx.mop == "mul" and scale is None and grad.dtype == torch.float32
+                    and grad.dim() == 3 and len(ctx.y_shape) == 3 and ctx.y_shape[2] == 1 and ctx.y_shape[1] == grad.shape[1]
+                    and tuple(ctx.x_shape[1:]) == tuple(grad.shape[1:]) and ops.sddmm_supported(grad.shape[1], grad.shape[2])):
+                # d/de of sum_e x[src] * e with e [E,H,1]: one SDDMM pass, no [E,H,D] gather is materialised
+                gy = ops.sddmm(x, grad, ctx.csr).reshape(ctx.y_shape)
+            elif has_y and ctx.needs_input_grad[1]:
+                # general broadcast shapes: composed from row gathers (materialises [E, out_tail])
                 gd = ops.gather_rows(grad, ctx.dst32)
                 if scale is not None:
                     gd = gd * ops.gather_rows(scale.reshape(-1, 1), ctx.dst32).reshape((-1,) + (1,) * (gd.dim() - 1))

@@ -394,6 +394,63 @@ __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(GatParams p) {
     }
 }
 
+// SDDMM over a dst-sorted edge stream: out[eid[p], h] = < x[col[p], h, :], y[row[p], h, :] >.
+// This is d loss / d (edge feature) of send_ue_recv(x, e, "mul", "sum") when e is [E,H,1]
+// (x = node features gathered by source, y = the incoming gradient rows): the reference composes it
+// from two [E,H,D] gathers; here neither is materialised.  Same lane geometry as gat_bwd_edge_kernel.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
+    constexpr int U = 8;
+    using V = FV<VEC>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    const int j0 = lane * VEC;
+    const bool act = j0 < p.d;
+    const int lph = p.D / VEC;
+    const int head = act ? j0 / p.D : 0;
+    const bool writer = act && (lane % lph) == 0;
+    const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
+    if (lb < 0) return;
+    const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
+    if (c >= p.n_chunks) return;
+    const int e0 = c * p.chunk, e1 = min(e0 + p.chunk, p.E);
+    const cptr<int> rowp = as_const(p.row);
+    const cptr<int> colp = as_const(p.col);
+    const cptr<int> eidp = as_const(p.eid);
+    int cur = -1;
+    V gv{};
+    auto load_batch = [&](int e, int nb, int (&rr)[U], int (&ee)[U], V (&fx)[U]) {
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+            if (i < nb) {
+                rr[i] = rowp[e + i]; ee[i] = eidp ? eidp[e + i] : e + i;
+                const int cc = colp[e + i];
+                if (act) fx[i] = *reinterpret_cast<const V*>(p.f + (int64_t)cc * p.d + j0);
+            }
+    };
+    int rA[U], eA[U]; V fA[U];
+    int nA = min(U, e1 - e0);
+    load_batch(e0, nA, rA, eA, fA);
+    for (int e = e0; e < e1; e += U) {
+        int rB[U], eB[U]; V fB[U];
+        const int nB = max(0, min(U, e1 - (e + U)));
+        if (nB > 0) load_batch(e + U, nB, rB, eB, fB);
+#pragma unroll
+        for (int i = 0; i < U; ++i)
+            if (i < nA) {
+                if (rA[i] != cur) { cur = rA[i]; if (act) gv = *reinterpret_cast<const V*>(p.g + (int64_t)cur * p.d + j0); }
+                float dot = 0.f;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) dot += gv.v[k] * fA[i].v[k];
+                for (int off = 1; off < lph; off <<= 1) dot += __shfl_xor(dot, off);
+                if (writer) p.dpre[(int64_t)eA[i] * p.H + head] = dot;
+            }
+#pragma unroll
+        for (int i = 0; i < U; ++i) { rA[i] = rB[i]; eA[i] = eB[i]; fA[i] = fB[i]; }
+        nA = nB;
+    }
+}
+
 static int gat_chunk_edges() {
     static int k = [] {
         const char* s = getenv("PGLAMD_CHUNK");
@@ -555,4 +612,30 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
         case 2: return launch_gat<2, 1>(p, st);
         default: return launch_gat<4, 1>(p, st);
     }
+}
+
+extern "C" int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, int64_t heads, int64_t head_dim,
+                                const int32_t* row, const int32_t* col, const int32_t* eid, int64_t num_edges, float* out,
+                                void* stream) {
+    if (heads <= 0 || head_dim <= 0 || num_edges < 0 || (num_edges > 0 && (!x_by_col || !y_by_row || !row || !col || !out)))
+        return fail(PGLAMD_E_ARG, "sddmm: bad argument");
+    if (num_edges >= INT32_MAX) return fail(PGLAMD_E_RANGE, "sddmm: sizes beyond int32 engine range");
+    if (num_edges == 0) return PGLAMD_OK;
+    const int vec = gat_vec(heads, head_dim, x_by_col, y_by_row, nullptr, true);
+    if (vec == 0 || heads > kWave)
+        return fail(PGLAMD_E_SHAPE, "sddmm: heads*head_dim = %lld needs one 64-lane tile and head_dim/VEC a power of two", (long long)(heads * head_dim));
+    GatParams p{};
+    p.H = (int)heads; p.D = (int)head_dim; p.d = (int)(heads * head_dim);
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.row = row; p.col = col; p.eid = eid; p.f = x_by_col; p.g = y_by_row; p.dpre = out;
+    const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
+    p.n_blocks = (int)nb;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (vec) {
+        case 1: hipLaunchKernelGGL(sddmm_kernel<1>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p); break;
+        case 2: hipLaunchKernelGGL(sddmm_kernel<2>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p); break;
+        default: hipLaunchKernelGGL(sddmm_kernel<4>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p); break;
+    }
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
 }

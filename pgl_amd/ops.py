@@ -356,6 +356,28 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     return gf, g_src, g_dst
 
 
+def sddmm(x, y, csr):
+    """out[e, h] = <x[src[e], h, :], y[dst[e], h, :]> in ORIGINAL edge order (csr = dst-sorted CSR).
+    x, y: [N, H, D] fp32.  Returns [E, H]."""
+    _need_cuda(x, y)
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.dim() != 3 or y.dim() != 3:
+        raise TypeError("sddmm: float32 [N, heads, head_dim] operands")
+    x = x.contiguous(); y = y.contiguous()
+    H, D = int(x.shape[1]), int(x.shape[2])
+    out = torch.empty((csr.num_edges, H), dtype=torch.float32, device=x.device)
+    if csr.num_edges:
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().pglamd_sddmm(_ptr(x), _ptr(y), H, D, _ptr(csr.row32), _ptr(csr.col32), _ptr(csr.eid32),
+                                               csr.num_edges, _ptr(out), _stream(x)), "sddmm")
+    return out
+
+
+def sddmm_supported(H, D):
+    vec = 4 if D % 4 == 0 else 2 if D % 2 == 0 else 1
+    lph = D // vec
+    return H * D <= 64 * vec and H <= 64 and (lph & (lph - 1)) == 0
+
+
 # ------------------------------------------------------------------------------------------------
 # row moves, degree norm
 # ------------------------------------------------------------------------------------------------

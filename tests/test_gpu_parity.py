@@ -660,3 +660,25 @@ def test_gat_fused_dropout_is_consistent_between_forward_and_backward(pgl):
             args = lambda v: [v if t is x else x.detach() for x in (f, a_s, a_d)]
             num = (loss(*args(tp)) - loss(*args(tm))) / (2 * eps)
             assert abs(num - float(gr[idx])) <= 2e-2 * max(1.0, abs(num)), (idx, num, float(gr[idx]))
+
+
+@pytest.mark.parametrize("H,D", [(8, 16), (4, 4), (1, 32), (3, 8)])
+def test_sddmm_and_send_ue_recv_edge_gradient(pgl, H, D):
+    n, e = 1500, 20000
+    edges, rng = rand_graph(n, e, 900 + H)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, H, D)).astype(np.float32))
+    y = dev(rng.standard_normal((n, H, D)).astype(np.float32))
+    got = host(pgl.ops.sddmm(x, y, g.adj_dst_index.csr))
+    want = (host(x)[edges[:, 0]] * host(y)[edges[:, 1]]).sum(-1)
+    close(got, want, scale=np.abs(want).max())
+    # gradient of send_ue_recv(mul, sum) w.r.t. the edge operand [E,H,1] and the node features
+    ef = dev(rng.standard_normal((e, H, 1)).astype(np.float32)).requires_grad_(True)
+    xf = x.clone().requires_grad_(True)
+    w = dev(rng.standard_normal((n, H, D)).astype(np.float32))
+    (g.send_ue_recv(xf, ef, "mul", "sum") * w).sum().backward()
+    want_e = (host(x)[edges[:, 0]] * host(w)[edges[:, 1]]).sum(-1, keepdims=True)
+    close(host(ef.grad), want_e, scale=np.abs(want_e).max())
+    want_x = np.zeros((n, H, D), np.float32)
+    np.add.at(want_x, edges[:, 0], host(w)[edges[:, 1]] * host(ef.detach()))
+    close(host(xf.grad), want_x, scale=np.abs(want_x).max())
