@@ -16,6 +16,7 @@ from . import message
 from . import nn
 from . import partition
 from .graph import Graph
+from .bigraph import BiGraph, HeterGraph
 from .message import Message
 
-__all__ = ["Graph", "Message", "math", "message", "nn", "ops", "partition"]
+__all__ = ["Graph", "BiGraph", "HeterGraph", "Message", "math", "message", "nn", "ops", "partition"]

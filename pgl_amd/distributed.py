@@ -94,6 +94,35 @@ class HaloPlan(object):
         self.local_edges = int(ld.shape[0])
 
 
+_PLAN_ARRAYS = ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "halo_global", "send_idx", "in_degree")
+_PLAN_META = ("rank", "world", "num_nodes", "n_own", "n_halo", "local_edges", "offsets", "recv_splits", "send_splits")
+
+
+def _plan_dump(plan, path):
+    """On-disk cache of one rank's share ("next" row f2): int64 .npy arrays + meta.json under
+    <path>/rank_<r>/, in the spirit of Graph.dump's .npy directory (pgl/graph.py:1177-1302), so the
+    partitioner and the plan construction are one-off costs for graphs at config 4/5 scale."""
+    import json
+    d = os.path.join(path, "rank_%d" % plan.rank)
+    os.makedirs(d, exist_ok=True)
+    for k in _PLAN_ARRAYS:
+        np.save(os.path.join(d, k + ".npy"), getattr(plan, k).cpu().numpy())
+    with open(os.path.join(d, "meta.json"), "w") as f:
+        json.dump({k: getattr(plan, k) for k in _PLAN_META}, f)
+
+
+def _plan_load(path, rank, device=None, mmap_mode=None):
+    import json
+    d = os.path.join(path, "rank_%d" % rank)
+    plan = HaloPlan.__new__(HaloPlan)
+    for k, v in json.load(open(os.path.join(d, "meta.json"))).items():
+        setattr(plan, k, v)
+    for k in _PLAN_ARRAYS:
+        t = torch.from_numpy(np.array(np.load(os.path.join(d, k + ".npy"), mmap_mode=mmap_mode)))
+        setattr(plan, k, t.to(device) if device is not None else t)
+    return plan
+
+
 class DistGraph(object):
     """One rank's share of a row-partitioned graph.  send_recv(x_own, reduce) == the rows this rank
     owns of Graph.send_recv(x_global, reduce) on the whole graph (un-permute with own_global)."""
@@ -165,6 +194,16 @@ class DistGraph(object):
             dist.broadcast(buf, src=0, group=group)
             part = buf.cpu()
         return part
+
+    def dump(self, path):
+        """Cache this rank's partition share + halo plan under <path>/rank_<r>/ (see _plan_dump)."""
+        _plan_dump(self.plan, path)
+
+    @classmethod
+    def load(cls, path, rank, device=None, group=None, aggregate_fn=None):
+        dg = cls(_plan_load(path, rank, device), device=device, group=group, aggregate_fn=aggregate_fn)
+        dg.method = "cached"
+        return dg
 
     # ---- helpers -----------------------------------------------------------------------------
     def take_owned(self, x_global):

@@ -106,3 +106,19 @@ def test_plan_consistency_in_process(world):
         full[p.own_global.numpy()] = _oracle_agg(x_cat, rows, cols, p.n_own, "sum").numpy()
         assert np.array_equal(p.in_degree.numpy(), np.bincount(edges[:, 1], minlength=n)[p.own_global.numpy()])
     np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())   # order of summation differs
+
+
+def test_plan_cache_roundtrip(tmp_path):
+    """f2: DistGraph.dump / load reproduce the plan (and therefore the aggregation) exactly."""
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    edges, x = _graph(n=250, e=3000, seed=8)
+    n, world = x.shape[0], 3
+    part = np.random.default_rng(1).integers(0, world, n)
+    for r in range(world):
+        dg = DistGraph(HaloPlan(torch.from_numpy(edges), n, part, r, world), aggregate_fn=_oracle_agg)
+        dg.dump(str(tmp_path))
+        back = DistGraph.load(str(tmp_path), r, aggregate_fn=_oracle_agg)
+        for k in ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "send_idx", "in_degree"):
+            assert torch.equal(getattr(dg.plan, k), getattr(back.plan, k)), k
+        assert back.plan.send_splits == dg.plan.send_splits and back.plan.recv_splits == dg.plan.recv_splits
+        assert back.stats()["partition"] == "cached" and back.plan.n_halo == dg.plan.n_halo

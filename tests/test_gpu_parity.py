@@ -682,3 +682,54 @@ def test_sddmm_and_send_ue_recv_edge_gradient(pgl, H, D):
     want_x = np.zeros((n, H, D), np.float32)
     np.add.at(want_x, edges[:, 0], host(w)[edges[:, 1]] * host(ef.detach()))
     close(host(xf.grad), want_x, scale=np.abs(want_x).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row f4: BiGraph / HeterGraph on the same kernels (golden G9 = tests/test_bigraph.py:390-507)
+# ------------------------------------------------------------------------------------------------
+def test_g9_bigraph_golden(pgl):
+    g = pgl.BiGraph(edges=G.G9_EDGES, src_num_nodes=G.G9_SRC_N, dst_num_nodes=G.G9_DST_N,
+                    src_node_feat={"src_nfeat": G.G9_SRC_X}, dst_node_feat={"dst_nfeat": G.G9_DST_X}).tensor()
+    assert g.src_num_nodes == 5 and g.dst_num_nodes == 4
+    assert np.array_equal(host(g.send_recv(g.src_node_feat["src_nfeat"], "sum")), G.G9_SEND_RECV)
+    msg = g.send(lambda sf, df, ef: {"h": sf["h"]}, src_feat={"h": g.src_node_feat["src_nfeat"]})
+    assert np.array_equal(host(msg["h"]), G.G9_SRC_X[G.G9_EDGES[:, 0]])
+    assert np.array_equal(host(g.recv(lambda m: m.reduce_sum(m["h"]), msg)), G.G9_SEND_RECV)
+    msg = g.send(lambda sf, df, ef: {"h": df["h"]}, dst_feat={"h": g.dst_node_feat["dst_nfeat"]})
+    assert np.array_equal(host(msg["h"]), G.G9_DST_MSG)
+    assert np.array_equal(host(g.recv(lambda m: m.reduce_sum(m["h"]), msg, recv_mode="src")), G.G9_RECV_SRC)
+    assert np.array_equal(host(g.indegree()), np.bincount(G.G9_EDGES[:, 1], minlength=4))
+    assert np.array_equal(host(g.outdegree()), np.bincount(G.G9_EDGES[:, 0], minlength=5))
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "max", "min"])
+def test_bigraph_random_and_gradient(pgl, op):
+    ns, nd, e, d = 700, 1900, 30000, 24
+    rng = np.random.default_rng(33)
+    edges = np.stack([rng.integers(0, ns, e), rng.integers(0, nd, e)], 1).astype(np.int64)
+    x = rng.standard_normal((ns, d)).astype(np.float32)
+    g = pgl.BiGraph(edges=edges, src_num_nodes=ns, dst_num_nodes=nd).tensor()
+    want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op, out_size=nd)
+    xt = dev(x).requires_grad_(True)
+    out = g.send_recv(xt, op)
+    assert tuple(out.shape) == (nd, d)
+    close(host(out.detach()), want, scale=np.abs(want).max())
+    if op in ("sum", "mean"):
+        w = dev(rng.standard_normal((nd, d)).astype(np.float32))
+        (out * w).sum().backward()
+        deg = np.maximum(np.bincount(edges[:, 1], minlength=nd), 1)[:, None] if op == "mean" else 1.0
+        gx = np.zeros((ns, d), np.float32)
+        np.add.at(gx, edges[:, 0], (host(w) / deg)[edges[:, 1]].astype(np.float32))
+        close(host(xt.grad), gx, scale=np.abs(gx).max())
+
+
+def test_hetergraph_per_relation(pgl):
+    rng = np.random.default_rng(5)
+    n = 500
+    rel = {"cites": rng.integers(0, n, (4000, 2)), "writes": rng.integers(0, n, (2500, 2))}
+    hg = pgl.HeterGraph(edges=rel, num_nodes=n).tensor()
+    x = rng.standard_normal((n, 16)).astype(np.float32)
+    for et, e in rel.items():
+        want = R.c_send_u_recv(x, e[:, 0].astype(np.int64), e[:, 1].astype(np.int64), "mean")
+        close(host(hg[et].send_recv(dev(x), "mean")), want, scale=np.abs(want).max())
+    assert sorted(hg.edge_types) == ["cites", "writes"]
