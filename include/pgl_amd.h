@@ -268,6 +268,29 @@ int32_t pglamd_degree_norm(const int64_t* degree, int64_t n, void* out, int32_t 
                            void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Neighbour sampling + relabel on the GPU ("next" row f3; the step before the hot path in the
+ * GraphSAGE mini-batch loop).  Replaces paddle.geometric.sample_neighbors / reindex_graph as used
+ * by pgl.sampling.NeighborSampler (pgl/sampling/sage.py:130-155) and the CPU path
+ * Graph.sample_predecessor -> graph_kernel.sample_subset(_with_eid) (pgl/graph_kernel.pyx:266-339).
+ *   count:  count[i] = min(degree(nodes[i]), k)   (k < 0: all neighbours)
+ *   fill :  neighbours of nodes[i] written at offsets[i] (exclusive scan of count, made by the
+ *           caller): all of them if degree <= k, else k uniformly WITHOUT replacement (Floyd),
+ *           randomness = hash(seed, node, draw).  indptr/col/eid = the dst-sorted CSR; k <= 64.
+ *   reindex: out_nodes = nodes, then every new neighbour id in order of first appearance;
+ *           reindex_src[j] = new id of neighbors[j]; *num_out = len(out_nodes).  Deterministic.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t pglamd_sample_neighbors_count(const int64_t* indptr, const int64_t* nodes, int64_t n,
+                                      int64_t k, int64_t* count, void* stream);
+int32_t pglamd_sample_neighbors_fill(const int64_t* indptr, const int32_t* col, const int32_t* eid,
+                                     const int64_t* nodes, int64_t n, int64_t k, uint64_t seed,
+                                     const int64_t* offsets, int64_t* out_neighbors,
+                                     int64_t* out_eids, void* stream);
+size_t pglamd_reindex_workspace_bytes(int64_t num_nodes, int64_t num_neighbors);
+int32_t pglamd_reindex(const int64_t* nodes, int64_t num_nodes, const int64_t* neighbors,
+                       int64_t num_neighbors, int64_t* reindex_src, int64_t* out_nodes,
+                       int64_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-side (CPU) helpers.  Pointers here are HOST pointers.
  * pglamd_map_ids replaces graph_kernel.map_edges / map_nodes (pgl/graph_kernel.pyx:104-138):
  *     out[i] = value of key in[i] in the (keys -> vals) dictionary; missing key -> 0, like

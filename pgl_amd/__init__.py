@@ -15,8 +15,9 @@ from . import math
 from . import message
 from . import nn
 from . import partition
+from . import sampling
 from .graph import Graph
 from .bigraph import BiGraph, HeterGraph
 from .message import Message
 
-__all__ = ["Graph", "BiGraph", "HeterGraph", "Message", "math", "message", "nn", "ops", "partition"]
+__all__ = ["Graph", "BiGraph", "HeterGraph", "Message", "math", "message", "nn", "ops", "partition", "sampling"]

@@ -47,6 +47,10 @@ _SIGNATURES = {
     "pglamd_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "pglamd_scatter_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "pglamd_degree_norm": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp]),
+    "pglamd_sample_neighbors_count": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "pglamd_sample_neighbors_fill": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_u64, c_vp, c_vp, c_vp, c_vp]),
+    "pglamd_reindex_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "pglamd_reindex": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_build_index_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pglamd_map_ids": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "pglamd_partition_kway": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_u64, c_vp, c_vp]),

@@ -429,6 +429,50 @@ def degree_norm(degree, dtype=torch.float32):
 
 
 # ------------------------------------------------------------------------------------------------
+# neighbour sampling + relabel (row f3)
+# ------------------------------------------------------------------------------------------------
+def sample_neighbors(csr, nodes, sample_size, seed=0, return_eids=False):
+    """paddle.geometric.sample_neighbors (pgl/sampling/sage.py:144-145) over the dst-sorted CSR:
+    -> (neighbors [sum count], count [len(nodes)][, eids])."""
+    _need_cuda(nodes)
+    nodes = nodes.to(torch.int64).contiguous()
+    n, dev = int(nodes.shape[0]), nodes.device
+    L = _ffi.lib()
+    count = torch.empty(n, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        _ffi.check(L.pglamd_sample_neighbors_count(_ptr(csr.indptr), _ptr(nodes), n, int(sample_size), _ptr(count),
+                                                   _stream(nodes)), "sample_neighbors_count")
+    offsets = torch.cumsum(count, 0) - count
+    total = int(count.sum().item()) if n else 0
+    nbr = torch.empty(total, dtype=torch.int64, device=dev)
+    eids = torch.empty(total, dtype=torch.int64, device=dev) if return_eids else None
+    if total:
+        with torch.cuda.device(dev):
+            _ffi.check(L.pglamd_sample_neighbors_fill(_ptr(csr.indptr), _ptr(csr.col32), _ptr(csr.eid32), _ptr(nodes), n,
+                                                      int(sample_size), int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(offsets), _ptr(nbr),
+                                                      _ptr(eids), _stream(nodes)), "sample_neighbors_fill")
+    return (nbr, count, eids) if return_eids else (nbr, count)
+
+
+def reindex_graph(nodes, neighbors, count):
+    """paddle.geometric.reindex_graph (pgl/sampling/sage.py:146-147): -> (reindex_src, reindex_dst,
+    out_nodes) with out_nodes = nodes followed by the new neighbour ids in order of first appearance."""
+    _need_cuda(nodes, neighbors, count)
+    nodes = nodes.to(torch.int64).contiguous(); neighbors = neighbors.to(torch.int64).contiguous()
+    n, m, dev = int(nodes.shape[0]), int(neighbors.shape[0]), nodes.device
+    L = _ffi.lib()
+    src = torch.empty(m, dtype=torch.int64, device=dev)
+    out_nodes = torch.empty(n + m, dtype=torch.int64, device=dev)
+    num = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = _ws(L.pglamd_reindex_workspace_bytes(n, m), dev)
+    with torch.cuda.device(dev):
+        _ffi.check(L.pglamd_reindex(_ptr(nodes), n, _ptr(neighbors), m, _ptr(src), _ptr(out_nodes), _ptr(num), _ptr(ws),
+                                    ws.numel(), _stream(nodes)), "reindex")
+    dst = torch.repeat_interleave(torch.arange(n, device=dev), count)
+    return src, dst, out_nodes[:int(num.item())]
+
+
+# ------------------------------------------------------------------------------------------------
 # host (CPU, numpy) helpers -- same shared library, HOST pointers
 # ------------------------------------------------------------------------------------------------
 def _np_i64(a):

@@ -733,3 +733,66 @@ def test_hetergraph_per_relation(pgl):
         want = R.c_send_u_recv(x, e[:, 0].astype(np.int64), e[:, 1].astype(np.int64), "mean")
         close(host(hg[et].send_recv(dev(x), "mean")), want, scale=np.abs(want).max())
     assert sorted(hg.edge_types) == ["cites", "writes"]
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row f3: GPU neighbour sampling + relabel
+# ------------------------------------------------------------------------------------------------
+def test_sample_neighbors_and_reindex(pgl):
+    n, e, k = 4000, 60000, 10
+    edges, rng = rand_graph(n, e, 1000, hub=3000)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    csr = g.adj_dst_index.csr
+    seeds = dev(rng.choice(n, 500, replace=False).astype(np.int64))
+    nbr, cnt, eids = pgl.ops.sample_neighbors(csr, seeds, k, seed=7, return_eids=True)
+    deg = np.bincount(edges[:, 1], minlength=n)[host(seeds)]
+    assert np.array_equal(host(cnt), np.minimum(deg, k))
+    off = np.concatenate([[0], np.cumsum(host(cnt))])
+    nb, ei, sd = host(nbr), host(eids), host(seeds)
+    for i in range(len(sd)):
+        es = ei[off[i]:off[i + 1]]
+        assert len(set(es.tolist())) == len(es)                              # without replacement
+        assert (edges[es, 1] == sd[i]).all() and np.array_equal(edges[es, 0], nb[off[i]:off[i + 1]])   # real in-edges
+    # reproducible for a seed, different for another, and roughly uniform over a hub's neighbours
+    nbr2, _ = pgl.ops.sample_neighbors(csr, seeds, k, seed=7)
+    assert torch.equal(nbr, nbr2)
+    hub = dev(np.array([n // 2], dtype=np.int64))
+    picks = np.concatenate([host(pgl.ops.sample_neighbors(csr, hub, 16, seed=s, return_eids=True)[2]) for s in range(400)])
+    hub_eids = np.flatnonzero(edges[:, 1] == n // 2)
+    freq = np.bincount(np.searchsorted(hub_eids, picks), minlength=len(hub_eids))
+    assert freq.max() <= 12 and (freq > 0).mean() > 0.8                      # 6400 draws over ~3000 edges, no hot spot
+    full, cntf = pgl.ops.sample_neighbors(csr, seeds, -1)
+    assert np.array_equal(host(cntf), deg)
+    # reindex: contract of paddle.geometric.reindex_graph
+    src, dst, out_nodes = pgl.ops.reindex_graph(seeds, nbr, cnt)
+    on = host(out_nodes)
+    assert np.array_equal(on[:len(sd)], sd) and len(set(on.tolist())) == len(on)
+    assert np.array_equal(on[host(src)], nb) and np.array_equal(host(dst), np.repeat(np.arange(len(sd)), host(cnt)))
+    seen, order = set(sd.tolist()), []
+    for v in nb.tolist():
+        if v not in seen:
+            seen.add(v); order.append(v)
+    assert on[len(sd):].tolist() == order                                     # order of first appearance
+
+
+def test_neighbor_sampler_blocks_feed_graphsage(pgl):
+    torch.manual_seed(0)
+    n, e, d = 3000, 40000, 32
+    edges, rng = rand_graph(n, e, 1100)
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    sampler = pgl.sampling.NeighborSampler(g, [5, 5], seed=3)
+    batch = dev(np.arange(64, dtype=np.int64))
+    blocks, nodes = sampler.sample_neighbors(batch)
+    assert blocks[-1][1] == 64 and host(nodes)[:64].tolist() == list(range(64))
+    l1 = pgl.nn.GraphSageConv(d, 16, "mean").cuda(); l2 = pgl.nn.GraphSageConv(16, 8, "mean").cuda()
+    h = x[nodes]
+    for (blk, n_dst), layer in zip(blocks, (l1, l2)):
+        h = layer(blk, (h, h[:n_dst]))
+    assert tuple(h.shape) == (64, 8) and torch.isfinite(h).all()
+    # with fan-out >= max degree the sampled 1-layer block reproduces the full-graph aggregation of the batch rows
+    full = pgl.sampling.NeighborSampler(g, [-1]).sample_neighbors(batch)
+    blk, n_dst = full[0][0]
+    agg = blk.send_recv(x[full[1]], "sum", out_size=n_dst)
+    want = g.send_recv(x, "sum")[:64]
+    close(host(agg), host(want), scale=float(want.abs().max()))
