@@ -149,7 +149,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = E * args.steps / dt
         B = algorithmic_bytes(E if world == 1 else halo["local_edges"], N if world == 1 else halo["local_rows"], d, 4)
-        kms = kern_ms / max(launches, 1)
+        kms = kern_ms / max(args.steps, 1)          # flat-kernel time per step (1 launch at N=1; local + halo launches at N>1)
         achieved = B / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         rec = {
             "metric": "aggregated edges/sec (GCN send+recv_sum, d=%d)" % d, "value": value, "unit": "edges/s",
