@@ -1,5 +1,7 @@
 """pgl_amd.nn -- GNN layers over the engine.  Mirrors pgl/nn (conv layers on the graded path)."""
 from . import functional
 from .conv import GCNConv, GATConv, GraphSageConv
+from .conv_more import GATv2Conv, APPNP, GCNII, TransformerConv, GINConv, SGCConv, LightGCNConv
 
-__all__ = ["GCNConv", "GATConv", "GraphSageConv", "functional"]
+__all__ = ["GCNConv", "GATConv", "GraphSageConv", "GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv",
+           "LightGCNConv", "functional"]

@@ -1,0 +1,207 @@
+"""More pgl.nn conv layers, all expressed with the same four graph calls (send_recv / send_uv /
+send_ue_recv / send+recv), to back the claim that the remaining reference layers "work for free once
+the seam is complete" (SURVEY section 2, row 10).  Each mirrors the reference layer's constructor and
+forward order: GATv2Conv (pgl/nn/conv.py:349-437), APPNP (:438-499), GCNII (:645-723),
+TransformerConv (:724-885, the UDF send/recv + Message.reduce_softmax path), GINConv (:888-960),
+SGCConv (:1027-1103), LightGCNConv (:1252-1286).  The symmetric degree normalisation
+(x * norm -> send_recv -> * norm) is issued as one fused aggregation where the layer allows it.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as GF
+from .conv import _act, _linear
+
+__all__ = ["GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv", "LightGCNConv"]
+
+
+def _norm_propagate(graph, feature, norm):
+    """feature * norm -> send_recv(sum) -> * norm  (one kernel for fp32 features)."""
+    if feature.dtype == torch.float32 and norm.dtype == torch.float32 and hasattr(graph, "send_recv_scaled"):
+        return graph.send_recv_scaled(feature, norm, norm)
+    return graph.send_recv(feature * norm, "sum") * norm
+
+
+class LightGCNConv(nn.Module):
+    def forward(self, graph, feature):
+        return _norm_propagate(graph, feature, GF.degree_norm(graph))
+
+
+class SGCConv(nn.Module):
+    def __init__(self, input_size, output_size, k_hop=2, cached=True, activation=None, bias=False):
+        super(SGCConv, self).__init__()
+        self.k_hop, self.cached, self.cached_output = k_hop, cached, None
+        self.linear = _linear(input_size, output_size, bias=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(output_size))
+        self.activation = _act(activation)
+
+    def _propagate(self, graph, feature):
+        norm = GF.degree_norm(graph)
+        for _ in range(self.k_hop):
+            feature = _norm_propagate(graph, feature, norm)
+        return feature
+
+    def forward(self, graph, feature):
+        if self.cached:
+            if self.cached_output is None:
+                self.cached_output = self._propagate(graph, feature)
+            feature = self.cached_output
+        else:
+            feature = self._propagate(graph, feature)
+        output = self.linear(feature)
+        if hasattr(self, "bias"):
+            output = output + self.bias
+        if self.activation is not None:
+            output = self.activation(output)
+        return output
+
+
+class APPNP(nn.Module):
+    def __init__(self, alpha=0.2, k_hop=10, self_loop=False):
+        super(APPNP, self).__init__()
+        self.alpha, self.k_hop, self.self_loop = alpha, k_hop, self_loop
+
+    def forward(self, graph, feature, norm=None):
+        if self.self_loop:
+            from ..graph import Graph
+            index = torch.arange(graph.num_nodes, device=feature.device)
+            keep = graph.edges[graph.edges[:, 0] != graph.edges[:, 1]]
+            graph = Graph(num_nodes=graph.num_nodes, edges=torch.cat([torch.stack([index, index], 1), keep], 0))
+        if norm is None:
+            norm = GF.degree_norm(graph)
+        h0 = feature
+        for _ in range(self.k_hop):
+            feature = _norm_propagate(graph, feature, norm)
+            feature = self.alpha * h0 + (1 - self.alpha) * feature
+        return feature
+
+
+class GCNII(nn.Module):
+    def __init__(self, hidden_size, activation=None, lambda_l=0.5, alpha=0.2, k_hop=10, dropout=0.6):
+        super(GCNII, self).__init__()
+        self.hidden_size, self.lambda_l, self.alpha, self.k_hop = hidden_size, lambda_l, alpha, k_hop
+        self.drop_fn = nn.Dropout(dropout)
+        self.mlps = nn.ModuleList([_linear(hidden_size, hidden_size) for _ in range(k_hop)])
+        self.activation = _act(activation)
+
+    def forward(self, graph, feature, norm=None):
+        if norm is None:
+            norm = GF.degree_norm(graph)
+        h0 = feature
+        for i in range(self.k_hop):
+            beta_i = math.log(1.0 * self.lambda_l / (i + 1) + 1)
+            feature = _norm_propagate(graph, self.drop_fn(feature), norm)
+            feature = self.alpha * h0 + (1 - self.alpha) * feature
+            feature = beta_i * self.mlps[i](feature) + (1 - beta_i) * feature
+            if self.activation is not None:
+                feature = self.activation(feature)
+        return feature
+
+
+class GINConv(nn.Module):
+    def __init__(self, input_size, output_size, activation=None, init_eps=0.0, train_eps=False):
+        super(GINConv, self).__init__()
+        self.linear1 = _linear(input_size, output_size)
+        self.linear2 = _linear(output_size, output_size)
+        self.layer_norm = nn.LayerNorm(output_size)
+        self.epsilon = nn.Parameter(torch.full((1, 1), float(init_eps))) if train_eps else init_eps
+        self.activation = _act(activation)
+
+    def forward(self, graph, feature):
+        neigh_feature = graph.send_recv(feature, reduce_func="sum")
+        output = neigh_feature + feature * (self.epsilon + 1.0)
+        output = self.layer_norm(self.linear1(output))
+        if self.activation is not None:
+            output = self.activation(output)
+        return self.linear2(output)
+
+
+class GATv2Conv(nn.Module):
+    def __init__(self, input_size, hidden_size, feat_drop=0.6, attn_drop=0.6, num_heads=1, concat=True, activation=None):
+        super(GATv2Conv, self).__init__()
+        self.hidden_size, self.num_heads, self.feat_drop, self.attn_drop, self.concat = hidden_size, num_heads, feat_drop, attn_drop, concat
+        self.linear = _linear(input_size, num_heads * hidden_size)
+        self.attn = nn.Parameter(torch.empty(1, num_heads, hidden_size))
+        nn.init.xavier_uniform_(self.attn)
+        self.feat_dropout, self.attn_dropout = nn.Dropout(p=feat_drop), nn.Dropout(p=attn_drop)
+        self.leaky_relu = nn.LeakyReLU(negative_slope=0.2)
+        self.activation = _act(activation)
+
+    def forward(self, graph, feature):
+        if self.feat_drop > 1e-15:
+            feature = self.feat_dropout(feature)
+        feature = self.linear(feature).reshape(-1, self.num_heads, self.hidden_size)
+        alpha = self.leaky_relu(graph.send_uv(feature, feature, "add"))
+        alpha = torch.sum(alpha * self.attn, dim=-1)
+        alpha = GF.edge_softmax(graph, alpha).reshape(-1, self.num_heads, 1)
+        if self.attn_drop > 1e-15:
+            alpha = self.attn_dropout(alpha)
+        output = graph.send_ue_recv(feature, alpha, "mul", "sum")
+        output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(output, dim=1)
+        if self.activation is not None:
+            output = self.activation(output)
+        return output
+
+
+class TransformerConv(nn.Module):
+    """UDF path: Graph.send with a message function, Graph.recv with a reducer using
+    Message.reduce_softmax / Message.reduce (pgl/nn/conv.py:796-834)."""
+
+    def __init__(self, input_size, hidden_size, num_heads=4, feat_drop=0.6, attn_drop=0.6, concat=True, skip_feat=True,
+                 gate=False, layer_norm=True, activation="relu"):
+        super(TransformerConv, self).__init__()
+        self.hidden_size, self.num_heads, self.feat_drop, self.attn_drop, self.concat = hidden_size, num_heads, feat_drop, attn_drop, concat
+        self.q, self.k, self.v = (_linear(input_size, num_heads * hidden_size) for _ in range(3))
+        self.feat_dropout, self.attn_dropout = nn.Dropout(p=feat_drop), nn.Dropout(p=attn_drop)
+        out = num_heads * hidden_size if concat else hidden_size
+        self.skip_feat = _linear(input_size, out) if skip_feat else None
+        self.gate = _linear(3 * out, 1) if gate else None
+        self.layer_norm = nn.LayerNorm(out) if layer_norm else None
+        self.activation = _act(activation)
+
+    def send_attention(self, src_feat, dst_feat, edge_feat):
+        if "edge_feat" in edge_feat:
+            alpha = dst_feat["q"] * (src_feat["k"] + edge_feat["edge_feat"])
+            v = src_feat["v"] + edge_feat["edge_feat"]
+        else:
+            alpha = dst_feat["q"] * src_feat["k"]
+            v = src_feat["v"]
+        return {"alpha": torch.sum(alpha, dim=-1), "v": v}
+
+    def reduce_attention(self, msg):
+        alpha = msg.reduce_softmax(msg["alpha"]).reshape(-1, self.num_heads, 1)
+        if self.attn_drop > 1e-15:
+            alpha = self.attn_dropout(alpha)
+        feature = msg["v"] * alpha
+        feature = feature.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(feature, dim=1)
+        return msg.reduce(feature, pool_type="sum")
+
+    def forward(self, graph, feature, edge_feat=None):
+        if self.feat_drop > 1e-5:
+            feature = self.feat_dropout(feature)
+        shape = (-1, self.num_heads, self.hidden_size)
+        q = self.q(feature).reshape(shape) / (self.hidden_size ** 0.5)
+        k, v = self.k(feature).reshape(shape), self.v(feature).reshape(shape)
+        kw = {}
+        if edge_feat is not None:
+            if self.feat_drop > 1e-5:
+                edge_feat = self.feat_dropout(edge_feat)
+            kw["edge_feat"] = {"edge_feat": edge_feat.reshape(shape)}
+        msg = graph.send(self.send_attention, src_feat={"k": k, "v": v}, dst_feat={"q": q}, **kw)
+        output = graph.recv(reduce_func=self.reduce_attention, msg=msg)
+        if self.skip_feat is not None:
+            skip = self.skip_feat(feature)
+            if self.gate is not None:
+                gate = torch.sigmoid(self.gate(torch.cat([skip, output, skip - output], dim=-1)))
+                output = gate * skip + (1 - gate) * output
+            else:
+                output = skip + output
+        if self.layer_norm is not None:
+            output = self.layer_norm(output)
+        if self.activation is not None:
+            output = self.activation(output)
+        return output

@@ -867,3 +867,70 @@ def test_eight_way_partition_in_process_rmat(pgl):
         full[dg.plan.own_global] = dg.aggregate_with_halo(dg.take_owned(x), recv, "mean")
     close(host(full), host(want), scale=float(want.abs().max()))
     assert sum(dg.plan.local_edges for dg in dgs) == E
+
+
+# ------------------------------------------------------------------------------------------------
+# the other reference layers "work for free" on the same four graph calls (incl. the UDF path)
+# ------------------------------------------------------------------------------------------------
+def test_more_conv_layers_vs_dense_formulas(pgl):
+    torch.manual_seed(4)
+    n, e, d = 600, 5000, 24
+    edges, rng = rand_graph(n, e, 1200)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    A = torch.zeros(n, n, dtype=torch.float64, device="cuda")
+    A.index_put_((dev(edges[:, 1]), dev(edges[:, 0])), torch.ones(e, dtype=torch.float64, device="cuda"), accumulate=True)
+    nrm = A.sum(1).clamp(min=1).pow(-0.5)
+    An = nrm[:, None] * A * nrm[None, :]
+    xd = x.double()
+    with torch.no_grad():
+        close(host(pgl.nn.LightGCNConv()(g, x)), host((An @ xd).float()), scale=3.0)
+        h = xd
+        for _ in range(3):
+            h = 0.8 * (An @ h) + 0.2 * xd
+        close(host(pgl.nn.APPNP(alpha=0.2, k_hop=3)(g, x)), host(h.float()), scale=3.0)
+        sgc = pgl.nn.SGCConv(d, 7, k_hop=2).cuda()
+        close(host(sgc(g, x)), host(((An @ (An @ xd)) @ sgc.linear.weight.double().T).float()), scale=3.0, rtol=5e-5)
+        gin = pgl.nn.GINConv(d, 9, activation="relu", init_eps=0.3).cuda()
+        z = gin.linear2(torch.relu(gin.layer_norm(gin.linear1((A @ xd + 1.3 * xd).float()))))
+        close(host(gin(g, x)), host(z), scale=float(z.abs().max()), rtol=5e-5)
+        g2 = pgl.nn.GCNII(d, k_hop=2, dropout=0.0).cuda().eval()
+        assert torch.isfinite(g2(g, x)).all()
+
+
+def test_gatv2_and_transformer_conv_udf_path(pgl):
+    """GATv2 (send_uv on [N,H,D] -> edge_softmax -> send_ue_recv) and TransformerConv (UDF send/recv with
+    reduce_softmax) against dense per-destination softmax attention in fp64, forward and backward."""
+    torch.manual_seed(5)
+    n, e, d, H, D = 200, 1500, 12, 3, 4
+    edges, rng = rand_graph(n, e, 1300)
+    edges = np.unique(edges, axis=0)                      # dense reference below assumes simple edges
+    e = len(edges)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    src, dst = dev(edges[:, 0]), dev(edges[:, 1])
+    mask = torch.zeros(n, n, dtype=torch.bool, device="cuda"); mask[dst, src] = True
+    x = dev(rng.standard_normal((n, d)).astype(np.float32)).requires_grad_(True)
+    # --- TransformerConv
+    tc = pgl.nn.TransformerConv(d, D, num_heads=H, feat_drop=0.0, attn_drop=0.0, skip_feat=False, layer_norm=False, activation=None).cuda()
+    out = tc(g, x)
+    xd = x.detach().double()
+    q = (tc.q(x.detach()).double().reshape(n, H, D)) / (D ** 0.5)
+    k = tc.k(x.detach()).double().reshape(n, H, D); v = tc.v(x.detach()).double().reshape(n, H, D)
+    logits = torch.einsum("vhd,uhd->vuh", q, k).masked_fill(~mask[:, :, None], float("-inf"))
+    att = torch.nan_to_num(torch.softmax(logits, dim=1), nan=0.0)
+    want = torch.einsum("vuh,uhd->vhd", att, v).reshape(n, H * D)
+    close(host(out.detach()), host(want.float()), scale=float(want.abs().max()), rtol=5e-5)
+    out.square().sum().backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+    # --- GATv2
+    x.grad = None
+    gv = pgl.nn.GATv2Conv(d, D, feat_drop=0.0, attn_drop=0.0, num_heads=H).cuda()
+    out = gv(g, x)
+    f = gv.linear(x.detach()).double().reshape(n, H, D)
+    pair = torch.nn.functional.leaky_relu(f[None, :, :, :] + f[:, None, :, :], 0.2)          # [v, u, H, D]
+    logits = (pair * gv.attn.double()).sum(-1).masked_fill(~mask[:, :, None], float("-inf"))
+    att = torch.nan_to_num(torch.softmax(logits, dim=1), nan=0.0)
+    want = torch.einsum("vuh,uhd->vhd", att, f).reshape(n, H * D)
+    close(host(out.detach()), host(want.float()), scale=float(want.abs().max()), rtol=5e-5)
+    out.square().sum().backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
