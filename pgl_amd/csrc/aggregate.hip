@@ -110,7 +110,7 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
 }
 
 // RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector
-template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false>
+template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     constexpr int U = 8;
     using V = VecT<T, VEC>;
@@ -276,16 +276,23 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
             }
     };
 
+    // Software pipeline, three batches deep: feature rows of batch g are being consumed while the rows
+    // of batch g+1 are in flight AND the (scalar) indices of batch g+2 are being fetched, so neither
+    // the scalar-load latency nor the gather latency sits on the per-batch critical path.
     int e = e0;
     const int n_full = (e1 - e0) / U;
     int cA[U], rA[U], yA[U]; float sA[U];
+    int cB[U], rB[U], yB[U]; float sB[U];
     V xA[U][NT], wA[U][NT];
     if (n_full > 0) { load_idx(e, cA, rA, yA, sA); load_rows(cA, yA, xA, wA); }
+    if (PIPE3 && n_full > 1) load_idx(e + U, cB, rB, yB, sB);
     for (int g = 0; g < n_full; ++g) {
-        int cB[U], rB[U], yB[U]; float sB[U];
+        int cC[U], rC[U], yC[U]; float sC[U];
         V xB[U][NT], wB[U][NT];
-        const bool more = g + 1 < n_full;
-        if (more) { load_idx(e + U, cB, rB, yB, sB); load_rows(cB, yB, xB, wB); }
+        const bool more = g + 1 < n_full, more2 = PIPE3 && g + 2 < n_full;
+        if (!PIPE3 && more) load_idx(e + U, cB, rB, yB, sB);    // two-deep variant: fewer SGPRs, 8 workgroups per CU
+        if (more) load_rows(cB, yB, xB, wB);                    // PIPE3: indices of g+1 are already in SGPRs
+        if (more2) load_idx(e + 2 * U, cC, rC, yC, sC);
 #pragma unroll
         for (int i = 0; i < U; ++i) consume_one(rA[i], sA[i], xA[i], wA[i]);
         if (more) {
@@ -295,6 +302,10 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { xA[i][t] = xB[i][t]; wA[i][t] = wB[i][t]; }
             }
+        }
+        if (more2) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) { cB[i] = cC[i]; rB[i] = rC[i]; yB[i] = yC[i]; sB[i] = sC[i]; }
         }
         e += U;
     }
@@ -605,6 +616,16 @@ static int32_t launch_flat(AggParams p, hipStream_t st) {
         PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
     }
     constexpr bool can_scale = RCLS == 0 && std::is_floating_point_v<typename AccT<T>::type>;
+    // 256-byte rows (d=64 fp32, d=128 fp16) are occupancy-bound: the two-deep pipeline (69 SGPRs, 8
+    // workgroups/CU) measured 4 % faster there; everywhere else the three-deep one wins (up to 20 % on [E,8]).
+    const size_t row_bytes = (size_t)p.tile_cols * sizeof(T);
+    if constexpr (NT == 1 && YMODE == 0) {
+        if (row_bytes >= 192 && row_bytes <= 320 && !p.src_scale) {
+            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+            PGLAMD_LAUNCH_CHECK();
+            goto launched;
+        }
+    }
     if constexpr (can_scale) {
         if (p.src_scale)
             hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
@@ -614,6 +635,7 @@ static int32_t launch_flat(AggParams p, hipStream_t st) {
         hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     }
     PGLAMD_LAUNCH_CHECK();
+launched:
     if (prof().on) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
         prof().ev.emplace_back(e0, e1);

@@ -201,6 +201,38 @@ class Graph(object):
         return self._num_graph
 
     @property
+    def graph_edge_id(self):
+        """pgl/graph.py graph_edge_id: graph id of each edge in a batched graph."""
+        from .utils.helper import generate_segment_id_from_index
+        ids = generate_segment_id_from_index(np.asarray(self._graph_edge_index))
+        return to_device_tensor(ids, self._device) if self._is_tensor else ids
+
+    @classmethod
+    def disjoint(cls, graph_list, merged_graph_index=False):
+        """pgl/graph.py Graph.disjoint: one big graph out of several, node ids offset graph by graph.
+        merged_graph_index=True treats the result as ONE graph, False keeps per-graph node/edge ranges
+        (graph_node_id / graph_edge_id, used by graph_pool / graph_norm readouts)."""
+        assert len(graph_list) > 0, "The input graph_list of Graph.disjoint has length $d. It should be greater than 0. " % len(graph_list)
+        is_tensor = graph_list[0].is_tensor()
+        cat = (lambda xs: torch.cat(xs, 0)) if is_tensor else (lambda xs: np.concatenate(xs, axis=0))
+        offs = np.concatenate([[0], np.cumsum([g.num_nodes for g in graph_list])]).astype("int64")
+        eoffs = np.concatenate([[0], np.cumsum([g.num_edges for g in graph_list])]).astype("int64")
+        edges = cat([g.edges + int(o) for g, o in zip(graph_list, offs[:-1])])
+        def join(feats):
+            keys = feats[0].keys()
+            return {k: cat([f[k] for f in feats]) for k in keys}
+        kw = {}
+        if not merged_graph_index:
+            kw = dict(_num_graph=len(graph_list), _graph_node_index=offs, _graph_edge_index=eoffs)
+        return cls(edges=edges, num_nodes=int(offs[-1]), node_feat=join([g.node_feat for g in graph_list]),
+                   edge_feat=join([g.edge_feat for g in graph_list]), **kw)
+
+    @staticmethod
+    def batch(graph_list):
+        """Alias of Graph.disjoint(graph_list, merged_graph_index=False) (pgl/graph.py:1040-1043)."""
+        return Graph.disjoint(graph_list, merged_graph_index=False)
+
+    @property
     def graph_node_id(self):
         """pgl/graph.py graph_node_id: graph id of each node in a batched graph."""
         from .utils.helper import generate_segment_id_from_index

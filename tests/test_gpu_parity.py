@@ -934,3 +934,25 @@ def test_gatv2_and_transformer_conv_udf_path(pgl):
     close(host(out.detach()), host(want.float()), scale=float(want.abs().max()), rtol=5e-5)
     out.square().sum().backward()
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
+
+
+def test_batched_graph_readout_golden(pgl):
+    """tests/test_graph_op.py:25-54 (graph_norm on a disjoint batch) + graph_pool readouts."""
+    g1 = pgl.Graph(edges=[(0, 1), (1, 2)], num_nodes=3)
+    g2 = pgl.Graph(edges=[(0, 2), (0, 3), (1, 2)], num_nodes=4)
+    mg = pgl.Graph.disjoint([g1, g2])
+    assert mg.num_graph == 2 and mg.num_nodes == 7 and mg.num_edges == 5
+    assert mg.graph_node_id.tolist() == [0, 0, 0, 1, 1, 1, 1] and mg.graph_edge_id.tolist() == [0, 0, 1, 1, 1]
+    assert mg.edges.tolist() == [[0, 1], [1, 2], [3, 5], [3, 6], [4, 5]]
+    mg.tensor()
+    feat = np.repeat(np.arange(0, 7).reshape(-1, 1), 3, axis=1).astype("float32")
+    want = feat.copy(); want[0:3] /= np.sqrt(3); want[3:] /= np.sqrt(4)
+    assert host(pgl.nn.functional.graph_norm(mg, dev(feat))).tolist() == want.tolist()
+    assert host(pgl.nn.functional.graph_pool(mg, dev(feat), "sum")).tolist() == [[3, 3, 3], [18, 18, 18]]
+    assert host(pgl.nn.functional.graph_pool(mg, dev(feat), "max")).tolist() == [[2, 2, 2], [6, 6, 6]]
+    # message passing on the batch == per-graph message passing
+    out = host(mg.send_recv(dev(feat), "sum"))
+    a = host(pgl.Graph(edges=[(0, 1), (1, 2)], num_nodes=3).tensor().send_recv(dev(feat[:3]), "sum"))
+    b = host(pgl.Graph(edges=[(0, 2), (0, 3), (1, 2)], num_nodes=4).tensor().send_recv(dev(feat[3:]), "sum"))
+    assert np.array_equal(out, np.concatenate([a, b]))
+    assert pgl.Graph.batch([g1, g2]).num_graph == 2 and pgl.Graph.disjoint([g1, g2], merged_graph_index=True).num_graph == 1
