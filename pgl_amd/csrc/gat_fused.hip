@@ -59,7 +59,7 @@ __device__ __forceinline__ float drop_factor(unsigned seed, int eid, int head, f
 // MODE 0: forward (online softmax).  MODE 1: backward w.r.t. features (additive, alpha recomputed).
 template <int VEC, int MODE, bool DROP>
 __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
-    constexpr int U = 8;
+    constexpr int U = 4;
     constexpr int PW = MODE == 0 ? 3 : 1;               // floats per column in a partial
     using V = FV<VEC>;
     const int lane = threadIdx.x & (kWave - 1);
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
 // lanes of a head (a power of two); lane 0 of each head writes dpre[eid, h].
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(GatParams p) {
-    constexpr int U = 8;
+    constexpr int U = 4;
     using V = FV<VEC>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
