@@ -27,6 +27,7 @@
 //     the same XCD: partition-ordered graphs then reuse source rows in that XCD's private L2.
 #include "common.hpp"
 
+#include <algorithm>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -641,9 +642,9 @@ launched:
         prof().ev.emplace_back(e0, e1);
     }
     if (p.n_chunks > 1) {
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), dim3(kFixGridShort), dim3(kBlock), 0, st, p);
+        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), dim3((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), dim3(kFixGridLong), dim3(kFixWaves * kWave), 0, st, p);
+        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), dim3((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks)), dim3(kFixWaves * kWave), 0, st, p);
     }
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;

@@ -26,6 +26,8 @@
 // softmax merge, or plain sums for the backward): atomic-free, bit-reproducible.
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace pglamd {
 
 struct GatParams {
@@ -474,9 +476,9 @@ static int32_t launch_gat(GatParams p, hipStream_t st) {
         hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (p.n_chunks > 1) {
-        hipLaunchKernelGGL((gat_fixup_kernel<VEC, false, MODE>), dim3(kGatFixGridShort), dim3(kBlock), 0, st, p);
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, false, MODE>), dim3((unsigned)std::min<int64_t>(kGatFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gat_fixup_kernel<VEC, true, MODE>), dim3(kGatFixGridLong), dim3(kGatFixWaves * kWave), 0, st, p);
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, true, MODE>), dim3((unsigned)std::min<int64_t>(kGatFixGridLong, p.n_chunks)), dim3(kGatFixWaves * kWave), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
     }
     return PGLAMD_OK;
