@@ -293,6 +293,35 @@ class Graph(object):
             return self.adj_dst_index.view_v(nodes), self.adj_dst_index.view_eid(nodes)
         return self.adj_dst_index.view_v(nodes)
 
+    def _sample_from_index(self, index, nodes, max_degree, return_eids, shuffle):
+        """Host sampling over a numpy EdgeIndex: all neighbours if degree <= max_degree (optionally
+        shuffled), else max_degree of them without replacement -- the contract of
+        graph_kernel.sample_subset(_with_eid) (pgl/graph_kernel.pyx:266-339), numpy's RNG as there."""
+        if self.is_tensor():
+            raise ValueError("You must call Graph.numpy() first. Tensor object don't supprt sampling on the host; "
+                             "use pgl_amd.sampling.NeighborSampler for the GPU path.")
+        nodes = np.arange(index.degree.shape[0]) if nodes is None else np.asarray(nodes, dtype="int64")
+        nbrs, eids = [], []
+        for v in nodes:
+            b, e = int(index._indptr[v]), int(index._indptr[v + 1])
+            if e - b > max_degree:
+                pick = b + np.random.choice(e - b, max_degree, replace=False)
+            elif shuffle:
+                pick = b + np.random.permutation(e - b)
+            else:
+                pick = np.arange(b, e)
+            nbrs.append(np.asarray(index._sorted_v[pick], dtype="int64"))
+            eids.append(np.asarray(index._sorted_eid[pick], dtype="int64"))
+        return (nbrs, eids) if return_eids else nbrs
+
+    def sample_predecessor(self, nodes, max_degree, return_eids=False, shuffle=False):
+        """pgl/graph.py:644-688."""
+        return self._sample_from_index(self.adj_dst_index, nodes, max_degree, return_eids, shuffle)
+
+    def sample_successor(self, nodes, max_degree, return_eids=False, shuffle=False):
+        """pgl/graph.py:530-570."""
+        return self._sample_from_index(self.adj_src_index, nodes, max_degree, return_eids, shuffle)
+
     def get_segment_ids(self, src, dst, segment_by="dst"):
         """pgl/graph.py:1397-1407 -- cached (uniq_ind, segment_ids) of the sorted key column."""
         if segment_by not in self._seg_cache:

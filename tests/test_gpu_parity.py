@@ -969,3 +969,16 @@ def test_training_step_is_hip_graph_capturable(pgl):
     mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
     eager, replay, l0, l1 = mod.main("gcn", iters=60)
     assert l1 < l0 and replay < eager * 1.2
+
+
+def test_chunk_size_stress_in_subprocess(pgl):
+    """The partial / fix-up machinery under extreme chunk sizes: chunk = 8 splits every row longer than 8
+    edges (two-level work lists, block-parallel merges everywhere), chunk = 4096 almost never splits."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for k in ("8", "4096"):
+        env = dict(os.environ, PGLAMD_CHUNK=k)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                            "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute"],
+                           env=env, capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:]

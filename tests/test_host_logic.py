@@ -184,3 +184,31 @@ def test_rmat_generator_is_deterministic():
     assert a.shape == (5000, 2) and bool((a == b).all()) and int(a.max()) < 1024 and int(a.min()) >= 0
     deg = np.bincount(a[:, 1].numpy(), minlength=1024)
     assert deg.max() > 20 * max(1, int(np.median(deg)))              # power-law skew
+
+
+def test_host_sampling_and_graphsage_sample():
+    """numpy-mode sampling path of examples/graphsage (pgl/sampling/sage.py:59-127, custom.py:23-83)."""
+    import pgl_amd
+    rng = np.random.default_rng(3)
+    n = 300
+    edges = np.unique(np.stack([rng.integers(0, n, 4000), rng.integers(0, n, 4000)], 1), axis=0).astype(np.int64)
+    g = pgl_amd.Graph(edges=edges, num_nodes=n, node_feat={"h": rng.standard_normal((n, 4)).astype(np.float32)})
+    np.random.seed(0)
+    preds, eids = g.sample_predecessor([5, 6, 7], 3, return_eids=True)
+    for v, p, e in zip([5, 6, 7], preds, eids):
+        assert len(p) == min(3, int(g.indegree()[v])) and len(set(e.tolist())) == len(e)
+        assert (edges[e, 1] == v).all() and np.array_equal(edges[e, 0], p)
+    succ = g.sample_successor([1], 1000)
+    assert sorted(succ[0].tolist()) == sorted(edges[edges[:, 0] == 1, 1].tolist())
+    batch = [0, 1, 2, 3]
+    layers = pgl_amd.sampling.graphsage_sample(g, batch, [4, 4])
+    assert len(layers) == 2
+    for sg, sample_index, node_index in layers:
+        assert sg.num_nodes == len(sample_index) and np.array_equal(sample_index[node_index], np.array(batch))
+        se = sample_index[sg.edges]                                  # every sampled edge is a real edge
+        real = {tuple(x) for x in edges.tolist()}
+        assert all(tuple(x) in real for x in se.tolist())
+        assert np.array_equal(sg.node_feat["h"], g.node_feat["h"][sample_index])
+    assert layers[0][0].num_edges >= layers[1][0].num_edges          # outer layer sees more edges
+    sub = pgl_amd.sampling.subgraph(g, nodes=[3, 9, 27], edges=[(3, 9), (27, 3)])
+    assert sub.edges.tolist() == [[0, 1], [2, 0]]
