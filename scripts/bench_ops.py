@@ -59,6 +59,27 @@ ms = timeit(lambda: pgl.ops.gat_aggregate(xf, a_s, a_d, csr, 0.2)); report("gat_
 gat = pgl.nn.GATConv(128, D, feat_drop=0.0, attn_drop=0.0, num_heads=H).to(dev)
 with torch.no_grad():
     ms = timeit(lambda: gat(g, x), iters=10); report("GATConv forward (fused inference)", ms, (E * 620 + N * 552) / 1e9)
+# f3: sampling + relabel, one GraphSAGE fan-out of 25 over 1 M seeds
+seeds = torch.randperm(N, generator=gen, device=dev)[: min(N, 1_000_000)]
+ms = timeit(lambda: pgl.ops.sample_neighbors(csr, seeds, 25, seed=1), iters=5)
+nbr, cnt = pgl.ops.sample_neighbors(csr, seeds, 25, seed=1)
+print("%-34s %8.3f ms  (%d seeds -> %d sampled edges, %.1f M edges/s)" % ("sample_neighbors k=25", ms, len(seeds), len(nbr), len(nbr) / ms / 1e3))
+ms = timeit(lambda: pgl.ops.reindex_graph(seeds, nbr, cnt), iters=5)
+print("%-34s %8.3f ms  (%.1f M ids/s)" % ("reindex_graph", ms, (len(seeds) + len(nbr)) / ms / 1e3))
+# CPU side of the same box: the REFERENCE's own compiled build_index (oracle/_ref) and the C port of the Paddle CPU kernel
+try:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import ref_native, ref_ops
+    gk = ref_native.load(build_if_missing=False)
+    e_cpu = edges.cpu().numpy()
+    if gk is not None:
+        t0 = time.perf_counter(); gk.build_index(e_cpu[:, 1].copy(), e_cpu[:, 0].copy(), N); dt = time.perf_counter() - t0
+        print("%-34s %8.1f ms  (reference graph_kernel.build_index, 1 core, %.1f M edges/s)" % ("CPU reference build_index", dt * 1e3, E / dt / 1e6))
+    x_cpu = x.cpu().numpy()
+    t0 = time.perf_counter(); ref_ops.c_send_u_recv(x_cpu, e_cpu[:, 0], e_cpu[:, 1], "sum"); dt = time.perf_counter() - t0
+    print("%-34s %8.1f ms  (C port of Paddle CPU send_u_recv, 1 core, %.1f M edges/s)" % ("CPU port send_u_recv d=128", dt * 1e3, E / dt / 1e6))
+except Exception as ex:
+    print("cpu side skipped:", ex)
 gcn = pgl.nn.GCNConv(128, 128).to(dev)
 with torch.no_grad():
     ms = timeit(lambda: gcn(g, x), iters=10); report("GCNConv forward", ms, (E * 516 + N * 520) / 1e9)
