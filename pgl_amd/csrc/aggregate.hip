@@ -25,7 +25,7 @@
 //     third kernel from indptr (the reference guarantees 0, not +-inf, for every reduce op).
 //   * Logical blocks are remapped so consecutive chunks (consecutive destination rows) run on
 //     the same XCD: partition-ordered graphs then reuse source rows in that XCD's private L2.
-#include "common.hpp"
+#include "aggregate.hpp"
 
 #include <algorithm>
 #include <string>
@@ -34,81 +34,6 @@
 #include <vector>
 
 namespace pglamd {
-
-struct AggParams {
-    const void* x; const void* y; void* out;
-    const int* row; const int* col; const int* eid;
-    const int64_t* indptr;
-    const float* src_scale; const float* dst_scale;
-    void* part_head; void* part_tail;     // [n_chunks, tile_cols] of ACC each
-    int* long_count; int* long_list;      // [2] counters + work list of split-row fix-up tasks (workspace)
-    int* long_list2;                      // second-level list: rows with more than kFixShort partials
-    int64_t ldx, ldy, ldo;                // row strides (elements) of x, y, out
-    int64_t out_rows, n_csr_rows;
-    int E, n_chunks, chunk, n_blocks;
-    int n_grid_chunks;                    // blocks [0, n_grid_chunks) walk edge chunks, the rest zero-fill
-    int j_base, tile_cols;                // this launch covers out columns [j_base, j_base+tile_cols)
-    int gy;                               // y column = j / gy   (YMODE 1)
-    int mop, is_max, is_mean;
-    int zvec;                             // vector width the zero-fill role may use (1, 2, 4)
-    int accumulate;                       // 1: combine with the existing out row instead of overwriting
-    int align;                            // 1: never split rows of <= chunk edges (chunk_cut)
-};
-
-template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
-
-// storage type T -> accumulator type A: 16-bit floats are accumulated (and their partials kept) in fp32
-template <typename T> struct AccT { using type = T; };
-template <> struct AccT<__half> { using type = float; };
-template <> struct AccT<__hip_bfloat16> { using type = float; };
-template <typename T> __device__ __forceinline__ typename AccT<T>::type to_acc(T v) { return v; }
-template <> __device__ __forceinline__ float to_acc<__half>(__half v) { return __half2float(v); }
-template <> __device__ __forceinline__ float to_acc<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
-template <typename T> __device__ __forceinline__ T from_acc(typename AccT<T>::type v) { return v; }
-template <> __device__ __forceinline__ __half from_acc<__half>(float v) { return __float2half(v); }
-template <> __device__ __forceinline__ __hip_bfloat16 from_acc<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
-
-template <typename T> struct Limits;
-template <> struct Limits<float> { static __device__ float lo() { return -INFINITY; } static __device__ float hi() { return INFINITY; } };
-template <> struct Limits<double> { static __device__ double lo() { return -INFINITY; } static __device__ double hi() { return INFINITY; } };
-template <> struct Limits<int32_t> { static __device__ int32_t lo() { return INT32_MIN; } static __device__ int32_t hi() { return INT32_MAX; } };
-template <> struct Limits<int64_t> { static __device__ int64_t lo() { return INT64_MIN; } static __device__ int64_t hi() { return INT64_MAX; } };
-
-template <typename T> __device__ __forceinline__ T apply_mop(T a, T b, int mop) {
-    switch (mop) {
-        case PGLAMD_ADD: return a + b;
-        case PGLAMD_SUB: return a - b;
-        case PGLAMD_MUL: return a * b;
-        default: return a / b;
-    }
-}
-
-// Zero-fills the columns [j_base, j_base+tile_cols) of output rows that receive no edge: rows
-// r < n_csr_rows with indptr[r]==indptr[r+1], and rows in [n_csr_rows, out_rows).  One wave
-// inspects 64 rows (coalesced indptr read) and clears the empty ones, lanes across the columns.
-template <typename T>
-__device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t zb, int lane) {
-    const int64_t w = zb * kWavesPerBlock + (threadIdx.x >> 6);
-    const int64_t r0 = w * kWave;
-    if (r0 >= p.out_rows) return;
-    const int64_t r = r0 + lane;
-    bool empty = false;
-    if (r < p.out_rows) empty = (r >= p.n_csr_rows) || (p.indptr[r] == p.indptr[r + 1]);
-    unsigned long long m = __ballot(empty);
-    T* out = static_cast<T*>(p.out) + p.j_base;
-    while (m) {
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        T* dst = out + (r0 + l) * p.ldo;
-        if (p.zvec == 4) {
-            for (int j = lane * 4; j < p.tile_cols; j += kWave * 4) *reinterpret_cast<VecT<T, 4>*>(dst + j) = VecT<T, 4>{};
-        } else if (p.zvec == 2) {
-            for (int j = lane * 2; j < p.tile_cols; j += kWave * 2) *reinterpret_cast<VecT<T, 2>*>(dst + j) = VecT<T, 2>{};
-        } else {
-            for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = from_acc<T>(typename AccT<T>::type(0));
-        }
-    }
-}
 
 // RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector
 template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true>
@@ -574,7 +499,7 @@ __global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-static int chunk_edges() {
+int chunk_edges() {
     static int k = [] {
         const char* s = getenv("PGLAMD_CHUNK");
         int v = s ? atoi(s) : 256;
@@ -648,6 +573,57 @@ launched:
     }
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
+}
+
+template <typename T>
+static int32_t launch_fixup_typed(const AggParams& p, int rcls, hipStream_t st) {
+    const unsigned gs = (unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock));
+    const unsigned gl = (unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks);
+    if (rcls == 0) {
+        hipLaunchKernelGGL((agg_fixup_kernel<T, 1, 1, 0, false>), dim3(gs), dim3(kBlock), 0, st, p);
+        PGLAMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL((agg_fixup_kernel<T, 1, 1, 0, true>), dim3(gl), dim3(kFixWaves * kWave), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((agg_fixup_kernel<T, 1, 1, 1, false>), dim3(gs), dim3(kBlock), 0, st, p);
+        PGLAMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL((agg_fixup_kernel<T, 1, 1, 1, true>), dim3(gl), dim3(kFixWaves * kWave), 0, st, p);
+    }
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+int32_t launch_fixup_cols(const AggParams& p, int32_t dtype, int rcls, hipStream_t st) {
+    switch (dtype) {
+        case PGLAMD_F32: return launch_fixup_typed<float>(p, rcls, st);
+        case PGLAMD_F64: return launch_fixup_typed<double>(p, rcls, st);
+        case PGLAMD_I32: return launch_fixup_typed<int32_t>(p, rcls, st);
+        case PGLAMD_I64: return launch_fixup_typed<int64_t>(p, rcls, st);
+        case PGLAMD_F16: return launch_fixup_typed<__half>(p, rcls, st);
+        case PGLAMD_BF16: return launch_fixup_typed<__hip_bfloat16>(p, rcls, st);
+        default: return fail(PGLAMD_E_DTYPE, "fix-up: dtype %d", dtype);
+    }
+}
+
+template <typename T> constexpr int32_t dtype_code() {
+    return std::is_same_v<T, float> ? PGLAMD_F32 : std::is_same_v<T, double> ? PGLAMD_F64 : std::is_same_v<T, int32_t> ? PGLAMD_I32 :
+           std::is_same_v<T, int64_t> ? PGLAMD_I64 : std::is_same_v<T, __half> ? PGLAMD_F16 : PGLAMD_BF16;
+}
+
+// rows at most this many elements wide (and <= 64 bytes of accumulator) take the lane-per-edge kernel
+static int narrow_max() {
+    static int k = [] { const char* s = getenv("PGLAMD_NARROW"); return s ? atoi(s) : 16; }();
+    return k;
+}
+// The lane-per-edge kernels walk 64 edges per step, so they amortise their per-chunk prologue over longer chunks:
+// 512 edges measured best at C2 sizes (d=1: 0.21 -> 0.13 ms against 256; 1024 equal, 4096 slower).
+int narrow_chunk_edges() {
+    static int k = [] {
+        const char* s = getenv("PGLAMD_NCHUNK");
+        int v = s ? atoi(s) : 512;
+        if (getenv("PGLAMD_CHUNK")) v = chunk_edges();       // stress tests drive both kernels with one knob
+        return v < 8 ? 8 : v / 8 * 8;
+    }();
+    return k;
 }
 
 template <typename T, int VEC, int NT>
@@ -804,6 +780,20 @@ static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t
         p.long_count = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half);
         p.long_list = p.long_count + 64;
         p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half + lst);
+        // measured at C2 sizes: the lane-per-edge kernel wins up to 32 B of accumulator per row for every reduce op
+        // (2.6-3.4x at d <= 8 fp32) and up to 64 B for sum / mean (1.3x at d = 16 fp32)
+        if (dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= (rcls == 0 ? 64u : 32u)) {
+            AggParams q = p;
+            const int nk = std::max(K, narrow_chunk_edges());                   // fewer, longer chunks: the carved arrays still fit
+            q.chunk = nk; q.n_chunks = (int)ceil_div(E, nk);
+            q.j_base = 0; q.tile_cols = (int)dout;
+            const size_t lv = std::min<size_t>(16, (size_t)dout * sizeof(T));
+            q.narrow_vec = (lv & (lv - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+                                                    (y && dy == dout ? reinterpret_cast<uintptr_t>(y) : 0)) % lv == 0;
+            bool handled = false;
+            rc = launch_narrow(q, dtype_code<T>(), rcls, y ? dy : 0, st, &handled);
+            if (rc != PGLAMD_OK || handled) return rc;
+        }
         for (int64_t jb = 0; jb < dout; jb += max_cols) {
             p.j_base = (int)jb;
             p.tile_cols = (int)((dout - jb) < max_cols ? (dout - jb) : max_cols);

@@ -1,0 +1,102 @@
+// aggregate.hpp -- launch parameters and device helpers shared by the aggregation kernels
+// (aggregate.hip: lanes across the feature dimension; aggregate_narrow.hip: one lane per edge).
+#pragma once
+#include "common.hpp"
+
+#include <type_traits>
+
+namespace pglamd {
+
+struct AggParams {
+    const void* x; const void* y; void* out;
+    const int* row; const int* col; const int* eid;
+    const int64_t* indptr;
+    const float* src_scale; const float* dst_scale;
+    void* part_head; void* part_tail;     // [n_chunks, tile_cols] of ACC each
+    int* long_count; int* long_list;      // [2] counters + work list of split-row fix-up tasks (workspace)
+    int* long_list2;                      // second-level list: rows with more than kFixShort partials
+    int64_t ldx, ldy, ldo;                // row strides (elements) of x, y, out
+    int64_t out_rows, n_csr_rows;
+    int E, n_chunks, chunk, n_blocks;
+    int n_grid_chunks;                    // blocks [0, n_grid_chunks) walk edge chunks, the rest zero-fill
+    int j_base, tile_cols;                // this launch covers out columns [j_base, j_base+tile_cols)
+    int gy;                               // y column = j / gy   (YMODE 1)
+    int mop, is_max, is_mean;
+    int zvec;                             // vector width the zero-fill role may use (1, 2, 4)
+    int accumulate;                       // 1: combine with the existing out row instead of overwriting
+    int align;                            // 1: never split rows of <= chunk edges (chunk_cut)
+    int narrow_vec;                       // aggregate_narrow: rows may be moved with (<=16-byte) vector loads / stores
+};
+
+template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
+
+// storage type T -> accumulator type A: 16-bit floats are accumulated (and their partials kept) in fp32
+template <typename T> struct AccT { using type = T; };
+template <> struct AccT<__half> { using type = float; };
+template <> struct AccT<__hip_bfloat16> { using type = float; };
+template <typename T> __device__ __forceinline__ typename AccT<T>::type to_acc(T v) { return v; }
+template <> __device__ __forceinline__ float to_acc<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float to_acc<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_acc(typename AccT<T>::type v) { return v; }
+template <> __device__ __forceinline__ __half from_acc<__half>(float v) { return __float2half(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 from_acc<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <typename T> struct Limits;
+template <> struct Limits<float> { static __device__ float lo() { return -INFINITY; } static __device__ float hi() { return INFINITY; } };
+template <> struct Limits<double> { static __device__ double lo() { return -INFINITY; } static __device__ double hi() { return INFINITY; } };
+template <> struct Limits<int32_t> { static __device__ int32_t lo() { return INT32_MIN; } static __device__ int32_t hi() { return INT32_MAX; } };
+template <> struct Limits<int64_t> { static __device__ int64_t lo() { return INT64_MIN; } static __device__ int64_t hi() { return INT64_MAX; } };
+
+template <typename T> __device__ __forceinline__ T apply_mop(T a, T b, int mop) {
+    switch (mop) {
+        case PGLAMD_ADD: return a + b;
+        case PGLAMD_SUB: return a - b;
+        case PGLAMD_MUL: return a * b;
+        default: return a / b;
+    }
+}
+
+// Zero-fills the columns [j_base, j_base+tile_cols) of output rows that receive no edge: rows
+// r < n_csr_rows with indptr[r]==indptr[r+1], and rows in [n_csr_rows, out_rows).  One wave
+// inspects 64 rows (coalesced indptr read) and clears the empty ones, lanes across the columns.
+template <typename T>
+__device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t zb, int lane) {
+    const int64_t w = zb * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t r0 = w * kWave;
+    if (r0 >= p.out_rows) return;
+    const int64_t r = r0 + lane;
+    bool empty = false;
+    if (r < p.out_rows) empty = (r >= p.n_csr_rows) || (p.indptr[r] == p.indptr[r + 1]);
+    unsigned long long m = __ballot(empty);
+    T* out = static_cast<T*>(p.out) + p.j_base;
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        T* dst = out + (r0 + l) * p.ldo;
+        if (p.zvec == 4) {
+            for (int j = lane * 4; j < p.tile_cols; j += kWave * 4) *reinterpret_cast<VecT<T, 4>*>(dst + j) = VecT<T, 4>{};
+        } else if (p.zvec == 2) {
+            for (int j = lane * 2; j < p.tile_cols; j += kWave * 2) *reinterpret_cast<VecT<T, 2>*>(dst + j) = VecT<T, 2>{};
+        } else {
+            for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = from_acc<T>(typename AccT<T>::type(0));
+        }
+    }
+}
+
+// aggregate.hip: edges per chunk (256; PGLAMD_CHUNK overrides, used by the stress tests)
+int chunk_edges();
+int narrow_chunk_edges();
+// aggregate.hip: combines the T[a] / H[c] partials the edge kernels leave for rows longer than a chunk
+// (tile_cols <= 64 columns, one column per lane).
+int32_t launch_fixup_cols(const AggParams& p, int32_t dtype, int rcls, hipStream_t st);
+// aggregate_narrow.hip: rows of <= 16 elements, one lane per edge.  *handled = false when the shape is not covered.
+int32_t launch_narrow(const AggParams& p, int32_t dtype, int rcls, int64_t dy, hipStream_t st, bool* handled);
+
+// aggregate_narrow.hip: one-pass (online) softmax statistics for rows of <= 16 fp32 / <= 8 fp64 elements.
+bool narrow_softmax_covers(int64_t d, int32_t dtype);
+size_t narrow_softmax_workspace_bytes(int64_t num_rows, int64_t d, int32_t dtype, int chunk);
+int32_t narrow_softmax_stats(const void* data, int32_t dtype, int64_t num_rows, int64_t d, const int32_t* row32,
+                             const int32_t* perm32, const int64_t* seg_ptr, int64_t n_seg, void* stats,
+                             int chunk, void* ws, size_t ws_bytes, hipStream_t st);
+
+}  // namespace pglamd

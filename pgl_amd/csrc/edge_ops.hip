@@ -1,6 +1,8 @@
 // edge_ops.hip -- K3 send_uv, K4 segment softmax / fused edge_softmax, K5 segment reduce wrapper,
 // K6/K7 row gather / scatter, K9 degree_norm, K1' COO atomic scatter-add.
-#include "common.hpp"
+#include "aggregate.hpp"
+
+#include <algorithm>
 
 #include <type_traits>
 
@@ -84,7 +86,8 @@ template <typename T> __device__ __forceinline__ T exp_t(T v);
 template <> __device__ __forceinline__ float exp_t<float>(float v) { return expf(v); }
 template <> __device__ __forceinline__ double exp_t<double>(double v) { return exp(v); }
 
-template <typename T, int VEC, bool DIV>
+// MODE 0: exp(x - stat[seg])   1: x / stat[seg]   2: exp(x - max[seg]) / sum[seg] with stat = [n_seg, 2, d] (whole normalisation in one pass)
+template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(kBlock) void softmax_elem_kernel(const T* x, const T* __restrict__ stat,
                                                               const int32_t* __restrict__ seg, int64_t n, int64_t d,
                                                               T* out) {   // x may alias out (in-place divide)
@@ -94,22 +97,31 @@ __global__ __launch_bounds__(kBlock) void softmax_elem_kernel(const T* x, const 
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t e = i / per, j = (i - e * per) * VEC;
         const V a = *reinterpret_cast<const V*>(x + e * d + j);
-        const V b = *reinterpret_cast<const V*>(stat + (int64_t)seg[e] * d + j);
+        const int64_t so = (int64_t)seg[e] * (MODE == 2 ? 2 * d : d) + j;     // MODE 2: [n_seg, 2, d] maxima | sums
+        const V b = *reinterpret_cast<const V*>(stat + so);
         V o;
+        if constexpr (MODE == 2) {
+            const V c = *reinterpret_cast<const V*>(stat + so + d);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o.v[k] = DIV ? a.v[k] / b.v[k] : exp_t<T>(a.v[k] - b.v[k]);
+            for (int k = 0; k < VEC; ++k) o.v[k] = exp_t<T>(a.v[k] - b.v[k]) / c.v[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o.v[k] = MODE == 1 ? a.v[k] / b.v[k] : exp_t<T>(a.v[k] - b.v[k]);
+        }
         *reinterpret_cast<V*>(out + e * d + j) = o;
     }
 }
 
-template <typename T, bool DIV>
+template <typename T, int MODE>
 static int32_t softmax_elem(const T* x, const T* stat, const int32_t* seg, int64_t n, int64_t d, T* out, hipStream_t st) {
     constexpr int VMAX = 16 / sizeof(T);
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(stat) | reinterpret_cast<uintptr_t>(out);
     if (d % VMAX == 0 && al % 16 == 0)
-        hipLaunchKernelGGL((softmax_elem_kernel<T, VMAX, DIV>), dim3(grid_for(n * (d / VMAX))), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
+        hipLaunchKernelGGL((softmax_elem_kernel<T, VMAX, MODE>), dim3(grid_for(n * (d / VMAX))), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
+    else if (d % 2 == 0 && al % (2 * sizeof(T)) == 0)
+        hipLaunchKernelGGL((softmax_elem_kernel<T, 2, MODE>), dim3(grid_for(n * (d / 2))), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
     else
-        hipLaunchKernelGGL((softmax_elem_kernel<T, 1, DIV>), dim3(grid_for(n * d)), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
+        hipLaunchKernelGGL((softmax_elem_kernel<T, 1, MODE>), dim3(grid_for(n * d)), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }
@@ -204,7 +216,9 @@ extern "C" int32_t pglamd_send_uv(const void* x, const void* y, int32_t dtype, i
 
 extern "C" size_t pglamd_segment_softmax_workspace_bytes(int64_t num_rows, int64_t d, int64_t n_seg, int32_t dtype) {
     const size_t es = dtype_size(dtype);
-    return 2 * align_up((size_t)(n_seg > 0 ? n_seg : 1) * d * es, 256) + pglamd_aggregate_workspace_bytes(num_rows, d, dtype) + 256;
+    size_t agg = pglamd_aggregate_workspace_bytes(num_rows, d, dtype);
+    if (narrow_softmax_covers(d, dtype)) agg = std::max(agg, narrow_softmax_workspace_bytes(num_rows, d, dtype, narrow_chunk_edges()));
+    return 2 * align_up((size_t)(n_seg > 0 ? n_seg : 1) * d * es, 256) + agg + 256;
 }
 
 extern "C" int32_t pglamd_segment_softmax(const void* data, int32_t dtype, int64_t num_rows, int64_t d, const int32_t* row32,
@@ -223,17 +237,27 @@ extern "C" int32_t pglamd_segment_softmax(const void* data, int32_t dtype, int64
     void* aw = w + 2 * stat_bytes;
     const size_t aw_bytes = workspace_bytes - 2 * stat_bytes;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int32_t rc = pglamd_aggregate(data, dtype, num_rows, d, nullptr, 0, nullptr, row32, perm32, seg_ptr, num_rows, n_seg, n_seg, d,
-                                  0, PGLAMD_MAX, nullptr, nullptr, 0, mx, aw, aw_bytes, stream);
+    int32_t rc;
+    if (narrow_softmax_covers(d, dtype)) {
+        // narrow rows: (max, sum of exp) per segment in ONE pass over the data (online softmax, lane per element),
+        // then one element-parallel pass writes exp(x - max) / sum.
+        rc = narrow_softmax_stats(data, dtype, num_rows, d, row32, perm32, seg_ptr, n_seg, mx, narrow_chunk_edges(), aw, aw_bytes, st);
+        if (rc != PGLAMD_OK) return rc;
+        if (dtype == PGLAMD_F32)
+            return softmax_elem<float, 2>((const float*)data, (const float*)mx, seg_of_elem32, num_rows, d, (float*)out, st);
+        return softmax_elem<double, 2>((const double*)data, (const double*)mx, seg_of_elem32, num_rows, d, (double*)out, st);
+    }
+    rc = pglamd_aggregate(data, dtype, num_rows, d, nullptr, 0, nullptr, row32, perm32, seg_ptr, num_rows, n_seg, n_seg, d,
+                          0, PGLAMD_MAX, nullptr, nullptr, 0, mx, aw, aw_bytes, stream);
     if (rc != PGLAMD_OK) return rc;
-    if (dtype == PGLAMD_F32) rc = softmax_elem<float, false>((const float*)data, (const float*)mx, seg_of_elem32, num_rows, d, (float*)out, st);
-    else rc = softmax_elem<double, false>((const double*)data, (const double*)mx, seg_of_elem32, num_rows, d, (double*)out, st);
+    if (dtype == PGLAMD_F32) rc = softmax_elem<float, 0>((const float*)data, (const float*)mx, seg_of_elem32, num_rows, d, (float*)out, st);
+    else rc = softmax_elem<double, 0>((const double*)data, (const double*)mx, seg_of_elem32, num_rows, d, (double*)out, st);
     if (rc != PGLAMD_OK) return rc;
     rc = pglamd_aggregate(out, dtype, num_rows, d, nullptr, 0, nullptr, row32, perm32, seg_ptr, num_rows, n_seg, n_seg, d, 0,
                           PGLAMD_SUM, nullptr, nullptr, 0, sm, aw, aw_bytes, stream);
     if (rc != PGLAMD_OK) return rc;
-    if (dtype == PGLAMD_F32) return softmax_elem<float, true>((const float*)out, (const float*)sm, seg_of_elem32, num_rows, d, (float*)out, st);
-    return softmax_elem<double, true>((const double*)out, (const double*)sm, seg_of_elem32, num_rows, d, (double*)out, st);
+    if (dtype == PGLAMD_F32) return softmax_elem<float, 1>((const float*)out, (const float*)sm, seg_of_elem32, num_rows, d, (float*)out, st);
+    return softmax_elem<double, 1>((const double*)out, (const double*)sm, seg_of_elem32, num_rows, d, (double*)out, st);
 }
 
 extern "C" size_t pglamd_segment_reduce_workspace_bytes(int64_t num_rows, int64_t d, int64_t n_out_rows, int32_t dtype) {

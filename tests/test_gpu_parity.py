@@ -971,6 +971,109 @@ def test_training_step_is_hip_graph_capturable(pgl):
     assert l1 < l0 and replay < eager * 1.2
 
 
+# ------------------------------------------------------------------------------------------------
+# narrow rows (<= 16 elements): the lane-per-edge kernel and the one-pass softmax statistics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 8, 12, 16])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+def test_narrow_rows_send_recv(pgl, op, d, dtype):
+    n, e = 5000, 90000
+    edges, rng = rand_graph(n, e, 300 + d, hub=20000)           # the hub row spans ~80 chunks of 256 edges
+    edges[edges[:, 1] % 7 == 0, 1] = 11                         # a second long row + many empty rows
+    x = (rng.standard_normal((n, d)) * 50).astype(dtype)
+    want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    got = host(g.send_recv(dev(x), op))
+    if np.issubdtype(dtype, np.integer):
+        assert np.array_equal(got, want)
+    else:
+        close(got, want, scale=np.abs(want).max(), rtol=RTOL if dtype == np.float32 else 1e-12)
+    assert torch.equal(g.send_recv(dev(x), op), g.send_recv(dev(x), op))
+    # out_size larger than the row count: the extra rows are zero
+    big = host(g.send_recv(dev(x), op, out_size=n + 77))
+    assert big.shape[0] == n + 77 and (big[n:] == 0).all() and np.array_equal(big[:n], got)
+
+
+@pytest.mark.parametrize("mop", ["add", "sub", "mul", "div"])
+@pytest.mark.parametrize("rop", ["sum", "mean"])
+@pytest.mark.parametrize("dx,dy", [(1, 1), (8, 8), (8, 1), (3, 3), (5, 1), (16, 16)])
+def test_narrow_rows_send_ue_recv(pgl, mop, rop, dx, dy):
+    n, e = 3000, 50000
+    edges, rng = rand_graph(n, e, 400 + dx + dy, hub=9000)
+    x = rng.standard_normal((n, dx)).astype(np.float32)
+    y = (rng.standard_normal((e, dy)) + 3.0).astype(np.float32)
+    want = R.c_send_ue_recv(x, y, edges[:, 0], edges[:, 1], mop, rop)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    got = host(g.send_ue_recv(dev(x), dev(y), mop, rop))
+    close(got, want, scale=np.abs(want).max())
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("d", [1, 4, 8, 16])
+def test_narrow_rows_16bit_storage(pgl, tdt, d):
+    n, e = 3000, 60000
+    edges, rng = rand_graph(n, e, 500 + d, hub=10000)
+    x = torch.as_tensor(rng.standard_normal((n, d)).astype(np.float32)).to(tdt)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    for op in ("sum", "mean", "max"):
+        want = R.c_send_u_recv(x.float().numpy(), edges[:, 0], edges[:, 1], op)
+        got = g.send_recv(x.cuda(), op)
+        assert got.dtype == tdt
+        # fp32 accumulation: the only error is the final rounding to 16 bits
+        np.testing.assert_allclose(host(got.float()), want, rtol=2 ** -7 if tdt == torch.bfloat16 else 2 ** -10,
+                                   atol=1e-3 * np.abs(want).max())
+
+
+def test_narrow_rows_fused_scales_and_accumulate(pgl):
+    n, e, d = 4000, 70000, 8
+    edges, rng = rand_graph(n, e, 77, hub=12000)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    ss = rng.random(n).astype(np.float32) + 0.5
+    ds = rng.random(n).astype(np.float32) + 0.5
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    csr = g.adj_dst_index.csr
+    want = R.c_send_u_recv(x * ss[:, None], edges[:, 0], edges[:, 1], "sum") * ds[:, None]
+    got = pgl.ops.aggregate(dev(x), csr, "sum", src_scale=dev(ss), dst_scale=dev(ds))
+    close(host(got), want, scale=np.abs(want).max())
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    acc = dev(base.copy())
+    pgl.ops.aggregate(dev(x), csr, "sum", out=acc, accumulate=True)
+    close(host(acc), base + R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "sum"), scale=np.abs(want).max())
+    mx = dev(base.copy())
+    pgl.ops.aggregate(dev(x), csr, "max", out=mx, accumulate=True)
+    w = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "max")
+    has = np.isin(np.arange(n), edges[:, 1])
+    assert np.array_equal(host(mx), np.where(has[:, None], np.maximum(base, w), base))
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_narrow_segment_softmax_one_pass(pgl, d, dtype):
+    if dtype == np.float64 and d > 8:
+        pytest.skip("fp64 d>8 takes the wide path (covered by test_segment_softmax_random)")
+    rng = np.random.default_rng(600 + d)
+    ids = rng.integers(0, 500, 60000)
+    ids[2000:32000] = 250                                       # one segment of 30k elements (~120 chunks)
+    ids[40000:40300] = 251
+    ids = np.sort(ids).astype(np.int64)
+    data = (rng.standard_normal((60000, d)) * 6).astype(dtype)
+    data[100] = 80.0                                            # large logits: the running maximum must protect exp
+    want = R.c_segment_softmax(data, ids)
+    got = host(pgl.math.segment_softmax(dev(data), dev(ids)))
+    if dtype == np.float32:
+        # the 30k-element segment is summed serially in fp32 by the reference loop (its own rounding noise is ~3e-5
+        # there): <=1e-5 against the same loop in fp64, and within that noise of the fp32 loop itself
+        exact = R.c_segment_softmax(data.astype(np.float64), ids)
+        np.testing.assert_allclose(got, exact, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-7)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-15)
+    sums = np.zeros((500, d)); np.add.at(sums, ids, got)
+    present = np.isin(np.arange(500), ids)
+    np.testing.assert_allclose(sums[present], 1.0, rtol=1e-4)
+
+
 def test_chunk_size_stress_in_subprocess(pgl):
     """The partial / fix-up machinery under extreme chunk sizes: chunk = 8 splits every row longer than 8
     edges (two-level work lists, block-parallel merges everywhere), chunk = 4096 almost never splits."""
@@ -979,6 +1082,6 @@ def test_chunk_size_stress_in_subprocess(pgl):
     for k in ("8", "4096"):
         env = dict(os.environ, PGLAMD_CHUNK=k)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                            "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute"],
+                            "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute or narrow or softmax"],
                            env=env, capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:]
