@@ -434,6 +434,10 @@ class Graph(object):
             raise ValueError("You must call Graph.tensor()")
         ss = None if src_scale is None else src_scale.reshape(-1).contiguous()
         ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()
+        if ss is not None and ss.numel() != feature.shape[0]:
+            raise ValueError("src_scale must hold one value per source node (%d), got %d" % (feature.shape[0], ss.numel()))
+        if ds is not None and ds.numel() != feature.shape[0]:
+            raise ValueError("dst_scale must hold one value per destination node (%d), got %d" % (feature.shape[0], ds.numel()))
         return ag.aggregate(feature, self._csr_dst(), self._csr_src, "sum", None, None, "add", None, None, ss, ds)
 
     def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2, attn_drop=0.0, seed=0):

@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/layers/*.npz by running the REFERENCE's own Python code (pgl/graph.py, pgl/message.py,
+pgl/math.py, pgl/nn/conv.py, pgl/nn/functional/graph_op.py ... imported read-only from /root/reference) on seeded inputs.
+
+Build container only.  PaddlePaddle is not installed, so `paddle` is the oracle's stand-in (oracle/paddle_stub, torch-CPU)
+and the four paddle.geometric primitives are the oracle's restatement (oracle/ref_ops.py): what these fixtures pin is
+everything the reference composes AROUND those primitives -- the layer glue (normalisation, attention, head reshape /
+mean, residuals, self-loops, k-hop loops), send/recv with user functions, edge_softmax's gather/scatter, batched-graph
+read-outs -- as computed by the reference's own source.
+
+    python tests/golden/make_golden_layers.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "..", "oracle"))
+import ref_python  # noqa: E402
+
+pgl = ref_python.load()
+assert pgl is not None, "reference python package unavailable (build container only)"
+import paddle  # noqa: E402  (the stand-in)
+import pgl.nn as gnn  # noqa: E402
+import pgl.nn.functional as GF  # noqa: E402
+
+OUT = os.path.join(HERE, "layers")
+os.makedirs(OUT, exist_ok=True)
+
+
+def graph_case(n, e, seed, hub=0, self_loops=False):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e); dst = rng.integers(0, n, e)
+    if hub:
+        dst[rng.choice(e, hub, replace=False)] = n // 3
+    edges = np.stack([src, dst], 1).astype(np.int64)
+    if self_loops:
+        edges = np.concatenate([edges, np.stack([np.arange(n), np.arange(n)], 1)]).astype(np.int64)
+    return edges, rng
+
+
+def save(name, **arrays):
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **arrays)
+    print("wrote", name, {k: getattr(v, "shape", None) for k, v in arrays.items() if not k.startswith("param::")})
+
+
+def params_of(layer):
+    return {"param::" + k: v.detach().numpy().copy() for k, v in layer.state_dict().items()}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layers: (class name, ctor kwargs, input dim); dropout rates are 0 so the forward is deterministic
+# ---------------------------------------------------------------------------------------------------------
+LAYERS = [
+    ("GCNConv", dict(input_size=24, output_size=8, activation="relu", norm=True)),
+    ("GCNConv", dict(input_size=8, output_size=24, activation=None, norm=True)),
+    ("GCNConv", dict(input_size=16, output_size=16, activation=None, norm=False)),
+    ("GATConv", dict(input_size=20, hidden_size=16, feat_drop=0.0, attn_drop=0.0, num_heads=8, concat=True, activation="elu")),
+    ("GATConv", dict(input_size=20, hidden_size=8, feat_drop=0.0, attn_drop=0.0, num_heads=2, concat=False, activation=None)),
+    ("GATConv", dict(input_size=12, hidden_size=5, feat_drop=0.0, attn_drop=0.0, num_heads=3, concat=True, activation=None)),
+    ("GraphSageConv", dict(input_size=16, hidden_size=12, aggr_func="sum", normalize=True)),
+    ("GraphSageConv", dict(input_size=16, hidden_size=12, aggr_func="mean", normalize=False)),
+    ("GraphSageConv", dict(input_size=16, hidden_size=12, aggr_func="max", normalize=True)),
+    ("GraphSageConv", dict(input_size=16, hidden_size=12, aggr_func="min", normalize=False)),
+    ("GATv2Conv", dict(input_size=20, hidden_size=8, feat_drop=0.0, attn_drop=0.0, num_heads=4, concat=True, activation=None)),
+    ("APPNP", dict(alpha=0.2, k_hop=4, self_loop=False)),
+    ("APPNP", dict(alpha=0.1, k_hop=3, self_loop=True)),
+    ("GCNII", dict(hidden_size=16, activation="relu", lambda_l=0.5, alpha=0.2, k_hop=3, dropout=0.0)),      # caller-supplied [N,d] norm
+    ("TransformerConv", dict(input_size=16, hidden_size=8, num_heads=4, feat_drop=0.0, attn_drop=0.0, concat=True,
+                             skip_feat=True, gate=False, layer_norm=True, activation="relu")),
+    ("TransformerConv", dict(input_size=16, hidden_size=8, num_heads=2, feat_drop=0.0, attn_drop=0.0, concat=False,
+                             skip_feat=True, gate=True, layer_norm=False, activation=None)),
+    ("GINConv", dict(input_size=16, output_size=12, activation="relu", init_eps=0.3, train_eps=True)),
+    ("SGCConv", dict(input_size=16, output_size=6, k_hop=3, cached=False, activation=None, bias=True)),
+    ("LightGCNConv", dict()),
+    ("GCNII", dict(hidden_size=16, activation=None, lambda_l=0.5, alpha=0.1, k_hop=4, dropout=0.0)),        # default degree norm
+    ("GCNConv", dict(input_size=12, output_size=12, activation=None, norm=True)),                          # caller-supplied [N,1] norm
+]
+CALLER_NORM = {13: "wide", 20: "column"}
+
+for i, (cls, kw) in enumerate(LAYERS):
+    n, e = 300, 2400
+    edges, rng = graph_case(n, e, 1000 + i, hub=400)
+    din = kw.get("input_size", kw.get("hidden_size", 16))
+    x = rng.standard_normal((n, din)).astype(np.float32)
+    paddle.seed(2000 + i)
+    layer = getattr(gnn, cls)(**kw)
+    # biases start at zero in the reference: give every parameter a non-trivial value so the fixture can tell them apart
+    with paddle.no_grad():
+        for p in layer.parameters():
+            if float(p.abs().sum()) == 0.0:
+                p.copy_(paddle.to_tensor(rng.standard_normal(tuple(p.shape)).astype(np.float32) * 0.1))
+    layer.eval()
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    xt = paddle.to_tensor(x)
+    extra = {}
+    if i in CALLER_NORM:        # both layers take forward(graph, feature, norm=None)
+        nrm = (np.abs(x) * 0.5 + 0.1) if CALLER_NORM[i] == "wide" else (rng.random((n, 1)).astype(np.float32) + 0.5)
+        extra["norm"] = nrm.astype(np.float32)
+        out = layer(g, xt, paddle.to_tensor(extra["norm"]))
+    else:
+        out = layer(g, xt)
+    save("layer_%02d_%s" % (i, cls), edges=edges, num_nodes=np.int64(n), x=x, out=out.detach().numpy(),
+         cls=np.array(cls), kwargs=np.array(json.dumps(kw)), **extra, **params_of(layer))
+
+# ---------------------------------------------------------------------------------------------------------
+# graph-level ops through the reference's Graph / Message / math code
+# ---------------------------------------------------------------------------------------------------------
+n, e = 200, 1500
+edges, rng = graph_case(n, e, 77, hub=300)
+g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+x = rng.standard_normal((n, 4, 6)).astype(np.float32)
+ef = rng.standard_normal((e, 4, 1)).astype(np.float32)
+logits = (rng.standard_normal((e, 4)) * 3).astype(np.float32)
+ops = {"edges": edges, "num_nodes": np.int64(n), "x": x, "ef": ef, "logits": logits}
+xt, eft = paddle.to_tensor(x), paddle.to_tensor(ef)
+for rop in ("sum", "mean", "max", "min"):
+    ops["send_recv_" + rop] = g.send_recv(xt, rop).numpy()
+    ops["send_ue_recv_mul_" + rop] = g.send_ue_recv(xt, eft, "mul", rop).numpy()
+ops["send_recv_sum_out250"] = g.send_recv(xt, "sum", out_size=250).numpy() if "out_size" in g.send_recv.__code__.co_varnames else np.zeros(0)
+ops["send_uv_add"] = g.send_uv(xt, xt, "add").numpy()
+ops["send_uv_mul"] = g.send_uv(xt, xt, "mul").numpy()
+ops["edge_softmax_dst"] = GF.edge_softmax(g, paddle.to_tensor(logits), norm_by="dst").numpy()
+ops["edge_softmax_src"] = GF.edge_softmax(g, paddle.to_tensor(logits), norm_by="src").numpy()
+ops["degree_norm_in"] = GF.degree_norm(g, "indegree").numpy()
+ops["degree_norm_out"] = GF.degree_norm(g, "outdegree").numpy()
+ops["indegree"] = g.indegree().numpy()
+ops["outdegree"] = g.outdegree().numpy()
+
+
+# user-defined send / recv (pgl/graph.py:694-832, pgl/message.py): the README-style example and an attention reducer
+def send_copy(src_feat, dst_feat, edge_feat):
+    return {"h": src_feat["h"] * edge_feat["w"], "a": src_feat["s"] + dst_feat["s"]}
+
+
+def recv_softmax_sum(msg):
+    alpha = msg.reduce_softmax(msg["a"])
+    return msg.reduce_sum(msg["h"] * alpha)
+
+
+def recv_mixed(msg):
+    return paddle.concat([msg.reduce_sum(msg["h"]), msg.reduce_mean(msg["h"]), msg.reduce_max(msg["h"]), msg.reduce_min(msg["h"])], axis=-1)
+
+
+h = rng.standard_normal((n, 5)).astype(np.float32)
+s = rng.standard_normal((n, 1)).astype(np.float32)
+w = (rng.random((e, 1)) + 0.5).astype(np.float32)
+ops.update(udf_h=h, udf_s=s, udf_w=w)
+msg = g.send(send_copy, src_feat={"h": paddle.to_tensor(h), "s": paddle.to_tensor(s)}, dst_feat={"s": paddle.to_tensor(s)},
+             edge_feat={"w": paddle.to_tensor(w)})
+ops["udf_softmax_sum"] = g.recv(recv_softmax_sum, msg).numpy()
+ops["udf_mixed"] = g.recv(recv_mixed, msg).numpy()
+save("graph_ops", **ops)
+
+# batched graph read-outs (pgl/graph.py disjoint + graph_node_id, pgl/nn/functional/graph_op.py graph_pool / graph_norm)
+sizes = [7, 1, 12, 30, 5]
+gl, feats = [], []
+rngb = np.random.default_rng(5)
+for k, m in enumerate(sizes):
+    ee = rngb.integers(0, m, (3 * m, 2)).astype(np.int64)
+    gl.append(pgl.Graph(edges=ee, num_nodes=m))
+    feats.append(rngb.standard_normal((m, 6)).astype(np.float32))
+bg = pgl.Graph.disjoint(gl).tensor()
+feat = np.concatenate(feats)
+b = {"sizes": np.array(sizes), "edges": bg.edges.numpy(), "feat": feat, "graph_node_id": bg.graph_node_id.numpy(),
+     "graph_edge_id": bg.graph_edge_id.numpy(), "graph_norm": GF.graph_norm(bg, paddle.to_tensor(feat)).numpy()}
+for k, m in enumerate(sizes):
+    b["edges_%d" % k] = gl[k].edges
+for pool in ("sum", "mean", "max", "min"):
+    b["graph_pool_" + pool] = GF.graph_pool(bg, paddle.to_tensor(feat), pool).numpy()
+conv = gnn.GCNConv(6, 6)
+paddle.seed(9)
+b["gcn_on_batch"] = conv(bg, paddle.to_tensor(feat)).detach().numpy()
+b.update({"param::" + k: v.detach().numpy().copy() for k, v in conv.state_dict().items()})
+save("batched_graph", **b)

@@ -40,8 +40,8 @@ def test_product_never_touches_the_oracle():
                         names = [a.name for a in node.names]
                     elif isinstance(node, ast.ImportFrom):
                         names = [node.module or ""]
-                    bad += [(f, n) for n in names if n.split(".")[0] in ("ref_ops", "ref_native", "build_ref", "oracle")]
-            if re.search(r"oracle/(ref_|_ref|_build)|libref_ops", txt):
+                    bad += [(f, n) for n in names if n.split(".")[0] in ("ref_ops", "ref_native", "ref_python", "build_ref", "oracle", "paddle")]
+            if re.search(r"oracle/(ref_|_ref|_build|paddle_stub)|libref_ops", txt):
                 bad.append((f, "path reference"))
     assert not bad, bad
 

@@ -219,3 +219,19 @@ def test_csr_omp_equals_serial():
     _, sv, _, _, ip = R.c_build_index(dst, src, n)
     np.testing.assert_allclose(R.c_csr_spmm_sum_omp(x, ip, sv), R.c_send_u_recv(x, src, dst, "sum"),
                                rtol=1e-5, atol=1e-5)
+
+
+def test_reference_unit_tests_pass_on_the_oracle():
+    """The reference's OWN test files for this path (tests/test_graph.py, test_math.py, test_graph_op.py, test_conv.py,
+    test_bigraph.py, test_pool.py, test_hetergraph.py), executed unchanged from /root/reference with `paddle` = the
+    oracle's stand-in: every assertion they make holds for the restatement.  Build container only."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/pgl"):
+        pytest.skip("reference tree not present (GPU box)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "run_reference_tests.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    ran = sum(int(line.split()[2]) for line in r.stdout.splitlines() if " ran " in line)
+    assert ran >= 40, r.stdout
