@@ -97,6 +97,11 @@ def split(x, num_or_sections, axis=0, name=None):      # paddle: an int is the N
 
 
 _t.Tensor.split = split
+# paddle.Tensor defines no in-place arithmetic dunders: `a += b` rebinds `a` to a NEW tensor (aliases keep the old value)
+_t.Tensor.__iadd__ = lambda self, o: self + o
+_t.Tensor.__isub__ = lambda self, o: self - o
+_t.Tensor.__imul__ = lambda self, o: self * o
+_t.Tensor.__itruediv__ = lambda self, o: self / o
 
 
 class CPUPlace:

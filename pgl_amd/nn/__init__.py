@@ -1,7 +1,10 @@
 """pgl_amd.nn -- GNN layers over the engine.  Mirrors pgl/nn (conv layers on the graded path)."""
 from . import functional
 from .conv import GCNConv, GATConv, GraphSageConv
-from .conv_more import GATv2Conv, APPNP, GCNII, TransformerConv, GINConv, SGCConv, LightGCNConv
+from .conv_more import (GATv2Conv, APPNP, GCNII, TransformerConv, GINConv, SGCConv, LightGCNConv, PinSageConv, GPRConv,
+                        RGCNConv, SSGCConv, NGCFConv, FAConv)
+from .pool import GraphPool, GraphNorm, GlobalAttention
 
 __all__ = ["GCNConv", "GATConv", "GraphSageConv", "GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv",
-           "LightGCNConv", "functional"]
+           "LightGCNConv", "PinSageConv", "GPRConv", "RGCNConv", "SSGCConv", "NGCFConv", "FAConv", "GraphPool", "GraphNorm",
+           "GlobalAttention", "functional"]

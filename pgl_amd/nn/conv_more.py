@@ -3,7 +3,8 @@ send_ue_recv / send+recv), to back the claim that the remaining reference layers
 the seam is complete" (SURVEY section 2, row 10).  Each mirrors the reference layer's constructor and
 forward order: GATv2Conv (pgl/nn/conv.py:349-437), APPNP (:438-499), GCNII (:645-723),
 TransformerConv (:724-885, the UDF send/recv + Message.reduce_softmax path), GINConv (:888-960),
-SGCConv (:1027-1103), LightGCNConv (:1252-1286).  The symmetric degree normalisation
+SGCConv (:1027-1103), LightGCNConv (:1252-1286), PinSageConv (:118-186), GPRConv (:500-642), RGCNConv (:961-1024),
+SSGCConv (:1104-1199), NGCFConv (:1202-1249), FAConv (:1287-1340).  The symmetric degree normalisation
 (x * norm -> send_recv -> * norm) is issued as one fused aggregation where the layer allows it.
 """
 import math
@@ -15,7 +16,8 @@ import torch.nn.functional as F
 from . import functional as GF
 from .conv import _act, _linear
 
-__all__ = ["GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv", "LightGCNConv"]
+__all__ = ["GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv", "LightGCNConv", "PinSageConv", "GPRConv",
+           "RGCNConv", "SSGCConv", "NGCFConv", "FAConv"]
 
 
 def _norm_propagate(graph, feature, norm):
@@ -206,3 +208,181 @@ class TransformerConv(nn.Module):
         if self.activation is not None:
             output = self.activation(output)
         return output
+
+
+def _rebuild_with_self_loops(graph):
+    """Drops existing self loops and prepends one (i, i) edge per node, as APPNP / GPRConv do with self_loop=True."""
+    from ..graph import Graph
+    edges = graph.edges
+    n = graph.num_nodes
+    idx = torch.arange(n, dtype=edges.dtype, device=edges.device)
+    keep = edges[edges[:, 0] != edges[:, 1]]
+    return Graph(num_nodes=n, edges=torch.cat([torch.stack([idx, idx], 1), keep], 0))
+
+
+class PinSageConv(nn.Module):
+    """Edge-weighted neighbour aggregation + self / neighbour projections, L2-normalised output."""
+
+    def __init__(self, input_size, hidden_size, aggr_func="sum"):
+        super(PinSageConv, self).__init__()
+        assert aggr_func in ["sum", "mean", "max", "min"], "Only support 'sum', 'mean', 'max', 'min' built-in receive function."
+        self.aggr_func = aggr_func
+        self.self_linear = _linear(input_size, hidden_size)
+        self.neigh_linear = _linear(input_size, hidden_size)
+
+    def forward(self, graph, nfeat, efeat, act=None):
+        # the reference materialises src_feat * edge_weight through send/recv; send_ue_recv is the same arithmetic
+        # without the [E, d] message
+        neigh_feature = graph.send_ue_recv(nfeat, efeat, "mul", self.aggr_func)
+        output = self.self_linear(nfeat) + self.neigh_linear(neigh_feature)
+        if act is not None:
+            output = getattr(F, act)(output)
+        return F.normalize(output, dim=1)
+
+
+class GPRConv(nn.Module):
+    """Generalised PageRank: two-layer MLP, then a learned polynomial sum_k temp[k] * (D^-1/2 A D^-1/2)^k."""
+
+    def __init__(self, input_size, hidden_size, output_size, drop=0.5, dprate=0.5, activation="relu", self_loop=False,
+                 alpha=0.1, k_hop=10, init_method="PPR", gamma=None):
+        super(GPRConv, self).__init__()
+        import numpy as np
+        assert init_method in ["SGC", "PPR", "NPPR", "Random", "WS"]
+        self.alpha, self.k_hop, self.init_method, self.gamma, self.self_loop = alpha, k_hop, init_method, gamma, self_loop
+        if init_method == "SGC":
+            coef = np.zeros(k_hop + 1); coef[alpha] = 1.0
+        elif init_method == "PPR":
+            coef = alpha * (1 - alpha) ** np.arange(k_hop + 1); coef[-1] = (1 - alpha) ** k_hop
+        elif init_method == "NPPR":
+            coef = alpha ** np.arange(k_hop + 1); coef = coef / np.abs(coef).sum()
+        elif init_method == "Random":
+            bound = np.sqrt(3 / (k_hop + 1))
+            coef = np.random.uniform(-bound, bound, k_hop + 1); coef = coef / np.abs(coef).sum()
+        else:
+            coef = np.asarray(gamma)
+        self.temp = nn.Parameter(torch.as_tensor(coef, dtype=torch.float32))
+        self.linear_1 = _linear(input_size, hidden_size)
+        self.linear_2 = _linear(hidden_size, output_size)
+        self.drop, self.dprate = drop, dprate
+        self.feat_dropout_1 = nn.Dropout(p=drop)
+        self.feat_dropout_2 = nn.Dropout(p=dprate)
+        self.activation = _act(activation)
+
+    def forward(self, graph, feature, norm=None):
+        if self.self_loop:
+            graph = _rebuild_with_self_loops(graph)
+        feature = self.feat_dropout_1(feature)
+        feature = self.activation(self.linear_1(feature))
+        feature = self.linear_2(self.feat_dropout_1(feature))
+        if self.dprate > 0.0:
+            feature = self.feat_dropout_2(feature)
+        if norm is None:
+            norm = GF.degree_norm(graph)
+        hidden = feature * self.temp[0]
+        for k in range(self.k_hop):
+            feature = _norm_propagate(graph, feature, norm)
+            hidden = hidden + self.temp[k + 1] * feature
+        return hidden
+
+
+class RGCNConv(nn.Module):
+    """Per-relation projection + mean aggregation over that relation's graph, summed over relations
+    (optional basis decomposition of the relation weights)."""
+
+    def __init__(self, in_dim, out_dim, etypes, num_bases=0):
+        super(RGCNConv, self).__init__()
+        self.in_dim, self.out_dim, self.etypes = in_dim, out_dim, etypes
+        self.num_rels = len(etypes)
+        self.num_bases = num_bases if 0 < num_bases < self.num_rels else self.num_rels
+        self.weight = nn.Parameter(torch.empty(self.num_bases, in_dim, out_dim))
+        nn.init.xavier_uniform_(self.weight)
+        if self.num_bases < self.num_rels:
+            self.w_comp = nn.Parameter(torch.empty(self.num_rels, self.num_bases))
+            nn.init.xavier_uniform_(self.w_comp)
+
+    def forward(self, graph, feat):
+        weight = self.weight
+        if self.num_bases < self.num_rels:
+            weight = torch.einsum("rb,bio->rio", self.w_comp, self.weight)
+        out = None
+        for idx, etype in enumerate(self.etypes):
+            h = graph[etype].send_recv(torch.matmul(feat, weight[idx]), reduce_func="mean")
+            out = h if out is None else out + h
+        return out
+
+
+class SSGCConv(nn.Module):
+    """Simple spectral graph convolution: mean of the first k_hop (1 - alpha)-damped propagation steps plus alpha * x."""
+
+    def __init__(self, input_size, output_size, k_hop=16, alpha=0.05, cached=True, activation=None, bias=False):
+        super(SSGCConv, self).__init__()
+        self.input_size, self.output_size, self.k_hop, self.alpha = input_size, output_size, k_hop, alpha
+        self.linear = _linear(input_size, output_size, bias=False)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(output_size))
+        self.cached = cached
+        self.cached_output = None
+        self.activation = _act(activation)
+
+    def _propagate(self, graph, feature):
+        norm = GF.degree_norm(graph)
+        ori_feature = feature
+        sum_feature = feature
+        for _ in range(self.k_hop):
+            feature = (1 - self.alpha) * _norm_propagate(graph, feature, norm)
+            sum_feature = sum_feature + feature
+        return sum_feature / self.k_hop + self.alpha * ori_feature
+
+    def forward(self, graph, feature):
+        if self.cached:
+            if self.cached_output is None:
+                self.cached_output = self._propagate(graph, feature)
+            feature = self.cached_output
+        else:
+            feature = self._propagate(graph, feature)
+        output = self.linear(feature)
+        if hasattr(self, "bias"):
+            output = output + self.bias
+        if self.activation is not None:
+            output = self.activation(output)
+        return output
+
+
+class NGCFConv(nn.Module):
+    """Neural graph collaborative filtering layer."""
+
+    def __init__(self, input_size, output_size):
+        super(NGCFConv, self).__init__()
+        self.input_size, self.output_size = input_size, output_size
+        self.linear = _linear(input_size, output_size)
+        self.linear2 = _linear(input_size, output_size)
+        for lin in (self.linear, self.linear2):
+            bound = math.sqrt(6.0 / (1 + output_size))
+            nn.init.uniform_(lin.bias, -bound, bound)
+        self.leaky_relu = nn.LeakyReLU(negative_slope=0.2)
+
+    def forward(self, graph, feature):
+        norm = GF.degree_norm(graph)
+        output = (graph.send_recv(feature, "sum") + feature) * norm
+        return self.leaky_relu(self.linear(output) + self.linear2(feature * output))
+
+
+class FAConv(nn.Module):
+    """Frequency-adaptive convolution: a signed gate tanh(W [h_src ; h_dst]) * d_src * d_dst weighs every edge."""
+
+    def __init__(self, hidden_size, drop=0.5):
+        super(FAConv, self).__init__()
+        self.dropout = nn.Dropout(p=drop)
+        self.gate = _linear(2 * hidden_size, 1)
+
+    def forward(self, graph, feature):
+        norm = GF.degree_norm(graph)
+        # gate([h_src ; h_dst]) = h_src . w_s + h_dst . w_d + b: two [N,1] projections and one send_uv instead of the
+        # reference's [E, 2*hidden] concatenation
+        hs = feature.shape[1]
+        w = self.gate.weight
+        p_src = feature @ w[:, :hs].t() + self.gate.bias
+        p_dst = feature @ w[:, hs:].t()
+        alpha = torch.tanh(graph.send_uv(p_src, p_dst, "add")) * graph.send_uv(norm, norm, "mul")
+        alpha = self.dropout(alpha)
+        return graph.send_ue_recv(feature, alpha, "mul", "sum")

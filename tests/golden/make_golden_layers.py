@@ -78,6 +78,17 @@ LAYERS = [
     ("GCNII", dict(hidden_size=16, activation=None, lambda_l=0.5, alpha=0.1, k_hop=4, dropout=0.0)),        # default degree norm
     ("GCNConv", dict(input_size=12, output_size=12, activation=None, norm=True)),                          # caller-supplied [N,1] norm
 ]
+LAYERS += [
+    ("PinSageConv", dict(input_size=16, hidden_size=12, aggr_func="sum")),
+    ("PinSageConv", dict(input_size=16, hidden_size=12, aggr_func="max")),
+    ("GPRConv", dict(input_size=16, hidden_size=24, output_size=7, drop=0.0, dprate=0.0, activation="relu", self_loop=False,
+                     alpha=0.1, k_hop=5, init_method="PPR")),
+    ("GPRConv", dict(input_size=16, hidden_size=24, output_size=7, drop=0.0, dprate=0.0, activation="relu", self_loop=True,
+                     alpha=0.3, k_hop=4, init_method="NPPR")),
+    ("SSGCConv", dict(input_size=16, output_size=6, k_hop=5, alpha=0.05, cached=False, activation=None, bias=True)),
+    ("NGCFConv", dict(input_size=16, output_size=16)),
+    ("FAConv", dict(hidden_size=16, drop=0.0)),
+]
 CALLER_NORM = {13: "wide", 20: "column"}
 
 for i, (cls, kw) in enumerate(LAYERS):
@@ -100,10 +111,28 @@ for i, (cls, kw) in enumerate(LAYERS):
         nrm = (np.abs(x) * 0.5 + 0.1) if CALLER_NORM[i] == "wide" else (rng.random((n, 1)).astype(np.float32) + 0.5)
         extra["norm"] = nrm.astype(np.float32)
         out = layer(g, xt, paddle.to_tensor(extra["norm"]))
+    elif cls == "PinSageConv":
+        extra["efeat"] = (rng.random((len(edges), 1)) + 0.25).astype(np.float32)
+        out = layer(g, xt, paddle.to_tensor(extra["efeat"]), act="relu")
     else:
         out = layer(g, xt)
     save("layer_%02d_%s" % (i, cls), edges=edges, num_nodes=np.int64(n), x=x, out=out.detach().numpy(),
          cls=np.array(cls), kwargs=np.array(json.dumps(kw)), **extra, **params_of(layer))
+
+# RGCNConv over a HeterGraph (pgl/nn/conv.py:961-1024, pgl/heter_graph.py): per-relation mean aggregation
+rngh = np.random.default_rng(31)
+nh = 120
+het_edges = {"cites": rngh.integers(0, nh, (500, 2)).astype(np.int64), "writes": rngh.integers(0, nh, (300, 2)).astype(np.int64),
+             "likes": rngh.integers(0, nh, (40, 2)).astype(np.int64)}
+hg = pgl.HeterGraph(edges={k: [tuple(e) for e in v.tolist()] for k, v in het_edges.items()},
+                    node_types=[(i, "n") for i in range(nh)], num_nodes=nh).tensor()
+xh = rngh.standard_normal((nh, 10)).astype(np.float32)
+for tag, nb in (("full", 0), ("bases2", 2)):
+    paddle.seed(50 + nb)
+    rg = gnn.RGCNConv(10, 6, ["cites", "writes", "likes"], num_bases=nb)
+    out = rg(hg, paddle.to_tensor(xh))
+    save("rgcn_" + tag, x=xh, num_nodes=np.int64(nh), num_bases=np.int64(nb), out=out.detach().numpy(),
+         **{"edges::" + k: v for k, v in het_edges.items()}, **params_of(rg))
 
 # ---------------------------------------------------------------------------------------------------------
 # graph-level ops through the reference's Graph / Message / math code
@@ -170,8 +199,15 @@ for k, m in enumerate(sizes):
     b["edges_%d" % k] = gl[k].edges
 for pool in ("sum", "mean", "max", "min"):
     b["graph_pool_" + pool] = GF.graph_pool(bg, paddle.to_tensor(feat), pool).numpy()
-conv = gnn.GCNConv(6, 6)
+import paddle.nn as pnn  # noqa: E402
+paddle.seed(8)
+ga = gnn.GlobalAttention(pnn.Linear(6, 1), pnn.Linear(6, 4))
+b["global_attention"] = ga(bg, paddle.to_tensor(feat)).detach().numpy()
+b.update({"ga::" + k: v.detach().numpy().copy() for k, v in ga.state_dict().items()})
+b["graph_pool_layer_sum"] = gnn.GraphPool("sum")(bg, paddle.to_tensor(feat)).numpy()
+b["graph_norm_layer"] = gnn.GraphNorm()(bg, paddle.to_tensor(feat)).numpy()
 paddle.seed(9)
+conv = gnn.GCNConv(6, 6)
 b["gcn_on_batch"] = conv(bg, paddle.to_tensor(feat)).detach().numpy()
 b.update({"param::" + k: v.detach().numpy().copy() for k, v in conv.state_dict().items()})
 save("batched_graph", **b)

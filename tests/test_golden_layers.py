@@ -29,8 +29,8 @@ def _dense_adj(edges, n):
 
 
 def test_fixtures_present():
-    assert len(LAYER_FILES) == 21
-    for f in ("graph_ops.npz", "batched_graph.npz"):
+    assert len(LAYER_FILES) == 28
+    for f in ("graph_ops.npz", "batched_graph.npz", "rgcn_full.npz", "rgcn_bases2.npz"):
         assert os.path.exists(os.path.join(HERE, "golden", "layers", f))
 
 
@@ -103,7 +103,12 @@ def test_layer_matches_reference_python(pgl, path):
     g = pgl.Graph(edges=z["edges"], num_nodes=int(z["num_nodes"])).tensor()
     x = torch.as_tensor(z["x"]).cuda()
     with torch.no_grad():
-        out = layer(g, x, torch.as_tensor(z["norm"]).cuda()) if "norm" in z.files else layer(g, x)
+        if "norm" in z.files:
+            out = layer(g, x, torch.as_tensor(z["norm"]).cuda())
+        elif "efeat" in z.files:
+            out = layer(g, x, torch.as_tensor(z["efeat"]).cuda(), act="relu")
+        else:
+            out = layer(g, x)
     want = z["out"]
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=5 * RTOL, atol=RTOL * float(np.abs(want).max()))
     if cls == "GATConv":        # the unfused composition (send_uv -> edge_softmax -> send_ue_recv), as the reference wires it
@@ -111,6 +116,21 @@ def test_layer_matches_reference_python(pgl, path):
         with torch.no_grad():
             out2 = layer(g, x)
         np.testing.assert_allclose(out2.cpu().numpy(), want, rtol=5 * RTOL, atol=RTOL * float(np.abs(want).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["full", "bases2"])
+def test_rgcn_over_hetergraph_matches_reference_python(pgl, tag):
+    z = np.load(os.path.join(HERE, "golden", "layers", "rgcn_%s.npz" % tag))
+    etypes = ["cites", "writes", "likes"]
+    hg = pgl.HeterGraph(edges={k: z["edges::" + k] for k in etypes}, num_nodes=int(z["num_nodes"])).tensor()
+    layer = pgl.nn.RGCNConv(10, 6, etypes, num_bases=int(z["num_bases"]))
+    ref = _params(z)
+    assert set(dict(layer.state_dict())) == set(ref)
+    layer.load_state_dict({k: torch.as_tensor(v) for k, v in ref.items()})      # no Linear inside: same layouts
+    with torch.no_grad():
+        out = layer.cuda()(hg, torch.as_tensor(z["x"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), z["out"], rtol=5 * RTOL, atol=RTOL * float(np.abs(z["out"]).max()))
 
 
 @pytest.mark.gpu
@@ -173,6 +193,13 @@ def test_batched_graph_matches_reference_python(pgl):
     np.testing.assert_allclose(GF.graph_norm(bg, feat).cpu().numpy(), z["graph_norm"], rtol=RTOL, atol=1e-7)
     for pool in ("sum", "mean", "max", "min"):
         np.testing.assert_allclose(GF.graph_pool(bg, feat, pool).cpu().numpy(), z["graph_pool_" + pool], rtol=5 * RTOL, atol=1e-6)
+    np.testing.assert_allclose(pgl.nn.GraphPool("sum")(bg, feat).cpu().numpy(), z["graph_pool_layer_sum"], rtol=5 * RTOL, atol=1e-6)
+    np.testing.assert_allclose(pgl.nn.GraphNorm()(bg, feat).cpu().numpy(), z["graph_norm_layer"], rtol=RTOL, atol=1e-7)
+    ga = pgl.nn.GlobalAttention(torch.nn.Linear(6, 1), torch.nn.Linear(6, 4))
+    _load_params(ga, {k[4:]: z[k] for k in z.files if k.startswith("ga::")})
+    with torch.no_grad():
+        att = ga.cuda()(bg, feat)
+    np.testing.assert_allclose(att.cpu().numpy(), z["global_attention"], rtol=5 * RTOL, atol=1e-6)
     conv = pgl.nn.GCNConv(6, 6)
     _load_params(conv, _params(z))
     with torch.no_grad():
