@@ -106,6 +106,7 @@ for i, (cls, kw) in enumerate(LAYERS):
     layer.eval()
     g = pgl.Graph(edges=edges, num_nodes=n).tensor()
     xt = paddle.to_tensor(x)
+    xt.requires_grad_(True)
     extra = {}
     if i in CALLER_NORM:        # both layers take forward(graph, feature, norm=None)
         nrm = (np.abs(x) * 0.5 + 0.1) if CALLER_NORM[i] == "wide" else (rng.random((n, 1)).astype(np.float32) + 0.5)
@@ -116,6 +117,13 @@ for i, (cls, kw) in enumerate(LAYERS):
         out = layer(g, xt, paddle.to_tensor(extra["efeat"]), act="relu")
     else:
         out = layer(g, xt)
+    # gradients of <out, ct> w.r.t. the input and every parameter, through the reference's layer code
+    ct = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    (out * paddle.to_tensor(ct)).sum().backward()
+    extra["ct"] = ct
+    extra["grad::x"] = xt.grad.numpy().copy()
+    for k, prm in layer.named_parameters():
+        extra["gparam::" + k] = (prm.grad if prm.grad is not None else paddle.zeros_like(prm)).numpy().copy()
     save("layer_%02d_%s" % (i, cls), edges=edges, num_nodes=np.int64(n), x=x, out=out.detach().numpy(),
          cls=np.array(cls), kwargs=np.array(json.dumps(kw)), **extra, **params_of(layer))
 
@@ -181,6 +189,39 @@ msg = g.send(send_copy, src_feat={"h": paddle.to_tensor(h), "s": paddle.to_tenso
              edge_feat={"w": paddle.to_tensor(w)})
 ops["udf_softmax_sum"] = g.recv(recv_softmax_sum, msg).numpy()
 ops["udf_mixed"] = g.recv(recv_mixed, msg).numpy()
+
+# gradients through the reference's graph ops (cotangents are seeded random tensors)
+def grads_of(fn, *arrays):
+    ts = [paddle.to_tensor(a) for a in arrays]
+    for t in ts:
+        t.requires_grad_(True)
+    out = fn(*ts)
+    ct = np.random.default_rng(int(out.numel())).standard_normal(tuple(out.shape)).astype(np.float32)
+    (out * paddle.to_tensor(ct)).sum().backward()
+    return ct, [t.grad.numpy().copy() for t in ts]
+
+
+ct, (gx, gef) = grads_of(lambda a, b: g.send_ue_recv(a, b, "mul", "sum"), x, ef)
+ops.update({"g_ue_mul_sum_ct": ct, "g_ue_mul_sum_dx": gx, "g_ue_mul_sum_dy": gef})
+ct, (gx, gef) = grads_of(lambda a, b: g.send_ue_recv(a, b, "add", "mean"), x, ef)
+ops.update({"g_ue_add_mean_ct": ct, "g_ue_add_mean_dx": gx, "g_ue_add_mean_dy": gef})
+ct, (gx,) = grads_of(lambda a: g.send_recv(a, "max"), x)
+ops.update({"g_sr_max_ct": ct, "g_sr_max_dx": gx})
+ct, (gx,) = grads_of(lambda a: g.send_recv(a, "mean"), x)
+ops.update({"g_sr_mean_ct": ct, "g_sr_mean_dx": gx})
+ct, (ga, gb) = grads_of(lambda a, b: g.send_uv(a, b, "mul"), x, x * 0.5 + 1.0)
+ops.update({"g_uv_mul_ct": ct, "g_uv_mul_da": ga, "g_uv_mul_db": gb, "g_uv_b": x * 0.5 + 1.0})
+ct, (gl_,) = grads_of(lambda a: GF.edge_softmax(g, a, norm_by="dst"), logits)
+ops.update({"g_esm_ct": ct, "g_esm_dlogits": gl_})
+
+
+def udf_loss(hh, ss, ww):
+    m = g.send(send_copy, src_feat={"h": hh, "s": ss}, dst_feat={"s": ss}, edge_feat={"w": ww})
+    return g.recv(recv_softmax_sum, m)
+
+
+ct, (gh, gs, gw) = grads_of(udf_loss, h, s, w)
+ops.update({"g_udf_ct": ct, "g_udf_dh": gh, "g_udf_ds": gs, "g_udf_dw": gw})
 save("graph_ops", **ops)
 
 # batched graph read-outs (pgl/graph.py disjoint + graph_node_id, pgl/nn/functional/graph_op.py graph_pool / graph_norm)

@@ -92,6 +92,31 @@ def _load_params(layer, ref):
     layer.load_state_dict(sd)
 
 
+def _run_layer(layer, g, x, z):
+    if "norm" in z.files:
+        return layer(g, x, torch.as_tensor(z["norm"]).cuda())
+    if "efeat" in z.files:
+        return layer(g, x, torch.as_tensor(z["efeat"]).cuda(), act="relu")
+    return layer(g, x)
+
+
+def _check_grads(layer, x, out, z, tag=""):
+    """d<out, ct>/d(input, parameters) against the gradients the reference's layer code produced (autograd over an
+    independent torch formulation of the four primitives, oracle/paddle_stub/paddle/geometric)."""
+    for prm in layer.parameters():
+        prm.grad = None
+    x.grad = None
+    (out * torch.as_tensor(z["ct"]).cuda()).sum().backward()
+    want = z["grad::x"]
+    np.testing.assert_allclose(x.grad.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()) + 1e-7, err_msg=tag + " d/dx")
+    for k, prm in layer.named_parameters():
+        want = z["gparam::" + k]
+        if k.endswith(".weight") and want.ndim == 2:
+            want = want.T
+        got = prm.grad.cpu().numpy() if prm.grad is not None else np.zeros_like(want)
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()) + 1e-5, err_msg=tag + " d/d" + k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", LAYER_FILES, ids=os.path.basename)
 def test_layer_matches_reference_python(pgl, path):
@@ -101,21 +126,16 @@ def test_layer_matches_reference_python(pgl, path):
     _load_params(layer, _params(z))
     layer = layer.cuda().eval()
     g = pgl.Graph(edges=z["edges"], num_nodes=int(z["num_nodes"])).tensor()
-    x = torch.as_tensor(z["x"]).cuda()
-    with torch.no_grad():
-        if "norm" in z.files:
-            out = layer(g, x, torch.as_tensor(z["norm"]).cuda())
-        elif "efeat" in z.files:
-            out = layer(g, x, torch.as_tensor(z["efeat"]).cuda(), act="relu")
-        else:
-            out = layer(g, x)
+    x = torch.as_tensor(z["x"]).cuda().requires_grad_(True)
+    out = _run_layer(layer, g, x, z)
     want = z["out"]
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=5 * RTOL, atol=RTOL * float(np.abs(want).max()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=5 * RTOL, atol=RTOL * float(np.abs(want).max()))
+    _check_grads(layer, x, out, z, cls)
     if cls == "GATConv":        # the unfused composition (send_uv -> edge_softmax -> send_ue_recv), as the reference wires it
         layer.fused = False
-        with torch.no_grad():
-            out2 = layer(g, x)
-        np.testing.assert_allclose(out2.cpu().numpy(), want, rtol=5 * RTOL, atol=RTOL * float(np.abs(want).max()))
+        out2 = _run_layer(layer, g, x, z)
+        np.testing.assert_allclose(out2.detach().cpu().numpy(), want, rtol=5 * RTOL, atol=RTOL * float(np.abs(want).max()))
+        _check_grads(layer, x, out2, z, cls + " unfused")
 
 
 @pytest.mark.gpu
@@ -178,6 +198,33 @@ def test_graph_ops_match_reference_python(pgl):
     msg = g.send(send_copy, src_feat={"h": h, "s": s}, dst_feat={"s": s}, edge_feat={"w": w})
     check(g.recv(recv_softmax_sum, msg), "udf_softmax_sum")
     check(g.recv(recv_mixed, msg), "udf_mixed")
+
+    # gradients (transposed-CSR aggregation, SDDMM edge gradient, softmax backward, UDF path) vs the reference's
+    def grads(fn, ct_key, *arrays):
+        ts = [torch.as_tensor(a).cuda().requires_grad_(True) for a in arrays]
+        (fn(*ts) * torch.as_tensor(z[ct_key]).cuda()).sum().backward()
+        return [t.grad for t in ts]
+
+    def gcheck(got, key):
+        want = z[key]
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()) + 1e-6, err_msg=key)
+
+    gx, gy = grads(lambda a, b: g.send_ue_recv(a, b, "mul", "sum"), "g_ue_mul_sum_ct", z["x"], z["ef"])
+    gcheck(gx, "g_ue_mul_sum_dx"); gcheck(gy, "g_ue_mul_sum_dy")
+    gx, gy = grads(lambda a, b: g.send_ue_recv(a, b, "add", "mean"), "g_ue_add_mean_ct", z["x"], z["ef"])
+    gcheck(gx, "g_ue_add_mean_dx"); gcheck(gy, "g_ue_add_mean_dy")
+    gcheck(grads(lambda a: g.send_recv(a, "max"), "g_sr_max_ct", z["x"])[0], "g_sr_max_dx")
+    gcheck(grads(lambda a: g.send_recv(a, "mean"), "g_sr_mean_ct", z["x"])[0], "g_sr_mean_dx")
+    ga, gb = grads(lambda a, b: g.send_uv(a, b, "mul"), "g_uv_mul_ct", z["x"], z["g_uv_b"])
+    gcheck(ga, "g_uv_mul_da"); gcheck(gb, "g_uv_mul_db")
+    gcheck(grads(lambda a: GF.edge_softmax(g, a, "dst"), "g_esm_ct", z["logits"])[0], "g_esm_dlogits")
+
+    def udf_loss(hh, ss, ww):
+        m = g.send(send_copy, src_feat={"h": hh, "s": ss}, dst_feat={"s": ss}, edge_feat={"w": ww})
+        return g.recv(recv_softmax_sum, m)
+
+    gh, gs, gw = grads(udf_loss, "g_udf_ct", z["udf_h"], z["udf_s"], z["udf_w"])
+    gcheck(gh, "g_udf_dh"); gcheck(gs, "g_udf_ds"); gcheck(gw, "g_udf_dw")
 
 
 @pytest.mark.gpu
