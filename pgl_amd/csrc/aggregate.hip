@@ -58,7 +58,6 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     const int e1 = p.align ? chunk_cut(rowp, as_const(p.indptr), c * p.chunk + p.chunk, p.chunk, p.E) : min(c * p.chunk + p.chunk, p.E);
     if (e0 >= e1) return;
     const cptr<int> eidp = as_const(p.eid);
-    const cptr<float> sscale = as_const(p.src_scale);
     const T* __restrict__ x = static_cast<const T*>(p.x);
     const T* __restrict__ y = static_cast<const T*>(p.y);
     constexpr bool has_ss = SS;       // per-source scale compiled in only where asked for (keeps 16 SGPRs free otherwise)
@@ -156,17 +155,34 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         head_open = false;
     };
 
-    auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U], int (&yy)[U], float (&ss)[U]) {
+    // Per-source scales never touch SGPRs: lane i (i < U) of a batch fetches the column id of edge i with ONE vector
+    // load in the index stage and its scale with ONE dependent vector load in the row stage; consume reads lane i back
+    // (v_readlane) right where it multiplies.  What the scales do cost is memory: one random 4-byte access per edge
+    // into an [N] array that the streaming feature rows keep evicting from L2 (+0.25 ms at C2 whatever the load path;
+    // with the addresses pinned to one line the cost vanishes).  The host side therefore pre-multiplies narrow
+    // feature rows instead (ops.aggregate) and keeps this path for wide ones.
+    const float* __restrict__ sscale_v = p.src_scale;
+    const int* __restrict__ col_v = p.col;
+    auto scale_of = [&](int col) -> float {     // remainder loop: wave-uniform index through the vector path
+        int ci = col;
+        asm volatile("" : "+v"(ci));
+        return sscale_v[ci];
+    };
+    auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U], int (&yy)[U]) {
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             rr[i] = rowp[e + i];
             cc[i] = colp ? colp[e + i] : e + i;
             if constexpr (YMODE != 0) yy[i] = eidp ? eidp[e + i] : e + i;
         }
-#pragma unroll
-        for (int i = 0; i < U; ++i) ss[i] = has_ss ? sscale[cc[i]] : 1.f;
     };
-    auto load_rows = [&](const int (&cc)[U], const int (&yy)[U], V (&vx)[U][NT], V (&vy)[U][NT]) {
+    // Vector loads retire in issue order (vmcnt), so the id load of batch g+2 is issued BEFORE the rows of batch g+1:
+    // waiting for it one iteration later then never waits for younger row gathers.
+    auto load_cl = [&](int e, int& cl) {
+        if constexpr (has_ss) cl = col_v ? col_v[e + (lane & (U - 1))] : e + (lane & (U - 1));
+    };
+    auto load_rows = [&](const int (&cc)[U], const int (&yy)[U], V (&vx)[U][NT], V (&vy)[U][NT], int cl, float& sv) {
+        if constexpr (has_ss) sv = sscale_v[cl];
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             const T* xr = x + (int64_t)cc[i] * p.ldx;
@@ -201,44 +217,56 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                 else acc[t][k] = is_max ? (m > acc[t][k] ? m : acc[t][k]) : (m < acc[t][k] ? m : acc[t][k]);
             }
     };
+    auto lane_scale = [&](float sv, int i) -> float {
+        if constexpr (has_ss) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
+        else return 1.f;
+    };
 
     // Software pipeline, three batches deep: feature rows of batch g are being consumed while the rows
     // of batch g+1 are in flight AND the (scalar) indices of batch g+2 are being fetched, so neither
     // the scalar-load latency nor the gather latency sits on the per-batch critical path.
     int e = e0;
     const int n_full = (e1 - e0) / U;
-    int cA[U], rA[U], yA[U]; float sA[U];
-    int cB[U], rB[U], yB[U]; float sB[U];
+    int cA[U], rA[U], yA[U];
+    int cB[U], rB[U], yB[U];
+    int clA = 0, clB = 0; float svA = 1.f;
     V xA[U][NT], wA[U][NT];
-    if (n_full > 0) { load_idx(e, cA, rA, yA, sA); load_rows(cA, yA, xA, wA); }
-    if (PIPE3 && n_full > 1) load_idx(e + U, cB, rB, yB, sB);
+    if (n_full > 0) { load_cl(e, clA); load_idx(e, cA, rA, yA); }
+    if (n_full > 1) load_cl(e + U, clB);
+    if (n_full > 0) load_rows(cA, yA, xA, wA, clA, svA);
+    if (PIPE3 && n_full > 1) load_idx(e + U, cB, rB, yB);
     for (int g = 0; g < n_full; ++g) {
-        int cC[U], rC[U], yC[U]; float sC[U];
+        int cC[U], rC[U], yC[U]; int clC = 0; float svB = 1.f;
         V xB[U][NT], wB[U][NT];
-        const bool more = g + 1 < n_full, more2 = PIPE3 && g + 2 < n_full;
-        if (!PIPE3 && more) load_idx(e + U, cB, rB, yB, sB);    // two-deep variant: fewer SGPRs, 8 workgroups per CU
-        if (more) load_rows(cB, yB, xB, wB);                    // PIPE3: indices of g+1 are already in SGPRs
-        if (more2) load_idx(e + 2 * U, cC, rC, yC, sC);
+        const bool more = g + 1 < n_full, more2 = g + 2 < n_full;
+        if (more2) load_cl(e + 2 * U, clC);
+        if (!PIPE3 && more) load_idx(e + U, cB, rB, yB);        // two-deep variant: fewer SGPRs, 8 workgroups per CU
+        if (more) load_rows(cB, yB, xB, wB, clB, svB);          // PIPE3: indices of g+1 are already in SGPRs
+        if (PIPE3 && more2) load_idx(e + 2 * U, cC, rC, yC);
 #pragma unroll
-        for (int i = 0; i < U; ++i) consume_one(rA[i], sA[i], xA[i], wA[i]);
+        for (int i = 0; i < U; ++i) consume_one(rA[i], lane_scale(svA, i), xA[i], wA[i]);
         if (more) {
+            svA = svB;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                rA[i] = rB[i]; sA[i] = sB[i];
+                rA[i] = rB[i];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) { xA[i][t] = xB[i][t]; wA[i][t] = wB[i][t]; }
             }
         }
         if (more2) {
+            clB = clC;
+            if constexpr (PIPE3) {
 #pragma unroll
-            for (int i = 0; i < U; ++i) { cB[i] = cC[i]; rB[i] = rC[i]; yB[i] = yC[i]; sB[i] = sC[i]; }
+                for (int i = 0; i < U; ++i) { cB[i] = cC[i]; rB[i] = rC[i]; yB[i] = yC[i]; }
+            }
         }
         e += U;
     }
     for (; e < e1; ++e) {   // remainder (< U edges): one at a time
         int r = rowp[e];
         int cc = colp ? colp[e] : e;
-        float s = has_ss ? sscale[cc] : 1.f;
+        float s = has_ss ? scale_of(cc) : 1.f;
         V vx[NT], vy[NT];
         const T* xr = x + (int64_t)cc * p.ldx;
 #pragma unroll

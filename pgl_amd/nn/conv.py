@@ -22,9 +22,49 @@ def _act(activation):
     return activation
 
 
+class _TallLinearFn(torch.autograd.Function):
+    """y = x W^T + b for x [N, in] with N in the millions.  The weight gradient g^T x is a [out, N] x [N, in] product with
+    a reduction length of N and a tiny output: the stock GEMM picks one 32x32 tile per workgroup and runs the whole
+    reduction serially (1.9 ms at N = 2^20, in = out = 128 on MI355X).  Here it is split along N into batches
+    (bmm -> sum): 0.33 ms, the same MFMA work spread over the chip."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            n = x.shape[0]
+            split = 256
+            m = n // split * split
+            gw = torch.bmm(g[:m].view(split, m // split, -1).transpose(1, 2), x[:m].view(split, m // split, -1)).sum(0)
+            if m < n:
+                gw = gw + g[m:].t() @ x[m:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb
+
+
+class _Linear(nn.Linear):
+    """nn.Linear whose backward uses the split-reduction weight gradient for tall inputs (same values up to fp32
+    re-association; parameters and state_dict are nn.Linear's)."""
+
+    def forward(self, x):
+        if x.dim() == 2 and x.shape[0] >= 65536 and x.is_contiguous() and torch.is_grad_enabled() and self.weight.requires_grad:
+            return _TallLinearFn.apply(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
 def _linear(n_in, n_out, bias=True):
     """paddle.nn.Linear defaults: Xavier-uniform weight, zero bias."""
-    lin = nn.Linear(n_in, n_out, bias=bias)
+    lin = _Linear(n_in, n_out, bias=bias)
     nn.init.xavier_uniform_(lin.weight)
     if bias:
         nn.init.zeros_(lin.bias)
@@ -75,14 +115,21 @@ class GCNConv(nn.Module):
             feature = self.linear(feature)
         fuse = norm is not None and feature.dtype == torch.float32 and norm.dtype == torch.float32 \
             and norm.numel() == feature.shape[0] and hasattr(graph, "send_recv_scaled")
-        if fuse and self.input_size > self.output_size:
-            # same arithmetic as the three reference steps, one pass over the edges:
-            # (feature * norm) -> send_recv(sum) -> (* norm)
+        if fuse:
+            # (feature * norm) -> send_recv(sum) -> (* norm) as ONE pass over the edges.  Row scaling commutes with the
+            # right-multiplication by W, so in the aggregate-first order the destination norm is applied inside the
+            # kernel as well and the bias rides in the GEMM epilogue: two [N, d] element passes fewer.
             output = graph.send_recv_scaled(feature, norm, norm)
+            if self.input_size <= self.output_size:
+                output = _TallLinearFn.apply(output, self.linear.weight, self.bias) if (output.shape[0] >= 65536 and torch.is_grad_enabled()) \
+                    else F.linear(output, self.linear.weight, self.bias)
+                if self.activation is not None:
+                    output = self.activation(output)
+                return output
         else:
-            if norm is not None and not fuse:
+            if norm is not None:
                 feature = feature * norm
-            output = graph.send_recv_scaled(feature, norm, None) if fuse else graph.send_recv(feature, "sum")
+            output = graph.send_recv(feature, "sum")
             if self.input_size <= self.output_size:
                 output = self.linear(output)
             if norm is not None:
@@ -120,8 +167,18 @@ class GATConv(nn.Module):
             feature = self.feat_dropout(feature)
         feature = self.linear(feature)
         feature = feature.reshape(-1, self.num_heads, self.hidden_size)
-        attn_src = torch.sum(feature * self.weight_src, dim=-1)
-        attn_dst = torch.sum(feature * self.weight_dst, dim=-1)
+        if feature.shape[0] >= 4096:
+            # sum_d feat[n,h,d] * w[h,d] for both weight vectors as ONE [N, H*D] x [H*D, 2H] GEMM with block-diagonal
+            # weights (one read of the features instead of four element passes over [N, H, D])
+            eye = torch.eye(self.num_heads, dtype=feature.dtype, device=feature.device).unsqueeze(1)
+            proj = torch.cat([(self.weight_src.unsqueeze(2) * eye).reshape(-1, self.num_heads),
+                              (self.weight_dst.unsqueeze(2) * eye).reshape(-1, self.num_heads)], dim=1)
+            att = feature.reshape(-1, self.num_heads * self.hidden_size) @ proj
+            attn_src = att[:, :self.num_heads].contiguous()
+            attn_dst = att[:, self.num_heads:].contiguous()
+        else:
+            attn_src = torch.sum(feature * self.weight_src, dim=-1)
+            attn_dst = torch.sum(feature * self.weight_dst, dim=-1)
         D = self.hidden_size
         vec = 4 if D % 4 == 0 else 2 if D % 2 == 0 else 1
         fusable = (feature.dtype == torch.float32 and hasattr(graph, "gat_aggregate") and self.fused

@@ -10,6 +10,8 @@ Each function names the reference call site it stands in for (reference = Paddle
 import ctypes
 
 import numpy as np
+import os
+
 import torch
 
 from . import _ffi
@@ -139,6 +141,9 @@ def _bcast(x, y):
 # ------------------------------------------------------------------------------------------------
 # aggregation (send_u_recv / send_ue_recv)
 # ------------------------------------------------------------------------------------------------
+_PRESCALE_ROW_BYTES = int(os.environ.get("PGLAMD_PRESCALE_ROW_BYTES", "704"))
+
+
 def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None,
               out=None, accumulate=False):
     """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
@@ -146,6 +151,12 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     _need_cuda(x, y, src_scale, dst_scale)
     L = _ffi.lib()
     x = x.contiguous()
+    if src_scale is not None and y is None and x.dim() >= 2 and x.is_floating_point() \
+            and _prod(x.shape[1:]) * x.element_size() <= _PRESCALE_ROW_BYTES and src_scale.numel() == x.shape[0]:
+        # The fused per-source scale costs one random 4-byte access per EDGE (+0.25 ms at 20 M edges, any row width);
+        # scaling the rows first costs one pass over [N, d] (0.17 ms at d = 128 fp32): cheaper up to ~700-byte rows.
+        x = x * src_scale.reshape((-1,) + (1,) * (x.dim() - 1)).to(x.dtype)
+        src_scale = None
     M = int(out_size) if (out_size is not None and int(out_size) > 0) else int(x.shape[0])
     if y is not None:
         if y.dtype != x.dtype:

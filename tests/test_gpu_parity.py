@@ -1085,3 +1085,20 @@ def test_chunk_size_stress_in_subprocess(pgl):
                             "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute or narrow or softmax"],
                            env=env, capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_tall_linear_split_reduction_gradient(pgl):
+    """The layers' Linear switches to a split-reduction weight gradient for >= 65536 rows: same values as nn.Linear."""
+    from pgl_amd.nn.conv import _linear
+    torch.manual_seed(0)
+    for n in (65536, 70001):
+        lin = _linear(24, 10).cuda()
+        ref = torch.nn.Linear(24, 10).cuda()
+        ref.load_state_dict(lin.state_dict())
+        x = torch.randn(n, 24, device="cuda", requires_grad=True)
+        x2 = x.detach().clone().requires_grad_(True)
+        ct = torch.randn(n, 10, device="cuda")
+        (lin(x) * ct).sum().backward(); (ref(x2) * ct).sum().backward()
+        close(host(x.grad), host(x2.grad), scale=float(x2.grad.abs().max()))
+        close(host(lin.weight.grad), host(ref.weight.grad), scale=float(ref.weight.grad.abs().max()), rtol=1e-4)
+        close(host(lin.bias.grad), host(ref.bias.grad), scale=float(ref.bias.grad.abs().max()), rtol=1e-4)
