@@ -16,8 +16,6 @@ Output: one JSON line on rank 0 with the driver's contract fields plus
   cpu_baseline -- the oracle's C port of the Paddle CPU kernel (serial, raw COO order), timed on
                   this box's host cores (rank 0, N = 1 only); the checker, never the product.
 """
-import argparse
-import json
 import os
 import sys
 import time

@@ -216,24 +216,27 @@ int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const 
                              float* row_sum, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of pglamd_gat_aggregate (row "next" f1: fused backward), alpha recomputed per edge from
- * the forward's statistics, nothing of size [E,H,D] is materialised:
- *   grad_feature[u,h,:] = sum_{e=(u->v)} drop_e alpha_e grad_out[v,h,:]          (src-sorted walk)
- *   grad_pre[e,h]       = d loss / d (attn_src[u,h] + attn_dst[v,h])  in ORIGINAL edge order;
- *                         grad attn_src / attn_dst are its segment sums by src / dst, which the
- *                         caller takes with two pglamd_aggregate calls (x = grad_pre, col = eid).
- *   t [N,H]             = sum_d grad_out[v,h,d] * out[v,h,d], supplied by the caller.
- *   dst_* / src_*       the dst-sorted and src-sorted CSRs (int32 row / col / eid, int64 indptr).
- * Workspace: pglamd_gat_aggregate_workspace_bytes.  Same shape limits as the forward, and
- * head_dim / VEC must be a power of two (per-head dot products are shuffle reductions). */
+ * the forward's statistics; nothing of size [E,H] or [E,H,D] is materialised:
+ *   grad_feature[u,h,:] = sum_{e=(u->v)} drop_e alpha_e grad_out[v,h,:]
+ *   grad_attn_src[u,h]  = sum_{e=(u->v)} d pre_e          (both from ONE walk of the src-sorted CSR)
+ *   grad_attn_dst[v,h]  = sum_{e=(u->v)} d pre_e          (one walk of the dst-sorted CSR)
+ *   d pre_e = alpha_e (drop_e <grad_out[v,h,:], feature[u,h,:]> - t[v,h]) * leaky_relu'(attn_src[u,h] + attn_dst[v,h])
+ *   t [N,H] = sum_d grad_out[v,h,d] * out[v,h,d], supplied by the caller.
+ *   dst_* / src_*  the dst-sorted and src-sorted CSRs (int32 row / col / eid, int64 indptr).
+ * Replaces the backward of the four-op composition at pgl/nn/conv.py:331-339 (send_uv -> leaky_relu ->
+ * edge_softmax -> send_ue_recv).  Workspace (256-byte aligned): pglamd_gat_backward_workspace_bytes.  Same shape
+ * limits as the forward, and head_dim / VEC must be a power of two (per-head dot products are shuffle reductions). */
+size_t pglamd_gat_backward_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t heads,
+                                           int64_t head_dim);
 int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const float* attn_src,
                             const float* attn_dst, const float* row_max, const float* row_sum,
                             const float* t, int64_t heads, int64_t head_dim, float negative_slope,
                             float drop_p, uint32_t seed, const int32_t* dst_row,
-                            const int32_t* dst_col, const int32_t* dst_eid, const int32_t* src_row,
-                            const int32_t* src_col, const int32_t* src_eid,
+                            const int32_t* dst_col, const int32_t* dst_eid, const int64_t* dst_indptr,
+                            const int32_t* src_row, const int32_t* src_col, const int32_t* src_eid,
                             const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
-                            float* grad_feature, float* grad_pre, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            float* grad_feature, float* grad_attn_src, float* grad_attn_dst,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* SDDMM over a sorted edge stream:  out[eid[p], h] = < x_by_col[col[p], h, :], y_by_row[row[p], h, :] >
  * (eid NULL: out[p, h]).  With (row, col, eid) = the dst-sorted CSR, x = node features and

@@ -13,13 +13,15 @@
 //   f[u] (H*D*4 B) + a_src[u] (H*4 B) + 8 B of index per edge + one output row: a plain SpMM + 6 %.
 //   The per-row statistics (m, s) are optionally written out ([N,H] each): they are all a backward
 //   pass needs to recompute alpha_e = exp(leaky(a_src[u]+a_dst[v]) - m[v]) / s[v] on the fly.
-// BACKWARD
-//   d f[u]      = sum_{e=(u->v)} drop_e alpha_e g[v]          gat_flat_kernel<VEC, 1> over the SRC-sorted
-//                                                              stream, alpha recomputed per edge
-//   d logit_e   = alpha_e (drop_e <g[v], f[u]>_h - t[v,h]),   t[v,h] = <g[v,h,:], out[v,h,:]>
-//   d pre_e     = d logit_e * (pre_e > 0 ? 1 : slope)          gat_bwd_edge_kernel (dst-sorted stream),
-//                 written to [E,H] in ORIGINAL edge order; d a_src / d a_dst are its segment sums by
-//                 src / dst (two small pglamd_aggregate calls made by the caller).
+// BACKWARD: two symmetric walks, each a plain gather pass that keeps everything it produces in registers per row
+//   alpha_e   = exp(leaky(pre_e) - m[v]) / s[v],  pre_e = a_src[u] + a_dst[v]        (recomputed from the forward's statistics)
+//   d pre_e   = alpha_e (drop_e <g[v], f[u]>_h - t[v,h]) * (pre_e > 0 ? 1 : slope),  t[v,h] = <g[v,h,:], out[v,h,:]>
+//   MODE 2, SRC-sorted stream (row = u, gathers g[v] and the scalars of v):
+//             d f[u]     = sum_{e=(u->v)} drop_e alpha_e g[v]        and        d a_src[u,h] = sum_{e=(u->v)} d pre_e
+//   MODE 3, DST-sorted stream (row = v, gathers f[u] and a_src[u]):             d a_dst[v,h] = sum_{e=(u->v)} d pre_e
+//   The row's own vector (f[u] resp. g[v]) rides along with every edge like the per-row scalars do (an L1 hit after the
+//   row's first edge); the per-head dot product is a xor-shuffle over the lanes of a head.  No [E,H] tensor exists at
+//   any point (the reference-style composition writes and re-reads four of them).
 // Attention dropout is a counter-based hash of (seed, original edge id, head): forward and both
 // backward kernels regenerate the same mask, nothing is stored.
 // Rows longer than a chunk leave partials merged in a fixed order by gat_fixup_kernel (associative
@@ -29,6 +31,8 @@
 #include <algorithm>
 
 namespace pglamd {
+
+struct alignas(16) F4 { float a, m, s, t; };       // per (node, head): a_dst, softmax max, 1 / softmax sum, <g, out>
 
 struct GatParams {
     const float* x;                 // gathered by col: f (forward) or g = dL/dout (backward-feature)
@@ -45,11 +49,33 @@ struct GatParams {
     int d, H, D;
     float slope, drop_p, drop_scale;
     unsigned seed;
-    // backward-edge only
-    const float* f; const float* g; const float* t; float* dpre;
+    // backward with attention gradients (MODE 2 / 3)
+    const float* row_vec;           // the row node's own vector: f[u] (MODE 2) / g[v] (MODE 3)
+    const F4* packed;               // [N,H] (a_dst, m, 1/s, t) of every node as a destination
+    float* out_a;                   // [out_rows,H] d a_src (MODE 2) / d a_dst (MODE 3)
+    // sddmm only
+    const float* f; const float* g; float* dpre;
 };
 
 template <int VEC> struct alignas(4 * VEC) FV { float v[VEC]; };
+
+// Sum over aligned groups of `group` lanes (a power of two <= 64), result in every lane of the group.  The first four
+// steps are DPP lane permutes (VALU latency, no LDS round trip): quad_perm xor-1 / xor-2, then row_half_mirror and
+// row_mirror -- once every lane of a quad (resp. 8-lane half row) holds the same partial sum, ANY lane of the
+// neighbouring quad (half row) supplies the missing term.  Only groups wider than 16 lanes cross DPP rows (bpermute).
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group_sum(float v, int group) {
+    float t;                                     // selects, not branches: the four DPP steps are always issued
+    t = dpp_add<0xB1>(v);  v = group > 1 ? t : v;        // quad_perm [1,0,3,2]
+    t = dpp_add<0x4E>(v);  v = group > 2 ? t : v;        // quad_perm [2,3,0,1]
+    t = dpp_add<0x141>(v); v = group > 4 ? t : v;        // row_half_mirror
+    t = dpp_add<0x140>(v); v = group > 8 ? t : v;        // row_mirror
+    if (group > 16) v += __shfl_xor(v, 16);
+    if (group > 32) v += __shfl_xor(v, 32);
+    return v;
+}
 
 // keep-mask of attention dropout: stateless hash of (seed, original edge id, head) -> [0,1)
 __device__ __forceinline__ float drop_factor(unsigned seed, int eid, int head, float p, float scale) {
@@ -58,17 +84,21 @@ __device__ __forceinline__ float drop_factor(unsigned seed, int eid, int head, f
     return ((h >> 8) * (1.0f / 16777216.0f)) >= p ? scale : 0.f;
 }
 
-// MODE 0: forward (online softmax).  MODE 1: backward w.r.t. features (additive, alpha recomputed).
+// MODE 0: forward (online softmax).  MODE 1: backward w.r.t. features only (additive, alpha recomputed).
+// MODE 2: MODE 1 + d a_src over the src-sorted stream.  MODE 3: d a_dst over the dst-sorted stream (no feature output).
 template <int VEC, int MODE, bool DROP>
 __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     constexpr int U = 4;
-    constexpr int PW = MODE == 0 ? 3 : 1;               // floats per column in a partial
+    constexpr int PW = MODE == 0 ? 3 : MODE == 2 ? 2 : 1;   // floats per column in a partial
+    constexpr bool ATT = MODE >= 2;                     // accumulates the attention-score gradient of the row node
+    constexpr bool FEAT = MODE != 3;                    // accumulates / writes a feature row
     using V = FV<VEC>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
     const int j0 = lane * VEC;
     const bool act = j0 < p.d;
     const int head = act ? j0 / p.D : 0;
+    const int lph = p.D / VEC;                          // lanes per head (a power of two when ATT)
 
     if ((int)blockIdx.x >= p.n_grid_chunks) {           // zero-fill role: rows that receive no edge
         const int64_t w = ((int64_t)blockIdx.x - p.n_grid_chunks) * kWavesPerBlock + wib;
@@ -81,7 +111,8 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
         while (mk) {
             const int l = __builtin_ctzll(mk);
             mk &= mk - 1;
-            if (act) *reinterpret_cast<V*>(p.out + (r0 + l) * p.d + j0) = V{};
+            if (FEAT && act) *reinterpret_cast<V*>(p.out + (r0 + l) * p.d + j0) = V{};
+            if (ATT && lane < p.H) p.out_a[(r0 + l) * p.H + lane] = 0.f;
             if (MODE == 0 && p.row_max && lane < p.H) { p.row_max[(r0 + l) * p.H + lane] = 0.f; p.row_sum[(r0 + l) * p.H + lane] = 0.f; }
         }
         return;
@@ -104,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     const float slope = p.slope;
     constexpr bool drop = DROP;
 
-    float m = -INFINITY, s = 0.f, acc[VEC];
+    float m = -INFINITY, s = 0.f, acc[VEC], acc_a = 0.f;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
     int cur = rowp[e0];
@@ -115,8 +146,13 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             float* dst = (headp ? p.part_head : p.part_tail) + (int64_t)c * PW * p.d;
             V o;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
+            for (int k = 0; k < VEC; ++k) o.v[k] = FEAT ? acc[k] : acc_a;
             *reinterpret_cast<V*>(dst + j0) = o;
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) o.v[k] = acc_a;
+                *reinterpret_cast<V*>(dst + p.d + j0) = o;
+            }
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = m;
@@ -130,6 +166,8 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     };
     auto store_final = [&](int r) {
         if (r >= p.out_rows || !act) return;
+        if constexpr (ATT) { if ((j0 % p.D) == 0) p.out_a[(int64_t)r * p.H + head] = acc_a; }
+        if constexpr (!FEAT) return;
         V o;
         const float inv = MODE == 0 ? 1.f / s : 1.f;
 #pragma unroll
@@ -139,17 +177,17 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     };
     // per-row scalars ride along with every edge of the batch (an L1/L2 hit after the first edge of
     // a row) instead of being fetched on the row change, which would stall the wave once per row.
-    auto consume = [&](int r, int ed, float vc, float vr, float vm, float vs, const V& xv) {
+    auto consume = [&](int r, int ed, float vc, float vr, float vm, float vs, float vt, const V& xv, const V& yv) {
         if (r != cur) {
             if (head_open) store_partial(true); else store_final(cur);
             head_open = false;
             cur = r;
-            m = -INFINITY; s = 0.f;
+            m = -INFINITY; s = 0.f; acc_a = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
         }
-        float l = vc + vr;
-        l = l > 0.f ? l : slope * l;
+        const float pre = vc + vr;
+        const float l = pre > 0.f ? pre : slope * pre;
         const float df = drop ? drop_factor(p.seed, ed, head, p.drop_p, p.drop_scale) : 1.f;
         if constexpr (MODE == 0) {
             const float mn = fmaxf(m, l);
@@ -161,56 +199,155 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * sc + w * xv.v[k];
             m = mn;
         } else {
-            const float w = expf(l - vm) / vs * df;  // alpha_e of the destination's softmax, recomputed
+            const float alpha = expf(l - vm) / vs;   // alpha_e of the destination's softmax, recomputed
+            if constexpr (FEAT) {
+                const float w = alpha * df;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) acc[k] += w * xv.v[k];
+                for (int k = 0; k < VEC; ++k) acc[k] += w * xv.v[k];
+            }
         }
     };
+    const float* __restrict__ rvec = p.row_vec;
     auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U], int (&ee)[U]) {
 #pragma unroll
         for (int i = 0; i < U; ++i) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; ee[i] = drop ? eidp[e + i] : 0; }
     };
-    auto load_rows = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], float (&vc)[U], float (&vr)[U], float (&vm)[U], float (&vs)[U]) {
+    // the destination's statistics (and t) are indexed by col on the src-sorted stream, by row on the dst-sorted one
+    auto load_rows = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], V (&vy)[U], float (&vc)[U], float (&vr)[U],
+                         float (&vm)[U], float (&vs)[U], float (&vt)[U]) {
 #pragma unroll
         for (int i = 0; i < U; ++i)
             if (act) {
                 vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc[i] * p.d + j0);
                 vc[i] = pcol[(int64_t)cc[i] * p.H + head];
                 vr[i] = prow[(int64_t)rr[i] * p.H + head];
-                if constexpr (MODE == 1) { vm[i] = sm[(int64_t)cc[i] * p.H + head]; vs[i] = ss[(int64_t)cc[i] * p.H + head]; }
+                if constexpr (MODE >= 1) {
+                    const int64_t si = (int64_t)(MODE == 3 ? rr[i] : cc[i]) * p.H + head;
+                    vm[i] = sm[si]; vs[i] = ss[si];
+                }
             }
     };
 
     int e = e0;
     const int n_full = (e1 - e0) / U;
-    int cA[U], rA[U], eA[U]; V xA[U]; float vcA[U], vrA[U], vmA[U], vsA[U];
-    if (n_full > 0) { load_idx(e, cA, rA, eA); load_rows(cA, rA, xA, vcA, vrA, vmA, vsA); }
-    for (int g = 0; g < n_full; ++g) {
-        int cB[U], rB[U], eB[U]; V xB[U]; float vcB[U], vrB[U], vmB[U], vsB[U];
-        const bool more = g + 1 < n_full;
-        if (more) { load_idx(e + U, cB, rB, eB); load_rows(cB, rB, xB, vcB, vrB, vmB, vsB); }
+    if constexpr (!ATT) {
+        int cA[U], rA[U], eA[U]; V xA[U], yA[U]; float vcA[U], vrA[U], vmA[U], vsA[U], vtA[U];
+        if (n_full > 0) { load_idx(e, cA, rA, eA); load_rows(cA, rA, xA, yA, vcA, vrA, vmA, vsA, vtA); }
+        for (int g = 0; g < n_full; ++g) {
+            int cB[U], rB[U], eB[U]; V xB[U], yB[U]; float vcB[U], vrB[U], vmB[U], vsB[U], vtB[U];
+            const bool more = g + 1 < n_full;
+            if (more) { load_idx(e + U, cB, rB, eB); load_rows(cB, rB, xB, yB, vcB, vrB, vmB, vsB, vtB); }
+    #pragma unroll
+            for (int i = 0; i < U; ++i) consume(rA[i], eA[i], vcA[i], vrA[i], vmA[i], vsA[i], vtA[i], xA[i], yA[i]);
+            if (more) {
+    #pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    rA[i] = rB[i]; eA[i] = eB[i]; xA[i] = xB[i]; vcA[i] = vcB[i]; vrA[i] = vrB[i];
+                    if constexpr (MODE >= 1) { vmA[i] = vmB[i]; vsA[i] = vsB[i]; }
+                    if constexpr (ATT) { vtA[i] = vtB[i]; yA[i] = yB[i]; }
+                }
+            }
+            e += U;
+        }
+        for (; e < e1; ++e) {
+            const int r = rowp[e], cc = colp[e];
+            const int ed = drop ? eidp[e] : 0;
+            V xv{}, yv{}; float vc = 0.f, vr = 0.f, vm = 0.f, vs = 1.f, vt = 0.f;
+            if (act) {
+                xv = *reinterpret_cast<const V*>(x + (int64_t)cc * p.d + j0);
+                vc = pcol[(int64_t)cc * p.H + head];
+                vr = prow[(int64_t)r * p.H + head];
+                if constexpr (MODE >= 1) {
+                    const int64_t si = (int64_t)(MODE == 3 ? r : cc) * p.H + head;
+                    vm = sm[si]; vs = ss[si];
+                    }
+            }
+            consume(r, ed, vc, vr, vm, vs, vt, xv, yv);
+        }
+    } else {
+        // Attention-gradient walks.  The destination's four per-head scalars come PACKED (a_dst, m, s, t: one 16-byte
+        // load); what belongs to the row node itself (its vector, and a_src[u] resp. the packed scalars of v) is fetched
+        // only for edges that OPEN a row inside the batch and held in registers until the next row change -- on a
+        // power-law graph most edges continue a row, so an edge costs two vector loads, not seven.
+        const F4* __restrict__ pk = p.packed;
+        V y_held{}; F4 p_held{}; float a_held = 0.f;
+        if (act) {
+            y_held = *reinterpret_cast<const V*>(rvec + (int64_t)cur * p.d + j0);
+            if constexpr (MODE == 2) a_held = prow[(int64_t)cur * p.H + head];
+            else p_held = pk[(int64_t)cur * p.H + head];
+        }
+        auto consume_att = [&](int r, int ed, const V& xv, const F4& pc, float ac, const V& yo, const F4& po, float ao) {
+            if (r != cur) {
+                if (head_open) store_partial(true); else store_final(cur);
+                head_open = false;
+                cur = r;
+                acc_a = 0.f;
 #pragma unroll
-        for (int i = 0; i < U; ++i) consume(rA[i], eA[i], vcA[i], vrA[i], vmA[i], vsA[i], xA[i]);
-        if (more) {
+                for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+                y_held = yo;
+                if constexpr (MODE == 2) a_held = ao; else p_held = po;
+            }
+            const F4 q = MODE == 2 ? pc : p_held;                  // (a_dst, m, s, t) of the destination v
+            const float pre = q.a + (MODE == 2 ? a_held : ac);     // + a_src[u]
+            const float l = pre > 0.f ? pre : slope * pre;
+            const float df = drop ? drop_factor(p.seed, ed, head, p.drop_p, p.drop_scale) : 1.f;
+            const float alpha = expf(l - q.m) * q.s;              // q.s holds 1 / softmax sum
+            if constexpr (FEAT) {
+                const float w = alpha * df;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += w * xv.v[k];
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) dot += xv.v[k] * y_held.v[k];       // <g[v], f[u]> restricted to this lane
+            dot = group_sum(dot, lph);
+            const float dl = alpha * (df * dot - q.t);
+            acc_a += pre > 0.f ? dl : slope * dl;
+        };
+        auto load_att = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], F4 (&pc)[U], float (&ac)[U], V (&yo)[U],
+                            F4 (&po)[U], float (&ao)[U]) {
+            if (!act) return;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                rA[i] = rB[i]; eA[i] = eB[i]; xA[i] = xB[i]; vcA[i] = vcB[i]; vrA[i] = vrB[i];
-                if constexpr (MODE == 1) { vmA[i] = vmB[i]; vsA[i] = vsB[i]; }
+                vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc[i] * p.d + j0);
+                if constexpr (MODE == 2) pc[i] = pk[(int64_t)cc[i] * p.H + head];
+                else ac[i] = pcol[(int64_t)cc[i] * p.H + head];
+                if (i == 0 || rr[i] != rr[i - 1]) {                // wave-uniform: this edge may open a row
+                    yo[i] = *reinterpret_cast<const V*>(rvec + (int64_t)rr[i] * p.d + j0);
+                    if constexpr (MODE == 2) ao[i] = prow[(int64_t)rr[i] * p.H + head];
+                    else po[i] = pk[(int64_t)rr[i] * p.H + head];
+                }
             }
+        };
+        int cA[U], rA[U], eA[U]; V xA[U], yA[U]; F4 pcA[U], poA[U]; float acA[U], aoA[U];
+        if (n_full > 0) { load_idx(e, cA, rA, eA); load_att(cA, rA, xA, pcA, acA, yA, poA, aoA); }
+        for (int g = 0; g < n_full; ++g) {
+            int cB[U], rB[U], eB[U]; V xB[U], yB[U]; F4 pcB[U], poB[U]; float acB[U], aoB[U];
+            const bool more = g + 1 < n_full;
+            if (more) { load_idx(e + U, cB, rB, eB); load_att(cB, rB, xB, pcB, acB, yB, poB, aoB); }
+#pragma unroll
+            for (int i = 0; i < U; ++i) consume_att(rA[i], eA[i], xA[i], pcA[i], acA[i], yA[i], poA[i], aoA[i]);
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) {
+                    rA[i] = rB[i]; eA[i] = eB[i]; xA[i] = xB[i]; yA[i] = yB[i];
+                    if constexpr (MODE == 2) { pcA[i] = pcB[i]; aoA[i] = aoB[i]; } else { acA[i] = acB[i]; poA[i] = poB[i]; }
+                }
+            }
+            e += U;
         }
-        e += U;
-    }
-    for (; e < e1; ++e) {
-        const int r = rowp[e], cc = colp[e];
-        const int ed = drop ? eidp[e] : 0;
-        V xv{}; float vc = 0.f, vr = 0.f, vm = 0.f, vs = 1.f;
-        if (act) {
-            xv = *reinterpret_cast<const V*>(x + (int64_t)cc * p.d + j0);
-            vc = pcol[(int64_t)cc * p.H + head];
-            vr = prow[(int64_t)r * p.H + head];
-            if constexpr (MODE == 1) { vm = sm[(int64_t)cc * p.H + head]; vs = ss[(int64_t)cc * p.H + head]; }
+        for (; e < e1; ++e) {
+            const int r = rowp[e], cc = colp[e];
+            const int ed = drop ? eidp[e] : 0;
+            V xv{}, yo{}; F4 pc{}, po{}; float ac = 0.f, ao = 0.f;
+            if (act) {
+                xv = *reinterpret_cast<const V*>(x + (int64_t)cc * p.d + j0);
+                yo = *reinterpret_cast<const V*>(rvec + (int64_t)r * p.d + j0);
+                if constexpr (MODE == 2) { pc = pk[(int64_t)cc * p.H + head]; ao = prow[(int64_t)r * p.H + head]; }
+                else { ac = pcol[(int64_t)cc * p.H + head]; po = pk[(int64_t)r * p.H + head]; }
+            }
+            consume_att(r, ed, xv, pc, ac, yo, po, ao);
         }
-        consume(r, ed, vc, vr, vm, vs, xv);
     }
     const bool tail_open = e1 < p.E && rowp[e1] == cur;
     if (head_open) store_partial(true);
@@ -232,7 +369,7 @@ template <int VEC, bool LONG, int MODE>
 __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixup_kernel(GatParams p) {
     using V = FV<VEC>;
     constexpr int NW = LONG ? kGatFixWaves : 1;
-    constexpr int PW = MODE == 0 ? 3 : 1;
+    constexpr int PW = MODE == 0 ? 3 : MODE == 2 ? 2 : 1;
     __shared__ float red[LONG ? kGatFixWaves : 1][3][LONG ? kWave * VEC : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
@@ -267,14 +404,16 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * c1 + va.v[k] * c2;
                 m = mn;
-            } else {
+            } else {                                   // additive modes: `m` doubles as the second component (MODE 2)
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] += va.v[k];
+                m += m2;
                 s = 1.f;
             }
         };
         auto merge = [&](const float* base) {
             if constexpr (MODE == 0) merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], base[2 * p.d + j0]);
+            else if constexpr (MODE == 2) merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], 1.f);
             else merge_vals(*reinterpret_cast<const V*>(base + j0), 0.f, 1.f);
         };
         if constexpr (!LONG) {
@@ -309,6 +448,8 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
             }
         }
         if (!act || r >= p.out_rows) continue;
+        if constexpr (MODE == 2) { if ((j0 % p.D) == 0) p.out_a[(int64_t)r * p.H + j0 / p.D] = m; }
+        if constexpr (MODE == 3) { if ((j0 % p.D) == 0) p.out_a[(int64_t)r * p.H + j0 / p.D] = acc[0]; continue; }
         V o;
         const float inv = MODE == 0 ? 1.f / s : 1.f;
 #pragma unroll
@@ -318,88 +459,11 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
     }
 }
 
-// d pre_e for every edge (dst-sorted walk, result scattered to ORIGINAL edge order):
-//   alpha_e = exp(l_e - m[v]) / s[v],  l_e = leaky(pre_e),  pre_e = a_src[u] + a_dst[v]
-//   d pre_e = alpha_e * (drop_e * <g[v,h,:], f[u,h,:]> - t[v,h]) * (pre_e > 0 ? 1 : slope)
-// Lanes span the H*D columns; the per-head dot product is a xor-shuffle reduction over the D/VEC
-// lanes of a head (a power of two); lane 0 of each head writes dpre[eid, h].
-template <int VEC>
-__global__ __launch_bounds__(kBlock) void gat_bwd_edge_kernel(GatParams p) {
-    constexpr int U = 4;
-    using V = FV<VEC>;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wib = wave_uniform(threadIdx.x >> 6);
-    const int j0 = lane * VEC;
-    const bool act = j0 < p.d;
-    const int lph = p.D / VEC;                           // lanes per head (power of two)
-    const int head = act ? j0 / p.D : 0;
-    const bool writer = act && (lane % lph) == 0;
-    const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
-    if (lb < 0) return;
-    const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
-    if (c >= p.n_chunks) return;
-    const int e0 = c * p.chunk, e1 = min(e0 + p.chunk, p.E);
-    const cptr<int> rowp = as_const(p.row);
-    const cptr<int> colp = as_const(p.col);
-    const cptr<int> eidp = as_const(p.eid);
-    const bool drop = p.drop_p > 0.f;
-    int cur = -1;
-    V gv{}; float ad = 0.f, mv = 0.f, sv = 1.f, tv = 0.f;
-    auto row_change = [&](int r) {
-        cur = r;
-        if (act) {
-            gv = *reinterpret_cast<const V*>(p.g + (int64_t)r * p.d + j0);
-            ad = p.p_row[(int64_t)r * p.H + head];
-            mv = p.stat_m[(int64_t)r * p.H + head];
-            sv = p.stat_s[(int64_t)r * p.H + head];
-            tv = p.t[(int64_t)r * p.H + head];
-        }
-    };
-    auto consume = [&](int r, int ed, float as_val, const V& fv) {
-        if (r != cur) row_change(r);
-        float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) dot += gv.v[k] * fv.v[k];
-        for (int off = 1; off < lph; off <<= 1) dot += __shfl_xor(dot, off);
-        const float pre = as_val + ad;
-        const float l = pre > 0.f ? pre : p.slope * pre;
-        const float alpha = expf(l - mv) / sv;
-        const float df = drop ? drop_factor(p.seed, ed, head, p.drop_p, p.drop_scale) : 1.f;
-        const float dl = alpha * (df * dot - tv);
-        if (writer) p.dpre[(int64_t)ed * p.H + head] = pre > 0.f ? dl : p.slope * dl;
-    };
-    auto load_batch = [&](int e, int nb, int (&rr)[U], int (&ee)[U], V (&fx)[U], float (&av)[U]) {
-        int cc[U];
-#pragma unroll
-        for (int i = 0; i < U; ++i)
-            if (i < nb) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; ee[i] = eidp[e + i]; }
-#pragma unroll
-        for (int i = 0; i < U; ++i)
-            if (i < nb && act) {
-                fx[i] = *reinterpret_cast<const V*>(p.f + (int64_t)cc[i] * p.d + j0);
-                av[i] = p.p_col[(int64_t)cc[i] * p.H + head];
-            }
-    };
-    int rA[U], eA[U]; V fA[U]; float aA[U];
-    int nA = min(U, e1 - e0);
-    load_batch(e0, nA, rA, eA, fA, aA);
-    for (int e = e0; e < e1; e += U) {
-        int rB[U], eB[U]; V fB[U]; float aB[U];
-        const int nB = max(0, min(U, e1 - (e + U)));
-        if (nB > 0) load_batch(e + U, nB, rB, eB, fB, aB);          // next batch in flight while this one is consumed
-#pragma unroll
-        for (int i = 0; i < U; ++i)
-            if (i < nA) consume(rA[i], eA[i], aA[i], fA[i]);
-#pragma unroll
-        for (int i = 0; i < U; ++i) { rA[i] = rB[i]; eA[i] = eB[i]; fA[i] = fB[i]; aA[i] = aB[i]; }
-        nA = nB;
-    }
-}
-
 // SDDMM over a dst-sorted edge stream: out[eid[p], h] = < x[col[p], h, :], y[row[p], h, :] >.
 // This is d loss / d (edge feature) of send_ue_recv(x, e, "mul", "sum") when e is [E,H,1]
 // (x = node features gathered by source, y = the incoming gradient rows): the reference composes it
-// from two [E,H,D] gathers; here neither is materialised.  Same lane geometry as gat_bwd_edge_kernel.
+// from two [E,H,D] gathers; here neither is materialised.  Lanes span the H*D columns; the per-head dot
+// product is a xor-shuffle reduction over the D/VEC lanes of a head (a power of two); lane 0 of each head writes.
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
     constexpr int U = 8;
@@ -444,13 +508,20 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
                 float dot = 0.f;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) dot += gv.v[k] * fA[i].v[k];
-                for (int off = 1; off < lph; off <<= 1) dot += __shfl_xor(dot, off);
+                dot = group_sum(dot, lph);
                 if (writer) p.dpre[(int64_t)eA[i] * p.H + head] = dot;
             }
 #pragma unroll
         for (int i = 0; i < U; ++i) { rA[i] = rB[i]; eA[i] = eB[i]; fA[i] = fB[i]; }
         nA = nB;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void gat_pack_kernel(const float* __restrict__ a_dst, const float* __restrict__ m,
+                                                         const float* __restrict__ sm, const float* __restrict__ t, int64_t n,
+                                                         F4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = F4{a_dst[i], m[i], 1.f / sm[i], t[i]};
 }
 
 static int gat_chunk_edges() {
@@ -559,17 +630,22 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
     }
 }
 
+extern "C" size_t pglamd_gat_backward_workspace_bytes(int64_t num_edges, int64_t num_nodes, int64_t heads, int64_t head_dim) {
+    return align_up((size_t)(num_nodes > 0 ? num_nodes : 1) * heads * sizeof(F4), 256) +
+           pglamd_gat_aggregate_workspace_bytes(num_edges, heads, head_dim);
+}
+
 extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const float* attn_src,
                                        const float* attn_dst, const float* row_max, const float* row_sum, const float* t,
                                        int64_t heads, int64_t head_dim, float negative_slope, float drop_p, uint32_t seed,
                                        const int32_t* dst_row, const int32_t* dst_col, const int32_t* dst_eid,
-                                       const int32_t* src_row, const int32_t* src_col, const int32_t* src_eid,
-                                       const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
-                                       float* grad_feature, float* grad_pre, void* workspace, size_t workspace_bytes,
-                                       void* stream) {
-    if (heads <= 0 || head_dim <= 0 || num_nodes < 0 || num_edges < 0 || !grad_feature || (num_edges > 0 && (!grad_out || !feature ||
-        !attn_src || !attn_dst || !row_max || !row_sum || !t || !dst_row || !dst_col || !dst_eid || !src_row ||
-        !src_col || !src_eid || !src_indptr || !grad_pre)))
+                                       const int64_t* dst_indptr, const int32_t* src_row, const int32_t* src_col,
+                                       const int32_t* src_eid, const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
+                                       float* grad_feature, float* grad_attn_src, float* grad_attn_dst, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (heads <= 0 || head_dim <= 0 || num_nodes < 0 || num_edges < 0 || !grad_feature || !grad_attn_src || !grad_attn_dst ||
+        (num_edges > 0 && (!grad_out || !feature || !attn_src || !attn_dst || !row_max || !row_sum || !t || !dst_row || !dst_col ||
+                           !dst_eid || !dst_indptr || !src_row || !src_col || !src_eid || !src_indptr)))
         return fail(PGLAMD_E_ARG, "gat_backward: bad argument");
     if (drop_p < 0.f || drop_p >= 1.f) return fail(PGLAMD_E_ARG, "gat_backward: dropout needs 0 <= p < 1");
     if (num_edges >= INT32_MAX || num_nodes >= INT32_MAX) return fail(PGLAMD_E_RANGE, "gat_backward: sizes beyond int32 engine range");
@@ -578,42 +654,43 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     if (num_nodes == 0) return PGLAMD_OK;
     if (num_edges == 0) {
         PGLAMD_HIP_CHECK(hipMemsetAsync(grad_feature, 0, (size_t)num_nodes * d * sizeof(float), st));
+        PGLAMD_HIP_CHECK(hipMemsetAsync(grad_attn_src, 0, (size_t)num_nodes * heads * sizeof(float), st));
+        PGLAMD_HIP_CHECK(hipMemsetAsync(grad_attn_dst, 0, (size_t)num_nodes * heads * sizeof(float), st));
         return PGLAMD_OK;
     }
     const int vec = gat_vec(heads, head_dim, feature, grad_out, grad_feature, true);
-    if (vec == 0 || heads > kWave || reinterpret_cast<uintptr_t>(workspace) % 16)
+    if (vec == 0 || heads > kWave || reinterpret_cast<uintptr_t>(workspace) % 256)
         return fail(PGLAMD_E_SHAPE, "gat_backward: heads*head_dim = %lld needs one 64-lane tile and head_dim/VEC a power of two", (long long)d);
-    if (!workspace || workspace_bytes < pglamd_gat_aggregate_workspace_bytes(num_edges, heads, head_dim))
+    if (!workspace || workspace_bytes < pglamd_gat_backward_workspace_bytes(num_edges, num_nodes, heads, head_dim))
         return fail(PGLAMD_E_WORKSPACE, "gat_backward: workspace too small");
+    // (0) the destination-side scalars of every (node, head), packed so that an edge fetches them with one 16-byte load
+    const size_t pack_bytes = align_up((size_t)num_nodes * heads * sizeof(F4), 256);
+    F4* packed = static_cast<F4*>(workspace);
+    workspace = static_cast<char*>(workspace) + pack_bytes;
+    hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)ceil_div(num_nodes * heads, kBlock)), dim3(kBlock), 0, st, attn_dst, row_max,
+                       row_sum, t, num_nodes * heads, packed);
+    PGLAMD_LAUNCH_CHECK();
     GatParams p{};
     p.H = (int)heads; p.D = (int)head_dim; p.d = (int)d; p.slope = negative_slope;
     p.drop_p = drop_p; p.drop_scale = 1.f / (1.f - drop_p); p.seed = seed;
     p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
-    p.stat_m = row_max; p.stat_s = row_sum;
-    // (1) d pre_e, dst-sorted walk
+    p.packed = packed;
+    p.out_rows = num_nodes; p.n_csr_rows = num_nodes;
+    int32_t rc;
+    // (1) dst-sorted walk: row = v gathers f[u], a_src[u]; accumulates d a_dst[v]
     {
         GatParams q = p;
-        q.row = dst_row; q.col = dst_col; q.eid = dst_eid;
-        q.f = feature; q.g = grad_out; q.t = t; q.dpre = grad_pre; q.p_col = attn_src; q.p_row = attn_dst;
-        const int64_t nb = ceil_div(q.n_chunks, kWavesPerBlock);
-        q.n_blocks = (int)nb;
-        switch (vec) {
-            case 1: hipLaunchKernelGGL(gat_bwd_edge_kernel<1>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, q); break;
-            case 2: hipLaunchKernelGGL(gat_bwd_edge_kernel<2>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, q); break;
-            default: hipLaunchKernelGGL(gat_bwd_edge_kernel<4>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, q); break;
-        }
-        PGLAMD_LAUNCH_CHECK();
+        q.row = dst_row; q.col = dst_col; q.eid = dst_eid; q.indptr = dst_indptr;
+        q.x = feature; q.p_col = attn_src; q.p_row = attn_dst; q.row_vec = grad_out; q.out = nullptr; q.out_a = grad_attn_dst;
+        gat_setup_partials(q, workspace, 1);
+        rc = vec == 1 ? launch_gat<1, 3>(q, st) : vec == 2 ? launch_gat<2, 3>(q, st) : launch_gat<4, 3>(q, st);
+        if (rc != PGLAMD_OK) return rc;
     }
-    // (2) d f[u] = sum over out-edges of alpha_e * g[v]: src-sorted walk, alpha recomputed
-    p.x = grad_out; p.p_col = attn_dst; p.p_row = attn_src; p.out = grad_feature;
+    // (2) src-sorted walk: row = u gathers g[v] and v's scalars; accumulates d f[u] and d a_src[u]
     p.row = src_row; p.col = src_col; p.eid = src_eid; p.indptr = src_indptr;
-    p.out_rows = num_nodes; p.n_csr_rows = num_nodes;
-    gat_setup_partials(p, workspace, 1);
-    switch (vec) {
-        case 1: return launch_gat<1, 1>(p, st);
-        case 2: return launch_gat<2, 1>(p, st);
-        default: return launch_gat<4, 1>(p, st);
-    }
+    p.x = grad_out; p.p_col = attn_dst; p.p_row = attn_src; p.row_vec = feature; p.out = grad_feature; p.out_a = grad_attn_src;
+    gat_setup_partials(p, workspace, 2);
+    return vec == 1 ? launch_gat<1, 2>(p, st) : vec == 2 ? launch_gat<2, 2>(p, st) : launch_gat<4, 2>(p, st);
 }
 
 extern "C" int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, int64_t heads, int64_t head_dim,

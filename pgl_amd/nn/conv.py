@@ -173,7 +173,10 @@ class GATConv(nn.Module):
             eye = torch.eye(self.num_heads, dtype=feature.dtype, device=feature.device).unsqueeze(1)
             proj = torch.cat([(self.weight_src.unsqueeze(2) * eye).reshape(-1, self.num_heads),
                               (self.weight_dst.unsqueeze(2) * eye).reshape(-1, self.num_heads)], dim=1)
-            att = feature.reshape(-1, self.num_heads * self.hidden_size) @ proj
+            feat2d = feature.reshape(-1, self.num_heads * self.hidden_size)
+            # (its weight gradient is again a [H*D, N] x [N, 2H] reduction over N: split-reduction variant)
+            att = _TallLinearFn.apply(feat2d, proj.t().contiguous(), None) if (torch.is_grad_enabled() and feat2d.shape[0] >= 65536) \
+                else feat2d @ proj
             attn_src = att[:, :self.num_heads].contiguous()
             attn_dst = att[:, self.num_heads:].contiguous()
         else:

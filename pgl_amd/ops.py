@@ -347,23 +347,17 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     n, H, D = (int(v) for v in feature.shape)
     t = (grad_out * out).sum(-1).contiguous()                      # [N,H] row-local dot, elementwise plumbing
     gf = torch.empty_like(feature)
-    gpre = torch.empty((csr_dst.num_edges, H), dtype=torch.float32, device=feature.device)
+    g_src = torch.empty((n, H), dtype=torch.float32, device=feature.device)
+    g_dst = torch.empty((n, H), dtype=torch.float32, device=feature.device)
     L = _ffi.lib()
-    ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr_dst.num_edges, H, D), feature.device)
+    ws = _ws(L.pglamd_gat_backward_workspace_bytes(csr_dst.num_edges, n, H, D), feature.device)
     with torch.cuda.device(feature.device):
         _ffi.check(L.pglamd_gat_backward(_ptr(grad_out), _ptr(feature), _ptr(attn_src), _ptr(attn_dst), _ptr(row_max),
                                          _ptr(row_sum), _ptr(t), H, D, float(negative_slope), float(drop_p),
                                          int(seed) & 0xFFFFFFFF, _ptr(csr_dst.row32), _ptr(csr_dst.col32),
-                                         _ptr(csr_dst.eid32), _ptr(csr_src.row32), _ptr(csr_src.col32), _ptr(csr_src.eid32),
-                                         _ptr(csr_src.indptr), csr_dst.num_edges, n, _ptr(gf), _ptr(gpre), _ptr(ws),
-                                         ws.numel(), _stream(feature)), "gat_backward")
-
-    class _E(object):       # edge rows gathered through the original edge id
-        def __init__(self, c):
-            self.row32, self.col32, self.eid32, self.indptr = c.row32, c.eid32, c.eid32, c.indptr
-            self.num_edges, self.num_nodes = c.num_edges, c.num_nodes
-    g_src = aggregate(gpre, _E(csr_src), "sum", n)
-    g_dst = aggregate(gpre, _E(csr_dst), "sum", n)
+                                         _ptr(csr_dst.eid32), _ptr(csr_dst.indptr), _ptr(csr_src.row32), _ptr(csr_src.col32),
+                                         _ptr(csr_src.eid32), _ptr(csr_src.indptr), csr_dst.num_edges, n, _ptr(gf),
+                                         _ptr(g_src), _ptr(g_dst), _ptr(ws), ws.numel(), _stream(feature)), "gat_backward")
     return gf, g_src, g_dst
 
 
