@@ -175,8 +175,9 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
         *reinterpret_cast<V*>(p.out + (int64_t)r * p.d + j0) = o;
         if (MODE == 0 && p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + head] = m; p.row_sum[(int64_t)r * p.H + head] = s; }
     };
-    // per-row scalars ride along with every edge of the batch (an L1/L2 hit after the first edge of
-    // a row) instead of being fetched on the row change, which would stall the wave once per row.
+    // the row node's scalar is fetched (asynchronously, with the batch) only for edges that may OPEN a row and held
+    // in a register until the next row change: no stall on the change, no per-edge reload either.
+    float vr_held = act ? prow[(int64_t)cur * p.H + head] : 0.f;
     auto consume = [&](int r, int ed, float vc, float vr, float vm, float vs, float vt, const V& xv, const V& yv) {
         if (r != cur) {
             if (head_open) store_partial(true); else store_final(cur);
@@ -185,19 +186,22 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             m = -INFINITY; s = 0.f; acc_a = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+            vr_held = vr;
         }
-        const float pre = vc + vr;
+        const float pre = vc + vr_held;
         const float l = pre > 0.f ? pre : slope * pre;
         const float df = drop ? drop_factor(p.seed, ed, head, p.drop_p, p.drop_scale) : 1.f;
         if constexpr (MODE == 0) {
-            const float mn = fmaxf(m, l);
-            const float sc = expf(m - mn);          // m = -inf on the first edge of a row: e^{-inf} = 0
-            const float pe = expf(l - mn);
+            // online softmax: one of exp(m - mn), exp(l - mn) is always exp(0) = 1, so ONE exponential per edge
+            const float dlt = l - m;                 // +inf on the first edge of a row (m = -inf): e^{-inf} = 0
+            const float ed2 = expf(-fabsf(dlt));
+            const bool up = dlt > 0.f;
+            const float sc = up ? ed2 : 1.f, pe = up ? 1.f : ed2;
             s = s * sc + pe;
             const float w = pe * df;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * sc + w * xv.v[k];
-            m = mn;
+            m = up ? l : m;
         } else {
             const float alpha = expf(l - vm) / vs;   // alpha_e of the destination's softmax, recomputed
             if constexpr (FEAT) {
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             if (act) {
                 vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc[i] * p.d + j0);
                 vc[i] = pcol[(int64_t)cc[i] * p.H + head];
-                vr[i] = prow[(int64_t)rr[i] * p.H + head];
+                if (i == 0 || rr[i] != rr[i - 1]) vr[i] = prow[(int64_t)rr[i] * p.H + head];   // only where a row may open
                 if constexpr (MODE >= 1) {
                     const int64_t si = (int64_t)(MODE == 3 ? rr[i] : cc[i]) * p.H + head;
                     vm[i] = sm[si]; vs[i] = ss[si];
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             const float pre = q.a + (MODE == 2 ? a_held : ac);     // + a_src[u]
             const float l = pre > 0.f ? pre : slope * pre;
             const float df = drop ? drop_factor(p.seed, ed, head, p.drop_p, p.drop_scale) : 1.f;
-            const float alpha = expf(l - q.m) * q.s;              // q.s holds 1 / softmax sum
+            const float alpha = __expf(l - q.m) * q.s;              // q.s = 1 / softmax sum; hardware exp2 (rel. error < 1e-6 where alpha is not negligible): gradients only
             if constexpr (FEAT) {
                 const float w = alpha * df;
 #pragma unroll
