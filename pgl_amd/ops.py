@@ -62,9 +62,11 @@ class CSR(object):
                  "num_nodes", "num_edges")
 
 
-def csr_build(u, v, num_nodes):
+def csr_build(u, v, num_nodes, want_i64=True):
     """EdgeIndex.from_edges (pgl/utils/edge_index.py:38-58) / build_index (graph_kernel.pyx:59-88).
-    u, v: 1-D int64 CUDA tensors (may be strided views of the [E,2] edge tensor)."""
+    u, v: 1-D int64 CUDA tensors (may be strided views of the [E,2] edge tensor).
+    want_i64=False skips the three int64 [E] outputs (sorted_v / sorted_u / sorted_eid stay None): the kernels only
+    read the int32 copies, and EdgeIndex widens them on first access -- 480 MB less to write and hold at |E| = 20 M."""
     _need_cuda(u, v)
     if u.dtype != torch.int64 or v.dtype != torch.int64:
         u, v = u.to(torch.int64), v.to(torch.int64)
@@ -75,7 +77,9 @@ def csr_build(u, v, num_nodes):
     i64 = dict(dtype=torch.int64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
     c.degree = torch.empty(N, **i64); c.indptr = torch.empty(N + 1, **i64)
-    c.sorted_v = torch.empty(E, **i64); c.sorted_u = torch.empty(E, **i64); c.sorted_eid = torch.empty(E, **i64)
+    c.sorted_v = c.sorted_u = c.sorted_eid = None
+    if want_i64:
+        c.sorted_v = torch.empty(E, **i64); c.sorted_u = torch.empty(E, **i64); c.sorted_eid = torch.empty(E, **i64)
     c.row32 = torch.empty(E, **i32); c.col32 = torch.empty(E, **i32); c.eid32 = torch.empty(E, **i32)
     su = u.stride(0) if E > 0 else 1
     sv = v.stride(0) if E > 0 else 1

@@ -17,9 +17,44 @@ from .helper import check_is_tensor, to_device_tensor
 
 class EdgeIndex(object):
     def __init__(self):
-        self._degree = self._sorted_v = self._sorted_u = self._sorted_eid = self._indptr = None
+        self._degree = self._indptr = None
+        self._sv64 = self._su64 = self._se64 = None
         self._is_tensor = False
         self._csr = None          # ops.CSR with the int32 engine copies (tensor mode only)
+
+    # The reference's three int64 [E] arrays.  In tensor mode the engine builds and reads int32 copies only; the int64
+    # views the reference API exposes (sorted_edges, dump, view_v ...) are widened from them on first access.
+    def _widened(self, held, name32):
+        if held is None and self._csr is not None:
+            held = getattr(self._csr, name32).to(torch.int64)
+        return held
+
+    @property
+    def _sorted_v(self):
+        self._sv64 = self._widened(self._sv64, "col32")
+        return self._sv64
+
+    @_sorted_v.setter
+    def _sorted_v(self, value):
+        self._sv64 = value
+
+    @property
+    def _sorted_u(self):
+        self._su64 = self._widened(self._su64, "row32")
+        return self._su64
+
+    @_sorted_u.setter
+    def _sorted_u(self, value):
+        self._su64 = value
+
+    @property
+    def _sorted_eid(self):
+        self._se64 = self._widened(self._se64, "eid32")
+        return self._se64
+
+    @_sorted_eid.setter
+    def _sorted_eid(self, value):
+        self._se64 = value
 
     # ---- construction ------------------------------------------------------------------------
     @classmethod
@@ -27,7 +62,7 @@ class EdgeIndex(object):
         self = cls()
         self._is_tensor = check_is_tensor(u, v)
         if self._is_tensor:
-            c = ops.csr_build(u, v, int(num_nodes))
+            c = ops.csr_build(u, v, int(num_nodes), want_i64=False)
             self._adopt(c)
         else:
             self._degree, self._sorted_v, self._sorted_u, self._sorted_eid, self._indptr = \
@@ -46,8 +81,8 @@ class EdgeIndex(object):
 
     def _adopt(self, c):
         self._csr = c
-        self._degree, self._sorted_v, self._sorted_u = c.degree, c.sorted_v, c.sorted_u
-        self._sorted_eid, self._indptr = c.sorted_eid, c.indptr
+        self._degree, self._indptr = c.degree, c.indptr
+        self._sv64, self._su64, self._se64 = c.sorted_v, c.sorted_u, c.sorted_eid      # None when built without them
 
     def _make_engine_copies(self):
         c = ops.CSR()

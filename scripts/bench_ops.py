@@ -33,10 +33,13 @@ def report(name, ms, gbytes):
 
 
 ms = timeit(lambda: pgl.ops.csr_build(edges[:, 1], edges[:, 0], N), iters=5)
-report("csr_build (K8)", ms, (E * (16 + 12 + 24) + N * 16) / 1e9)       # reads u,v int64; writes 3 int32 + 3 int64 + N*2 int64
+report("csr_build (K8), + int64 copies", ms, (E * (16 + 12 + 24) + N * 16) / 1e9)       # reads u,v int64; writes 3 int32 + 3 int64 + N*2 int64
+ms = timeit(lambda: pgl.ops.csr_build(edges[:, 1], edges[:, 0], N, want_i64=False), iters=5)
+report("csr_build (K8), engine index", ms, (E * (16 + 12) + N * 16) / 1e9)            # 28 B/edge (as Graph.adj_dst_index builds it)
 g = pgl.Graph(edges=edges, num_nodes=N)
 csr = g.adj_dst_index.csr; g.adj_src_index
-ms = timeit(lambda: pgl.ops.unique_segment(csr.degree, csr.sorted_u), iters=5)
+su64 = g.adj_dst_index._sorted_u
+ms = timeit(lambda: pgl.ops.unique_segment(csr.degree, su64), iters=5)
 report("unique_segment", ms, (E * 16 + N * 24) / 1e9)
 ms = timeit(lambda: g.send_recv(x, "sum")); report("send_recv sum d=128", ms, (E * 516 + N * 520) / 1e9)
 ms = timeit(lambda: g.send_recv(x, "mean")); report("send_recv mean d=128", ms, (E * 516 + N * 520) / 1e9)

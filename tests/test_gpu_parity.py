@@ -414,9 +414,12 @@ def test_full_size_gcn_spmm_vs_oracle(pgl, rmat20, ref_native):
     e = host(g.edges)
     # (1) index parity at full size, bit-exact vs the reference's compiled build_index
     ref = ref_native.build_index(e[:, 1].copy(), e[:, 0].copy(), g.num_nodes)
-    c = g.adj_dst_index.csr
-    assert np.array_equal(host(c.indptr), ref[4]) and np.array_equal(host(c.sorted_eid), ref[3])
-    assert np.array_equal(host(c.sorted_v), ref[1])
+    ix = g.adj_dst_index
+    c = ix.csr
+    assert np.array_equal(host(c.indptr), ref[4]) and np.array_equal(host(c.eid32), ref[3]) and np.array_equal(host(c.col32), ref[1])
+    # the int64 arrays of the reference API are widened from the engine's int32 copies on first access
+    assert c.sorted_eid is None and ix._sorted_eid.dtype == torch.int64
+    assert np.array_equal(host(ix._sorted_eid), ref[3]) and np.array_equal(host(ix._sorted_v), ref[1]) and np.array_equal(host(ix._sorted_u), ref[2])
     # (2) values vs the serial C port of the Paddle CPU kernel (raw COO order)
     want = R.c_send_u_recv(host(x), e[:, 0], e[:, 1], "sum")
     got = host(out)
