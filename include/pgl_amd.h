@@ -221,7 +221,7 @@ int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const 
  *   grad_attn_src[u,h]  = sum_{e=(u->v)} d pre_e          (both from ONE walk of the src-sorted CSR)
  *   grad_attn_dst[v,h]  = sum_{e=(u->v)} d pre_e          (one walk of the dst-sorted CSR)
  *   d pre_e = alpha_e (drop_e <grad_out[v,h,:], feature[u,h,:]> - t[v,h]) * leaky_relu'(attn_src[u,h] + attn_dst[v,h])
- *   t [N,H] = sum_d grad_out[v,h,d] * out[v,h,d], supplied by the caller.
+ *   t[v,h]  = sum_d grad_out[v,h,d] * out[v,h,d]  (out = the forward's output; computed here).
  *   dst_* / src_*  the dst-sorted and src-sorted CSRs (int32 row / col / eid, int64 indptr).
  * Replaces the backward of the four-op composition at pgl/nn/conv.py:331-339 (send_uv -> leaky_relu ->
  * edge_softmax -> send_ue_recv).  Workspace (256-byte aligned): pglamd_gat_backward_workspace_bytes.  Same shape
@@ -230,7 +230,7 @@ size_t pglamd_gat_backward_workspace_bytes(int64_t num_edges, int64_t num_nodes,
                                            int64_t head_dim);
 int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const float* attn_src,
                             const float* attn_dst, const float* row_max, const float* row_sum,
-                            const float* t, int64_t heads, int64_t head_dim, float negative_slope,
+                            const float* out, int64_t heads, int64_t head_dim, float negative_slope,
                             float drop_p, uint32_t seed, const int32_t* dst_row,
                             const int32_t* dst_col, const int32_t* dst_eid, const int64_t* dst_indptr,
                             const int32_t* src_row, const int32_t* src_col, const int32_t* src_eid,

@@ -521,11 +521,26 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
     }
 }
 
+// One thread per (node, head): t = <g[v,h,:], out[v,h,:]> (the softmax-backward row term) and the destination-side
+// scalars, packed so that an edge fetches them with one 16-byte load.
 __global__ __launch_bounds__(kBlock) void gat_pack_kernel(const float* __restrict__ a_dst, const float* __restrict__ m,
-                                                         const float* __restrict__ sm, const float* __restrict__ t, int64_t n,
-                                                         F4* __restrict__ out) {
+                                                         const float* __restrict__ sm, const float* __restrict__ g,
+                                                         const float* __restrict__ out, int64_t n, int D,
+                                                         F4* __restrict__ packed) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) out[i] = F4{a_dst[i], m[i], 1.f / sm[i], t[i]};
+    if (i >= n) return;
+    const float* gp = g + i * D;
+    const float* op = out + i * D;
+    float t = 0.f;
+    if ((D & 3) == 0) {
+        for (int k = 0; k < D; k += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(gp + k), b = *reinterpret_cast<const float4*>(op + k);
+            t += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+    } else {
+        for (int k = 0; k < D; ++k) t += gp[k] * op[k];
+    }
+    packed[i] = F4{a_dst[i], m[i], 1.f / sm[i], t};
 }
 
 static int gat_chunk_edges() {
@@ -640,7 +655,7 @@ extern "C" size_t pglamd_gat_backward_workspace_bytes(int64_t num_edges, int64_t
 }
 
 extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const float* attn_src,
-                                       const float* attn_dst, const float* row_max, const float* row_sum, const float* t,
+                                       const float* attn_dst, const float* row_max, const float* row_sum, const float* out,
                                        int64_t heads, int64_t head_dim, float negative_slope, float drop_p, uint32_t seed,
                                        const int32_t* dst_row, const int32_t* dst_col, const int32_t* dst_eid,
                                        const int64_t* dst_indptr, const int32_t* src_row, const int32_t* src_col,
@@ -648,7 +663,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
                                        float* grad_feature, float* grad_attn_src, float* grad_attn_dst, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     if (heads <= 0 || head_dim <= 0 || num_nodes < 0 || num_edges < 0 || !grad_feature || !grad_attn_src || !grad_attn_dst ||
-        (num_edges > 0 && (!grad_out || !feature || !attn_src || !attn_dst || !row_max || !row_sum || !t || !dst_row || !dst_col ||
+        (num_edges > 0 && (!grad_out || !feature || !attn_src || !attn_dst || !row_max || !row_sum || !out || !dst_row || !dst_col ||
                            !dst_eid || !dst_indptr || !src_row || !src_col || !src_eid || !src_indptr)))
         return fail(PGLAMD_E_ARG, "gat_backward: bad argument");
     if (drop_p < 0.f || drop_p >= 1.f) return fail(PGLAMD_E_ARG, "gat_backward: dropout needs 0 <= p < 1");
@@ -663,7 +678,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
         return PGLAMD_OK;
     }
     const int vec = gat_vec(heads, head_dim, feature, grad_out, grad_feature, true);
-    if (vec == 0 || heads > kWave || reinterpret_cast<uintptr_t>(workspace) % 256)
+    if (vec == 0 || heads > kWave || reinterpret_cast<uintptr_t>(workspace) % 256 || (reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(grad_out)) % 16)
         return fail(PGLAMD_E_SHAPE, "gat_backward: heads*head_dim = %lld needs one 64-lane tile and head_dim/VEC a power of two", (long long)d);
     if (!workspace || workspace_bytes < pglamd_gat_backward_workspace_bytes(num_edges, num_nodes, heads, head_dim))
         return fail(PGLAMD_E_WORKSPACE, "gat_backward: workspace too small");
@@ -672,7 +687,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     F4* packed = static_cast<F4*>(workspace);
     workspace = static_cast<char*>(workspace) + pack_bytes;
     hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)ceil_div(num_nodes * heads, kBlock)), dim3(kBlock), 0, st, attn_dst, row_max,
-                       row_sum, t, num_nodes * heads, packed);
+                       row_sum, grad_out, out, num_nodes * heads, (int)head_dim, packed);
     PGLAMD_LAUNCH_CHECK();
     GatParams p{};
     p.H = (int)heads; p.D = (int)head_dim; p.d = (int)d; p.slope = negative_slope;

@@ -349,7 +349,7 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     _need_cuda(grad_out, feature, out)
     grad_out = grad_out.contiguous(); feature = feature.contiguous()
     n, H, D = (int(v) for v in feature.shape)
-    t = (grad_out * out).sum(-1).contiguous()                      # [N,H] row-local dot, elementwise plumbing
+    out = out.contiguous()
     gf = torch.empty_like(feature)
     g_src = torch.empty((n, H), dtype=torch.float32, device=feature.device)
     g_dst = torch.empty((n, H), dtype=torch.float32, device=feature.device)
@@ -357,7 +357,7 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     ws = _ws(L.pglamd_gat_backward_workspace_bytes(csr_dst.num_edges, n, H, D), feature.device)
     with torch.cuda.device(feature.device):
         _ffi.check(L.pglamd_gat_backward(_ptr(grad_out), _ptr(feature), _ptr(attn_src), _ptr(attn_dst), _ptr(row_max),
-                                         _ptr(row_sum), _ptr(t), H, D, float(negative_slope), float(drop_p),
+                                         _ptr(row_sum), _ptr(out), H, D, float(negative_slope), float(drop_p),
                                          int(seed) & 0xFFFFFFFF, _ptr(csr_dst.row32), _ptr(csr_dst.col32),
                                          _ptr(csr_dst.eid32), _ptr(csr_dst.indptr), _ptr(csr_src.row32), _ptr(csr_src.col32),
                                          _ptr(csr_src.eid32), _ptr(csr_src.indptr), csr_dst.num_edges, n, _ptr(gf),
