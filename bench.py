@@ -17,10 +17,13 @@ Output: one JSON line on rank 0 with the driver's contract fields plus
                   this box's host cores (rank 0, N = 1 only); the checker, never the product.
 """
 import os
-import sys
-import time
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (set before HIP initialises)
+import argparse  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
 
-import torch
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
