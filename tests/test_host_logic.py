@@ -212,3 +212,15 @@ def test_host_sampling_and_graphsage_sample():
     assert layers[0][0].num_edges >= layers[1][0].num_edges          # outer layer sees more edges
     sub = pgl_amd.sampling.subgraph(g, nodes=[3, 9, 27], edges=[(3, 9), (27, 3)])
     assert sub.edges.tolist() == [[0, 1], [2, 0]]
+
+
+def test_bench_and_entry_scripts_import_cleanly():
+    """bench.py parses its arguments (argparse exits 0 on --help before touching a GPU) and __graft_entry__ exposes
+    build() / smoke(): a broken import in either would only show up on the GPU box otherwise."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout, r.stderr[-2000:]
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    assert callable(ge.build) and callable(ge.smoke)
