@@ -9,6 +9,8 @@ dst_num_nodes rows while gathered features have src_num_nodes rows -- which pgla
 takes as separate sizes -- so every kernel is reused unchanged.  (The reference implements
 send_recv here as a scatter-add over raw COO and only for "sum"; all four reducers work here.)
 """
+import os
+
 import numpy as np
 import torch
 
@@ -17,7 +19,7 @@ from .graph import Graph, _REDUCE
 from .message import Message
 from .utils import op
 from .utils.edge_index import EdgeIndex
-from .utils.helper import check_is_tensor, to_device_tensor
+from .utils.helper import check_is_tensor, generate_segment_id_from_index, to_device_tensor
 
 
 class BiGraph(Graph):
@@ -95,6 +97,127 @@ class BiGraph(Graph):
     def __repr__(self):
         return '{"class": "BiGraph", "src_num_nodes": %d, "dst_num_nodes": %d, "edges_shape": %s}' % (
             self._src_num_nodes, self._dst_num_nodes, list(self._edges.shape))
+
+    # ---- batched BiGraphs (pgl/bigraph.py:1228-1475): separate per-graph indices for the two node sets ----
+    def _process_graph_info(self, **kwargs):
+        self._graph_src_node_index = kwargs.get("_graph_src_node_index", None)
+        self._graph_dst_node_index = kwargs.get("_graph_dst_node_index", None)
+        self._graph_edge_index = kwargs.get("_graph_edge_index", None)
+        self._graph_node_index = None
+        self._num_graph = kwargs.get("_num_graph", None)
+        if self._num_graph is None:
+            self._num_graph = 1
+            self._graph_src_node_index = np.array([0, self._src_num_nodes], dtype="int64")
+            self._graph_dst_node_index = np.array([0, self._dst_num_nodes], dtype="int64")
+            self._graph_edge_index = np.array([0, int(self._edges.shape[0])], dtype="int64")
+
+    def _segment_ids(self, index):
+        ids = generate_segment_id_from_index(np.asarray(index.cpu() if isinstance(index, torch.Tensor) else index, dtype="int64"))
+        return torch.as_tensor(ids, device=self._device) if self._is_tensor else ids
+
+    @property
+    def graph_src_node_id(self):
+        return self._segment_ids(self._graph_src_node_index)
+
+    @property
+    def graph_dst_node_id(self):
+        return self._segment_ids(self._graph_dst_node_index)
+
+    @property
+    def graph_edge_id(self):
+        return self._segment_ids(self._graph_edge_index)
+
+    @property
+    def graph_node_id(self):
+        raise AttributeError("BiGraph has graph_src_node_id and graph_dst_node_id, not graph_node_id")
+
+    @classmethod
+    def disjoint(cls, graph_list, merged_graph_index=False):
+        assert len(graph_list) > 0, "The input graph_list of BiGraph.disjoint has length 0. It should be greater than 0."
+        is_tensor = graph_list[0].is_tensor()
+        cat = (lambda xs: torch.cat(list(xs), 0)) if is_tensor else (lambda xs: np.concatenate(list(xs), 0))
+        pieces, so, do = [], 0, 0
+        for g in graph_list:
+            e = g.edges
+            if e.shape[0] > 0:
+                shifted = e.clone() if is_tensor else np.array(e, dtype="int64")
+                shifted[:, 0] += so
+                shifted[:, 1] += do
+                pieces.append(shifted)
+            so += g.src_num_nodes
+            do += g.dst_num_nodes
+        edges = cat(pieces) if pieces else graph_list[0].edges[:0]
+
+        def join(get):
+            keys = []
+            for g in graph_list:
+                keys += [k for k in get(g) if k not in keys]
+            return {k: cat(get(g)[k] for g in graph_list if k in get(g)) for k in keys}
+
+        kw = {}
+        if not merged_graph_index:
+            def index(counts):
+                return np.concatenate([[0], np.cumsum(np.asarray(counts, dtype="int64"))]).astype("int64")
+            kw = dict(_num_graph=len(graph_list),
+                      _graph_src_node_index=index([g.src_num_nodes for g in graph_list]),
+                      _graph_dst_node_index=index([g.dst_num_nodes for g in graph_list]),
+                      _graph_edge_index=index([g.num_edges for g in graph_list]))
+        return cls(edges, src_num_nodes=so, dst_num_nodes=do, src_node_feat=join(lambda g: g.src_node_feat),
+                   dst_node_feat=join(lambda g: g.dst_node_feat), edge_feat=join(lambda g: g.edge_feat), **kw)
+
+    @staticmethod
+    def batch(graph_list):
+        return BiGraph.disjoint(graph_list, merged_graph_index=False)
+
+    # ---- on-disk format (pgl/bigraph.py:217-330): the reference's directory of .npy files ----------------
+    def dump(self, path):
+        if self._is_tensor:
+            return self.numpy(inplace=False).dump(path)
+        os.makedirs(path, exist_ok=True)
+        np.save(os.path.join(path, "src_num_nodes.npy"), self._src_num_nodes)
+        np.save(os.path.join(path, "dst_num_nodes.npy"), self._dst_num_nodes)
+        np.save(os.path.join(path, "edges.npy"), self._edges)
+        np.save(os.path.join(path, "num_graph.npy"), self._num_graph)
+        if self._adj_src_index is not None:
+            self._adj_src_index.dump(os.path.join(path, "adj_src"))
+        if self._adj_dst_index is not None:
+            self._adj_dst_index.dump(os.path.join(path, "adj_dst"))
+        for name in ("graph_src_node_index", "graph_dst_node_index", "graph_edge_index"):
+            v = getattr(self, "_" + name)
+            if v is not None:
+                np.save(os.path.join(path, name + ".npy"), np.asarray(v))
+        for sub, feats in (("src_node_feat", self._src_node_feat), ("dst_node_feat", self._dst_node_feat), ("edge_feat", self._edge_feat)):
+            if len(feats) == 0:
+                continue
+            os.makedirs(os.path.join(path, sub), exist_ok=True)
+            for k, v in feats.items():
+                np.save(os.path.join(path, sub, k + ".npy"), v)
+
+    @classmethod
+    def load(cls, path, mmap_mode="r"):
+        kw = {}
+        for name in ("adj_src", "adj_dst"):
+            p = os.path.join(path, name)
+            kw[name + "_index"] = EdgeIndex.load(p, mmap_mode=mmap_mode) if os.path.isdir(p) else None
+        for name in ("graph_src_node_index", "graph_dst_node_index", "graph_edge_index"):
+            f = os.path.join(path, name + ".npy")
+            kw["_" + name] = np.load(f, mmap_mode=mmap_mode) if os.path.exists(f) else None
+
+        def feats(sub):
+            d = os.path.join(path, sub)
+            if not os.path.isdir(d):
+                return {}
+            return {f[:-4]: np.load(os.path.join(d, f), mmap_mode=mmap_mode) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
+
+        return cls(np.load(os.path.join(path, "edges.npy"), mmap_mode=mmap_mode),
+                   src_num_nodes=int(np.load(os.path.join(path, "src_num_nodes.npy"))),
+                   dst_num_nodes=int(np.load(os.path.join(path, "dst_num_nodes.npy"))),
+                   src_node_feat=feats("src_node_feat"), dst_node_feat=feats("dst_node_feat"), edge_feat=feats("edge_feat"),
+                   _num_graph=int(np.load(os.path.join(path, "num_graph.npy"))), **kw)
+
+    def to_mmap(self, path="./tmp"):
+        self.dump(path)
+        return BiGraph.load(path, mmap_mode="r")
 
     # ---- message passing ------------------------------------------------------------------------
     def send(self, message_func, src_feat=None, dst_feat=None, edge_feat=None, node_feat=None):

@@ -144,10 +144,35 @@ class Graph(object):
             self._adj_src_index.dump(os.path.join(path, "adj_src"))
         if self._adj_dst_index is not None:
             self._adj_dst_index.dump(os.path.join(path, "adj_dst"))
+        if self._graph_node_index is not None:
+            np.save(os.path.join(path, "graph_node_index.npy"), np.asarray(self._graph_node_index))
+        if self._graph_edge_index is not None:
+            np.save(os.path.join(path, "graph_edge_index.npy"), np.asarray(self._graph_edge_index))
         for sub, feats in (("node_feat", self._node_feat), ("edge_feat", self._edge_feat)):
+            if len(feats) == 0:
+                continue
             os.makedirs(os.path.join(path, sub), exist_ok=True)
             for k, v in feats.items():
                 np.save(os.path.join(path, sub, k + ".npy"), v)
+
+    def to_mmap(self, path="./tmp"):
+        """pgl/graph.py:1297-1302: dump, then reload memory-mapped (shareable between processes)."""
+        self.dump(path)
+        return Graph.load(path, mmap_mode="r")
+
+    def node_batch_iter(self, batch_size, shuffle=True):
+        """pgl/graph.py:1369-1395."""
+        if self._is_tensor:
+            perm = torch.randperm(self.num_nodes, device=self._edges.device) if shuffle \
+                else torch.arange(self.num_nodes, device=self._edges.device)
+        else:
+            perm = np.arange(self.num_nodes)
+            if shuffle:
+                np.random.shuffle(perm)
+        start = 0
+        while start < self.num_nodes:
+            yield perm[start:start + batch_size]
+            start += batch_size
 
     @classmethod
     def load(cls, path, mmap_mode="r"):
@@ -165,9 +190,11 @@ class Graph(object):
                 return {}
             return {f[:-4]: np.load(os.path.join(d, f), mmap_mode=mmap_mode) for f in sorted(os.listdir(d)) if f.endswith(".npy")}
 
-        g = cls(edges=edges, num_nodes=num_nodes, node_feat=feats("node_feat"), edge_feat=feats("edge_feat"), **kw)
-        g._num_graph = num_graph
-        return g
+        for name in ("graph_node_index", "graph_edge_index"):
+            f = os.path.join(path, name + ".npy")
+            kw["_" + name] = np.load(f, mmap_mode=mmap_mode) if os.path.exists(f) else None
+        return cls(edges=edges, num_nodes=num_nodes, node_feat=feats("node_feat"), edge_feat=feats("edge_feat"),
+                   _num_graph=num_graph, **kw)
 
     # ---- basic properties ---------------------------------------------------------------------
     @property
