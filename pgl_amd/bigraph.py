@@ -256,37 +256,160 @@ class BiGraph(Graph):
 
 
 class HeterGraph(object):
-    """pgl/heter_graph.py: one Graph per edge type over a shared node set; `hg[etype]` is an ordinary
-    Graph, so every layer / kernel works per relation (RGCN-style loops, pgl/nn/conv.py:1014-1019)."""
+    """pgl/heter_graph.py: one Graph per edge type over a shared node set; `hg[etype]` is an ordinary Graph, so every
+    layer / kernel works per relation (RGCN-style loops, pgl/nn/conv.py:1014-1019).  Same constructor, queries and
+    on-disk layout (node_types.npy, edge_types.pkl, one Graph directory per edge type) as the reference."""
 
-    def __init__(self, edges, node_types=None, node_feat=None, edge_feat=None, num_nodes=None):
-        if num_nodes is None:
-            num_nodes = max(int(np.asarray(e).max()) for e in edges.values() if len(e)) + 1
-        self._num_nodes = int(num_nodes)
+    def __init__(self, edges, node_types=None, node_feat=None, edge_feat=None, num_nodes=None, **kwargs):
+        if isinstance(node_types, list):
+            node_types = np.array(node_types, dtype=object)[:, 1]
         self._node_types = node_types
-        self._node_feat = node_feat or {}
-        edge_feat = edge_feat or {}
-        self._graphs = {et: Graph(edges=np.asarray(e, dtype="int64").reshape(-1, 2), num_nodes=self._num_nodes,
-                                  node_feat=dict(self._node_feat), edge_feat=edge_feat.get(et))
-                        for et, e in edges.items()}
+        self._node_feat = node_feat if node_feat is not None else {}
+        self._edge_feat = edge_feat if edge_feat is not None else {}
+        if "multi_graph" in kwargs:
+            self._graphs = kwargs["multi_graph"]
+            self._num_nodes = next(iter(self._graphs.values())).num_nodes if self._graphs else 0
+        else:
+            if num_nodes is None:
+                if node_types is not None:
+                    num_nodes = len(node_types)
+                else:
+                    num_nodes = max(int(np.asarray(e).max()) for e in edges.values() if len(e)) + 1
+            self._num_nodes = int(num_nodes)
+            self._graphs = {}
+            for et, e in edges.items():
+                self._graphs[et] = Graph(edges=e if check_is_tensor(e) else np.asarray(e, dtype="int64").reshape(-1, 2),
+                                         num_nodes=self._num_nodes, node_feat=dict(self._node_feat),
+                                         edge_feat=self._edge_feat.get(et) if self._edge_feat else None)
+        self._nodes_type_dict = {}
+        if self._node_types is not None:
+            for ntype in np.unique(self._node_types):
+                self._nodes_type_dict[ntype] = np.where(self._node_types == ntype)[0]
+        self._edge_types = list(self._graphs)
+        self._is_tensor = next(iter(self._graphs.values())).is_tensor() if self._graphs else False
+        self._nodes = None
+
+    def is_tensor(self):
+        return self._is_tensor
 
     def __getitem__(self, edge_type):
         return self._graphs[edge_type]
 
     @property
     def edge_types(self):
+        return self._edge_types
+
+    def edge_types_info(self):
         return list(self._graphs)
 
     @property
     def num_nodes(self):
-        return self._num_nodes
+        return self._graphs[self._edge_types[0]].num_nodes if self._edge_types else self._num_nodes
+
+    @property
+    def num_edges(self):
+        return {et: g.num_edges for et, g in self._graphs.items()}
+
+    @property
+    def node_types(self):
+        return self._node_types
+
+    @property
+    def edge_feat(self):
+        return {et: g.edge_feat for et, g in self._graphs.items()}
+
+    @property
+    def node_feat(self):
+        return self._graphs[self._edge_types[0]].node_feat
+
+    @property
+    def nodes(self):
+        if self._nodes is None:
+            self._nodes = self._graphs[self._edge_types[0]].nodes
+        return self._nodes
+
+    def num_nodes_by_type(self, n_type=None):
+        if n_type not in self._nodes_type_dict:
+            raise ValueError("%s is not in valid node type" % n_type)
+        return len(self._nodes_type_dict[n_type])
+
+    def _degree(self, which, nodes, edge_type):
+        if edge_type is not None:
+            return getattr(self._graphs[edge_type], which)(nodes)
+        per_type = [getattr(g, which)(nodes) for g in self._graphs.values()]
+        return torch.stack(per_type).sum(0) if self._is_tensor else np.sum(np.vstack(per_type), axis=0)
+
+    def indegree(self, nodes=None, edge_type=None):
+        """Total over the edge types when edge_type is None (pgl/heter_graph.py indegree)."""
+        return self._degree("indegree", nodes, edge_type)
+
+    def outdegree(self, nodes=None, edge_type=None):
+        return self._degree("outdegree", nodes, edge_type)
+
+    def successor(self, edge_type, nodes=None, return_eids=False):
+        return self._graphs[edge_type].successor(nodes, return_eids)
+
+    def predecessor(self, edge_type, nodes=None, return_eids=False):
+        return self._graphs[edge_type].predecessor(nodes, return_eids)
+
+    def sample_successor(self, edge_type, nodes, max_degree, return_eids=False, shuffle=False):
+        return self._graphs[edge_type].sample_successor(nodes=nodes, max_degree=max_degree, return_eids=return_eids, shuffle=shuffle)
+
+    def sample_predecessor(self, edge_type, nodes, max_degree, return_eids=False, shuffle=False):
+        return self._graphs[edge_type].sample_predecessor(nodes=nodes, max_degree=max_degree, return_eids=return_eids, shuffle=shuffle)
+
+    def node_batch_iter(self, batch_size, shuffle=False, n_type=None):
+        nodes = np.arange(self._num_nodes, dtype="int64") if n_type is None else np.array(self._nodes_type_dict[n_type])
+        if shuffle:
+            np.random.shuffle(nodes)
+        if self._is_tensor:
+            nodes = to_device_tensor(nodes, self._graphs[self._edge_types[0]]._device)
+        start = 0
+        while start < len(nodes):
+            yield nodes[start:start + batch_size]
+            start += batch_size
 
     def tensor(self, inplace=True, device=None):
-        for g in self._graphs.values():
-            g.tensor(inplace=True, device=device)
-        return self
+        if self._is_tensor:
+            return self
+        if inplace:
+            for g in self._graphs.values():
+                g.tensor(inplace=True, device=device)
+            self._is_tensor, self._nodes = True, None
+            return self
+        return self.__class__(edges=None, node_types=self._node_types,
+                              multi_graph={et: g.tensor(inplace=False, device=device) for et, g in self._graphs.items()})
 
     def numpy(self, inplace=True):
+        if not self._is_tensor:
+            return self
+        if inplace:
+            for g in self._graphs.values():
+                g.numpy(inplace=True)
+            self._is_tensor, self._nodes = False, None
+            return self
+        return self.__class__(edges=None, node_types=self._node_types,
+                              multi_graph={et: g.numpy(inplace=False) for et, g in self._graphs.items()})
+
+    def dump(self, path, indegree=False, outdegree=False):
+        import pickle
         for g in self._graphs.values():
-            g.numpy(inplace=True)
-        return self
+            if indegree:
+                g.indegree()
+            if outdegree:
+                g.outdegree()
+        os.makedirs(path, exist_ok=True)
+        np.save(os.path.join(path, "node_types.npy"), self._node_types)
+        with open(os.path.join(path, "edge_types.pkl"), "wb") as f:
+            pickle.dump(self._edge_types, f)
+        for et, g in self._graphs.items():
+            g.dump(os.path.join(path, et))
+
+    @classmethod
+    def load(cls, path, mmap_mode="r"):
+        import pickle
+        node_types = np.load(os.path.join(path, "node_types.npy"), allow_pickle=True)
+        with open(os.path.join(path, "edge_types.pkl"), "rb") as f:
+            edge_types = pickle.load(f)
+        return cls(edges=None, node_types=node_types,
+                   multi_graph={et: Graph.load(os.path.join(path, et), mmap_mode) for et in edge_types})

@@ -158,3 +158,55 @@ print("BIGRAPH_HOST_API_OK")
 def test_numpy_mode_bigraph_matches_reference_bigraph():
     r = subprocess.run([sys.executable, "-c", BI_SCRIPT % {"root": ROOT}], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0 and "BIGRAPH_HOST_API_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+HET_SCRIPT = r'''
+import os, sys, tempfile
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import ref_python
+ref = ref_python.load()
+sys.path.insert(0, %(root)r)
+import pgl_amd as mine
+
+def same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype == object:
+        assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), what
+    else:
+        assert a.shape == b.shape and np.array_equal(a, b), what
+
+rng = np.random.default_rng(9)
+n = 40
+node_types = [(i, "user" if i %% 3 else "item") for i in range(n)]
+edges = {"click": [tuple(e) for e in rng.integers(0, n, (120, 2)).tolist()], "buy": [tuple(e) for e in rng.integers(0, n, (30, 2)).tolist()]}
+nf = {"h": rng.standard_normal((n, 4)).astype(np.float32)}
+ef = {"click": {"w": rng.standard_normal((120, 1)).astype(np.float32)}, "buy": {"w": rng.standard_normal((30, 1)).astype(np.float32)}}
+hr = ref.HeterGraph(edges=edges, node_types=node_types, node_feat=nf, edge_feat=ef)
+hm = mine.HeterGraph(edges=edges, node_types=node_types, node_feat=nf, edge_feat=ef)
+assert hr.num_nodes == hm.num_nodes and hr.num_edges == hm.num_edges and list(hr.edge_types) == list(hm.edge_types)
+assert hr.num_nodes_by_type("user") == hm.num_nodes_by_type("user")
+same(hr.node_types, hm.node_types, "node_types"); same(hr.nodes, hm.nodes, "nodes"); same(hr.node_feat["h"], hm.node_feat["h"], "feat")
+q = np.array([1, 5, 5, 39])
+for f in ("indegree", "outdegree"):
+    same(getattr(hr, f)(), getattr(hm, f)(), f); same(getattr(hr, f)(q), getattr(hm, f)(q), f + "(q)")
+    same(getattr(hr, f)(q, "buy"), getattr(hm, f)(q, "buy"), f + "(q, buy)")
+for f in ("successor", "predecessor"):
+    (ra, rb), (ma, mb) = getattr(hr, f)("click", q, True), getattr(hm, f)("click", q, True)
+    same(ra, ma, f); same(rb, mb, f + " eids")
+for a, b in zip(hr.node_batch_iter(7, n_type="item"), hm.node_batch_iter(7, n_type="item")): same(a, b, "node_batch_iter")
+same(hr["buy"].edges, hm["buy"].edges, "per-type graph"); same(hr.edge_feat["click"]["w"], hm.edge_feat["click"]["w"], "edge feat")
+with tempfile.TemporaryDirectory() as td:
+    hr.dump(td + "/r", indegree=True, outdegree=True); hm.dump(td + "/m", indegree=True, outdegree=True)
+    assert sorted(os.listdir(td + "/r")) == sorted(os.listdir(td + "/m"))
+    x, y = ref.HeterGraph.load(td + "/m"), mine.HeterGraph.load(td + "/r")
+    same(x["click"].edges, hr["click"].edges, "ref loads mine"); same(y["buy"].edges, hr["buy"].edges, "mine loads ref")
+    same(y.indegree(q), hr.indegree(q), "indegree after load"); same(x.outdegree(q, "click"), hr.outdegree(q, "click"), "outdegree after load")
+    assert list(y.edge_types) == list(hr.edge_types) and y.num_nodes_by_type("item") == hr.num_nodes_by_type("item")
+print("HETER_HOST_API_OK")
+'''
+
+
+def test_numpy_mode_hetergraph_matches_reference_hetergraph():
+    r = subprocess.run([sys.executable, "-c", HET_SCRIPT % {"root": ROOT}], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and "HETER_HOST_API_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
