@@ -25,508 +25,10 @@
 //     third kernel from indptr (the reference guarantees 0, not +-inf, for every reduce op).
 //   * Logical blocks are remapped so consecutive chunks (consecutive destination rows) run on
 //     the same XCD: partition-ordered graphs then reuse source rows in that XCD's private L2.
-#include "aggregate.hpp"
-
-#include <algorithm>
-#include <string>
-#include <type_traits>
-#include <utility>
-#include <vector>
+#include "aggregate_flat.hpp"
 
 namespace pglamd {
 
-// RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector
-template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true>
-__global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
-    constexpr int U = 8;
-    using V = VecT<T, VEC>;
-    using A = typename AccT<T>::type;
-    using VA = VecT<A, VEC>;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wib = wave_uniform(threadIdx.x >> 6);
-    if ((int)blockIdx.x >= p.n_grid_chunks) {   // trailing blocks: zero-fill rows that receive no edge
-        zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
-        return;
-    }
-    const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
-    if (lb < 0) return;
-    const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
-    if (c >= p.n_chunks) return;
-    const cptr<int> rowp = as_const(p.row);
-    const cptr<int> colp = as_const(p.col);
-    const int e0 = p.align ? chunk_cut(rowp, as_const(p.indptr), c * p.chunk, p.chunk, p.E) : c * p.chunk;
-    const int e1 = p.align ? chunk_cut(rowp, as_const(p.indptr), c * p.chunk + p.chunk, p.chunk, p.E) : min(c * p.chunk + p.chunk, p.E);
-    if (e0 >= e1) return;
-    const cptr<int> eidp = as_const(p.eid);
-    const T* __restrict__ x = static_cast<const T*>(p.x);
-    const T* __restrict__ y = static_cast<const T*>(p.y);
-    constexpr bool has_ss = SS;       // per-source scale compiled in only where asked for (keeps 16 SGPRs free otherwise)
-    const bool is_max = p.is_max != 0;
-
-    // lane -> column mapping
-    int j0[NT]; bool act[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        j0[t] = (t * kWave + lane) * VEC;
-        act[t] = j0[t] < p.tile_cols;
-        j0[t] += p.j_base;
-    }
-
-    int yj[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) yj[t] = YMODE == 1 ? j0[t] / p.gy : 0;
-
-    A acc[NT][VEC];
-    auto reset = [&]() {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k)
-                acc[t][k] = RCLS == 0 ? A(0) : (is_max ? Limits<A>::lo() : Limits<A>::hi());
-    };
-    reset();
-
-    int cur = rowp[e0];
-    bool head_open = e0 > 0 && rowp[e0 - 1] == cur;   // current row began in an earlier chunk
-    int cnt = 0;
-
-    // Everything a row store needs (output base, strides, scales, flags) is re-read from the kernarg
-    // segment AT THE STORE through an opaque pointer, instead of living in ~25 SGPRs across the hot
-    // loop: stores happen once per row, the freed SGPRs buy one more resident workgroup per CU.
-    const cptr<AggParams> kargs = (cptr<AggParams>)__builtin_amdgcn_kernarg_segment_ptr();
-    auto cold = [&]() -> cptr<AggParams> {
-        cptr<AggParams> q = kargs;
-        asm volatile("" : "+s"(q));      // defeats hoisting of the field loads out of the store path
-        return q;
-    };
-    auto store_partial = [&](bool head) {
-        const cptr<AggParams> q = cold();
-        A* dst = static_cast<A*>(head ? q->part_head : q->part_tail) + (int64_t)c * q->tile_cols;
-        const int jb = q->j_base;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (act[t]) {
-                VA o;
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) o.v[k] = acc[t][k];
-                *reinterpret_cast<VA*>(dst + (j0[t] - jb)) = o;
-            }
-        if (!head && lane == 0) q->long_list[atomicAdd(q->long_count, 1)] = c;   // this chunk owns the row's fix-up
-    };
-    auto store_final = [&](int r, int n) {
-        const cptr<AggParams> q = cold();
-        if (r >= q->out_rows) return;
-        T* dst = static_cast<T*>(q->out) + (int64_t)r * q->ldo;
-        const float* dsp = q->dst_scale;
-        const bool is_mean = q->is_mean != 0, accumulate = q->accumulate != 0;
-        float ds = 1.f;
-        if constexpr (RCLS == 0) { if (dsp) ds = as_const(dsp)[r]; }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (act[t]) {
-                A ov[VEC];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    A a = acc[t][k];
-                    if constexpr (RCLS == 0) {
-                        if (is_mean) a = a / (A)n;
-                        if constexpr (std::is_floating_point_v<A>) { if (dsp) a = a * (A)ds; }
-                    }
-                    ov[k] = a;
-                }
-                if (accumulate) {
-                    const V old = *reinterpret_cast<const V*>(dst + j0[t]);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const A ol = to_acc<T>(old.v[k]);
-                        if constexpr (RCLS == 0) ov[k] = ol + ov[k];
-                        else ov[k] = is_max ? (ov[k] > ol ? ov[k] : ol) : (ov[k] < ol ? ov[k] : ol);
-                    }
-                }
-                V o;
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
-                *reinterpret_cast<V*>(dst + j0[t]) = o;
-            }
-    };
-    // closes row `cur` when the stream moved on to another row inside this chunk
-    auto flush_mid = [&]() {
-        if (head_open) store_partial(true); else store_final(cur, cnt);
-        head_open = false;
-    };
-
-    // Per-source scales never touch SGPRs: lane i (i < U) of a batch fetches the column id of edge i with ONE vector
-    // load in the index stage and its scale with ONE dependent vector load in the row stage; consume reads lane i back
-    // (v_readlane) right where it multiplies.  What the scales do cost is memory: one random 4-byte access per edge
-    // into an [N] array that the streaming feature rows keep evicting from L2 (+0.25 ms at C2 whatever the load path;
-    // with the addresses pinned to one line the cost vanishes).  The host side therefore pre-multiplies narrow
-    // feature rows instead (ops.aggregate) and keeps this path for wide ones.
-    const float* __restrict__ sscale_v = p.src_scale;
-    const int* __restrict__ col_v = p.col;
-    auto scale_of = [&](int col) -> float {     // remainder loop: wave-uniform index through the vector path
-        int ci = col;
-        asm volatile("" : "+v"(ci));
-        return sscale_v[ci];
-    };
-    auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U], int (&yy)[U]) {
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            rr[i] = rowp[e + i];
-            cc[i] = colp ? colp[e + i] : e + i;
-            if constexpr (YMODE != 0) yy[i] = eidp ? eidp[e + i] : e + i;
-        }
-    };
-    // Vector loads retire in issue order (vmcnt), so the id load of batch g+2 is issued BEFORE the rows of batch g+1:
-    // waiting for it one iteration later then never waits for younger row gathers.
-    auto load_cl = [&](int e, int& cl) {
-        if constexpr (has_ss) cl = col_v ? col_v[e + (lane & (U - 1))] : e + (lane & (U - 1));
-    };
-    auto load_rows = [&](const int (&cc)[U], const int (&yy)[U], V (&vx)[U][NT], V (&vy)[U][NT], int cl, float& sv) {
-        if constexpr (has_ss) sv = sscale_v[cl];
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const T* xr = x + (int64_t)cc[i] * p.ldx;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (act[t]) vx[i][t] = *reinterpret_cast<const V*>(xr + j0[t]);
-            if constexpr (YMODE == 1) {
-                const T* yr = y + (int64_t)yy[i] * p.ldy;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (act[t]) vy[i][t].v[0] = yr[yj[t]];
-            } else if constexpr (YMODE == 2) {
-                const T* yr = y + (int64_t)yy[i] * p.ldy;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (act[t]) vy[i][t] = *reinterpret_cast<const V*>(yr + j0[t]);
-            }
-        }
-    };
-    auto consume_one = [&](int r, float s, const V (&vx)[NT], const V (&vy)[NT]) {
-        if (r != cur) { flush_mid(); cur = r; cnt = 0; reset(); }
-        ++cnt;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                A m = to_acc<T>(vx[t].v[k]);
-                if constexpr (std::is_floating_point_v<A>) { if (has_ss) m = m * (A)s; }
-                if constexpr (YMODE == 1) m = apply_mop(m, to_acc<T>(vy[t].v[0]), p.mop);
-                if constexpr (YMODE == 2) m = apply_mop(m, to_acc<T>(vy[t].v[k]), p.mop);
-                if constexpr (RCLS == 0) acc[t][k] += m;
-                else acc[t][k] = is_max ? (m > acc[t][k] ? m : acc[t][k]) : (m < acc[t][k] ? m : acc[t][k]);
-            }
-    };
-    auto lane_scale = [&](float sv, int i) -> float {
-        if constexpr (has_ss) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
-        else return 1.f;
-    };
-
-    // Software pipeline, three batches deep: feature rows of batch g are being consumed while the rows
-    // of batch g+1 are in flight AND the (scalar) indices of batch g+2 are being fetched, so neither
-    // the scalar-load latency nor the gather latency sits on the per-batch critical path.
-    int e = e0;
-    const int n_full = (e1 - e0) / U;
-    int cA[U], rA[U], yA[U];
-    int cB[U], rB[U], yB[U];
-    int clA = 0, clB = 0; float svA = 1.f;
-    V xA[U][NT], wA[U][NT];
-    if (n_full > 0) { load_cl(e, clA); load_idx(e, cA, rA, yA); }
-    if (n_full > 1) load_cl(e + U, clB);
-    if (n_full > 0) load_rows(cA, yA, xA, wA, clA, svA);
-    if (PIPE3 && n_full > 1) load_idx(e + U, cB, rB, yB);
-    for (int g = 0; g < n_full; ++g) {
-        int cC[U], rC[U], yC[U]; int clC = 0; float svB = 1.f;
-        V xB[U][NT], wB[U][NT];
-        const bool more = g + 1 < n_full, more2 = g + 2 < n_full;
-        if (more2) load_cl(e + 2 * U, clC);
-        if (!PIPE3 && more) load_idx(e + U, cB, rB, yB);        // two-deep variant: fewer SGPRs, 8 workgroups per CU
-        if (more) load_rows(cB, yB, xB, wB, clB, svB);          // PIPE3: indices of g+1 are already in SGPRs
-        if (PIPE3 && more2) load_idx(e + 2 * U, cC, rC, yC);
-#pragma unroll
-        for (int i = 0; i < U; ++i) consume_one(rA[i], lane_scale(svA, i), xA[i], wA[i]);
-        if (more) {
-            svA = svB;
-#pragma unroll
-            for (int i = 0; i < U; ++i) {
-                rA[i] = rB[i];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) { xA[i][t] = xB[i][t]; wA[i][t] = wB[i][t]; }
-            }
-        }
-        if (more2) {
-            clB = clC;
-            if constexpr (PIPE3) {
-#pragma unroll
-                for (int i = 0; i < U; ++i) { cB[i] = cC[i]; rB[i] = rC[i]; yB[i] = yC[i]; }
-            }
-        }
-        e += U;
-    }
-    for (; e < e1; ++e) {   // remainder (< U edges): one at a time
-        int r = rowp[e];
-        int cc = colp ? colp[e] : e;
-        float s = has_ss ? scale_of(cc) : 1.f;
-        V vx[NT], vy[NT];
-        const T* xr = x + (int64_t)cc * p.ldx;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (act[t]) vx[t] = *reinterpret_cast<const V*>(xr + j0[t]);
-        if constexpr (YMODE != 0) {
-            int yy = eidp ? eidp[e] : e;
-            const T* yr = y + (int64_t)yy * p.ldy;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (act[t]) {
-                    if constexpr (YMODE == 1) vy[t].v[0] = yr[yj[t]];
-                    else vy[t] = *reinterpret_cast<const V*>(yr + j0[t]);
-                }
-        }
-        consume_one(r, s, vx, vy);
-    }
-
-    // the row open at the end of the chunk
-    const bool tail_open = e1 < p.E && rowp[e1] == cur;
-    if (head_open) store_partial(true);                 // middle or closing piece of a long row
-    else if (tail_open) store_partial(false);           // first piece of a LONG row that continues
-    else store_final(cur, cnt);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Fix-up: only rows LONGER than a chunk are ever split (chunk_cut), so only hub rows leave partials:
-// the row's value is T[a] (+) H[a+1] (+) ... (+) H[b] with a = the chunk where it starts.  The flat
-// kernel appends `a` to a work list when it writes T[a].
-//   pass 1 (LONG = false): one WAVE per listed task (grid-stride over the list).  Rows with <= 16
-//          partials (degree <= 17 chunks: almost all of them) are finished here, their loads issued
-//          in two batches of 8; longer ones go to a second list.
-//   pass 2 (LONG = true): a few 1024-thread blocks walk the second list; the 16 waves of a block split
-//          one row's partial list (8 loads in flight each) and combine through LDS in wave order, so
-//          a 10^5-edge hub is not one serial dependent chain.
-// List order is arbitrary; every row's own combination order is fixed => bit-reproducible.
-// ------------------------------------------------------------------------------------------------
-constexpr int kFixShort = 16;
-constexpr int kFixWaves = 16;
-constexpr int kFixGridShort = 2048;
-constexpr int kFixGridLong = 512;
-
-template <typename T, int VEC, int NT, int RCLS, bool LONG>
-__global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_kernel(AggParams p) {
-    using A = typename AccT<T>::type;
-    using V = VecT<A, VEC>;     // partials are stored in the accumulator type
-    using VO = VecT<T, VEC>;
-    constexpr int NW = LONG ? kFixWaves : 1;
-    __shared__ A red[LONG ? kFixWaves : 1][LONG ? NT * kWave * VEC : 1];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wib = wave_uniform(threadIdx.x >> 6);
-    const cptr<int> rowp = as_const(p.row);
-    const cptr<int64_t> ip = as_const(p.indptr);
-    const bool is_max = p.is_max != 0;
-    const A* __restrict__ ph = static_cast<const A*>(p.part_head);
-    const A* __restrict__ pt = static_cast<const A*>(p.part_tail);
-    auto comb = [&](A x, A y) -> A {
-        if constexpr (RCLS == 0) return x + y;
-        else return is_max ? (y > x ? y : x) : (y < x ? y : x);
-    };
-    int j0[NT]; bool act[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { j0[t] = (t * kWave + lane) * VEC; act[t] = j0[t] < p.tile_cols; }
-
-    const int* list = LONG ? p.long_list2 : p.long_list;
-    const int n_tasks = LONG ? p.long_count[1] : p.long_count[0];
-    const int first = LONG ? (int)blockIdx.x : (int)blockIdx.x * kWavesPerBlock + wib;
-    const int stride = LONG ? (int)gridDim.x : (int)gridDim.x * kWavesPerBlock;
-    for (int t_id = first; t_id < n_tasks; t_id += stride) {
-        const int a = wave_uniform(list[t_id]);
-        const int e1 = (a + 1) * p.chunk;
-        const int r = rowp[e1 - 1];
-        const int64_t rs = ip[r], re = ip[r + 1];
-        const int b = (int)((re - 1) / p.chunk);        // last chunk holding a piece of row r
-        if constexpr (!LONG) {
-            if (b - a > kFixShort) {                    // hub row: defer to the block-parallel pass
-                if (lane == 0) p.long_list2[atomicAdd(p.long_count + 1, 1)] = a;
-                continue;
-            }
-        }
-        A acc[NT][VEC];
-        if constexpr (!LONG) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (act[t]) {
-                    const V tv = *reinterpret_cast<const V*>(pt + (int64_t)a * p.tile_cols + j0[t]);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) acc[t][k] = tv.v[k];
-                }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int c0 = a + 1 + half * 8;
-                if (c0 > b) break;
-                V v[8][NT];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (c0 + u <= b) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            if (act[t]) v[u][t] = *reinterpret_cast<const V*>(ph + (int64_t)(c0 + u) * p.tile_cols + j0[t]);
-                    }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (c0 + u <= b) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t)
-                            if (act[t]) {
-#pragma unroll
-                                for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v[u][t].v[k]);
-                            }
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) acc[t][k] = RCLS == 0 ? A(0) : (is_max ? Limits<A>::lo() : Limits<A>::hi());
-            constexpr int UF = 8;
-            int c = a + 1 + wib;
-            for (; c + (UF - 1) * NW <= b; c += UF * NW) {
-                V v[UF][NT];
-#pragma unroll
-                for (int u = 0; u < UF; ++u)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (act[t]) v[u][t] = *reinterpret_cast<const V*>(ph + (int64_t)(c + u * NW) * p.tile_cols + j0[t]);
-#pragma unroll
-                for (int u = 0; u < UF; ++u)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        if (act[t]) {
-#pragma unroll
-                            for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v[u][t].v[k]);
-                        }
-            }
-            for (; c <= b; c += NW) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (act[t]) {
-                        const V v = *reinterpret_cast<const V*>(ph + (int64_t)c * p.tile_cols + j0[t]);
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) acc[t][k] = comb(acc[t][k], v.v[k]);
-                    }
-            }
-            __syncthreads();                            // previous task's readers are done with `red`
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) red[wib][(t * kWave + lane) * VEC + k] = acc[t][k];
-            __syncthreads();
-            if (wib != 0) continue;
-            // wave 0: tail partial of chunk a first, then the wave results in wave order
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (act[t]) {
-                    const V tv = *reinterpret_cast<const V*>(pt + (int64_t)a * p.tile_cols + j0[t]);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        A sv = tv.v[k];
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) sv = comb(sv, red[w][(t * kWave + lane) * VEC + k]);
-                        acc[t][k] = sv;
-                    }
-                }
-        }
-        if (r >= p.out_rows) continue;
-        T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
-        float ds = 1.f;
-        if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (act[t]) {
-                A ov[VEC];
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    A v = acc[t][k];
-                    if constexpr (RCLS == 0) {
-                        if (p.is_mean) v = v / (A)(re - rs);
-                        if constexpr (std::is_floating_point_v<A>) { if (p.dst_scale) v = v * (A)ds; }
-                    }
-                    ov[k] = v;
-                }
-                if (p.accumulate) {
-                    const VO old = *reinterpret_cast<const VO*>(dst + j0[t]);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) ov[k] = comb(to_acc<T>(old.v[k]), ov[k]);
-                }
-                VO o;
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
-                *reinterpret_cast<VO*>(dst + j0[t]) = o;
-            }
-    }
-}
-
-// Zero-fills output rows that receive no edge: rows r < n_csr_rows with indptr[r]==indptr[r+1],
-// and rows in [n_csr_rows, out_rows).  One wave inspects 64 rows (coalesced indptr read).
-template <typename W>
-__global__ __launch_bounds__(kBlock) void zero_empty_rows_kernel(const int64_t* __restrict__ indptr,
-                                                                int64_t n_csr_rows, int64_t out_rows,
-                                                                W* __restrict__ out, int64_t row_words) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int64_t r0 = w * kWave;
-    if (r0 >= out_rows) return;
-    const int64_t r = r0 + lane;
-    bool empty = false;
-    if (r < out_rows) empty = (r >= n_csr_rows) || (indptr[r] == indptr[r + 1]);
-    unsigned long long m = __ballot(empty);
-    W z{};
-    while (m) {
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        W* dst = out + (r0 + l) * row_words;
-        for (int64_t j = lane; j < row_words; j += kWave) dst[j] = z;
-    }
-}
-
-// Catch-all: any dtype handled as T, any trailing-dim broadcast (gx, gy), any width.
-// One wave per destination row, lanes stride over output columns, edges serial.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx) {
-    using A = typename AccT<T>::type;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (r >= p.out_rows) return;
-    const T* __restrict__ x = static_cast<const T*>(p.x);
-    const T* __restrict__ y = static_cast<const T*>(p.y);
-    T* out = static_cast<T*>(p.out) + r * p.ldo;
-    const int64_t n_csr = p.n_csr_rows;
-    int64_t s = 0, t = 0;
-    if (r < n_csr) { s = p.indptr[r]; t = p.indptr[r + 1]; }
-    const bool additive = !(p.is_max == 1 || p.is_max == 2);
-    for (int j = lane; j < p.tile_cols; j += kWave) {
-        A acc = A(0);
-        for (int64_t q = s; q < t; ++q) {
-            const int cc = p.col ? p.col[q] : (int)q;
-            A m = to_acc<T>(x[(int64_t)cc * p.ldx + j / gx]);
-            if (y) {
-                const int64_t yy = p.eid ? p.eid[q] : q;
-                m = apply_mop(m, to_acc<T>(y[yy * p.ldy + j / p.gy]), p.mop);
-            }
-            if (additive) acc += m;
-            else if (q == s) acc = m;
-            else if (p.is_max == 1) acc = m > acc ? m : acc;
-            else acc = m < acc ? m : acc;
-        }
-        if (additive && p.is_mean && t > s) acc = acc / (A)(t - s);
-        if (p.accumulate) {
-            const A ol = to_acc<T>(out[j]);
-            if (t > s) out[j] = from_acc<T>(additive ? ol + acc : (p.is_max == 1 ? (acc > ol ? acc : ol) : (acc < ol ? acc : ol)));
-        } else {
-            out[j] = from_acc<T>(acc);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// host launchers
-// ------------------------------------------------------------------------------------------------
 int chunk_edges() {
     static int k = [] {
         const char* s = getenv("PGLAMD_CHUNK");
@@ -539,69 +41,7 @@ int chunk_edges() {
 
 // Optional in-library timing of the dominant kernel (bench.py's roofline leg): while enabled,
 // every flat-kernel launch is bracketed by a pair of HIP events on the launch stream.
-struct ProfileState {
-    bool on = false;
-    std::string last_kernel;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-};
-static ProfileState& prof() { static ProfileState s; return s; }
-template <typename T> static const char* type_name() {
-    return std::is_same_v<T, float> ? "float" : std::is_same_v<T, double> ? "double" : std::is_same_v<T, int32_t> ? "int" :
-           std::is_same_v<T, int64_t> ? "long" : std::is_same_v<T, __half> ? "__half" : "__hip_bfloat16";
-}
-template <typename T> static std::string kernel_name(int vec, int nt, int rcls, int ymode) {
-    char b[96];
-    snprintf(b, sizeof(b), "agg_flat_kernel<%s, %d, %d, %d, %d>", type_name<T>(), vec, nt, rcls, ymode);
-    return b;
-}
-
-template <typename T, int VEC, int NT, int RCLS, int YMODE>
-static int32_t launch_flat(AggParams p, hipStream_t st) {
-    const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
-    p.n_blocks = (int)nb;
-    p.n_grid_chunks = (int)xcd_grid(nb);
-    const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
-    prof().last_kernel = kernel_name<T>(VEC, NT, RCLS, YMODE);
-    if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof().on) {
-        PGLAMD_HIP_CHECK(hipEventCreate(&e0));
-        PGLAMD_HIP_CHECK(hipEventCreate(&e1));
-        PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
-    }
-    constexpr bool can_scale = RCLS == 0 && std::is_floating_point_v<typename AccT<T>::type>;
-    // 256-byte rows (d=64 fp32, d=128 fp16) are occupancy-bound: the two-deep pipeline (69 SGPRs, 8
-    // workgroups/CU) measured 4 % faster there; everywhere else the three-deep one wins (up to 20 % on [E,8]).
-    const size_t row_bytes = (size_t)p.tile_cols * sizeof(T);
-    if constexpr (NT == 1 && YMODE == 0) {
-        if (row_bytes >= 192 && row_bytes <= 320 && !p.src_scale) {
-            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-            PGLAMD_LAUNCH_CHECK();
-            goto launched;
-        }
-    }
-    if constexpr (can_scale) {
-        if (p.src_scale)
-            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-        else
-            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-    } else {
-        hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-    }
-    PGLAMD_LAUNCH_CHECK();
-launched:
-    if (prof().on) {
-        PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
-        prof().ev.emplace_back(e0, e1);
-    }
-    if (p.n_chunks > 1) {
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), dim3((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
-        PGLAMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), dim3((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks)), dim3(kFixWaves * kWave), 0, st, p);
-    }
-    PGLAMD_LAUNCH_CHECK();
-    return PGLAMD_OK;
-}
+ProfileState& prof() { static ProfileState s; return s; }
 
 template <typename T>
 static int32_t launch_fixup_typed(const AggParams& p, int rcls, hipStream_t st) {
@@ -632,13 +72,7 @@ int32_t launch_fixup_cols(const AggParams& p, int32_t dtype, int rcls, hipStream
     }
 }
 
-template <typename T> constexpr int32_t dtype_code() {
-    return std::is_same_v<T, float> ? PGLAMD_F32 : std::is_same_v<T, double> ? PGLAMD_F64 : std::is_same_v<T, int32_t> ? PGLAMD_I32 :
-           std::is_same_v<T, int64_t> ? PGLAMD_I64 : std::is_same_v<T, __half> ? PGLAMD_F16 : PGLAMD_BF16;
-}
-
-// rows at most this many elements wide (and <= 64 bytes of accumulator) take the lane-per-edge kernel
-static int narrow_max() {
+int narrow_max() {
     static int k = [] { const char* s = getenv("PGLAMD_NARROW"); return s ? atoi(s) : 16; }();
     return k;
 }
@@ -654,75 +88,7 @@ int narrow_chunk_edges() {
     return k;
 }
 
-template <typename T, int VEC, int NT>
-static int32_t dispatch_mode(const AggParams& p, int rcls, int ymode, hipStream_t st, bool* handled) {
-    *handled = true;
-    if (rcls == 0) {
-        if (ymode == 0) return launch_flat<T, VEC, NT, 0, 0>(p, st);
-        if constexpr (std::is_floating_point_v<T>) {      // fp32 / fp64 only: 16-bit and integer operands take the generic path
-            if (ymode == 1) return launch_flat<T, VEC, NT, 0, 1>(p, st);
-            if (ymode == 2) return launch_flat<T, VEC, NT, 0, 2>(p, st);
-        }
-    } else if (ymode == 0) {
-        return launch_flat<T, VEC, NT, 1, 0>(p, st);
-    }
-    *handled = false;
-    return PGLAMD_OK;
-}
-
-// picks (VEC, NT) for one column tile of width w; widths are capped by max_tile_cols<T>()
-template <typename T>
-static int32_t dispatch_shape(const AggParams& p, int vec, int rcls, int ymode, hipStream_t st, bool* handled) {
-    const int w = p.tile_cols;
-    if constexpr (sizeof(T) == 2) {
-        if (vec >= 8) {
-            if (w <= 512) return dispatch_mode<T, 8, 1>(p, rcls, ymode, st, handled);
-            return dispatch_mode<T, 8, 2>(p, rcls, ymode, st, handled);
-        }
-        if (vec == 4) {
-            if (w <= 256) return dispatch_mode<T, 4, 1>(p, rcls, ymode, st, handled);
-            if (w <= 512) return dispatch_mode<T, 4, 2>(p, rcls, ymode, st, handled);
-            return dispatch_mode<T, 4, 4>(p, rcls, ymode, st, handled);
-        }
-        if (vec == 2) {
-            if (w <= 128) return dispatch_mode<T, 2, 1>(p, rcls, ymode, st, handled);
-            if (w <= 256) return dispatch_mode<T, 2, 2>(p, rcls, ymode, st, handled);
-            return dispatch_mode<T, 2, 4>(p, rcls, ymode, st, handled);
-        }
-        if (w <= 64) return dispatch_mode<T, 1, 1>(p, rcls, ymode, st, handled);
-        if (w <= 128) return dispatch_mode<T, 1, 2>(p, rcls, ymode, st, handled);
-        return dispatch_mode<T, 1, 4>(p, rcls, ymode, st, handled);
-    } else if constexpr (sizeof(T) == 4) {
-        if (vec >= 4) {
-            if (w <= 256) return dispatch_mode<T, 4, 1>(p, rcls, ymode, st, handled);
-            if (w <= 512) return dispatch_mode<T, 4, 2>(p, rcls, ymode, st, handled);
-            return dispatch_mode<T, 4, 4>(p, rcls, ymode, st, handled);
-        }
-        if (vec == 2) {
-            if (w <= 128) return dispatch_mode<T, 2, 1>(p, rcls, ymode, st, handled);
-            if (w <= 256) return dispatch_mode<T, 2, 2>(p, rcls, ymode, st, handled);
-            return dispatch_mode<T, 2, 4>(p, rcls, ymode, st, handled);
-        }
-        if (w <= 64) return dispatch_mode<T, 1, 1>(p, rcls, ymode, st, handled);
-        if (w <= 128) return dispatch_mode<T, 1, 2>(p, rcls, ymode, st, handled);
-        return dispatch_mode<T, 1, 4>(p, rcls, ymode, st, handled);
-    } else {
-        if (vec >= 2) {
-            if (w <= 128) return dispatch_mode<T, 2, 1>(p, rcls, ymode, st, handled);
-            if (w <= 256) return dispatch_mode<T, 2, 2>(p, rcls, ymode, st, handled);
-            return dispatch_mode<T, 2, 4>(p, rcls, ymode, st, handled);
-        }
-        if (w <= 64) return dispatch_mode<T, 1, 1>(p, rcls, ymode, st, handled);
-        if (w <= 128) return dispatch_mode<T, 1, 2>(p, rcls, ymode, st, handled);
-        return dispatch_mode<T, 1, 4>(p, rcls, ymode, st, handled);
-    }
-}
-
-template <typename T> static int max_vec() { return sizeof(T) == 2 ? 8 : sizeof(T) == 4 ? 4 : 2; }
-// columns one launch covers: 64 lanes x VEC x NT(max)
-template <typename T> static int max_tiles(int vec) { return (sizeof(T) == 2 && vec == 8) ? 2 : 4; }
-
-static int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_rows, void* out,
+int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_rows, void* out,
                                size_t row_bytes, hipStream_t st) {
     if (out_rows <= 0 || row_bytes == 0) return PGLAMD_OK;
     const int64_t waves = ceil_div(out_rows, kWave);
@@ -740,106 +106,15 @@ static int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_
     return PGLAMD_OK;
 }
 
-template <typename T>
-static int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, const int32_t* eid,
-                               const int32_t* row, const int32_t* col, const int64_t* indptr, int64_t E,
-                               int64_t n_csr_rows, int64_t out_rows, int64_t dout, int32_t mop, int32_t rop,
-                               const float* src_scale, const float* dst_scale, int accumulate, void* out, void* ws,
-                               size_t ws_bytes, hipStream_t st) {
-    int32_t rc = PGLAMD_OK;
-    if (accumulate && rop == PGLAMD_MEAN)
-        return fail(PGLAMD_E_ARG, "aggregate: accumulate with MEAN is undefined (use SUM with dst_scale = 1/degree)");
-    if (E == 0) return accumulate ? PGLAMD_OK : zero_empty_rows(indptr, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
-
-    AggParams p{};
-    p.x = x; p.y = y; p.out = out; p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
-    p.src_scale = src_scale; p.dst_scale = dst_scale;
-    p.ldx = dx; p.ldy = dy; p.ldo = dout; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)E;
-    p.mop = mop; p.is_mean = rop == PGLAMD_MEAN; p.is_max = rop == PGLAMD_MAX; p.accumulate = accumulate;
-    const int rcls = (rop == PGLAMD_SUM || rop == PGLAMD_MEAN) ? 0 : 1;
-    const int gx = (int)(dout / dx);
-    const int gy = y ? (int)(dout / dy) : 1;
-    p.gy = gy;
-
-    // fast path eligibility + lane geometry: VEC elements per lane.  Candidates are limited by
-    // divisibility / pointer alignment; among them take the one that needs the fewest 64-lane
-    // tiles and, for equal tiles, keeps the most lanes busy (d=128 fp32 -> VEC 2: 64 x 8 B).
-    bool fast = gx == 1;
-    int vmax = max_vec<T>();
-    const uintptr_t align_bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
-                                 (y && gy == 1 ? reinterpret_cast<uintptr_t>(y) : 0) |
-                                 reinterpret_cast<uintptr_t>(ws);
-    while (vmax > 1 && (dout % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0)) vmax >>= 1;
-    int ymode = 0;
-    if (y) {
-        if (gy == 1) ymode = 2;
-        else { ymode = 1; while (vmax > 1 && gy % vmax != 0) vmax >>= 1; }
-    }
-    int vec = vmax;
-    {
-        int64_t best_tiles = -1, best_lanes = -1;
-        for (int v = vmax; v >= 1; v >>= 1) {
-            const int64_t lanes = dout / v, tiles = ceil_div(lanes, kWave);
-            const int64_t busy = lanes < kWave ? lanes : kWave;
-            if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && busy > best_lanes)) {
-                best_tiles = tiles; best_lanes = busy; vec = v;
-            }
-        }
-        static const int forced = [] { const char* e = getenv("PGLAMD_VEC"); return e ? atoi(e) : 0; }();
-        if (forced >= 1 && forced <= vmax && (forced & (forced - 1)) == 0) vec = forced;
-    }
-    p.zvec = vec > 4 ? 4 : vec;
-    { static const int al = [] { const char* e = getenv("PGLAMD_ALIGN"); return e ? atoi(e) : 1; }(); p.align = al; }
-    if ((src_scale || dst_scale) && (rcls != 0 || !std::is_floating_point_v<typename AccT<T>::type>))
-        return fail(PGLAMD_E_ARG, "src_scale/dst_scale need a floating dtype and sum/mean");
-
-    if (fast) {
-        const int K = chunk_edges();
-        p.chunk = K;
-        p.n_chunks = (int)ceil_div(E, K);
-        const int max_cols = kWave * vec * max_tiles<T>(vec);
-        const int64_t tile_full = dout < max_cols ? dout : max_cols;
-        const size_t half = align_up((size_t)p.n_chunks * tile_full * sizeof(typename AccT<T>::type), 256);
-        const size_t lst = align_up((size_t)(p.n_chunks + 64) * sizeof(int), 256);
-        const size_t need = 2 * half + 2 * lst;
-        if (!ws || ws_bytes < need) return fail(PGLAMD_E_WORKSPACE, "aggregate: workspace %zu < %zu", ws_bytes, need);
-        p.part_head = ws;
-        p.part_tail = static_cast<char*>(ws) + half;
-        p.long_count = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half);
-        p.long_list = p.long_count + 64;
-        p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half + lst);
-        // measured at C2 sizes: the lane-per-edge kernel wins up to 32 B of accumulator per row for every reduce op
-        // (2.6-3.4x at d <= 8 fp32) and up to 64 B for sum / mean (1.3x at d = 16 fp32)
-        if (dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= (rcls == 0 ? 64u : 32u)) {
-            AggParams q = p;
-            const int nk = std::max(K, narrow_chunk_edges());                   // fewer, longer chunks: the carved arrays still fit
-            q.chunk = nk; q.n_chunks = (int)ceil_div(E, nk);
-            q.j_base = 0; q.tile_cols = (int)dout;
-            const size_t lv = std::min<size_t>(16, (size_t)dout * sizeof(T));
-            q.narrow_vec = (lv & (lv - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
-                                                    (y && dy == dout ? reinterpret_cast<uintptr_t>(y) : 0)) % lv == 0;
-            bool handled = false;
-            rc = launch_narrow(q, dtype_code<T>(), rcls, y ? dy : 0, st, &handled);
-            if (rc != PGLAMD_OK || handled) return rc;
-        }
-        for (int64_t jb = 0; jb < dout; jb += max_cols) {
-            p.j_base = (int)jb;
-            p.tile_cols = (int)((dout - jb) < max_cols ? (dout - jb) : max_cols);
-            bool handled = false;
-            rc = dispatch_shape<T>(p, vec, rcls, ymode, st, &handled);
-            if (rc != PGLAMD_OK) return rc;
-            if (!handled) { fast = false; break; }
-        }
-        if (fast) return PGLAMD_OK;
-    }
-    // generic fallback: rewrites every row < out_rows (rows without edges get 0)
-    p.tile_cols = (int)dout; p.j_base = 0;
-    p.is_max = rop == PGLAMD_MAX ? 1 : rop == PGLAMD_MIN ? 2 : 0;
-    if (src_scale || dst_scale) return fail(PGLAMD_E_SHAPE, "scales unsupported with this broadcast pattern");
-    hipLaunchKernelGGL(agg_generic_kernel<T>, dim3((unsigned)ceil_div(out_rows, kWavesPerBlock)), dim3(kBlock), 0, st, p, gx);
-    PGLAMD_LAUNCH_CHECK();
-    return PGLAMD_OK;
-}
+// float / double here; the other four storage types are instantiated in aggregate_more.hip
+#define PGLAMD_AGG_ARGS const void*, int64_t, const void*, int64_t, const int32_t*, const int32_t*, const int32_t*, const int64_t*, \
+                        int64_t, int64_t, int64_t, int64_t, int32_t, int32_t, const float*, const float*, int, void*, void*, size_t, hipStream_t
+template int32_t aggregate_typed<float>(PGLAMD_AGG_ARGS);
+template int32_t aggregate_typed<double>(PGLAMD_AGG_ARGS);
+extern template int32_t aggregate_typed<int32_t>(PGLAMD_AGG_ARGS);
+extern template int32_t aggregate_typed<int64_t>(PGLAMD_AGG_ARGS);
+extern template int32_t aggregate_typed<__half>(PGLAMD_AGG_ARGS);
+extern template int32_t aggregate_typed<__hip_bfloat16>(PGLAMD_AGG_ARGS);
 
 }  // namespace pglamd
 
@@ -863,7 +138,7 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
                                     void* workspace, size_t workspace_bytes, void* stream) {
     (void)n_x_rows;
     if (!out || !indptr || (num_edges > 0 && (!x || !row))) return fail(PGLAMD_E_ARG, "aggregate: NULL pointer");
-    if (num_edges < 0 || num_edges >= INT32_MAX || n_csr_rows >= INT32_MAX || out_rows >= INT32_MAX)
+    if (num_edges < 0 || num_edges > kMaxEdges || n_csr_rows >= INT32_MAX || out_rows >= INT32_MAX)
         return fail(PGLAMD_E_RANGE, "aggregate: sizes beyond int32 engine range");
     if (dout <= 0 || dx <= 0 || dout % dx != 0 || (y && (dy <= 0 || dout % dy != 0)))
         return fail(PGLAMD_E_SHAPE, "aggregate: dx=%lld dy=%lld dout=%lld is not a trailing-dim broadcast",

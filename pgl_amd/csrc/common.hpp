@@ -19,6 +19,9 @@ constexpr int kWave = 64;          // CDNA wavefront
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kXcds = 8;           // MI355X: block b is dispatched to XCD b % 8
+// Edge positions are 32-bit inside the kernels and chunk ends are computed as c * K + K before clamping, so the
+// engine accepts edge counts that leave that headroom (per graph / per partition).
+constexpr int64_t kMaxEdges = (int64_t)INT32_MAX - 65536;
 
 std::string& last_error_ref();
 int32_t fail(int32_t code, const char* fmt, ...);

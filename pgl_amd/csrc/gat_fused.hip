@@ -617,7 +617,7 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
         return fail(PGLAMD_E_ARG, "gat_aggregate: bad argument");
     if ((row_max == nullptr) != (row_sum == nullptr)) return fail(PGLAMD_E_ARG, "gat_aggregate: row_max/row_sum must both be given or both NULL");
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !eid)) return fail(PGLAMD_E_ARG, "gat_aggregate: dropout needs 0 <= p < 1 and eid");
-    if (num_edges < 0 || num_edges >= INT32_MAX || out_rows >= INT32_MAX) return fail(PGLAMD_E_RANGE, "gat_aggregate: sizes beyond int32 engine range");
+    if (num_edges < 0 || num_edges > kMaxEdges || out_rows >= INT32_MAX) return fail(PGLAMD_E_RANGE, "gat_aggregate: sizes beyond int32 engine range");
     const int64_t d = heads * head_dim;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (out_rows == 0) return PGLAMD_OK;
@@ -667,7 +667,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
                            !dst_eid || !dst_indptr || !src_row || !src_col || !src_eid || !src_indptr)))
         return fail(PGLAMD_E_ARG, "gat_backward: bad argument");
     if (drop_p < 0.f || drop_p >= 1.f) return fail(PGLAMD_E_ARG, "gat_backward: dropout needs 0 <= p < 1");
-    if (num_edges >= INT32_MAX || num_nodes >= INT32_MAX) return fail(PGLAMD_E_RANGE, "gat_backward: sizes beyond int32 engine range");
+    if (num_edges > kMaxEdges || num_nodes >= INT32_MAX) return fail(PGLAMD_E_RANGE, "gat_backward: sizes beyond int32 engine range");
     const int64_t d = heads * head_dim;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (num_nodes == 0) return PGLAMD_OK;
@@ -717,7 +717,7 @@ extern "C" int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, in
                                 void* stream) {
     if (heads <= 0 || head_dim <= 0 || num_edges < 0 || (num_edges > 0 && (!x_by_col || !y_by_row || !row || !col || !out)))
         return fail(PGLAMD_E_ARG, "sddmm: bad argument");
-    if (num_edges >= INT32_MAX) return fail(PGLAMD_E_RANGE, "sddmm: sizes beyond int32 engine range");
+    if (num_edges > kMaxEdges) return fail(PGLAMD_E_RANGE, "sddmm: sizes beyond int32 engine range");
     if (num_edges == 0) return PGLAMD_OK;
     const int vec = gat_vec(heads, head_dim, x_by_col, y_by_row, nullptr, true);
     if (vec == 0 || heads > kWave)
