@@ -97,11 +97,24 @@ def split(x, num_or_sections, axis=0, name=None):      # paddle: an int is the N
 
 
 _t.Tensor.split = split
-# paddle.Tensor defines no in-place arithmetic dunders: `a += b` rebinds `a` to a NEW tensor (aliases keep the old value)
-_t.Tensor.__iadd__ = lambda self, o: self + o
-_t.Tensor.__isub__ = lambda self, o: self - o
-_t.Tensor.__imul__ = lambda self, o: self * o
-_t.Tensor.__itruediv__ = lambda self, o: self / o
+# paddle.Tensor defines no in-place arithmetic dunders: `a += b` rebinds `a` to a NEW tensor (aliases keep the old
+# value).  torch's own Python code (optimizers: `step_t += 1`) relies on the in-place meaning, so the Paddle meaning is
+# applied only when the statement is NOT executed from inside the torch package.
+import sys as _sys
+
+
+def _paddle_inplace(orig, pure):
+    def op(self, other):
+        if _sys._getframe(1).f_globals.get("__name__", "").startswith("torch"):
+            return orig(self, other)
+        return pure(self, other)
+    return op
+
+
+_t.Tensor.__iadd__ = _paddle_inplace(_t.Tensor.__iadd__, lambda a, b: a + b)
+_t.Tensor.__isub__ = _paddle_inplace(_t.Tensor.__isub__, lambda a, b: a - b)
+_t.Tensor.__imul__ = _paddle_inplace(_t.Tensor.__imul__, lambda a, b: a * b)
+_t.Tensor.__itruediv__ = _paddle_inplace(_t.Tensor.__itruediv__, lambda a, b: a / b)
 
 
 class CPUPlace:

@@ -252,3 +252,43 @@ conv = gnn.GCNConv(6, 6)
 b["gcn_on_batch"] = conv(bg, paddle.to_tensor(feat)).detach().numpy()
 b.update({"param::" + k: v.detach().numpy().copy() for k, v in conv.state_dict().items()})
 save("batched_graph", **b)
+
+# ---------------------------------------------------------------------------------------------------------
+# Training trajectories of the reference's EXAMPLE models (examples/gcn/train.py GCN, examples/gat/train.py GAT), imported
+# unchanged from the reference tree and driven with the example's own train() step semantics (cross-entropy on the
+# training nodes, Adam(lr, weight_decay) as in the scripts); dropout 0 so the trajectory is deterministic.
+# ---------------------------------------------------------------------------------------------------------
+import importlib.util  # noqa: E402
+
+
+def example_module(rel):
+    path = os.path.join(ref_python.REFERENCE_ROOT, "examples", rel)
+    spec = importlib.util.spec_from_file_location("ref_example_" + rel.replace("/", "_").replace(".py", ""), path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+n, e, din, ncls, steps = 400, 3200, 32, 5, 12
+edges, rng = graph_case(n, e, 4242, hub=300, self_loops=True)
+x = rng.random((n, din)).astype(np.float32)
+labels = rng.integers(0, ncls, n).astype(np.int64)
+train_idx = rng.choice(n, 120, replace=False).astype(np.int64)
+for tag, rel, ctor in (("gcn", "gcn/train.py", lambda m: m.GCN(din, ncls, num_layers=1, hidden_size=16, dropout=0.0)),
+                       ("gat", "gat/train.py", lambda m: m.GAT(din, ncls, num_layers=1, feat_drop=0.0, attn_drop=0.0, num_heads=4, hidden_size=8))):
+    mod = example_module(rel)
+    paddle.seed(77)
+    model = ctor(mod)
+    init = {"init::" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    g = pgl.Graph(edges=edges, num_nodes=n, node_feat={"words": x}).tensor()
+    optim = mod.Adam(learning_rate=0.01, parameters=model.parameters(), weight_decay=0.0005)
+    crit = paddle.nn.loss.CrossEntropyLoss()
+    idx_t = paddle.to_tensor(np.expand_dims(train_idx, -1)); lab_t = paddle.to_tensor(np.expand_dims(labels[train_idx], -1))
+    losses = []
+    for _ in range(steps):
+        loss, pred = mod.train(idx_t, lab_t, model, g, crit, optim)      # the example's own training step
+        losses.append(float(loss))
+    model.eval()
+    logits = model(g, g.node_feat["words"]).detach().numpy()
+    save("train_" + tag, edges=edges, num_nodes=np.int64(n), x=x, labels=labels, train_idx=train_idx, losses=np.array(losses, np.float64),
+         final_logits=logits, **init)

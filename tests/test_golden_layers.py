@@ -252,3 +252,45 @@ def test_batched_graph_matches_reference_python(pgl):
     with torch.no_grad():
         out = conv.cuda()(bg, feat)
     np.testing.assert_allclose(out.cpu().numpy(), z["gcn_on_batch"], rtol=5 * RTOL, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["gcn", "gat"])
+def test_training_trajectory_matches_reference_example_model(pgl, tag):
+    """The models of the reference's examples/gcn/train.py and examples/gat/train.py, trained by the examples' own
+    train() step on the paddle stand-in (fixture), against the same architecture on this engine from the same initial
+    parameters: 12 Adam steps, loss after every step and the final logits."""
+    z = np.load(os.path.join(HERE, "golden", "layers", "train_%s.npz" % tag))
+    n = int(z["num_nodes"]); din = z["x"].shape[1]; ncls = 5
+    nn = torch.nn
+    if tag == "gcn":
+        layers = nn.ModuleList([pgl.nn.GCNConv(din, 16, activation="relu", norm=True), nn.Dropout(0.0), pgl.nn.GCNConv(16, ncls)])
+        prefix = "gcns."
+    else:
+        layers = nn.ModuleList([pgl.nn.GATConv(din, 8, 0.0, 0.0, 4, activation="elu")])
+        prefix = "gats."
+    _load_params(layers, {k[len("init::") + len(prefix):]: z[k] for k in z.files if k.startswith("init::")})
+    layers = layers.cuda()
+
+    def model(g, h):
+        for m in layers:
+            h = m(h) if isinstance(m, nn.Dropout) else m(g, h)
+        return h
+
+    g = pgl.Graph(edges=z["edges"], num_nodes=n).tensor()
+    x = torch.as_tensor(z["x"]).cuda()
+    idx = torch.as_tensor(z["train_idx"]).cuda(); lab = torch.as_tensor(z["labels"][z["train_idx"]]).cuda()
+    opt = torch.optim.Adam(layers.parameters(), lr=0.01, weight_decay=0.0005)
+    losses = []
+    layers.train()
+    for _ in range(len(z["losses"])):
+        loss = torch.nn.functional.cross_entropy(model(g, x)[idx], lab)
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        losses.append(float(loss))
+    np.testing.assert_allclose(losses, z["losses"], rtol=2e-4)
+    layers.eval()
+    with torch.no_grad():
+        logits = model(g, x).cpu().numpy()
+    np.testing.assert_allclose(logits, z["final_logits"], rtol=2e-3, atol=2e-3 * float(np.abs(z["final_logits"]).max()))
