@@ -521,26 +521,34 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
     }
 }
 
-// One thread per (node, head): t = <g[v,h,:], out[v,h,:]> (the softmax-backward row term) and the destination-side
-// scalars, packed so that an edge fetches them with one 16-byte load.
+// t[v,h] = <g[v,h,:], out[v,h,:]> (the softmax-backward row term) and the destination-side scalars of every
+// (node, head), packed so that an edge fetches them with one 16-byte load.  LANES = head_dim / 4 lanes share one
+// (node, head): fully coalesced float4 reads, a DPP group sum, one 16-byte store (LANES = 0: one thread per pair).
+template <int LANES>
 __global__ __launch_bounds__(kBlock) void gat_pack_kernel(const float* __restrict__ a_dst, const float* __restrict__ m,
                                                          const float* __restrict__ sm, const float* __restrict__ g,
                                                          const float* __restrict__ out, int64_t n, int D,
                                                          F4* __restrict__ packed) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float* gp = g + i * D;
-    const float* op = out + i * D;
-    float t = 0.f;
-    if ((D & 3) == 0) {
-        for (int k = 0; k < D; k += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(gp + k), b = *reinterpret_cast<const float4*>(op + k);
-            t += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-        }
+    if constexpr (LANES == 0) {
+        const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        if (i >= n) return;
+        float t = 0.f;
+        for (int k = 0; k < D; ++k) t += g[i * D + k] * out[i * D + k];
+        packed[i] = F4{a_dst[i], m[i], 1.f / sm[i], t};
     } else {
-        for (int k = 0; k < D; ++k) t += gp[k] * op[k];
+        const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;          // float4 index into [n, D]
+        const bool live = q < n * LANES;
+        float t = 0.f;
+        if (live) {
+            const float4 a = reinterpret_cast<const float4*>(g)[q], b = reinterpret_cast<const float4*>(out)[q];
+            t = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        t = group_sum(t, LANES);
+        if (live && (q % LANES) == 0) {
+            const int64_t i = q / LANES;
+            packed[i] = F4{a_dst[i], m[i], 1.f / sm[i], t};
+        }
     }
-    packed[i] = F4{a_dst[i], m[i], 1.f / sm[i], t};
 }
 
 static int gat_chunk_edges() {
@@ -686,8 +694,21 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     const size_t pack_bytes = align_up((size_t)num_nodes * heads * sizeof(F4), 256);
     F4* packed = static_cast<F4*>(workspace);
     workspace = static_cast<char*>(workspace) + pack_bytes;
-    hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)ceil_div(num_nodes * heads, kBlock)), dim3(kBlock), 0, st, attn_dst, row_max,
-                       row_sum, grad_out, out, num_nodes * heads, (int)head_dim, packed);
+    {
+        const int64_t pairs = num_nodes * heads;
+        const int lanes = (head_dim % 4 == 0) ? (int)(head_dim / 4) : 0;
+#define PGLAMD_PACK(L) hipLaunchKernelGGL(gat_pack_kernel<L>, dim3((unsigned)ceil_div(pairs * (L ? L : 1), kBlock)), dim3(kBlock), 0, st, \
+                                          attn_dst, row_max, row_sum, grad_out, out, pairs, (int)head_dim, packed)
+        switch (lanes) {
+            case 1: PGLAMD_PACK(1); break;
+            case 2: PGLAMD_PACK(2); break;
+            case 4: PGLAMD_PACK(4); break;
+            case 8: PGLAMD_PACK(8); break;
+            case 16: PGLAMD_PACK(16); break;
+            default: PGLAMD_PACK(0); break;
+        }
+#undef PGLAMD_PACK
+    }
     PGLAMD_LAUNCH_CHECK();
     GatParams p{};
     p.H = (int)heads; p.D = (int)head_dim; p.d = (int)d; p.slope = negative_slope;
