@@ -220,6 +220,10 @@ int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const 
  *   grad_feature[u,h,:] = sum_{e=(u->v)} drop_e alpha_e grad_out[v,h,:]
  *   grad_attn_src[u,h]  = sum_{e=(u->v)} d pre_e          (both from ONE walk of the src-sorted CSR)
  *   grad_attn_dst[v,h]  = sum_{e=(u->v)} d pre_e          (one walk of the dst-sorted CSR)
+ *   grad_pre (optional) : when non-NULL the src-sorted walk also writes d pre_e to grad_pre[E,H] (ORIGINAL edge
+ *                         order) and the dst-sorted walk is skipped; the caller then takes grad_attn_dst as the segment
+ *                         sum of grad_pre by destination (pglamd_aggregate with col = eid): 1.3 ms faster at C3 for
+ *                         4*E*H bytes of scratch.  grad_attn_dst may be NULL in that case.
  *   d pre_e = alpha_e (drop_e <grad_out[v,h,:], feature[u,h,:]> - t[v,h]) * leaky_relu'(attn_src[u,h] + attn_dst[v,h])
  *   t[v,h]  = sum_d grad_out[v,h,d] * out[v,h,d]  (out = the forward's output; computed here).
  *   dst_* / src_*  the dst-sorted and src-sorted CSRs (int32 row / col / eid, int64 indptr).
@@ -236,7 +240,7 @@ int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const f
                             const int32_t* src_row, const int32_t* src_col, const int32_t* src_eid,
                             const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
                             float* grad_feature, float* grad_attn_src, float* grad_attn_dst,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
 
 /* SDDMM over a sorted edge stream:  out[eid[p], h] = < x_by_col[col[p], h, :], y_by_row[row[p], h, :] >
  * (eid NULL: out[p, h]).  With (row, col, eid) = the dst-sorted CSR, x = node features and

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     const float* __restrict__ ss = p.stat_s;
     const float slope = p.slope;
     constexpr bool drop = DROP;
+    const bool need_eid = drop || (ATT && p.dpre != nullptr);     // original edge ids: dropout hash / d pre_e output
 
     float m = -INFINITY, s = 0.f, acc[VEC], acc_a = 0.f;
 #pragma unroll
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     const float* __restrict__ rvec = p.row_vec;
     auto load_idx = [&](int e, int (&cc)[U], int (&rr)[U], int (&ee)[U]) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; ee[i] = drop ? eidp[e + i] : 0; }
+        for (int i = 0; i < U; ++i) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; ee[i] = need_eid ? eidp[e + i] : 0; }
     };
     // the destination's statistics (and t) are indexed by col on the src-sorted stream, by row on the dst-sorted one
     auto load_rows = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], V (&vy)[U], float (&vc)[U], float (&vr)[U],
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
         // only for edges that OPEN a row inside the batch and held in registers until the next row change -- on a
         // power-law graph most edges continue a row, so an edge costs two vector loads, not seven.
         const F4* __restrict__ pk = p.packed;
+        float* __restrict__ dpre_out = p.dpre;
         V y_held{}; F4 p_held{}; float a_held = 0.f;
         if (act) {
             y_held = *reinterpret_cast<const V*>(rvec + (int64_t)cur * p.d + j0);
@@ -306,7 +308,9 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             for (int k = 0; k < VEC; ++k) dot += xv.v[k] * y_held.v[k];       // <g[v], f[u]> restricted to this lane
             dot = group_sum(dot, lph);
             const float dl = alpha * (df * dot - q.t);
-            acc_a += pre > 0.f ? dl : slope * dl;
+            const float dp = pre > 0.f ? dl : slope * dl;
+            acc_a += dp;
+            if (dpre_out && (lane & (lph - 1)) == 0 && act) dpre_out[(int64_t)ed * p.H + head] = dp;   // [E,H], original edge order
         };
         auto load_att = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], F4 (&pc)[U], float (&ac)[U], V (&yo)[U],
                             F4 (&po)[U], float (&ao)[U]) {
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
         }
         for (; e < e1; ++e) {
             const int r = rowp[e], cc = colp[e];
-            const int ed = drop ? eidp[e] : 0;
+            const int ed = need_eid ? eidp[e] : 0;
             V xv{}, yo{}; F4 pc{}, po{}; float ac = 0.f, ao = 0.f;
             if (act) {
                 xv = *reinterpret_cast<const V*>(x + (int64_t)cc * p.d + j0);
@@ -668,9 +672,9 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
                                        const int32_t* dst_row, const int32_t* dst_col, const int32_t* dst_eid,
                                        const int64_t* dst_indptr, const int32_t* src_row, const int32_t* src_col,
                                        const int32_t* src_eid, const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
-                                       float* grad_feature, float* grad_attn_src, float* grad_attn_dst, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
-    if (heads <= 0 || head_dim <= 0 || num_nodes < 0 || num_edges < 0 || !grad_feature || !grad_attn_src || !grad_attn_dst ||
+                                       float* grad_feature, float* grad_attn_src, float* grad_attn_dst, float* grad_pre,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    if (heads <= 0 || head_dim <= 0 || num_nodes < 0 || num_edges < 0 || !grad_feature || !grad_attn_src || (!grad_attn_dst && !grad_pre) ||
         (num_edges > 0 && (!grad_out || !feature || !attn_src || !attn_dst || !row_max || !row_sum || !out || !dst_row || !dst_col ||
                            !dst_eid || !dst_indptr || !src_row || !src_col || !src_eid || !src_indptr)))
         return fail(PGLAMD_E_ARG, "gat_backward: bad argument");
@@ -682,7 +686,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     if (num_edges == 0) {
         PGLAMD_HIP_CHECK(hipMemsetAsync(grad_feature, 0, (size_t)num_nodes * d * sizeof(float), st));
         PGLAMD_HIP_CHECK(hipMemsetAsync(grad_attn_src, 0, (size_t)num_nodes * heads * sizeof(float), st));
-        PGLAMD_HIP_CHECK(hipMemsetAsync(grad_attn_dst, 0, (size_t)num_nodes * heads * sizeof(float), st));
+        if (grad_attn_dst) PGLAMD_HIP_CHECK(hipMemsetAsync(grad_attn_dst, 0, (size_t)num_nodes * heads * sizeof(float), st));
         return PGLAMD_OK;
     }
     const int vec = gat_vec(heads, head_dim, feature, grad_out, grad_feature, true);
@@ -717,8 +721,9 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     p.packed = packed;
     p.out_rows = num_nodes; p.n_csr_rows = num_nodes;
     int32_t rc;
-    // (1) dst-sorted walk: row = v gathers f[u], a_src[u]; accumulates d a_dst[v]
-    {
+    // (1) dst-sorted walk: row = v gathers f[u], a_src[u]; accumulates d a_dst[v].  Skipped when the caller takes
+    //     d pre_e [E,H] from walk (2) instead and segment-sums it by destination itself (faster, 4*E*H bytes more memory).
+    if (!grad_pre) {
         GatParams q = p;
         q.row = dst_row; q.col = dst_col; q.eid = dst_eid; q.indptr = dst_indptr;
         q.x = feature; q.p_col = attn_src; q.p_row = attn_dst; q.row_vec = grad_out; q.out = nullptr; q.out_a = grad_attn_dst;
@@ -729,6 +734,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     // (2) src-sorted walk: row = u gathers g[v] and v's scalars; accumulates d f[u] and d a_src[u]
     p.row = src_row; p.col = src_col; p.eid = src_eid; p.indptr = src_indptr;
     p.x = grad_out; p.p_col = attn_dst; p.p_row = attn_src; p.row_vec = feature; p.out = grad_feature; p.out_a = grad_attn_src;
+    p.dpre = grad_pre;
     gat_setup_partials(p, workspace, 2);
     return vec == 1 ? launch_gat<1, 2>(p, st) : vec == 2 ? launch_gat<2, 2>(p, st) : launch_gat<4, 2>(p, st);
 }

@@ -145,6 +145,7 @@ def _bcast(x, y):
 # ------------------------------------------------------------------------------------------------
 # aggregation (send_u_recv / send_ue_recv)
 # ------------------------------------------------------------------------------------------------
+_GAT_BWD_EDGE_BUFFER = os.environ.get("PGLAMD_GAT_BWD_EDGE_BUFFER", "1") != "0"
 _PRESCALE_ROW_BYTES = int(os.environ.get("PGLAMD_PRESCALE_ROW_BYTES", "704"))
 
 
@@ -352,7 +353,11 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     out = out.contiguous()
     gf = torch.empty_like(feature)
     g_src = torch.empty((n, H), dtype=torch.float32, device=feature.device)
-    g_dst = torch.empty((n, H), dtype=torch.float32, device=feature.device)
+    # d a_dst either from a second (dst-sorted) walk inside the library, or -- 1.3 ms faster at C3, 4*E*H bytes of
+    # scratch -- as the segment sum by destination of the d pre_e the src-sorted walk can emit
+    use_pre = _GAT_BWD_EDGE_BUFFER
+    g_dst = None if use_pre else torch.empty((n, H), dtype=torch.float32, device=feature.device)
+    gpre = torch.empty((csr_dst.num_edges, H), dtype=torch.float32, device=feature.device) if use_pre else None
     L = _ffi.lib()
     ws = _ws(L.pglamd_gat_backward_workspace_bytes(csr_dst.num_edges, n, H, D), feature.device)
     with torch.cuda.device(feature.device):
@@ -361,7 +366,13 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
                                          int(seed) & 0xFFFFFFFF, _ptr(csr_dst.row32), _ptr(csr_dst.col32),
                                          _ptr(csr_dst.eid32), _ptr(csr_dst.indptr), _ptr(csr_src.row32), _ptr(csr_src.col32),
                                          _ptr(csr_src.eid32), _ptr(csr_src.indptr), csr_dst.num_edges, n, _ptr(gf),
-                                         _ptr(g_src), _ptr(g_dst), _ptr(ws), ws.numel(), _stream(feature)), "gat_backward")
+                                         _ptr(g_src), _ptr(g_dst), _ptr(gpre), _ptr(ws), ws.numel(), _stream(feature)), "gat_backward")
+    if use_pre:
+        class _E(object):       # edge rows gathered through the original edge id
+            def __init__(self, c):
+                self.row32, self.col32, self.eid32, self.indptr = c.row32, c.eid32, c.eid32, c.indptr
+                self.num_edges, self.num_nodes = c.num_edges, c.num_nodes
+        g_dst = aggregate(gpre, _E(csr_dst), "sum", n)
     return gf, g_src, g_dst
 
 

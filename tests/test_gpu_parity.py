@@ -1105,3 +1105,25 @@ def test_tall_linear_split_reduction_gradient(pgl):
         close(host(x.grad), host(x2.grad), scale=float(x2.grad.abs().max()))
         close(host(lin.weight.grad), host(ref.weight.grad), scale=float(ref.weight.grad.abs().max()), rtol=1e-4)
         close(host(lin.bias.grad), host(ref.bias.grad), scale=float(ref.bias.grad.abs().max()), rtol=1e-4)
+
+
+def test_gat_backward_variants_agree(pgl):
+    """d a_dst from the second (dst-sorted) walk == segment sum of the d pre_e buffer emitted by the src-sorted walk."""
+    n, e, H, D = 3000, 50000, 8, 16
+    edges, rng = rand_graph(n, e, 321, hub=8000)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    f = dev(rng.standard_normal((n, H, D)).astype(np.float32))
+    a_s = dev(rng.standard_normal((n, H)).astype(np.float32)); a_d = dev(rng.standard_normal((n, H)).astype(np.float32))
+    ct = dev(rng.standard_normal((n, H, D)).astype(np.float32))
+    grads = []
+    keep = pgl.ops._GAT_BWD_EDGE_BUFFER
+    try:
+        for variant in (True, False):
+            pgl.ops._GAT_BWD_EDGE_BUFFER = variant
+            x, s, d = (t.clone().requires_grad_(True) for t in (f, a_s, a_d))
+            (g.gat_aggregate(x, s, d, 0.2, 0.3, 1234) * ct).sum().backward()
+            grads.append([host(t.grad) for t in (x, s, d)])
+    finally:
+        pgl.ops._GAT_BWD_EDGE_BUFFER = keep
+    for a, b in zip(*grads):
+        close(a, b, scale=np.abs(b).max(), rtol=2e-5)
