@@ -272,6 +272,35 @@ def gat_attention(feature, attn_src, attn_dst, csr_dst, csr_src_fn, slope=0.2, d
     return ops.gat_aggregate(feature, attn_src, attn_dst, csr_dst, slope, None, False, drop_p, seed)
 
 
+class _SDDMM(torch.autograd.Function):
+    """out[e, h] = <x[src_e, h, :], y[dst_e, h, :]> in original edge order.  Backward = two edge-weighted aggregations
+    (the same flat kernel with an [E,H,1] edge operand): d x[u] = sum_{e: src=u} g_e y[dst_e] over the src-keyed CSR,
+    d y[v] = sum_{e: dst=v} g_e x[src_e] over the dst-keyed one.  No [E,H,D] tensor in either direction."""
+
+    @staticmethod
+    def forward(ctx, x, y, csr_dst, csr_src_fn):
+        ctx.csr_dst, ctx.csr_src_fn = csr_dst, csr_src_fn
+        ctx.save_for_backward(x, y)
+        return ops.sddmm(x, y, csr_dst)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.contiguous().reshape(g.shape[0], g.shape[1], 1)
+        gx = gy = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.aggregate(y, ctx.csr_src_fn(), "sum", int(x.shape[0]), g, "mul")
+        if ctx.needs_input_grad[1]:
+            gy = ops.aggregate(x, ctx.csr_dst, "sum", int(y.shape[0]), g, "mul")
+        return gx, gy, None, None
+
+
+def sddmm(x, y, csr_dst, csr_src_fn):
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad):
+        return _SDDMM.apply(x, y, csr_dst, csr_src_fn)
+    return ops.sddmm(x, y, csr_dst)
+
+
 class _ScatterRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n_rows, index, x):

@@ -454,6 +454,18 @@ class Graph(object):
     def send_ue(self, feature, edge_feature, message_op="add"):
         raise NotImplementedError
 
+    def sddmm(self, src_feature, dst_feature):
+        """alpha[e, h] = <src_feature[src_e, h, :], dst_feature[dst_e, h, :]> for [N, H, D] fp32 inputs: the dot-product
+        attention score of every edge in one pass, without the two [E, H, D] gathers a send_uv("mul") + sum would
+        materialise (engine extension; differentiable).  Shapes the kernel does not cover fall back to that composition."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        if (src_feature.dim() == 3 and src_feature.dtype == torch.float32 and dst_feature.dtype == torch.float32
+                and tuple(src_feature.shape[1:]) == tuple(dst_feature.shape[1:])
+                and ops.sddmm_supported(int(src_feature.shape[1]), int(src_feature.shape[2]))):
+            return ag.sddmm(src_feature.contiguous(), dst_feature.contiguous(), self._csr_dst(), self._csr_src)
+        return self.send_uv(src_feature, dst_feature, "mul").sum(-1)
+
     def send_recv_scaled(self, feature, src_scale=None, dst_scale=None):
         """out[v] = dst_scale[v] * sum_{u->v} src_scale[u] * feature[u] in ONE kernel: GCN's symmetric
         normalisation (pgl/nn/conv.py:242-250) fused into the aggregation (engine extension, fp32)."""

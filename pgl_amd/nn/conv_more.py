@@ -151,8 +151,9 @@ class GATv2Conv(nn.Module):
 
 
 class TransformerConv(nn.Module):
-    """UDF path: Graph.send with a message function, Graph.recv with a reducer using
-    Message.reduce_softmax / Message.reduce (pgl/nn/conv.py:796-834)."""
+    """pgl/nn/conv.py:724-885.  With edge features: the reference's UDF path (Graph.send with a message function,
+    Graph.recv with a reducer using Message.reduce_softmax / Message.reduce, :796-834).  Without: the same arithmetic
+    as SDDMM -> edge_softmax -> send_ue_recv."""
 
     def __init__(self, input_size, hidden_size, num_heads=4, feat_drop=0.6, attn_drop=0.6, concat=True, skip_feat=True,
                  gate=False, layer_norm=True, activation="relu"):
@@ -194,8 +195,17 @@ class TransformerConv(nn.Module):
             if self.feat_drop > 1e-5:
                 edge_feat = self.feat_dropout(edge_feat)
             kw["edge_feat"] = {"edge_feat": edge_feat.reshape(shape)}
-        msg = graph.send(self.send_attention, src_feat={"k": k, "v": v}, dst_feat={"q": q}, **kw)
-        output = graph.recv(reduce_func=self.reduce_attention, msg=msg)
+        if edge_feat is None and hasattr(graph, "sddmm") and k.dtype == torch.float32:
+            # same arithmetic as send_attention / reduce_attention below, as three fused graph ops: per-edge q.k scores
+            # (SDDMM), softmax over each destination's edges, alpha-weighted sum of v -- no [E, H, D] message tensor
+            alpha = GF.edge_softmax(graph, graph.sddmm(k, q)).reshape(-1, self.num_heads, 1)
+            if self.attn_drop > 1e-15:
+                alpha = self.attn_dropout(alpha)
+            output = graph.send_ue_recv(v, alpha, "mul", "sum")
+            output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(output, dim=1)
+        else:
+            msg = graph.send(self.send_attention, src_feat={"k": k, "v": v}, dst_feat={"q": q}, **kw)
+            output = graph.recv(reduce_func=self.reduce_attention, msg=msg)
         if self.skip_feat is not None:
             skip = self.skip_feat(feature)
             if self.gate is not None:
