@@ -95,7 +95,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device("cuda", local)
+    # PGLAMD_BENCH_DRYRUN=1: every rank on cuda:0 with the gloo backend -- exercises the N > 1 code path end to end on a
+    # single-GPU box (tests only; the numbers it prints mean nothing)
+    dryrun = os.environ.get("PGLAMD_BENCH_DRYRUN") == "1"
+    dev = torch.device("cuda", 0 if dryrun else local)
     torch.cuda.set_device(dev)
 
     import pgl_amd as pgl
@@ -106,7 +109,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
+        if dryrun:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
+        else:
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
 
     edges = rmat_edges(args.scale, E, seed=42, device=dev)           # identical on every rank
     gen = torch.Generator(device=dev); gen.manual_seed(7)

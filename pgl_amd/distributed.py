@@ -33,22 +33,29 @@ def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
     backend = dist.get_backend(group)
     if backend == "nccl":
         return dist.all_to_all_single(recv_buf, send_buf, list(recv_splits), list(send_splits), group=group, async_op=True)
+    # gloo (CPU tests; single-GPU dry runs of the multi-rank code path): point-to-point, staged through host memory
+    # when the buffers live on a GPU
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     so = np.concatenate([[0], np.cumsum(send_splits)])
     ro = np.concatenate([[0], np.cumsum(recv_splits)])
+    staged = send_buf.is_cuda
+    src = send_buf.cpu() if staged else send_buf
+    dst = torch.empty(recv_buf.shape, dtype=recv_buf.dtype) if staged else recv_buf
     reqs = []
     for q in range(world):
         if q == rank:
             continue
         if recv_splits[q]:
-            reqs.append(dist.irecv(recv_buf[ro[q]:ro[q + 1]], src=q, group=group))
+            reqs.append(dist.irecv(dst[ro[q]:ro[q + 1]], src=q, group=group))
         if send_splits[q]:
-            reqs.append(dist.isend(send_buf[so[q]:so[q + 1]].contiguous(), dst=q, group=group))
+            reqs.append(dist.isend(src[so[q]:so[q + 1]].contiguous(), dst=q, group=group))
 
     class _W(object):
         def wait(self_inner):
             for r in reqs:
                 r.wait()
+            if staged:
+                recv_buf.copy_(dst)
     return _W()
 
 
@@ -146,11 +153,12 @@ class DistGraph(object):
         if device is not None:
             edges = edges.to(device)
         if part is not None or method != "auto" or world == 1:
+            given = part is not None
             if part is None:
                 part = cls.partition(edges, num_nodes, world, "kway" if method == "auto" else method, rank, group, seed)
             dg = cls(HaloPlan(edges, num_nodes, part, rank, world), device=edges.device, group=group,
                      aggregate_fn=aggregate_fn)
-            dg.method = method if part is None else "given"
+            dg.method = "given" if given else method
             return dg
         # "auto": build both plans, keep the one whose slowest rank moves fewer halo rows.  Power-law
         # (RMAT) graphs have almost no locality for a k-way partitioner to find, and then the

@@ -1171,3 +1171,21 @@ def test_transformer_conv_fused_path_equals_udf_path(pgl):
     close(host(out), host(out2), scale=float(out2.abs().max()), rtol=2e-5)
     close(host(gx), host(x.grad), scale=float(x.grad.abs().max()), rtol=1e-4)
     close(host(gw), host(layer.k.weight.grad), scale=float(layer.k.weight.grad.abs().max()), rtol=1e-4)
+
+
+def test_bench_multi_rank_code_path_dry_run():
+    """bench.py --gpus 2 launched exactly as the driver launches it (torch.distributed.run, one process per rank), with
+    PGLAMD_BENCH_DRYRUN=1 so that both ranks share cuda:0 and talk over gloo: partition, halo plan, pack, exchange,
+    local + halo aggregation, max-over-ranks timing and the JSON line all execute (the RCCL transport itself cannot be
+    exercised on a single-GPU box)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGLAMD_BENCH_DRYRUN="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--scale", "16", "--edges", "1000000"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["halo"]["local_edges"] > 0 and "roofline" in rec
