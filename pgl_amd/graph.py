@@ -125,6 +125,7 @@ class Graph(object):
             self._is_tensor, self._device, self._nodes = False, None, None
             self._src32 = self._dst32 = None
             self._seg_cache = {}
+            self._csr_views = None
             return self
         return self.__class__(edges=edges, num_nodes=self._num_nodes, node_feat=nf, edge_feat=ef,
                               adj_src_index=None if self._adj_src_index is None else self._adj_src_index.numpy(False),
@@ -372,6 +373,25 @@ class Graph(object):
 
     def _csr_src(self):
         return self.adj_src_index.csr
+
+    def _csr_order_views(self):
+        """Index views for edge tensors kept in DST-SORTED (CSR) order instead of original edge order: the dst-keyed view
+        has no eid indirection at all (position p of the walk is row p of the tensor), the src-keyed view maps each of
+        its positions to the dst-sorted position of the same edge.  Layers that own a whole score -> softmax -> weighted
+        sum chain keep their [E,H] tensors in this order so that every pass over them is sequential."""
+        if getattr(self, "_csr_views", None) is None:
+            cd, cs = self._csr_dst(), self._csr_src()
+            inv = torch.empty(cd.num_edges, dtype=torch.int32, device=cd.eid32.device)
+            inv[cd.eid32.long()] = torch.arange(cd.num_edges, dtype=torch.int32, device=inv.device)
+            vd, vs = ops.CSR(), ops.CSR()
+            for v, c in ((vd, cd), (vs, cs)):
+                v.degree, v.indptr, v.row32, v.col32 = c.degree, c.indptr, c.row32, c.col32
+                v.num_nodes, v.num_edges = c.num_nodes, c.num_edges
+                v.sorted_v = v.sorted_u = v.sorted_eid = None
+            vd.eid32 = None
+            vs.eid32 = inv[cs.eid32.long()].contiguous()
+            self._csr_views = (vd, vs)
+        return self._csr_views
 
     # ---- message passing (pgl/graph.py:694-966) -------------------------------------------------
     def send(self, message_func, src_feat=None, dst_feat=None, edge_feat=None, node_feat=None):

@@ -150,6 +150,27 @@ class GATv2Conv(nn.Module):
         return output
 
 
+def _dot_attention(graph, k, q, v, dropout=None):
+    """out[v] = sum_{e=(u->v)} softmax_v(<k[u], q[v]>_h) * v[u]  as SDDMM -> segment softmax -> edge-weighted aggregation.
+    When the kernels cover the shape, the [E,H] score / weight tensors never leave DST-SORTED order (they are produced,
+    normalised and consumed by walks of the same CSR), so no pass over them is a random gather; autograd runs the same
+    kernels on the transposed index."""
+    from .. import autograd as ag
+    from .. import ops
+    H, D = int(k.shape[1]), int(k.shape[2])
+    if hasattr(graph, "_csr_order_views") and k.dtype == torch.float32 and ops.sddmm_supported(H, D):
+        cd, cs = graph._csr_order_views()
+        alpha = ag.sddmm(k.contiguous(), q.contiguous(), cd, lambda: cs)
+        alpha = ag.segment_softmax(alpha, ops.SegView(cd.indptr, cd.row32, cd.row32, None))
+        if dropout is not None:
+            alpha = dropout(alpha)
+        return ag.aggregate(v.contiguous(), cd, lambda: cs, "sum", None, alpha.reshape(-1, H, 1), "mul")
+    alpha = GF.edge_softmax(graph, graph.sddmm(k, q))
+    if dropout is not None:
+        alpha = dropout(alpha)
+    return graph.send_ue_recv(v, alpha.reshape(-1, H, 1), "mul", "sum")
+
+
 class TransformerConv(nn.Module):
     """pgl/nn/conv.py:724-885.  With edge features: the reference's UDF path (Graph.send with a message function,
     Graph.recv with a reducer using Message.reduce_softmax / Message.reduce, :796-834).  Without: the same arithmetic
@@ -198,10 +219,7 @@ class TransformerConv(nn.Module):
         if edge_feat is None and hasattr(graph, "sddmm") and k.dtype == torch.float32:
             # same arithmetic as send_attention / reduce_attention below, as three fused graph ops: per-edge q.k scores
             # (SDDMM), softmax over each destination's edges, alpha-weighted sum of v -- no [E, H, D] message tensor
-            alpha = GF.edge_softmax(graph, graph.sddmm(k, q)).reshape(-1, self.num_heads, 1)
-            if self.attn_drop > 1e-15:
-                alpha = self.attn_dropout(alpha)
-            output = graph.send_ue_recv(v, alpha, "mul", "sum")
+            output = _dot_attention(graph, k, q, v, self.attn_dropout if self.attn_drop > 1e-15 else None)
             output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(output, dim=1)
         else:
             msg = graph.send(self.send_attention, src_feat={"k": k, "v": v}, dst_feat={"q": q}, **kw)
