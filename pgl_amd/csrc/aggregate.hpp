@@ -20,7 +20,8 @@ struct AggParams {
     int E, n_chunks, chunk, n_blocks;
     int n_grid_chunks;                    // blocks [0, n_grid_chunks) walk edge chunks, the rest zero-fill
     int j_base, tile_cols;                // this launch covers out columns [j_base, j_base+tile_cols)
-    int gy;                               // y column = j / gy   (YMODE 1)
+    int gy;                               // y column = j / gy   (YMODE 1 / 3)
+    int ypad;                             // YMODE 3: y row length rounded up to a power of two (<= 8); 0 = not applicable
     int mop, is_max, is_mean;
     int zvec;                             // vector width the zero-fill role may use (1, 2, 4)
     int accumulate;                       // 1: combine with the existing out row instead of overwriting

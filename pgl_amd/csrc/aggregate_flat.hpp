@@ -23,7 +23,9 @@ int narrow_max();
 int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_rows, void* out, size_t row_bytes, hipStream_t st);
 
 
-// RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector
+// RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector,
+// 3 = as 1 for NT == 1 and y rows of <= 8 elements (attention weights [E,H,1]): the 8 x ypad operand values of a batch come
+//     from ONE wave-wide load (lane l: edge l / ypad, element l % ypad) and reach their lanes by ds_bpermute
 template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     constexpr int U = 8;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
 
     int yj[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) yj[t] = YMODE == 1 ? j0[t] / p.gy : 0;
+    for (int t = 0; t < NT; ++t) yj[t] = (YMODE == 1 || YMODE == 3) ? j0[t] / p.gy : 0;
 
     A acc[NT][VEC];
     auto reset = [&]() {
@@ -161,13 +163,24 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         for (int i = 0; i < U; ++i) {
             rr[i] = rowp[e + i];
             cc[i] = colp ? colp[e + i] : e + i;
-            if constexpr (YMODE != 0) yy[i] = eidp ? eidp[e + i] : e + i;
+            if constexpr (YMODE == 1 || YMODE == 2) yy[i] = eidp ? eidp[e + i] : e + i;
         }
     };
     // Vector loads retire in issue order (vmcnt), so the id load of batch g+2 is issued BEFORE the rows of batch g+1:
     // waiting for it one iteration later then never waits for younger row gathers.
     auto load_cl = [&](int e, int& cl) {
         if constexpr (has_ss) cl = col_v ? col_v[e + (lane & (U - 1))] : e + (lane & (U - 1));
+    };
+    // YMODE 3: lane l carries element (l % ypad) of the operand row of edge (l / ypad) of the batch
+    const int* __restrict__ eid_v = p.eid;
+    const int ypad = YMODE == 3 ? p.ypad : 1;
+    const int y_edge = lane / ypad, y_elem = lane % ypad;
+    const bool y_lane = YMODE == 3 && y_edge < U && y_elem < (int)p.ldy;
+    auto load_yl = [&](int e, int& yl) {
+        if constexpr (YMODE == 3) { if (y_lane) yl = eid_v ? eid_v[e + y_edge] : e + y_edge; }
+    };
+    auto load_yv = [&](int yl, T& yv) {
+        if constexpr (YMODE == 3) { if (y_lane) yv = y[(int64_t)yl * p.ldy + y_elem]; }
     };
     auto load_rows = [&](const int (&cc)[U], const int (&yy)[U], V (&vx)[U][NT], V (&vy)[U][NT], int cl, float& sv) {
         if constexpr (has_ss) sv = sscale_v[cl];
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
             }
         }
     };
-    auto consume_one = [&](int r, float s, const V (&vx)[NT], const V (&vy)[NT]) {
+    auto consume_one = [&](int r, float s, const V (&vx)[NT], const V (&vy)[NT], T ys = T{}) {
         if (r != cur) { flush_mid(); cur = r; cnt = 0; reset(); }
         ++cnt;
 #pragma unroll
@@ -201,6 +214,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                 if constexpr (std::is_floating_point_v<A>) { if (has_ss) m = m * (A)s; }
                 if constexpr (YMODE == 1) m = apply_mop(m, to_acc<T>(vy[t].v[0]), p.mop);
                 if constexpr (YMODE == 2) m = apply_mop(m, to_acc<T>(vy[t].v[k]), p.mop);
+                if constexpr (YMODE == 3) m = apply_mop(m, to_acc<T>(ys), p.mop);
                 if constexpr (RCLS == 0) acc[t][k] += m;
                 else acc[t][k] = is_max ? (m > acc[t][k] ? m : acc[t][k]) : (m < acc[t][k] ? m : acc[t][k]);
             }
@@ -218,23 +232,33 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     int cA[U], rA[U], yA[U];
     int cB[U], rB[U], yB[U];
     int clA = 0, clB = 0; float svA = 1.f;
+    int ylA = 0, ylB = 0; T yvA{};
     V xA[U][NT], wA[U][NT];
-    if (n_full > 0) { load_cl(e, clA); load_idx(e, cA, rA, yA); }
-    if (n_full > 1) load_cl(e + U, clB);
-    if (n_full > 0) load_rows(cA, yA, xA, wA, clA, svA);
+    if (n_full > 0) { load_cl(e, clA); load_yl(e, ylA); load_idx(e, cA, rA, yA); }
+    if (n_full > 1) { load_cl(e + U, clB); load_yl(e + U, ylB); }
+    if (n_full > 0) { load_yv(ylA, yvA); load_rows(cA, yA, xA, wA, clA, svA); }
     if (PIPE3 && n_full > 1) load_idx(e + U, cB, rB, yB);
     for (int g = 0; g < n_full; ++g) {
         int cC[U], rC[U], yC[U]; int clC = 0; float svB = 1.f;
+        int ylC = 0; T yvB{};
         V xB[U][NT], wB[U][NT];
         const bool more = g + 1 < n_full, more2 = g + 2 < n_full;
-        if (more2) load_cl(e + 2 * U, clC);
+        if (more2) { load_cl(e + 2 * U, clC); load_yl(e + 2 * U, ylC); }
         if (!PIPE3 && more) load_idx(e + U, cB, rB, yB);        // two-deep variant: fewer SGPRs, 8 workgroups per CU
-        if (more) load_rows(cB, yB, xB, wB, clB, svB);          // PIPE3: indices of g+1 are already in SGPRs
+        if (more) { load_yv(ylB, yvB); load_rows(cB, yB, xB, wB, clB, svB); }   // PIPE3: indices of g+1 are already in SGPRs
         if (PIPE3 && more2) load_idx(e + 2 * U, cC, rC, yC);
+        if constexpr (YMODE == 3) {
+            T ys[U];
 #pragma unroll
-        for (int i = 0; i < U; ++i) consume_one(rA[i], lane_scale(svA, i), xA[i], wA[i]);
+            for (int i = 0; i < U; ++i) ys[i] = __shfl(yvA, i * ypad + yj[0], kWave);     // operand of edge i for this lane's column group
+#pragma unroll
+            for (int i = 0; i < U; ++i) consume_one(rA[i], lane_scale(svA, i), xA[i], wA[i], ys[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < U; ++i) consume_one(rA[i], lane_scale(svA, i), xA[i], wA[i]);
+        }
         if (more) {
-            svA = svB;
+            svA = svB; yvA = yvB;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 rA[i] = rB[i];
@@ -243,7 +267,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
             }
         }
         if (more2) {
-            clB = clC;
+            clB = clC; ylB = ylC;
             if constexpr (PIPE3) {
 #pragma unroll
                 for (int i = 0; i < U; ++i) { cB[i] = cC[i]; rB[i] = rC[i]; yB[i] = yC[i]; }
@@ -266,11 +290,11 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (act[t]) {
-                    if constexpr (YMODE == 1) vy[t].v[0] = yr[yj[t]];
+                    if constexpr (YMODE == 1 || YMODE == 3) vy[t].v[0] = yr[yj[t]];
                     else vy[t] = *reinterpret_cast<const V*>(yr + j0[t]);
                 }
         }
-        consume_one(r, s, vx, vy);
+        consume_one(r, s, vx, vy, (YMODE == 3 && act[0]) ? vy[0].v[0] : T{});
     }
 
     // the row open at the end of the chunk
@@ -584,6 +608,7 @@ int32_t dispatch_mode(const AggParams& p, int rcls, int ymode, hipStream_t st, b
     if (rcls == 0) {
         if (ymode == 0) return launch_flat<T, VEC, NT, 0, 0>(p, st);
         if constexpr (std::is_floating_point_v<T>) {      // fp32 / fp64 only: 16-bit and integer operands take the generic path
+            if constexpr (NT == 1) { if (ymode == 1 && p.ypad > 0) return launch_flat<T, VEC, NT, 0, 3>(p, st); }
             if (ymode == 1) return launch_flat<T, VEC, NT, 0, 1>(p, st);
             if (ymode == 2) return launch_flat<T, VEC, NT, 0, 2>(p, st);
         }
@@ -679,7 +704,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     int ymode = 0;
     if (y) {
         if (gy == 1) ymode = 2;
-        else { ymode = 1; while (vmax > 1 && gy % vmax != 0) vmax >>= 1; }
+        else { ymode = 1; if (dy <= 8) { int pd = 1; while (pd < dy) pd <<= 1; p.ypad = pd; } while (vmax > 1 && gy % vmax != 0) vmax >>= 1; }
     }
     int vec = vmax;
     {

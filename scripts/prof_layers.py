@@ -9,7 +9,8 @@ x = torch.randn(N, 128, device=dev)
 which = sys.argv[1] if len(sys.argv) > 1 else "gat"
 train = len(sys.argv) > 2 and sys.argv[2] == "train"
 layer = (pgl.nn.GATConv(128, 16, feat_drop=0.0, attn_drop=0.0, num_heads=8) if which == "gat" else
-         pgl.nn.GCNConv(128, 128) if which == "gcn" else pgl.nn.GraphSageConv(128, 128, "mean")).cuda()
+         pgl.nn.GCNConv(128, 128) if which == "gcn" else pgl.nn.TransformerConv(128, 16, 8, 0.0, 0.0) if which == "transformer" else
+         pgl.nn.GraphSageConv(128, 128, "mean")).cuda()
 if train:
     x.requires_grad_(True)
     for _ in range(8):
