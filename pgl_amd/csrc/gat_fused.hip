@@ -236,12 +236,17 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     int e = e0;
     const int n_full = (e1 - e0) / U;
     if constexpr (!ATT) {
+        // three stages deep, as in agg_flat_kernel: rows of batch g consumed, rows of g+1 in flight, (scalar) indices of
+        // g+2 being fetched -- the scalar-load latency is off the per-batch critical path
         int cA[U], rA[U], eA[U]; V xA[U], yA[U]; float vcA[U], vrA[U], vmA[U], vsA[U], vtA[U];
+        int cB[U], rB[U], eB[U];
         if (n_full > 0) { load_idx(e, cA, rA, eA); load_rows(cA, rA, xA, yA, vcA, vrA, vmA, vsA, vtA); }
+        if (n_full > 1) load_idx(e + U, cB, rB, eB);
         for (int g = 0; g < n_full; ++g) {
-            int cB[U], rB[U], eB[U]; V xB[U], yB[U]; float vcB[U], vrB[U], vmB[U], vsB[U], vtB[U];
-            const bool more = g + 1 < n_full;
-            if (more) { load_idx(e + U, cB, rB, eB); load_rows(cB, rB, xB, yB, vcB, vrB, vmB, vsB, vtB); }
+            int cC[U], rC[U], eC[U]; V xB[U], yB[U]; float vcB[U], vrB[U], vmB[U], vsB[U], vtB[U];
+            const bool more = g + 1 < n_full, more2 = g + 2 < n_full;
+            if (more) load_rows(cB, rB, xB, yB, vcB, vrB, vmB, vsB, vtB);
+            if (more2) load_idx(e + 2 * U, cC, rC, eC);
     #pragma unroll
             for (int i = 0; i < U; ++i) consume(rA[i], eA[i], vcA[i], vrA[i], vmA[i], vsA[i], vtA[i], xA[i], yA[i]);
             if (more) {
@@ -251,6 +256,10 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
                     if constexpr (MODE >= 1) { vmA[i] = vmB[i]; vsA[i] = vsB[i]; }
                     if constexpr (ATT) { vtA[i] = vtB[i]; yA[i] = yB[i]; }
                 }
+            }
+            if (more2) {
+    #pragma unroll
+                for (int i = 0; i < U; ++i) { cB[i] = cC[i]; rB[i] = rC[i]; eB[i] = eC[i]; }
             }
             e += U;
         }
