@@ -242,6 +242,28 @@ int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const f
                             float* grad_feature, float* grad_attn_src, float* grad_attn_dst,
                             float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Additive attention score over a sorted edge stream (GATv2Conv, pgl/nn/conv.py:421-424: send_uv(f, f, "add") ->
+ * leaky_relu -> (alpha * attn).sum(-1), which materialises two [E,H,D] tensors):
+ *   out[eid[p], h] = sum_d w[h,d] * leaky_relu( x_by_col[col[p],h,d] + y_by_row[row[p],h,d] )      (eid NULL: out[p,h])
+ * F32, heads*head_dim <= 256, head_dim/VEC a power of two. */
+int32_t pglamd_add_score(const float* x_by_col, const float* y_by_row, const float* w, int64_t heads,
+                         int64_t head_dim, float negative_slope, const int32_t* row, const int32_t* col,
+                         const int32_t* eid, int64_t num_edges, float* out, void* stream);
+
+/* Backward of pglamd_add_score w.r.t. the ROW node's operand and (optionally) w, one walk of the sorted stream:
+ *   grad_rows[r,h,d]          = sum_{p in row r} grad_score[gi_p,h] * w[h,d] * leaky_relu'(x_by_col[col_p] + y_by_row[r])
+ *   grad_w_partials[c, h*D+d] = sum_{p in chunk c} grad_score[gi_p,h] * leaky_relu(x_by_col[col_p] + y_by_row[r])
+ * with gi_p = eid[p] (p when eid is NULL) and c over pglamd_add_score_chunks(num_edges) chunks (the caller sums the
+ * partials over c; NULL skips them).  The gradient w.r.t. the COLUMN node's operand is the same call on the transposed
+ * index with the two operands swapped.  Workspace: pglamd_gat_aggregate_workspace_bytes. */
+int64_t pglamd_add_score_chunks(int64_t num_edges);
+int32_t pglamd_add_score_backward(const float* x_by_col, const float* y_by_row, const float* w,
+                                  const float* grad_score, int64_t heads, int64_t head_dim,
+                                  float negative_slope, const int32_t* row, const int32_t* col,
+                                  const int32_t* eid, const int64_t* indptr, int64_t num_edges,
+                                  int64_t num_rows, float* grad_rows, float* grad_w_partials,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* SDDMM over a sorted edge stream:  out[eid[p], h] = < x_by_col[col[p], h, :], y_by_row[row[p], h, :] >
  * (eid NULL: out[p, h]).  With (row, col, eid) = the dst-sorted CSR, x = node features and
  * y = the incoming gradient this is d loss / d edge_feature of Graph.send_ue_recv(x, e, "mul", "sum")

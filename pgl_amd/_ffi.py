@@ -43,6 +43,10 @@ _SIGNATURES = {
     "pglamd_gat_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_uint32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp,
                                      c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "pglamd_add_score": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_float, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "pglamd_add_score_chunks": (c_i64, [c_i64]),
+    "pglamd_add_score_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
+                                           c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_sddmm": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "pglamd_seg_ptr_from_ids": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_vp]),
     "pglamd_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp]),

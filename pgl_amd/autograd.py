@@ -301,6 +301,36 @@ def sddmm(x, y, csr_dst, csr_src_fn):
     return ops.sddmm(x, y, csr_dst)
 
 
+class _AddScore(torch.autograd.Function):
+    """s[e, h] = sum_d w[h, d] * leaky(x[src_e] + y[dst_e]): one pass forward; backward is one walk per orientation of the
+    edge list (d y and d w over the dst-keyed index, d x over the src-keyed one)."""
+
+    @staticmethod
+    def forward(ctx, x, y, w, csr_dst, csr_src_fn, slope):
+        ctx.csr_dst, ctx.csr_src_fn, ctx.slope = csr_dst, csr_src_fn, slope
+        ctx.save_for_backward(x, y, w)
+        return ops.add_score(x, y, w, csr_dst, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, w = ctx.saved_tensors
+        g = g.contiguous()
+        gx = gy = gw = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            gy, gw = ops.add_score_backward(x, y, w, g, ctx.csr_dst, int(y.shape[0]), ctx.slope, want_w=ctx.needs_input_grad[2])
+            if gw is not None:
+                gw = gw.reshape(w.shape)
+        if ctx.needs_input_grad[0]:
+            gx, _ = ops.add_score_backward(y, x, w, g, ctx.csr_src_fn(), int(x.shape[0]), ctx.slope)
+        return gx, gy, gw, None, None, None
+
+
+def add_score(x, y, w, csr_dst, csr_src_fn, slope=0.2):
+    if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or w.requires_grad):
+        return _AddScore.apply(x, y, w, csr_dst, csr_src_fn, slope)
+    return ops.add_score(x, y, w, csr_dst, slope)
+
+
 class _ScatterRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, n_rows, index, x):

@@ -53,8 +53,10 @@ struct GatParams {
     const float* row_vec;           // the row node's own vector: f[u] (MODE 2) / g[v] (MODE 3)
     const F4* packed;               // [N,H] (a_dst, m, 1/s, t) of every node as a destination
     float* out_a;                   // [out_rows,H] d a_src (MODE 2) / d a_dst (MODE 3)
-    // sddmm only
+    // sddmm / additive score
     const float* f; const float* g; float* dpre;
+    const float* w;                 // [H*D] score weights (additive score)
+    const float* ge; float* part_w; // additive-score backward: upstream gradient [E,H]; per-chunk partials of d/dw [n_chunks, H*D]
 };
 
 template <int VEC> struct alignas(4 * VEC) FV { float v[VEC]; };
@@ -481,7 +483,8 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
 // (x = node features gathered by source, y = the incoming gradient rows): the reference composes it
 // from two [E,H,D] gathers; here neither is materialised.  Lanes span the H*D columns; the per-head dot
 // product is a xor-shuffle reduction over the D/VEC lanes of a head (a power of two); lane 0 of each head writes.
-template <int VEC>
+// ADDLEAKY: out = sum_d w[h,d] * leaky(x[col] + y[row]) instead of the plain dot product (GATv2's score, pgl/nn/conv.py:421-424)
+template <int VEC, bool ADDLEAKY = false>
 __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
     constexpr int U = 8;
     using V = FV<VEC>;
@@ -501,7 +504,8 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
     const cptr<int> colp = as_const(p.col);
     const cptr<int> eidp = as_const(p.eid);
     int cur = -1;
-    V gv{};
+    V gv{}, wv{};
+    if constexpr (ADDLEAKY) { if (act) wv = *reinterpret_cast<const V*>(p.w + j0); }
     auto load_batch = [&](int e, int nb, int (&rr)[U], int (&ee)[U], V (&fx)[U]) {
 #pragma unroll
         for (int i = 0; i < U; ++i)
@@ -524,7 +528,10 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
                 if (rA[i] != cur) { cur = rA[i]; if (act) gv = *reinterpret_cast<const V*>(p.g + (int64_t)cur * p.d + j0); }
                 float dot = 0.f;
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) dot += gv.v[k] * fA[i].v[k];
+                for (int k = 0; k < VEC; ++k) {
+                    if constexpr (ADDLEAKY) { const float z = gv.v[k] + fA[i].v[k]; dot += wv.v[k] * (z > 0.f ? z : p.slope * z); }
+                    else dot += gv.v[k] * fA[i].v[k];
+                }
                 dot = group_sum(dot, lph);
                 if (writer) p.dpre[(int64_t)eA[i] * p.H + head] = dot;
             }
@@ -532,6 +539,119 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
         for (int i = 0; i < U; ++i) { rA[i] = rB[i]; eA[i] = eB[i]; fA[i] = fB[i]; }
         nA = nB;
     }
+}
+
+// Backward of the additive score  s[p,h] = sum_d w[h,d] * leaky(x[col_p,h,d] + y[row_p,h,d])  w.r.t. the ROW node's operand:
+//     out[r,h,d]      = sum_{p in row r} ge[gi_p,h] * w[h,d] * leaky'(x[col_p,h,d] + y[r,h,d])
+//     part_w[c,h*D+d] = sum_{p in chunk c} ge[gi_p,h] * leaky(x[col_p,h,d] + y[r,h,d])            (optional: d/dw partials)
+// gi_p = eid[p] (or p when eid is NULL).  Same chunk walk, partials and fix-up as the additive mode of gat_flat_kernel; the
+// row node's own vector is fetched only where a row may open.  Called once per orientation of the edge list.
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void add_score_bwd_kernel(GatParams p) {
+    constexpr int U = 4;
+    using V = FV<VEC>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    const int j0 = lane * VEC;
+    const bool act = j0 < p.d;
+    const int head = act ? j0 / p.D : 0;
+    if ((int)blockIdx.x >= p.n_grid_chunks) {           // zero-fill role: rows that receive no edge
+        const int64_t w = ((int64_t)blockIdx.x - p.n_grid_chunks) * kWavesPerBlock + wib;
+        const int64_t r0 = w * kWave;
+        if (r0 >= p.out_rows) return;
+        const int64_t r = r0 + lane;
+        bool empty = false;
+        if (r < p.out_rows) empty = (r >= p.n_csr_rows) || (p.indptr[r] == p.indptr[r + 1]);
+        unsigned long long mk = __ballot(empty);
+        while (mk) {
+            const int l = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            if (act) *reinterpret_cast<V*>(p.out + (r0 + l) * p.d + j0) = V{};
+        }
+        return;
+    }
+    const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
+    if (lb < 0) return;
+    const int c = wave_uniform((int)lb * kWavesPerBlock + wib);
+    if (c >= p.n_chunks) return;
+    const cptr<int> rowp = as_const(p.row);
+    const cptr<int> colp = as_const(p.col);
+    const cptr<int> eidp = as_const(p.eid);
+    const int e0 = chunk_cut(rowp, as_const(p.indptr), c * p.chunk, p.chunk, p.E);
+    const int e1 = chunk_cut(rowp, as_const(p.indptr), c * p.chunk + p.chunk, p.chunk, p.E);
+    V accw{};
+    if (e0 < e1) {
+        const float* __restrict__ x = p.x;
+        const float* __restrict__ rvec = p.row_vec;
+        const float* __restrict__ ge = p.ge;
+        const float slope = p.slope;
+        V wv{};
+        if (act) wv = *reinterpret_cast<const V*>(p.w + j0);
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        int cur = rowp[e0];
+        bool head_open = e0 > 0 && rowp[e0 - 1] == cur;
+        V y_held{};
+        if (act) y_held = *reinterpret_cast<const V*>(rvec + (int64_t)cur * p.d + j0);
+        auto store_row = [&](bool partial, bool headp) {
+            if (!act) return;
+            V o;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
+            if (partial) *reinterpret_cast<V*>((headp ? p.part_head : p.part_tail) + (int64_t)c * p.d + j0) = o;
+            else if (cur < p.out_rows) *reinterpret_cast<V*>(p.out + (int64_t)cur * p.d + j0) = o;
+        };
+        auto consume = [&](int r, float gv, const V& xv, const V& yo) {
+            if (r != cur) {
+                store_row(head_open, true);
+                head_open = false;
+                cur = r;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+                y_held = yo;
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float z = xv.v[k] + y_held.v[k];
+                acc[k] += gv * wv.v[k] * (z > 0.f ? 1.f : slope);
+                accw.v[k] += gv * (z > 0.f ? z : slope * z);
+            }
+        };
+        auto load_batch = [&](int e, int nb, int (&rr)[U], V (&vx)[U], float (&gg)[U], V (&yo)[U]) {
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                if (i < nb) {
+                    rr[i] = rowp[e + i];
+                    const int cc = colp[e + i];
+                    const int gi = eidp ? eidp[e + i] : e + i;
+                    if (act) {
+                        vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc * p.d + j0);
+                        gg[i] = ge[(int64_t)gi * p.H + head];
+                        if (i == 0 || rr[i] != rr[i - 1]) yo[i] = *reinterpret_cast<const V*>(rvec + (int64_t)rr[i] * p.d + j0);
+                    }
+                }
+        };
+        int rA[U]; V xA[U], yA[U]; float gA[U];
+        int nA = min(U, e1 - e0);
+        load_batch(e0, nA, rA, xA, gA, yA);
+        for (int e = e0; e < e1; e += U) {
+            int rB[U]; V xB[U], yB[U]; float gB[U];
+            const int nB = max(0, min(U, e1 - (e + U)));
+            if (nB > 0) load_batch(e + U, nB, rB, xB, gB, yB);
+#pragma unroll
+            for (int i = 0; i < U; ++i)
+                if (i < nA) consume(rA[i], gA[i], xA[i], yA[i]);
+#pragma unroll
+            for (int i = 0; i < U; ++i) { rA[i] = rB[i]; xA[i] = xB[i]; yA[i] = yB[i]; gA[i] = gB[i]; }
+            nA = nB;
+        }
+        const bool tail_open = e1 < p.E && rowp[e1] == cur;
+        if (head_open) store_row(true, true);
+        else if (tail_open) { store_row(true, false); if (lane == 0) p.long_list[atomicAdd(p.long_count, 1)] = c; }
+        else store_row(false, false);
+    }
+    if (p.part_w && act) *reinterpret_cast<V*>(p.part_w + (int64_t)c * p.d + j0) = accw;     // every chunk writes (zeros if empty)
 }
 
 // t[v,h] = <g[v,h,:], out[v,h,:]> (the softmax-backward row term) and the destination-side scalars of every
@@ -771,5 +891,87 @@ extern "C" int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, in
         default: hipLaunchKernelGGL(sddmm_kernel<4>, dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p); break;
     }
     PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+extern "C" int64_t pglamd_add_score_chunks(int64_t num_edges) { return num_edges > 0 ? ceil_div(num_edges, gat_chunk_edges()) : 0; }
+
+extern "C" int32_t pglamd_add_score(const float* x_by_col, const float* y_by_row, const float* w, int64_t heads, int64_t head_dim,
+                                    float negative_slope, const int32_t* row, const int32_t* col, const int32_t* eid,
+                                    int64_t num_edges, float* out, void* stream) {
+    if (heads <= 0 || head_dim <= 0 || num_edges < 0 || (num_edges > 0 && (!x_by_col || !y_by_row || !w || !row || !col || !out)))
+        return fail(PGLAMD_E_ARG, "add_score: bad argument");
+    if (num_edges > kMaxEdges) return fail(PGLAMD_E_RANGE, "add_score: sizes beyond int32 engine range");
+    if (num_edges == 0) return PGLAMD_OK;
+    const int vec = gat_vec(heads, head_dim, x_by_col, y_by_row, w, true);
+    if (vec == 0 || heads > kWave)
+        return fail(PGLAMD_E_SHAPE, "add_score: heads*head_dim = %lld needs one 64-lane tile and head_dim/VEC a power of two", (long long)(heads * head_dim));
+    GatParams p{};
+    p.H = (int)heads; p.D = (int)head_dim; p.d = (int)(heads * head_dim); p.slope = negative_slope;
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.row = row; p.col = col; p.eid = eid; p.f = x_by_col; p.g = y_by_row; p.w = w; p.dpre = out;
+    const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
+    p.n_blocks = (int)nb;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (vec) {
+        case 1: hipLaunchKernelGGL((sddmm_kernel<1, true>), dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((sddmm_kernel<2, true>), dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p); break;
+        default: hipLaunchKernelGGL((sddmm_kernel<4, true>), dim3((unsigned)xcd_grid(nb)), dim3(kBlock), 0, st, p); break;
+    }
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+extern "C" int32_t pglamd_add_score_backward(const float* x_by_col, const float* y_by_row, const float* w, const float* grad_score,
+                                             int64_t heads, int64_t head_dim, float negative_slope, const int32_t* row,
+                                             const int32_t* col, const int32_t* eid, const int64_t* indptr, int64_t num_edges,
+                                             int64_t num_rows, float* grad_rows, float* grad_w_partials, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    if (heads <= 0 || head_dim <= 0 || num_edges < 0 || num_rows < 0 || !grad_rows ||
+        (num_edges > 0 && (!x_by_col || !y_by_row || !w || !grad_score || !row || !col || !indptr)))
+        return fail(PGLAMD_E_ARG, "add_score_backward: bad argument");
+    if (num_edges > kMaxEdges || num_rows >= INT32_MAX) return fail(PGLAMD_E_RANGE, "add_score_backward: sizes beyond int32 engine range");
+    const int64_t d = heads * head_dim;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (num_rows == 0) return PGLAMD_OK;
+    if (num_edges == 0) {
+        PGLAMD_HIP_CHECK(hipMemsetAsync(grad_rows, 0, (size_t)num_rows * d * sizeof(float), st));
+        return PGLAMD_OK;
+    }
+    const int vec = gat_vec(heads, head_dim, x_by_col, y_by_row, grad_rows, false);
+    if (vec == 0 || heads > kWave || reinterpret_cast<uintptr_t>(w) % 16 || reinterpret_cast<uintptr_t>(workspace) % 16 ||
+        (grad_w_partials && reinterpret_cast<uintptr_t>(grad_w_partials) % 16))
+        return fail(PGLAMD_E_SHAPE, "add_score_backward: heads*head_dim = %lld does not fit one 64-lane tile", (long long)d);
+    if (!workspace || workspace_bytes < pglamd_gat_aggregate_workspace_bytes(num_edges, heads, head_dim))
+        return fail(PGLAMD_E_WORKSPACE, "add_score_backward: workspace too small");
+    GatParams p{};
+    p.H = (int)heads; p.D = (int)head_dim; p.d = (int)d; p.slope = negative_slope;
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
+    p.x = x_by_col; p.row_vec = y_by_row; p.w = w; p.ge = grad_score; p.out = grad_rows; p.part_w = grad_w_partials;
+    p.out_rows = num_rows; p.n_csr_rows = num_rows;
+    gat_setup_partials(p, workspace, 1);
+    const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
+    p.n_blocks = (int)nb;
+    p.n_grid_chunks = (int)xcd_grid(nb);
+    const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
+    if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
+#define PGLAMD_ASB(V)                                                                                                                   \
+    do {                                                                                                                               \
+        hipLaunchKernelGGL(add_score_bwd_kernel<V>, dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);                    \
+        PGLAMD_LAUNCH_CHECK();                                                                                                         \
+        if (p.n_chunks > 1) {                                                                                                          \
+            hipLaunchKernelGGL((gat_fixup_kernel<V, false, 1>), dim3((unsigned)std::min<int64_t>(kGatFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p); \
+            PGLAMD_LAUNCH_CHECK();                                                                                                     \
+            hipLaunchKernelGGL((gat_fixup_kernel<V, true, 1>), dim3((unsigned)std::min<int64_t>(kGatFixGridLong, p.n_chunks)), dim3(kGatFixWaves * kWave), 0, st, p); \
+            PGLAMD_LAUNCH_CHECK();                                                                                                     \
+        }                                                                                                                              \
+    } while (0)
+    switch (vec) {
+        case 1: PGLAMD_ASB(1); break;
+        case 2: PGLAMD_ASB(2); break;
+        default: PGLAMD_ASB(4); break;
+    }
+#undef PGLAMD_ASB
     return PGLAMD_OK;
 }

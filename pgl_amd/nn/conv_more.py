@@ -138,12 +138,25 @@ class GATv2Conv(nn.Module):
         if self.feat_drop > 1e-15:
             feature = self.feat_dropout(feature)
         feature = self.linear(feature).reshape(-1, self.num_heads, self.hidden_size)
-        alpha = self.leaky_relu(graph.send_uv(feature, feature, "add"))
-        alpha = torch.sum(alpha * self.attn, dim=-1)
-        alpha = GF.edge_softmax(graph, alpha).reshape(-1, self.num_heads, 1)
-        if self.attn_drop > 1e-15:
-            alpha = self.attn_dropout(alpha)
-        output = graph.send_ue_recv(feature, alpha, "mul", "sum")
+        from .. import autograd as ag
+        from .. import ops
+        if (hasattr(graph, "_csr_order_views") and feature.dtype == torch.float32 and feature.is_cuda
+                and ops.sddmm_supported(self.num_heads, self.hidden_size)):
+            # the reference's send_uv(add) -> leaky_relu -> (* attn).sum(-1) -> edge_softmax -> send_ue_recv chain without its
+            # two [E, H, D] tensors: additive-score kernel, segment softmax and weighted aggregation, all in dst-sorted order
+            cd, cs = graph._csr_order_views()
+            alpha = ag.add_score(feature, feature, self.attn.reshape(self.num_heads, self.hidden_size), cd, lambda: cs, 0.2)
+            alpha = ag.segment_softmax(alpha, ops.SegView(cd.indptr, cd.row32, cd.row32, None))
+            if self.attn_drop > 1e-15:
+                alpha = self.attn_dropout(alpha)
+            output = ag.aggregate(feature.contiguous(), cd, lambda: cs, "sum", None, alpha.reshape(-1, self.num_heads, 1), "mul")
+        else:
+            alpha = self.leaky_relu(graph.send_uv(feature, feature, "add"))
+            alpha = torch.sum(alpha * self.attn, dim=-1)
+            alpha = GF.edge_softmax(graph, alpha).reshape(-1, self.num_heads, 1)
+            if self.attn_drop > 1e-15:
+                alpha = self.attn_dropout(alpha)
+            output = graph.send_ue_recv(feature, alpha, "mul", "sum")
         output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(output, dim=1)
         if self.activation is not None:
             output = self.activation(output)

@@ -392,6 +392,41 @@ def sddmm(x, y, csr):
     return out
 
 
+def add_score(x, y, w, csr, negative_slope=0.2):
+    """s[e, h] = sum_d w[h, d] * leaky_relu(x[src_e, h, d] + y[dst_e, h, d]) for the edges of the dst-sorted `csr`, in the
+    order its eid32 defines (None: CSR order).  GATv2's attention score without the [E, H, D] tensors."""
+    _need_cuda(x, y, w)
+    x = x.contiguous(); y = y.contiguous(); w = w.contiguous()
+    H, D = int(x.shape[1]), int(x.shape[2])
+    out = torch.empty((csr.num_edges, H), dtype=torch.float32, device=x.device)
+    if csr.num_edges:
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().pglamd_add_score(_ptr(x), _ptr(y), _ptr(w), H, D, float(negative_slope), _ptr(csr.row32),
+                                                   _ptr(csr.col32), _ptr(csr.eid32), csr.num_edges, _ptr(out), _stream(x)), "add_score")
+    return out
+
+
+def add_score_backward(x_by_col, y_by_row, w, grad_score, csr, n_rows, negative_slope=0.2, want_w=False):
+    """Gradient of add_score w.r.t. the operand of `csr`'s ROW nodes (and, if want_w, w): see include/pgl_amd.h."""
+    _need_cuda(x_by_col, y_by_row, w, grad_score)
+    x_by_col = x_by_col.contiguous(); y_by_row = y_by_row.contiguous(); w = w.contiguous(); grad_score = grad_score.contiguous()
+    H, D = int(x_by_col.shape[1]), int(x_by_col.shape[2])
+    L = _ffi.lib()
+    out = torch.empty((int(n_rows), H, D), dtype=torch.float32, device=x_by_col.device)
+    wpart = None
+    if want_w:
+        wpart = torch.empty((max(int(L.pglamd_add_score_chunks(csr.num_edges)), 1), H * D), dtype=torch.float32, device=out.device)
+        if csr.num_edges == 0:
+            wpart.zero_()
+    ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), out.device)
+    with torch.cuda.device(out.device):
+        _ffi.check(L.pglamd_add_score_backward(_ptr(x_by_col), _ptr(y_by_row), _ptr(w), _ptr(grad_score), H, D, float(negative_slope),
+                                               _ptr(csr.row32), _ptr(csr.col32), _ptr(csr.eid32), _ptr(csr.indptr), csr.num_edges,
+                                               int(n_rows), _ptr(out), _ptr(wpart), _ptr(ws), ws.numel(), _stream(out)),
+                   "add_score_backward")
+    return out, (wpart.sum(0) if want_w else None)
+
+
 def sddmm_supported(H, D):
     vec = 4 if D % 4 == 0 else 2 if D % 2 == 0 else 1
     lph = D // vec

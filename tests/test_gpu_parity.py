@@ -1189,3 +1189,30 @@ def test_bench_multi_rank_code_path_dry_run():
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["scaling"] == "strong"
     assert rec["halo"]["local_edges"] > 0 and "roofline" in rec
+
+
+@pytest.mark.parametrize("H,D", [(4, 8), (8, 16), (1, 64), (3, 4)])
+@pytest.mark.parametrize("order", ["edge", "csr"])
+def test_additive_score_and_gradients(pgl, H, D, order):
+    """GATv2's score sum_d w[h,d] * leaky(x[src] + y[dst]) and all three gradients vs the composed torch formulation;
+    hub rows span many chunks (partials + fix-up), in original edge order and in dst-sorted order."""
+    from pgl_amd import autograd as ag
+    n, e = 1500, 24000
+    edges, rng = rand_graph(n, e, 900 + H, hub=4000)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    mk = lambda *s: dev(rng.standard_normal(s).astype(np.float32)).requires_grad_(True)
+    x, y, w = mk(n, H, D), mk(n, H, D), mk(H, D)
+    if order == "edge":
+        cd, cs = g._csr_dst(), g._csr_src()
+        src, dst = torch.as_tensor(edges[:, 0]).cuda(), torch.as_tensor(edges[:, 1]).cuda()
+    else:
+        cd, cs = g._csr_order_views()
+        src, dst = cd.col32.long(), cd.row32.long()
+    out = ag.add_score(x, y, w, cd, lambda: cs, 0.2)
+    x2, y2, w2 = (t.detach().clone().requires_grad_(True) for t in (x, y, w))
+    ref = (torch.nn.functional.leaky_relu(x2[src] + y2[dst], 0.2) * w2).sum(-1)
+    close(host(out), host(ref), scale=float(ref.abs().max()), rtol=2e-5)
+    ct = dev(rng.standard_normal((e, H)).astype(np.float32))
+    (out * ct).sum().backward(); (ref * ct).sum().backward()
+    for a, b, name in ((x, x2, "x"), (y, y2, "y"), (w, w2, "w")):
+        close(host(a.grad), host(b.grad), scale=float(b.grad.abs().max()), rtol=1e-4)
