@@ -301,6 +301,38 @@ def sddmm(x, y, csr_dst, csr_src_fn):
     return ops.sddmm(x, y, csr_dst)
 
 
+class _PropagateStep(torch.autograd.Function):
+    """out = c * res + dst_scale (.) A x  in one aggregation launch: `out` starts as c * res and the kernel adds the
+    scaled row sums into it (accumulate mode).  The k-hop layers (APPNP, SGC, SSGC, GPR) iterate on g = norm (.) h, for
+    which one hop of  norm (.) A (norm (.) h)  is exactly this with dst_scale = norm^2 -- no per-hop scaling passes."""
+
+    @staticmethod
+    def forward(ctx, x, res, c, dst_scale, csr, csr_t_fn):
+        ctx.csr_t_fn, ctx.c, ctx.has_res = csr_t_fn, c, res is not None
+        ctx.save_for_backward(dst_scale)
+        ctx.n_x = int(x.shape[0])
+        if res is None:
+            return ops.aggregate(x, csr, "sum", None, dst_scale=dst_scale)
+        out = res * c
+        return ops.aggregate(x, csr, "sum", None, dst_scale=dst_scale, out=out, accumulate=True)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (dst_scale,) = ctx.saved_tensors
+        grad = grad.contiguous()
+        gx = ops.aggregate(grad, ctx.csr_t_fn(), "sum", ctx.n_x, src_scale=dst_scale) if ctx.needs_input_grad[0] else None
+        gres = grad * ctx.c if (ctx.has_res and ctx.needs_input_grad[1]) else None
+        return gx, gres, None, None, None, None
+
+
+def propagate_step(x, dst_scale, csr, csr_t_fn, res=None, c=0.0):
+    if torch.is_grad_enabled() and (x.requires_grad or (res is not None and res.requires_grad)):
+        return _PropagateStep.apply(x, res, c, dst_scale, csr, csr_t_fn)
+    if res is None:
+        return ops.aggregate(x, csr, "sum", None, dst_scale=dst_scale)
+    return ops.aggregate(x, csr, "sum", None, dst_scale=dst_scale, out=res * c, accumulate=True)
+
+
 class _AddScore(torch.autograd.Function):
     """s[e, h] = sum_d w[h, d] * leaky(x[src_e] + y[dst_e]): one pass forward; backward is one walk per orientation of the
     edge list (d y and d w over the dst-keyed index, d x over the src-keyed one)."""

@@ -499,6 +499,14 @@ class Graph(object):
             raise ValueError("dst_scale must hold one value per destination node (%d), got %d" % (feature.shape[0], ds.numel()))
         return ag.aggregate(feature, self._csr_dst(), self._csr_src, "sum", None, None, "add", None, None, ss, ds)
 
+    def propagate_step(self, feature, dst_scale, residual=None, residual_scale=0.0):
+        """residual_scale * residual + dst_scale (.) (sum over in-edges of feature[src]) in one launch (engine extension
+        for the k-hop propagation layers; fp32, dst_scale one value per node)."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        return ag.propagate_step(feature.contiguous(), dst_scale.reshape(-1).contiguous(), self._csr_dst(), self._csr_src,
+                                 None if residual is None else residual.contiguous(), float(residual_scale))
+
     def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2, attn_drop=0.0, seed=0):
         """send_uv(add) -> leaky_relu -> edge_softmax -> dropout -> send_ue_recv(mul, sum) of GATConv
         (pgl/nn/conv.py:331-339) fused into one pass, differentiable (engine extension; fp32)."""

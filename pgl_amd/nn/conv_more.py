@@ -28,6 +28,14 @@ def _norm_propagate(graph, feature, norm):
     return graph.send_recv(feature * norm, "sum") * norm
 
 
+def _g_domain(graph, feature, norm):
+    """True when k-hop propagation can iterate on g = norm (.) h: one hop of norm (.) A (norm (.) h) is then a single
+    aggregation with dst_scale = norm^2 (plus an optional residual folded into the same launch) instead of
+    scale -> aggregate -> scale (-> axpby): fp32 features, one norm value per node, strictly positive."""
+    return (hasattr(graph, "propagate_step") and feature.dtype == torch.float32 and norm.dtype == torch.float32
+            and feature.dim() == 2 and norm.numel() == feature.shape[0])
+
+
 class LightGCNConv(nn.Module):
     def forward(self, graph, feature):
         return _norm_propagate(graph, feature, GF.degree_norm(graph))
@@ -44,6 +52,12 @@ class SGCConv(nn.Module):
 
     def _propagate(self, graph, feature):
         norm = GF.degree_norm(graph)
+        if _g_domain(graph, feature, norm) and self.k_hop > 1:
+            n2 = norm * norm
+            g = feature * norm
+            for _ in range(self.k_hop):
+                g = graph.propagate_step(g, n2)
+            return g / norm
         for _ in range(self.k_hop):
             feature = _norm_propagate(graph, feature, norm)
         return feature
@@ -77,6 +91,14 @@ class APPNP(nn.Module):
         if norm is None:
             norm = GF.degree_norm(graph)
         h0 = feature
+        if _g_domain(graph, feature, norm):
+            # h <- alpha h0 + (1 - alpha) n (.) A (n (.) h)   ==   g <- alpha g0 + (1 - alpha) n^2 (.) A g   with g = n (.) h
+            scale = (1 - self.alpha) * norm * norm
+            g0 = feature * norm
+            g = g0
+            for _ in range(self.k_hop):
+                g = graph.propagate_step(g, scale, residual=g0, residual_scale=self.alpha)
+            return g / norm
         for _ in range(self.k_hop):
             feature = _norm_propagate(graph, feature, norm)
             feature = self.alpha * h0 + (1 - self.alpha) * feature
@@ -97,8 +119,13 @@ class GCNII(nn.Module):
         h0 = feature
         for i in range(self.k_hop):
             beta_i = math.log(1.0 * self.lambda_l / (i + 1) + 1)
-            feature = _norm_propagate(graph, self.drop_fn(feature), norm)
-            feature = self.alpha * h0 + (1 - self.alpha) * feature
+            feature = self.drop_fn(feature)
+            if _g_domain(graph, feature, norm):
+                # alpha h0 + (1 - alpha) n (.) A (n (.) f): residual and destination norm folded into the aggregation launch
+                feature = graph.propagate_step(feature * norm, (1 - self.alpha) * norm, residual=h0, residual_scale=self.alpha)
+            else:
+                feature = _norm_propagate(graph, feature, norm)
+                feature = self.alpha * h0 + (1 - self.alpha) * feature
             feature = beta_i * self.mlps[i](feature) + (1 - beta_i) * feature
             if self.activation is not None:
                 feature = self.activation(feature)
@@ -319,6 +346,14 @@ class GPRConv(nn.Module):
             feature = self.feat_dropout_2(feature)
         if norm is None:
             norm = GF.degree_norm(graph)
+        if _g_domain(graph, feature, norm):
+            n2 = norm * norm
+            g = feature * norm
+            hidden = g * self.temp[0]
+            for k in range(self.k_hop):
+                g = graph.propagate_step(g, n2)
+                hidden = hidden + self.temp[k + 1] * g
+            return hidden / norm
         hidden = feature * self.temp[0]
         for k in range(self.k_hop):
             feature = _norm_propagate(graph, feature, norm)
@@ -368,6 +403,14 @@ class SSGCConv(nn.Module):
     def _propagate(self, graph, feature):
         norm = GF.degree_norm(graph)
         ori_feature = feature
+        if _g_domain(graph, feature, norm):
+            scale = (1 - self.alpha) * norm * norm
+            g = feature * norm
+            sum_g = g
+            for _ in range(self.k_hop):
+                g = graph.propagate_step(g, scale)
+                sum_g = sum_g + g
+            return sum_g / (norm * self.k_hop) + self.alpha * ori_feature
         sum_feature = feature
         for _ in range(self.k_hop):
             feature = (1 - self.alpha) * _norm_propagate(graph, feature, norm)
