@@ -8,8 +8,11 @@ A "step" is ONE pass of Graph.send_recv(x, "sum") (= pglamd_aggregate through th
 whole synthetic graph with the feature matrix already resident in HBM.
 Workload (config.workload): BASELINE.json configs[1] -- RMAT (0.57,0.19,0.19,0.05) |V| = 2^20,
 |E| = 20 M, d = 128 fp32, graph seed 42, feature seed 7.
-N > 1: the SAME global graph is partitioned over the N ranks (strong scaling); one halo
-all-to-all-v (RCCL) per step overlapped with the interior rows; value = global |E| / max-rank time.
+N > 1: the SAME global graph and feature matrix (strong scaling), spread over the N ranks in one of two ways:
+  rows  row partition of the graph, one halo all-to-all-v (RCCL) per step overlapped with the interior rows (DistGraph);
+  cols  the graph replicated on every GPU, the feature COLUMNS split: out[:, cols_r] = A x[:, cols_r] needs no data-path
+        collective at all (FeatureShardedGraph) -- the better fit for graphs no partitioner can cut (RMAT: 82 % edge cut).
+--parallel auto (default) runs the warm-up steps of both and times the faster; value = global |E| / max-rank time.
 
 Output: one JSON line on rank 0 with the driver's contract fields plus
   roofline     -- dominant kernel (agg_flat_kernel) algorithmic bytes / its HIP-event time vs 8 TB/s
@@ -87,6 +90,10 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--partition", default="random", choices=["auto", "kway", "random"],
                     help="row partition for N > 1.  RMAT has no locality for a k-way partitioner to find (measured at C2, P=8: 82 %% of edges cut vs 87.5 %% random, slowest-rank halo 268 k vs 251 k rows), so the balanced random assignment is the default; auto = build both, keep the smaller slowest-rank halo")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "rows", "cols"],
+                    help="N > 1: 'rows' = row partition + RCCL halo all-to-all-v per step (DistGraph); 'cols' = graph replicated, "
+                         "feature columns split over the ranks, no data-path collective (FeatureShardedGraph); 'auto' = run the "
+                         "warm-up steps of both and keep the faster (max over ranks), falling back to 'cols' if the halo path fails")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -127,14 +134,49 @@ def main():
         halo = None
     else:
         import torch.distributed as dist
-        from pgl_amd.distributed import DistGraph
-        dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev)
-        x_own = dg.take_owned(x)
-        del x
-        step = lambda: dg.send_recv(x_own, "sum")
+        from pgl_amd.distributed import DistGraph, FeatureShardedGraph
         sync = lambda: torch.cuda.synchronize()
         barrier = lambda: dist.barrier()
-        halo = dg.stats()
+        cand = {}
+        if args.parallel in ("cols", "auto"):
+            g = pgl.Graph(edges=edges, num_nodes=N)
+            g.adj_dst_index
+            fs = FeatureShardedGraph(g, rank, world)
+            x_cols = fs.take_cols(x)
+            cand["cols"] = (lambda: fs.send_recv(x_cols, "sum"), fs.stats(), (int(x_cols.shape[1]), N, E))
+        if args.parallel in ("rows", "auto"):
+            try:
+                dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev)
+                x_own = dg.take_owned(x)
+                st = dg.stats()
+                cand["rows"] = (lambda: dg.send_recv(x_own, "sum"), st, (d, st["local_rows"], st["local_edges"]))
+            except Exception as ex:                                  # noqa: BLE001 -- report and keep the other mode
+                if args.parallel == "rows":
+                    raise
+                print("[bench] row-partition mode unavailable on rank %d: %r" % (rank, ex), file=sys.stderr, flush=True)
+        del x
+
+        def timed(fn, n):
+            sync(); barrier(); sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            sync()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        ok = torch.tensor([1 if "rows" in cand else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # every rank must have the same candidates
+        if not int(ok.item()):
+            cand.pop("rows", None)
+        trial = {}
+        for name, (fn, _, _) in cand.items():
+            fn(); fn()
+            trial[name] = timed(fn, max(args.warmup, 3))
+        mode = min(trial, key=trial.get)
+        step, halo, (d_loc, n_loc, e_loc) = cand[mode]
+        halo = dict(halo, mode=mode, trial_ms_per_step={k: v / max(args.warmup, 3) * 1e3 for k, v in trial.items()})
 
     for _ in range(args.warmup):
         step()
@@ -157,7 +199,7 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = E * args.steps / dt
-        B = algorithmic_bytes(E if world == 1 else halo["local_edges"], N if world == 1 else halo["local_rows"], d, 4)
+        B = algorithmic_bytes(E, N, d, 4) if world == 1 else algorithmic_bytes(e_loc, n_loc, d_loc, 4)
         kms = kern_ms / max(args.steps, 1)          # flat-kernel time per step (1 launch at N=1; local + halo launches at N>1)
         achieved = B / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         rec = {
@@ -168,7 +210,9 @@ def main():
             "config": {"workload": "RMAT(0.57,0.19,0.19,0.05) scale %d |V|=%d |E|=%d d=%d fp32, Graph.send_recv(sum) "
                                    "via pglamd_aggregate (BASELINE configs[1])" % (args.scale, N, E, d),
                        "graph_seed": 42, "feature_seed": 7,
-                       "parallelism": "single GPU" if world == 1 else "row partition (%s) x%d + RCCL halo all-to-all-v" % (halo["partition"], world)},
+                       "parallelism": "single GPU" if world == 1 else
+                       ("row partition (%s) x%d + RCCL halo all-to-all-v" % (halo["partition"], world) if halo["mode"] == "rows" else
+                        "feature columns x%d (graph replicated, %d of %d columns per GPU, no data-path collective)" % (world, d_loc, d))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.scale, E, d) if world == 1 else None,

@@ -3,7 +3,10 @@
 #pragma once
 #include "common.hpp"
 
+#include <string>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 namespace pglamd {
 
@@ -83,6 +86,15 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
         }
     }
 }
+
+// Optional in-library timing of the aggregation kernels (bench.py roofline leg): while enabled, every edge-kernel launch is
+// bracketed by a pair of HIP events on the launch stream.
+struct ProfileState {
+    bool on = false;
+    std::string last_kernel;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+ProfileState& prof();      // defined once, in aggregate.hip
 
 // aggregate.hip: edges per chunk (256; PGLAMD_CHUNK overrides, used by the stress tests)
 int chunk_edges();

@@ -12,13 +12,6 @@
 
 namespace pglamd {
 
-// defined once, in aggregate.hip
-struct ProfileState {
-    bool on = false;
-    std::string last_kernel;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-};
-ProfileState& prof();
 int narrow_max();
 int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_rows, void* out, size_t row_bytes, hipStream_t st);
 
@@ -741,7 +734,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half + lst);
         // measured at C2 sizes: the lane-per-edge kernel wins up to 32 B of accumulator per row for every reduce op
         // (2.6-3.4x at d <= 8 fp32) and up to 64 B for sum / mean (1.3x at d = 16 fp32)
-        if (dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= (rcls == 0 ? 64u : 32u)) {
+        if (dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {
             AggParams q = p;
             const int nk = std::max(K, narrow_chunk_edges());                   // fewer, longer chunks: the carved arrays still fit
             q.chunk = nk; q.n_chunks = (int)ceil_div(E, nk);

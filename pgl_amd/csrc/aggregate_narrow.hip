@@ -23,6 +23,39 @@ namespace pglamd {
 namespace {
 
 template <typename T> __device__ __forceinline__ T shfl_up_t(T v, int off) { return __shfl_up(v, off, kWave); }
+
+// value of lane (l - OFF) within the lane's 16-lane DPP row (row_shr:OFF; lanes whose source falls outside the row keep
+// their own value -- the caller masks them) and of one wave-uniform lane, for 32- and 64-bit element types: VALU / SALU
+// moves, no LDS round trip.
+template <int OFF> __device__ __forceinline__ unsigned dpp_row_shr_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x110 + OFF, 0xF, 0xF, false);
+}
+template <int OFF, typename T> __device__ __forceinline__ T dpp_row_shr(T v) {
+    if constexpr (sizeof(T) == 4) {
+        unsigned u; __builtin_memcpy(&u, &v, 4);
+        u = dpp_row_shr_u32<OFF>(u);
+        T o; __builtin_memcpy(&o, &u, 4);
+        return o;
+    } else {
+        unsigned u[2]; __builtin_memcpy(u, &v, 8);
+        u[0] = dpp_row_shr_u32<OFF>(u[0]); u[1] = dpp_row_shr_u32<OFF>(u[1]);
+        T o; __builtin_memcpy(&o, u, 8);
+        return o;
+    }
+}
+template <typename T> __device__ __forceinline__ T read_lane(T v, int src_lane) {       // src_lane wave-uniform
+    if constexpr (sizeof(T) == 4) {
+        unsigned u; __builtin_memcpy(&u, &v, 4);
+        u = (unsigned)__builtin_amdgcn_readlane((int)u, src_lane);
+        T o; __builtin_memcpy(&o, &u, 4);
+        return o;
+    } else {
+        unsigned u[2]; __builtin_memcpy(u, &v, 8);
+        u[0] = (unsigned)__builtin_amdgcn_readlane((int)u[0], src_lane); u[1] = (unsigned)__builtin_amdgcn_readlane((int)u[1], src_lane);
+        T o; __builtin_memcpy(&o, u, 8);
+        return o;
+    }
+}
 template <typename T> __device__ __forceinline__ T shfl_t(T v, int src) { return __shfl(v, src, kWave); }
 
 // Rescale factor exp(v), v <= 0, between two running maxima.  fp32 uses the hardware exp2 (relative error
@@ -42,14 +75,14 @@ template <typename A> __device__ __forceinline__ void softmax_merge(A m1, A s1, 
 //       of exp(x - max), one 64-byte line for d = 8 fp32; partials use the same layout).   YMODE: 0 none, 1 y is [E] / [E,1] (one value per edge), 2 y is [E,d]
 template <typename T, int D, int RCLS, int YMODE>
 __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
-    constexpr int NB = 4;                                  // batches of 64 edges whose loads are issued together
+    constexpr int NB = D * sizeof(typename AccT<T>::type) >= 64 ? 2 : 4;   // batches of 64 edges whose loads are issued together (fewer for 64-byte rows: registers)
     constexpr int VL = (D * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : D;   // elements per load instruction
     using A = typename AccT<T>::type;
     using VLoad = VecT<T, VL>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
     const int d = p.tile_cols;
-    const bool exact = d == D && p.narrow_vec != 0;
+    const bool exact = p.narrow_vec != 0 && d % VL == 0;    // rows move as whole VL-element vectors (d = 12: three 16-byte loads)
     const bool is_max = p.is_max != 0;
     T* __restrict__ out = static_cast<T*>(p.out);
 
@@ -61,7 +94,8 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
         T* dst = out + r * p.ldo;
         if (exact) {
 #pragma unroll
-            for (int k0 = 0; k0 < D; k0 += VL) *reinterpret_cast<VLoad*>(dst + k0) = VLoad{};
+            for (int k0 = 0; k0 < D; k0 += VL)
+                if (k0 < d) *reinterpret_cast<VLoad*>(dst + k0) = VLoad{};
         } else {
             for (int k = 0; k < d; ++k) dst[k] = from_acc<T>(A(0));
         }
@@ -86,10 +120,18 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
     const float* __restrict__ sscale = p.src_scale;
 
     constexpr bool SM = RCLS == 2;
-    auto ident = [&]() -> A { return RCLS == 0 ? A(0) : ((is_max || SM) ? Limits<A>::lo() : Limits<A>::hi()); };
+    // min runs as max over order-reversed values (-x for floats, ~x for integers: both exact), so the scan has ONE
+    // compare-select per step; values are flipped when loaded and flipped back wherever they leave the kernel
+    const bool flip_min = RCLS == 1 && !is_max;
+    auto flip = [&](A a) -> A {
+        if constexpr (std::is_floating_point_v<A>) return -a; else return ~a;
+    };
+    auto ident = [&]() -> A { return RCLS == 0 ? A(0) : Limits<A>::lo(); };
     auto comb = [&](A a, A b) -> A {                       // a = earlier edges, b = later edges
         if constexpr (RCLS == 0) return a + b;
-        else return is_max ? (b > a ? b : a) : (b < a ? b : a);
+        else if constexpr (std::is_same_v<A, float>) return __builtin_fmaxf(a, b);       // v_max_f32
+        else if constexpr (std::is_same_v<A, double>) return __builtin_fmax(a, b);
+        else return b > a ? b : a;
     };
 
     A carry[D], carry_s[SM ? D : 1];
@@ -119,7 +161,8 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                 if (exact) {
 #pragma unroll
                     for (int k0 = 0; k0 < D; k0 += VL) {
-                        const VLoad v = *reinterpret_cast<const VLoad*>(xr + k0);
+                        VLoad v{};
+                        if (k0 < d) v = *reinterpret_cast<const VLoad*>(xr + k0);
 #pragma unroll
                         for (int k = 0; k < VL; ++k) raw[b][k0 + k] = v.v[k];
                     }
@@ -133,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                     if (exact) {
 #pragma unroll
                         for (int k0 = 0; k0 < D; k0 += VL) {
-                            const VLoad v = *reinterpret_cast<const VLoad*>(yr + k0);
+                            VLoad v{};
+                            if (k0 < d) v = *reinterpret_cast<const VLoad*>(yr + k0);
 #pragma unroll
                             for (int k = 0; k < VL; ++k) yraw[b][k0 + k] = v.v[k];
                         }
@@ -156,6 +200,7 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                 if constexpr (std::is_floating_point_v<A>) { if (sscale) m = m * (A)ss[b]; }
                 if constexpr (YMODE == 1) { if (valid[b]) m = apply_mop(m, to_acc<T>(yraw[b][0]), p.mop); }
                 if constexpr (YMODE == 2) { if (valid[b]) m = apply_mop(m, to_acc<T>(yraw[b][k]), p.mop); }
+                if constexpr (RCLS == 1) { if (flip_min && valid[b]) m = flip(m); }
                 v[k] = m;
             }
             A sv[SM ? D : 1];
@@ -168,19 +213,34 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
             const bool head = lane == 0 || rp != r[b] || !valid[b];
             const unsigned long long hm = __ballot(head);
             const int start = 63 - __builtin_clzll(hm & (~0ull >> (63 - lane)));
-#pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-                const bool take = lane - off >= start;
+            // Segmented inclusive scan.  Phase 1: Hillis-Steele inside each 16-lane DPP row (row_shr 1, 2, 4, 8).  Phase 2: a run
+            // that began in an earlier row takes that row's (by then complete) last value, rows 1..3 in order.
+            auto merge_in = [&](bool take, const A (&tv)[D], const A (&ts)[SM ? D : 1]) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    const A t = shfl_up_t(v[k], off);
-                    if constexpr (SM) {
-                        const A ts = shfl_up_t(sv[k], off);
-                        if (take) softmax_merge(t, ts, v[k], sv[k], v[k], sv[k]);
-                    } else {
-                        if (take) v[k] = comb(t, v[k]);
-                    }
+                    if constexpr (SM) { if (take) softmax_merge(tv[k], ts[k], v[k], sv[k], v[k], sv[k]); }
+                    else v[k] = comb(take ? tv[k] : ident(), v[k]);       // identity for masked lanes: one select + one op
                 }
+            };
+            auto row_step = [&](auto off_tag) {
+                constexpr int OFF = decltype(off_tag)::value;
+                const bool take = (lane & 15) >= OFF && lane - OFF >= start;
+                A tv[D], ts[SM ? D : 1];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { tv[k] = dpp_row_shr<OFF>(v[k]); if constexpr (SM) ts[k] = dpp_row_shr<OFF>(sv[k]); }
+                merge_in(take, tv, ts);
+            };
+            row_step(std::integral_constant<int, 1>{});
+            row_step(std::integral_constant<int, 2>{});
+            row_step(std::integral_constant<int, 4>{});
+            row_step(std::integral_constant<int, 8>{});
+#pragma unroll
+            for (int rw = 1; rw < 4; ++rw) {
+                const bool take = (lane >> 4) == rw && start < 16 * rw;
+                A tv[D], ts[SM ? D : 1];
+#pragma unroll
+                for (int k = 0; k < D; ++k) { tv[k] = read_lane(v[k], 16 * rw - 1); if constexpr (SM) ts[k] = read_lane(sv[k], 16 * rw - 1); }
+                merge_in(take, tv, ts);
             }
             if (start == 0 && r[b] == carry_row) {          // run continues the last run of the previous batch
 #pragma unroll
@@ -190,11 +250,11 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                 }
             }
             const int last = min(kWave, e1 - ebb) - 1;      // last valid lane (wave-uniform)
-            carry_row = __shfl(r[b], last, kWave);
+            carry_row = __builtin_amdgcn_readlane(r[b], last);
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                carry[k] = shfl_t(v[k], last);
-                if constexpr (SM) carry_s[k] = shfl_t(sv[k], last);
+                carry[k] = read_lane(v[k], last);
+                if constexpr (SM) carry_s[k] = read_lane(sv[k], last);
             }
 
             if (!valid[b]) continue;
@@ -208,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                 A* dst = static_cast<A*>(piece_of_earlier ? p.part_head : p.part_tail) + (int64_t)c * d * (SM ? 2 : 1);
 #pragma unroll
                 for (int k = 0; k < D; ++k)
-                    if (k < d) { dst[k] = v[k]; if constexpr (SM) dst[d + k] = sv[k]; }
+                    if (k < d) { dst[k] = (RCLS == 1 && flip_min) ? flip(v[k]) : v[k]; if constexpr (SM) dst[d + k] = sv[k]; }
                 if (!piece_of_earlier) p.long_list[atomicAdd(p.long_count, 1)] = c;
                 continue;
             }
@@ -235,10 +295,20 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                     }
                 }
             }
+            if constexpr (RCLS == 1) {
+                if (flip_min) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v[k] = flip(v[k]);
+                }
+            }
             if (p.accumulate) {
 #pragma unroll
                 for (int k = 0; k < D; ++k)
-                    if (k < d) v[k] = comb(to_acc<T>(dst[k]), v[k]);
+                    if (k < d) {
+                        const A old = to_acc<T>(dst[k]);
+                        if constexpr (RCLS == 1) v[k] = is_max ? (v[k] > old ? v[k] : old) : (v[k] < old ? v[k] : old);
+                        else v[k] = old + v[k];
+                    }
             }
             if (exact) {
 #pragma unroll
@@ -246,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                     VLoad o;
 #pragma unroll
                     for (int k = 0; k < VL; ++k) o.v[k] = from_acc<T>(v[k0 + k]);
-                    *reinterpret_cast<VLoad*>(dst + k0) = o;
+                    if (k0 < d) *reinterpret_cast<VLoad*>(dst + k0) = o;
                 }
             } else {
 #pragma unroll
@@ -334,8 +404,21 @@ int32_t launch_one(AggParams p, int32_t dtype, hipStream_t st) {
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(p.out_rows, kBlock);
     if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (prof().on) {
+        char name[96];
+        snprintf(name, sizeof(name), "agg_narrow_kernel<%d-byte elements, %d, %d, %d>", (int)sizeof(T), D, RCLS, YMODE);
+        prof().last_kernel = name;
+        PGLAMD_HIP_CHECK(hipEventCreate(&ev0));
+        PGLAMD_HIP_CHECK(hipEventCreate(&ev1));
+        PGLAMD_HIP_CHECK(hipEventRecord(ev0, st));
+    }
     hipLaunchKernelGGL((agg_narrow_kernel<T, D, RCLS, YMODE>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
+    if (prof().on) {
+        PGLAMD_HIP_CHECK(hipEventRecord(ev1, st));
+        prof().ev.emplace_back(ev0, ev1);
+    }
     if (p.n_chunks > 1) return launch_fixup_cols(p, dtype, RCLS, st);
     return PGLAMD_OK;
 }

@@ -122,3 +122,50 @@ def test_plan_cache_roundtrip(tmp_path):
             assert torch.equal(getattr(dg.plan, k), getattr(back.plan, k)), k
         assert back.plan.send_splits == dg.plan.send_splits and back.plan.recv_splits == dg.plan.recv_splits
         assert back.stats()["partition"] == "cached" and back.plan.n_halo == dg.plan.n_halo
+
+
+# ------------------------------------------------------------------------------------------------
+# feature-sharded mode: columns split over the ranks, graph replicated
+# ------------------------------------------------------------------------------------------------
+class _NodesOnly(object):
+    def __init__(self, n):
+        self.num_nodes, self.num_edges = n, 0
+
+
+def _fs_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgl_amd.distributed import FeatureShardedGraph
+        n, d = 103, 13                                   # neither divisible by the world size
+        x = torch.arange(n * d, dtype=torch.float32).reshape(n, d)
+        fs = FeatureShardedGraph(_NodesOnly(n), rank, world)
+        xc = fs.take_cols(x)
+        xr = fs.cols_to_rows(xc, d)                      # my rows, all columns
+        back = fs.rows_to_cols(xr)                       # all rows, my columns again
+        q.put((rank, fs.row_range(), fs.col_range(d), xr.numpy(), back.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_feature_sharded_layout_changes_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, d = 103, 13
+    x = np.arange(n * d, dtype=np.float32).reshape(n, d)
+    rows_seen, cols_seen = [], []
+    for rank, (r0, r1), (c0, c1), xr, back in got:
+        assert np.array_equal(xr, x[r0:r1]), "cols_to_rows"
+        assert np.array_equal(back, x[:, c0:c1]), "rows_to_cols"
+        rows_seen += list(range(r0, r1)); cols_seen += list(range(c0, c1))
+    assert sorted(rows_seen) == list(range(n)) and sorted(cols_seen) == list(range(d))
