@@ -230,12 +230,24 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                 for (int k = 0; k < D; ++k) { tv[k] = dpp_row_shr<OFF>(v[k]); if constexpr (SM) ts[k] = dpp_row_shr<OFF>(sv[k]); }
                 merge_in(take, tv, ts);
             };
+            if constexpr (SM) {
+                // the softmax merge costs an exponential per step: six whole-wave steps (ds_bpermute) beat 4 + 3 here
+#pragma unroll
+                for (int off = 1; off < kWave; off <<= 1) {
+                    const bool take = lane - off >= start;
+                    A tv[D], ts[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { tv[k] = shfl_up_t(v[k], off); ts[k] = shfl_up_t(sv[k], off); }
+                    merge_in(take, tv, ts);
+                }
+            } else {
             row_step(std::integral_constant<int, 1>{});
             row_step(std::integral_constant<int, 2>{});
             row_step(std::integral_constant<int, 4>{});
             row_step(std::integral_constant<int, 8>{});
+            }
 #pragma unroll
-            for (int rw = 1; rw < 4; ++rw) {
+            for (int rw = 1; rw < (SM ? 1 : 4); ++rw) {
                 const bool take = (lane >> 4) == rw && start < 16 * rw;
                 A tv[D], ts[SM ? D : 1];
 #pragma unroll
