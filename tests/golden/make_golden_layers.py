@@ -23,6 +23,10 @@ import ref_python  # noqa: E402
 pgl = ref_python.load()
 assert pgl is not None, "reference python package unavailable (build container only)"
 import paddle  # noqa: E402  (the stand-in)
+import torch  # noqa: E402
+
+torch.set_num_threads(1)                         # index_add_ over several threads sums in a run-dependent order:
+torch.use_deterministic_algorithms(True)         # keep the gradient fixtures bit-reproducible
 import pgl.nn as gnn  # noqa: E402
 import pgl.nn.functional as GF  # noqa: E402
 
