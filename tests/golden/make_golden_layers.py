@@ -30,7 +30,7 @@ torch.use_deterministic_algorithms(True)         # keep the gradient fixtures bi
 import pgl.nn as gnn  # noqa: E402
 import pgl.nn.functional as GF  # noqa: E402
 
-OUT = os.path.join(HERE, "layers")
+OUT = os.environ.get("PGLAMD_GOLDEN_OUT", os.path.join(HERE, "layers"))      # the provenance test regenerates into a scratch directory
 os.makedirs(OUT, exist_ok=True)
 
 

@@ -69,6 +69,24 @@ def test_reference_gat_glue_equals_dense_formula():
     np.testing.assert_allclose(z["out"], out.numpy(), rtol=1e-4, atol=1e-5 * float(out.abs().max()))
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/pgl"), reason="reference tree not present (GPU box)")
+def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
+    """Provenance: re-running the generator (the reference's own Python code on the paddle stand-in) reproduces every
+    committed fixture bit for bit.  Build container only."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PGLAMD_GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_golden_layers.py")], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    committed = sorted(glob.glob(os.path.join(HERE, "golden", "layers", "*.npz")))
+    assert len(committed) == len(list(tmp_path.glob("*.npz"))) == 34
+    for f in committed:
+        a, b = np.load(f), np.load(os.path.join(str(tmp_path), os.path.basename(f)))
+        assert a.files == b.files, os.path.basename(f)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (os.path.basename(f), k)
+
+
 # ------------------------------------------------------------------------------------------------
 # GPU: pgl_amd reproduces the reference's outputs
 # ------------------------------------------------------------------------------------------------
