@@ -296,3 +296,27 @@ for tag, rel, ctor in (("gcn", "gcn/train.py", lambda m: m.GCN(din, ncls, num_la
     logits = model(g, g.node_feat["words"]).detach().numpy()
     save("train_" + tag, edges=edges, num_nodes=np.int64(n), x=x, labels=labels, train_idx=train_idx, losses=np.array(losses, np.float64),
          final_logits=logits, **init)
+
+# examples/graphsage/cpu_sample_version/model.py GraphSage (two GraphSageConv layers + Linear), trained full-batch with the same
+# step as above (its own train.py drives it through a sampling data loader; the model is what is pinned here)
+sage = example_module("graphsage/cpu_sample_version/model.py")
+paddle.seed(78)
+model = sage.GraphSage(din, ncls, num_layers=2, hidden_size=16, dropout=0.0)
+init = {"init::" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+gcn_mod = example_module("gcn/train.py")
+optim = gcn_mod.Adam(learning_rate=0.01, parameters=model.parameters(), weight_decay=0.0005)
+crit = paddle.nn.loss.CrossEntropyLoss()
+xt = paddle.to_tensor(x)
+idx_t = paddle.to_tensor(train_idx); lab_t = paddle.to_tensor(labels[train_idx])
+losses = []
+for _ in range(steps):
+    model.train()
+    loss = crit(paddle.gather(model(g, xt), idx_t), lab_t)
+    loss.backward()
+    optim.step()
+    optim.clear_grad()
+    losses.append(float(loss))
+model.eval()
+save("train_sage", edges=edges, num_nodes=np.int64(n), x=x, labels=labels, train_idx=train_idx, losses=np.array(losses, np.float64),
+     final_logits=model(g, xt).detach().numpy(), **init)

@@ -79,7 +79,7 @@ def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_golden_layers.py")], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     committed = sorted(glob.glob(os.path.join(HERE, "golden", "layers", "*.npz")))
-    assert len(committed) == len(list(tmp_path.glob("*.npz"))) == 34
+    assert len(committed) == len(list(tmp_path.glob("*.npz"))) == 35
     for f in committed:
         a, b = np.load(f), np.load(os.path.join(str(tmp_path), os.path.basename(f)))
         assert a.files == b.files, os.path.basename(f)
@@ -273,7 +273,7 @@ def test_batched_graph_matches_reference_python(pgl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["gcn", "gat"])
+@pytest.mark.parametrize("tag", ["gcn", "gat", "sage"])
 def test_training_trajectory_matches_reference_example_model(pgl, tag):
     """The models of the reference's examples/gcn/train.py and examples/gat/train.py, trained by the examples' own
     train() step on the paddle stand-in (fixture), against the same architecture on this engine from the same initial
@@ -284,13 +284,25 @@ def test_training_trajectory_matches_reference_example_model(pgl, tag):
     if tag == "gcn":
         layers = nn.ModuleList([pgl.nn.GCNConv(din, 16, activation="relu", norm=True), nn.Dropout(0.0), pgl.nn.GCNConv(16, ncls)])
         prefix = "gcns."
-    else:
+    elif tag == "gat":
         layers = nn.ModuleList([pgl.nn.GATConv(din, 8, 0.0, 0.0, 4, activation="elu")])
         prefix = "gats."
+    else:                                   # examples/graphsage: convs.{0,1} + linear
+        class Sage(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.convs = nn.ModuleList([pgl.nn.GraphSageConv(din, 16), pgl.nn.GraphSageConv(16, 16)])
+                self.linear = nn.Linear(16, ncls)
+        layers = Sage()
+        prefix = ""
     _load_params(layers, {k[len("init::") + len(prefix):]: z[k] for k in z.files if k.startswith("init::")})
     layers = layers.cuda()
 
     def model(g, h):
+        if tag == "sage":
+            for m in layers.convs:
+                h = m(g, h)
+            return layers.linear(h)
         for m in layers:
             h = m(h) if isinstance(m, nn.Dropout) else m(g, h)
         return h
