@@ -119,7 +119,7 @@ def main():
         if dryrun:
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=10))
         else:
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=30))
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))
 
     edges = rmat_edges(args.scale, E, seed=42, device=dev)           # identical on every rank
     gen = torch.Generator(device=dev); gen.manual_seed(7)
@@ -171,9 +171,21 @@ def main():
         if not int(ok.item()):
             cand.pop("rows", None)
         trial = {}
-        for name, (fn, _, _) in cand.items():
-            fn(); fn()
-            trial[name] = timed(fn, max(args.warmup, 3))
+        for name in [k for k in ("cols", "rows") if k in cand]:      # the collective-free layout first
+            fn = cand[name][0]
+            good = 1
+            try:
+                fn(); fn()
+                t_trial = timed(fn, max(args.warmup, 3))
+            except Exception as ex:                                  # noqa: BLE001 -- a failing layout is dropped, not fatal
+                if len(cand) == 1:
+                    raise
+                good = 0
+                print("[bench] layout %r failed on rank %d: %r" % (name, rank, ex), file=sys.stderr, flush=True)
+            flag = torch.tensor([good], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # keep a layout only if it worked on every rank
+            if int(flag.item()):
+                trial[name] = t_trial
         mode = min(trial, key=trial.get)
         step, halo, (d_loc, n_loc, e_loc) = cand[mode]
         halo = dict(halo, mode=mode, trial_ms_per_step={k: v / max(args.warmup, 3) * 1e3 for k, v in trial.items()})
