@@ -19,7 +19,8 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 // RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector,
 // 3 = as 1 for NT == 1 and y rows of <= 8 elements (attention weights [E,H,1]): the 8 x ypad operand values of a batch come
 //     from ONE wave-wide load (lane l: edge l / ypad, element l % ypad) and reach their lanes by ds_bpermute
-template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true>
+// UB > 0 selects the vector-index pipeline (NT == 1, no edge operand, no per-source scale): see the main loop
+template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true, int UB = 0>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     constexpr int U = 8;
     using V = VecT<T, VEC>;
@@ -217,11 +218,54 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         else return 1.f;
     };
 
+    int e = e0;
+    if constexpr (UB > 0) {
+        // Vector-index pipeline (rows of <= 256 bytes, whose rate is set by rows in flight x latency, not by bytes): the row
+        // and column ids of a batch of UB edges are ONE coalesced vector load each (lane l: edge l) instead of 2*UB scalar
+        // loads held in SGPRs; a column id reaches the address computation through v_readlane at issue time, a row id at
+        // consume time -- no index lives in an SGPR across iterations, so UB = 16 edges fit where 8 did (16..32 row gathers
+        // in flight per wave) at ~50 SGPRs.  Measured at C2: d=64 fp32 0.71 -> 0.63 ms, d=32 0.74 -> 0.62, fp16 d=128 0.86 -> 0.70;
+        // UB = 32 was slower again (0.72 at d=32), and 512-byte rows gain nothing (they are byte-bound), so it stops at 320 B.  Same three stages: ids of batch g+2 are issued BEFORE the rows of g+1
+        // (vector loads retire in issue order, so waiting for them one iteration later never waits for younger gathers).
+        static_assert(NT == 1 && YMODE == 0 && !SS, "vector-index pipeline: single tile, no operands");
+        const int* __restrict__ row_v = p.row;
+        const int* __restrict__ colv = p.col;
+        const int li = lane & (UB - 1);
+        auto load_iv = [&](int eb, int& rv, int& cv) { rv = row_v[eb + li]; cv = colv ? colv[eb + li] : eb + li; };
+        auto load_rows_v = [&](int cv, V (&vx)[UB][1]) {
+#pragma unroll
+            for (int i = 0; i < UB; ++i) {
+                const int cc = __builtin_amdgcn_readlane(cv, i);
+                if (act[0]) vx[i][0] = *reinterpret_cast<const V*>(x + (int64_t)cc * p.ldx + j0[0]);
+            }
+        };
+        const int n_fullv = (e1 - e0) / UB;
+        int rvA = 0, cvA = 0, rvB = 0, cvB = 0;
+        V xvA[UB][1], wdummy[1];
+        if (n_fullv > 0) load_iv(e, rvA, cvA);
+        if (n_fullv > 1) load_iv(e + UB, rvB, cvB);
+        if (n_fullv > 0) load_rows_v(cvA, xvA);
+        for (int g = 0; g < n_fullv; ++g) {
+            int rvC = 0, cvC = 0;
+            V xvB[UB][1];
+            const bool more = g + 1 < n_fullv, more2 = g + 2 < n_fullv;
+            if (more2) load_iv(e + 2 * UB, rvC, cvC);
+            if (more) load_rows_v(cvB, xvB);
+#pragma unroll
+            for (int i = 0; i < UB; ++i) consume_one(__builtin_amdgcn_readlane(rvA, i), 1.f, xvA[i], wdummy);
+            if (more) {
+                rvA = rvB; cvA = cvB;
+#pragma unroll
+                for (int i = 0; i < UB; ++i) xvA[i][0] = xvB[i][0];
+            }
+            if (more2) { rvB = rvC; cvB = cvC; }
+            e += UB;
+        }
+    }
     // Software pipeline, three batches deep: feature rows of batch g are being consumed while the rows
     // of batch g+1 are in flight AND the (scalar) indices of batch g+2 are being fetched, so neither
     // the scalar-load latency nor the gather latency sits on the per-batch critical path.
-    int e = e0;
-    const int n_full = (e1 - e0) / U;
+    const int n_full = UB > 0 ? 0 : (e1 - e0) / U;
     int cA[U], rA[U], yA[U];
     int cB[U], rB[U], yB[U];
     int clA = 0, clB = 0; float svA = 1.f;
@@ -561,6 +605,12 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     // workgroups/CU) measured 4 % faster there; everywhere else the three-deep one wins (up to 20 % on [E,8]).
     const size_t row_bytes = (size_t)p.tile_cols * sizeof(T);
     if constexpr (NT == 1 && YMODE == 0) {
+        static const int vidx_max = [] { const char* e = getenv("PGLAMD_VIDX_BYTES"); return e ? atoi(e) : 320; }();
+        if ((int)row_bytes <= vidx_max && !p.src_scale) {
+            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false, true, 16>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+            PGLAMD_LAUNCH_CHECK();
+            goto launched;
+        }
         if (row_bytes >= 192 && row_bytes <= 320 && !p.src_scale) {
             hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
             PGLAMD_LAUNCH_CHECK();
