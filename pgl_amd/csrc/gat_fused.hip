@@ -506,38 +506,56 @@ __global__ __launch_bounds__(kBlock) void sddmm_kernel(GatParams p) {
     int cur = -1;
     V gv{}, wv{};
     if constexpr (ADDLEAKY) { if (act) wv = *reinterpret_cast<const V*>(p.w + j0); }
-    auto load_batch = [&](int e, int nb, int (&rr)[U], int (&ee)[U], V (&fx)[U]) {
+    auto emit = [&](int r, int ed, const V& fx) {
+        if (r != cur) { cur = r; if (act) gv = *reinterpret_cast<const V*>(p.g + (int64_t)cur * p.d + j0); }
+        float dot = 0.f;
 #pragma unroll
-        for (int i = 0; i < U; ++i)
-            if (i < nb) {
-                rr[i] = rowp[e + i]; ee[i] = eidp ? eidp[e + i] : e + i;
-                const int cc = colp[e + i];
-                if (act) fx[i] = *reinterpret_cast<const V*>(p.f + (int64_t)cc * p.d + j0);
-            }
+        for (int k = 0; k < VEC; ++k) {
+            if constexpr (ADDLEAKY) { const float z = gv.v[k] + fx.v[k]; dot += wv.v[k] * (z > 0.f ? z : p.slope * z); }
+            else dot += gv.v[k] * fx.v[k];
+        }
+        dot = group_sum(dot, lph);
+        if (writer) p.dpre[(int64_t)ed * p.H + head] = dot;
     };
-    int rA[U], eA[U]; V fA[U];
-    int nA = min(U, e1 - e0);
-    load_batch(e0, nA, rA, eA, fA);
-    for (int e = e0; e < e1; e += U) {
-        int rB[U], eB[U]; V fB[U];
-        const int nB = max(0, min(U, e1 - (e + U)));
-        if (nB > 0) load_batch(e + U, nB, rB, eB, fB);
+    // three stages, as in agg_flat_kernel: rows of batch g consumed, rows of g+1 in flight, scalar ids of g+2 being fetched
+    auto load_idx = [&](int e, int (&rr)[U], int (&cc)[U], int (&ee)[U]) {
+#pragma unroll
+        for (int i = 0; i < U; ++i) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; ee[i] = eidp ? eidp[e + i] : e + i; }
+    };
+    auto load_rows = [&](const int (&cc)[U], V (&fx)[U]) {
 #pragma unroll
         for (int i = 0; i < U; ++i)
-            if (i < nA) {
-                if (rA[i] != cur) { cur = rA[i]; if (act) gv = *reinterpret_cast<const V*>(p.g + (int64_t)cur * p.d + j0); }
-                float dot = 0.f;
+            if (act) fx[i] = *reinterpret_cast<const V*>(p.f + (int64_t)cc[i] * p.d + j0);
+    };
+    int e = e0;
+    const int n_full = (e1 - e0) / U;
+    int rA[U], cA[U], eA[U], rB[U], cB[U], eB[U];
+    V fA[U];
+    if (n_full > 0) { load_idx(e, rA, cA, eA); load_rows(cA, fA); }
+    if (n_full > 1) load_idx(e + U, rB, cB, eB);
+    for (int g = 0; g < n_full; ++g) {
+        int rC[U], cC[U], eC[U];
+        V fB[U];
+        const bool more = g + 1 < n_full, more2 = g + 2 < n_full;
+        if (more) load_rows(cB, fB);
+        if (more2) load_idx(e + 2 * U, rC, cC, eC);
 #pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if constexpr (ADDLEAKY) { const float z = gv.v[k] + fA[i].v[k]; dot += wv.v[k] * (z > 0.f ? z : p.slope * z); }
-                    else dot += gv.v[k] * fA[i].v[k];
-                }
-                dot = group_sum(dot, lph);
-                if (writer) p.dpre[(int64_t)eA[i] * p.H + head] = dot;
-            }
+        for (int i = 0; i < U; ++i) emit(rA[i], eA[i], fA[i]);
+        if (more) {
 #pragma unroll
-        for (int i = 0; i < U; ++i) { rA[i] = rB[i]; eA[i] = eB[i]; fA[i] = fB[i]; }
-        nA = nB;
+            for (int i = 0; i < U; ++i) { rA[i] = rB[i]; eA[i] = eB[i]; fA[i] = fB[i]; }
+        }
+        if (more2) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) { rB[i] = rC[i]; cB[i] = cC[i]; eB[i] = eC[i]; }
+        }
+        e += U;
+    }
+    for (; e < e1; ++e) {
+        V fx{};
+        const int cc = colp[e];
+        if (act) fx = *reinterpret_cast<const V*>(p.f + (int64_t)cc * p.d + j0);
+        emit(rowp[e], eidp ? eidp[e] : e, fx);
     }
 }
 
