@@ -3,6 +3,7 @@
 // and aggregate_more.hip (int32, int64, fp16, bf16).  Design notes: see the head of aggregate.hip.
 #pragma once
 #include "aggregate.hpp"
+#include "aggregate_group.hpp"
 
 #include <algorithm>
 #include <string>
@@ -782,6 +783,21 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         p.long_count = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half);
         p.long_list = p.long_count + 64;
         p.long_list2 = reinterpret_cast<int*>(static_cast<char*>(ws) + 2 * half + lst);
+        // rows of 64..128 bytes without an edge operand: several edges per wave instruction (aggregate_group.hpp).  Below
+        // 64 bytes the lane-per-edge kernel keeps sum / mean (equal at d = 16 fp32, better below); min / max (0.45 -> 0.38 ms
+        // at d = 16) and the shapes it does not cover (fp16 d = 17..32: 0.63 -> 0.38) come here from 32 bytes up.
+        {
+            const int64_t rb = (int64_t)((size_t)dout * sizeof(T));
+            const bool narrow_ok = dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u;
+            const int64_t gmin = (rcls == 1 || !narrow_ok) ? std::min<int64_t>(32, group_min_bytes()) : group_min_bytes();
+            if (ymode == 0 && !src_scale && rb > gmin && rb <= group_row_bytes()) {
+                AggParams q = p;
+                q.j_base = 0; q.tile_cols = (int)dout;
+                bool handled = false;
+                rc = launch_group<T>(q, vmax, rcls, dtype_code<T>(), ws, ws_bytes, st, &handled);
+                if (rc != PGLAMD_OK || handled) return rc;
+            }
+        }
         // measured at C2 sizes: the lane-per-edge kernel wins up to 32 B of accumulator per row for every reduce op
         // (2.6-3.4x at d <= 8 fp32) and up to 64 B for sum / mean (1.3x at d = 16 fp32)
         if (dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {

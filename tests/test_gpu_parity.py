@@ -1050,6 +1050,103 @@ def test_narrow_rows_fused_scales_and_accumulate(pgl):
     assert np.array_equal(host(mx), np.where(has[:, None], np.maximum(base, w), base))
 
 
+# ------------------------------------------------------------------------------------------------
+# rows of 64..128 bytes: the grouped kernel (several edges per wave instruction, one chunk per lane group)
+# ------------------------------------------------------------------------------------------------
+GROUP_SHAPES = [(np.float32, 17), (np.float32, 18), (np.float32, 20), (np.float32, 24), (np.float32, 31), (np.float32, 32),
+                (np.float64, 9), (np.float64, 10), (np.float64, 16), (np.int32, 24), (np.int32, 29), (np.int64, 12), (np.int64, 15),
+                (np.float64, 20), (np.float64, 32), (np.int64, 17), (np.int64, 32)]          # 8-byte types: up to 256-byte rows
+
+
+@pytest.mark.parametrize("op", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("dtype,d", GROUP_SHAPES)
+def test_group_rows_send_recv(pgl, op, dtype, d):
+    n, e = 5000, 90000
+    edges, rng = rand_graph(n, e, 900 + d, hub=20000)           # hub row: > 16 partials (second fix-up pass)
+    edges[edges[:, 1] % 7 == 0, 1] = 11                         # a second long row + many empty rows
+    edges[edges[:, 1] % 13 == 1, 1] = 4001                      # a row of a few hundred edges (first fix-up pass)
+    x = (rng.standard_normal((n, d)) * 50).astype(dtype)
+    want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    pgl.ops.profile_begin()
+    got = g.send_recv(dev(x), op)
+    pgl.ops.profile_end()
+    import os
+    if os.environ.get("PGLAMD_GROUP_BYTES", "128") != "0":
+        assert "agg_group_kernel" in pgl.ops.profile_last_kernel()
+    if np.issubdtype(dtype, np.integer):
+        assert np.array_equal(host(got), want)
+    else:
+        close(host(got), want, scale=np.abs(want).max(), rtol=RTOL if dtype == np.float32 else 1e-12)
+    assert torch.equal(got, g.send_recv(dev(x), op))                                # bit-reproducible
+    big = host(g.send_recv(dev(x), op, out_size=n + 77))
+    assert big.shape[0] == n + 77 and (big[n:] == 0).all() and np.array_equal(big[:n], host(got))
+    empty = np.setdiff1d(np.arange(n), edges[:, 1])
+    assert len(empty) and (host(got)[empty] == 0).all()
+
+
+@pytest.mark.parametrize("op", ["max", "min"])
+@pytest.mark.parametrize("dtype,d", [(np.float32, 9), (np.float32, 12), (np.float32, 16), (np.int32, 16), (np.float64, 5), (np.float64, 8)])
+def test_group_rows_min_max_from_32_bytes(pgl, op, dtype, d):
+    """min / max of 32..64-byte rows take the grouped kernel too (sum / mean of those stay with the lane-per-edge one)."""
+    n, e = 5000, 90000
+    edges, rng = rand_graph(n, e, 930 + d, hub=20000)
+    edges[edges[:, 1] % 7 == 0, 1] = 11
+    x = (rng.standard_normal((n, d)) * 50).astype(dtype)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    pgl.ops.profile_begin()
+    got = g.send_recv(dev(x), op)
+    pgl.ops.profile_end()
+    import os
+    if "PGLAMD_GROUP_BYTES" not in os.environ and "PGLAMD_GROUP_MIN_BYTES" not in os.environ:
+        assert "agg_group_kernel" in pgl.ops.profile_last_kernel()
+    assert np.array_equal(host(got), R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op))          # min / max are exact in every dtype
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("d", [17, 24, 32, 34, 36, 40, 48, 64])
+def test_group_rows_16bit_storage(pgl, tdt, d):
+    n, e = 3000, 60000
+    edges, rng = rand_graph(n, e, 950 + d, hub=10000)
+    x = torch.as_tensor(rng.standard_normal((n, d)).astype(np.float32)).to(tdt)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    for op in ("sum", "mean", "max"):
+        want = R.c_send_u_recv(x.float().numpy(), edges[:, 0], edges[:, 1], op)
+        got = g.send_recv(x.cuda(), op)
+        assert got.dtype == tdt
+        np.testing.assert_allclose(host(got.float()), want, rtol=2 ** -7 if tdt == torch.bfloat16 else 2 ** -10,
+                                   atol=1e-3 * np.abs(want).max())
+
+
+def test_group_rows_scales_accumulate_and_gradient(pgl):
+    n, e, d = 4000, 70000, 32
+    edges, rng = rand_graph(n, e, 977, hub=12000)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    ds = rng.random(n).astype(np.float32) + 0.5
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    csr = g.adj_dst_index.csr
+    s = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "sum")
+    got = pgl.ops.aggregate(dev(x), csr, "sum", dst_scale=dev(ds))
+    close(host(got), s * ds[:, None], scale=np.abs(s).max())
+    base = rng.standard_normal((n, d)).astype(np.float32)
+    acc = dev(base.copy())
+    pgl.ops.aggregate(dev(x), csr, "sum", dst_scale=dev(ds), out=acc, accumulate=True)
+    close(host(acc), base + s * ds[:, None], scale=np.abs(s).max())
+    mx = dev(base.copy())
+    pgl.ops.aggregate(dev(x), csr, "max", out=mx, accumulate=True)
+    w = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "max")
+    has = np.isin(np.arange(n), edges[:, 1])
+    assert np.array_equal(host(mx), np.where(has[:, None], np.maximum(base, w), base))
+    # autograd: d/dx of sum aggregation = aggregation over the reversed edges
+    xt = dev(x).requires_grad_(True)
+    wgt = dev(rng.standard_normal((n, d)).astype(np.float32))
+    (g.send_recv(xt, "sum") * wgt).sum().backward()
+    close(host(xt.grad), R.c_send_u_recv(host(wgt), edges[:, 1], edges[:, 0], "sum"), scale=float(xt.grad.abs().max()))
+    # feature column slices (non-contiguous input is made contiguous by the host side; sliced widths hit this kernel)
+    wide = dev(rng.standard_normal((n, 128)).astype(np.float32))
+    close(host(g.send_recv(wide[:, 32:64], "sum")), host(g.send_recv(wide, "sum")[:, 32:64]), scale=float(wide.abs().max()) * 30)
+
+
 @pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_narrow_segment_softmax_one_pass(pgl, d, dtype):
@@ -1085,7 +1182,7 @@ def test_chunk_size_stress_in_subprocess(pgl):
     for k in ("8", "4096"):
         env = dict(os.environ, PGLAMD_CHUNK=k)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                            "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute or narrow or softmax"],
+                            "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute or narrow or softmax or group_rows"],
                            env=env, capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:]
 
