@@ -36,6 +36,18 @@ __device__ __forceinline__ int group_cut(const int* __restrict__ rowp, const int
     return (int)re;
 }
 
+// min is computed as max over order-reversed values (floats: negated, integers: complemented -- both exact), so the hot loop
+// has one v_max per element whatever the op; values are turned back wherever they leave the registers
+template <typename A> __device__ __forceinline__ A order_flip(A v, bool neg) {
+    if constexpr (std::is_floating_point_v<A>) return neg ? -v : v;
+    else return neg ? ~v : v;
+}
+template <typename A> __device__ __forceinline__ A max_of(A a, A b) {
+    if constexpr (std::is_same_v<A, float>) return __builtin_fmaxf(a, b);
+    else if constexpr (std::is_same_v<A, double>) return __builtin_fmax(a, b);
+    else return a > b ? a : b;
+}
+
 // 16 rows per batch while they are cheap to hold (<= 8-byte lanes, >= 16-lane groups), 8 otherwise
 template <typename T, int VEC, int G> constexpr int group_batch() { return (G >= 16 && VEC * (int)sizeof(T) <= 8) ? 16 : 8; }
 
@@ -72,9 +84,10 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
     A acc[VEC];
     auto reset = [&]() {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] = RCLS == 0 ? A(0) : (is_max ? Limits<A>::lo() : Limits<A>::hi());
+        for (int k = 0; k < VEC; ++k) acc[k] = RCLS == 0 ? A(0) : Limits<A>::lo();
     };
     reset();
+    const bool neg = RCLS == 1 && !is_max;
     int cur = -1, cnt = 0;
     bool head_open = false;
     if (e0 < e1) {
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         if (act) {
             VA o;
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) o.v[k] = acc[k];
+            for (int k = 0; k < VEC; ++k) o.v[k] = RCLS == 1 ? order_flip(acc[k], neg) : acc[k];
             *reinterpret_cast<VA*>(dst + j0) = o;
         }
         if (!head && gl == 0) q->long_list[atomicAdd(q->long_count, 1)] = c;     // this chunk owns the row's fix-up
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         const float* dsp = q->dst_scale;
         A ov[VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) ov[k] = acc[k];
+        for (int k = 0; k < VEC; ++k) ov[k] = RCLS == 1 ? order_flip(acc[k], neg) : acc[k];
         if constexpr (RCLS == 0) {
             if (q->is_mean != 0) {
 #pragma unroll
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         for (int k = 0; k < VEC; ++k) {
             const A m = to_acc<T>(vx.v[k]);
             if constexpr (RCLS == 0) acc[k] += m;
-            else acc[k] = is_max ? (m > acc[k] ? m : acc[k]) : (m < acc[k] ? m : acc[k]);
+            else acc[k] = max_of(acc[k], order_flip(m, neg));
         }
     };
 
