@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpglamd.so")
 OBJ = os.path.join(CSRC, "build")
 SOURCES = ["aggregate.hip", "aggregate_more.hip", "aggregate_narrow.hip", "csr_build.hip", "edge_ops.hip", "gat_fused.hip", "sampling.hip", "common.cpp", "host_ops.cpp"]
-HEADERS = ["common.hpp", "aggregate.hpp", "aggregate_flat.hpp", os.path.join("..", "..", "include", "pgl_amd.h")]
+HEADERS = ["common.hpp", "aggregate.hpp", "aggregate_flat.hpp", "aggregate_group.hpp", os.path.join("..", "..", "include", "pgl_amd.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wno-unused-result", "-Wno-unused-value"]
@@ -33,8 +33,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defines=(), lib=None, obj=None):
+    """defines / lib / obj: build a variant (extra -D macros) into its own object directory and library file."""
+    global LIB, OBJ
     hipcc = _hipcc()
+    LIB_, OBJ_ = LIB, OBJ
+    if lib: LIB = lib
+    if obj: OBJ = obj
+    try:
+        return _build(hipcc, force, verbose, ["-D" + d for d in defines])
+    finally:
+        LIB, OBJ = LIB_, OBJ_
+
+
+def _build(hipcc, force, verbose, extra):
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
 
@@ -42,7 +54,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpglamd.so")
+# PGLAMD_LIB: load another build of the same ABI (kernel experiments: scripts/build_variant.py)
+LIB_PATH = os.environ.get("PGLAMD_LIB") or os.path.join(_HERE, "csrc", "libpglamd.so")
 _lib = None
 
 c_i32, c_i64, c_sz, c_vp, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint64

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
     };
     reset();
     const bool neg = RCLS == 1 && !is_max;
-    int cur = -1, cnt = 0;
+    int cur = -1;
     bool head_open = false;
     if (e0 < e1) {
         cur = rowp[e0];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         }
         if (!head && gl == 0) q->long_list[atomicAdd(q->long_count, 1)] = c;     // this chunk owns the row's fix-up
     };
-    auto store_final = [&](int r, int n) {
+    auto store_final = [&](int r) {      // (row wholly inside the chunk: a mean divides by its degree, read from indptr)
         const cptr<AggParams> q = cold();
         if (r >= q->out_rows || !act) return;
         T* dst = static_cast<T*>(q->out) + (int64_t)r * q->ldo + q->j_base + j0;
@@ -123,6 +123,8 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         for (int k = 0; k < VEC; ++k) ov[k] = RCLS == 1 ? order_flip(acc[k], neg) : acc[k];
         if constexpr (RCLS == 0) {
             if (q->is_mean != 0) {
+                const int64_t* ipq = q->indptr;
+                const int64_t n = ipq[r + 1] - ipq[r];
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) ov[k] = ov[k] / (A)n;
             }
@@ -150,11 +152,10 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
     };
     auto consume = [&](int r, const V& vx) {
         if (r != cur) {
-            if (head_open) store_partial(true); else store_final(cur, cnt);
+            if (head_open) store_partial(true); else store_final(cur);
             head_open = false;
-            cur = r; cnt = 0; reset();
+            cur = r; reset();
         }
-        ++cnt;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const A m = to_acc<T>(vx.v[k]);
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         const bool tail_open = e1 < p.E && rowp[e1] == cur;
         if (head_open) store_partial(true);                 // middle or closing piece of a long row
         else if (tail_open) store_partial(false);           // first piece of a long row that continues
-        else store_final(cur, cnt);
+        else store_final(cur);
     }
 }
 

@@ -22,8 +22,8 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) / iters
 
 
-print("PGLAMD_GROUP_MIN_BYTES =", os.environ.get("PGLAMD_GROUP_MIN_BYTES", "(default)"), " PGLAMD_GROUP_BYTES =", os.environ.get("PGLAMD_GROUP_BYTES", "(default)"), " PGLAMD_GCHUNK =", os.environ.get("PGLAMD_GCHUNK", "(default)"))
-for dt, ds in ((torch.float32, (8, 12, 16, 17, 18, 20, 24, 32, 48, 64)), (torch.float16, (32, 40, 64, 128)), (torch.float64, (8, 16, 32))):
+print("PGLAMD_LIB =", os.path.basename(os.environ.get("PGLAMD_LIB", "(product)")), " PGLAMD_ALIGN =", os.environ.get("PGLAMD_ALIGN", "(default)"), " PGLAMD_GROUP_MIN_BYTES =", os.environ.get("PGLAMD_GROUP_MIN_BYTES", "(default)"), " PGLAMD_GROUP_BYTES =", os.environ.get("PGLAMD_GROUP_BYTES", "(default)"), " PGLAMD_GCHUNK =", os.environ.get("PGLAMD_GCHUNK", "(default)"))
+for dt, ds in ((torch.float32, (8, 12, 16, 17, 18, 20, 24, 32, 48, 64, 128)), (torch.float16, (32, 40, 64, 128)), (torch.float64, (8, 16, 32))):
     for d in ds:
         x = torch.randn(N, d, generator=gen, device="cuda").to(dt)
         for op in ("sum", "max"):
