@@ -95,15 +95,10 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         head_open = e0 > 0 && rowp[e0 - 1] == cur;       // the row began in an earlier chunk
     }
 
-    // row stores re-read what they need from the kernarg segment (as the flat kernel does): once per row
-    const cptr<AggParams> kargs = (cptr<AggParams>)__builtin_amdgcn_kernarg_segment_ptr();
-    auto cold = [&]() -> cptr<AggParams> {
-        cptr<AggParams> q = kargs;
-        asm volatile("" : "+s"(q));
-        return q;
-    };
+    // Row stores happen for SOME group at almost every step (8 groups x 1/degree), so what they need stays in SGPRs (the
+    // flat kernel, short of SGPRs, re-reads it from the kernarg segment at each store: a scalar-load round trip per row).
     auto store_partial = [&](bool head) {
-        const cptr<AggParams> q = cold();
+        const AggParams* q = &p;
         A* dst = static_cast<A*>(head ? q->part_head : q->part_tail) + (int64_t)c * q->tile_cols;
         if (act) {
             VA o;
@@ -114,7 +109,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
         if (!head && gl == 0) q->long_list[atomicAdd(q->long_count, 1)] = c;     // this chunk owns the row's fix-up
     };
     auto store_final = [&](int r) {      // (row wholly inside the chunk: a mean divides by its degree, read from indptr)
-        const cptr<AggParams> q = cold();
+        const AggParams* q = &p;
         if (r >= q->out_rows || !act) return;
         T* dst = static_cast<T*>(q->out) + (int64_t)r * q->ldo + q->j_base + j0;
         const float* dsp = q->dst_scale;
