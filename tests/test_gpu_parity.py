@@ -1147,6 +1147,55 @@ def test_group_rows_scales_accumulate_and_gradient(pgl):
     close(host(g.send_recv(wide[:, 32:64], "sum")), host(g.send_recv(wide, "sum")[:, 32:64]), scale=float(wide.abs().max()) * 30)
 
 
+BOUNDARY_WIDTHS = {np.float32: [7, 8, 9, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 80, 81, 127, 129, 255, 257],
+                   np.float64: [3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 65],
+                   np.int32: [8, 9, 16, 17, 32, 33, 64, 65], np.int64: [4, 5, 8, 9, 16, 17, 32, 33]}
+
+
+@pytest.mark.parametrize("dtype", list(BOUNDARY_WIDTHS))
+def test_send_recv_at_every_dispatch_boundary(pgl, dtype):
+    """Three edge kernels share send_recv (lane-per-edge <= 64 B, grouped <= 128 B / 256 B for 8-byte types, flat above): every
+    width next to a threshold, every reduce op, hubs that need both fix-up passes, empty rows, out_size, dst_scale + accumulate."""
+    n, e = 3000, 60000
+    edges, rng = rand_graph(n, e, 4242, hub=15000)
+    edges[edges[:, 1] % 6 == 0, 1] = 9
+    edges[edges[:, 1] % 17 == 2, 1] = 2001
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    csr = g.adj_dst_index.csr
+    ds = rng.random(n).astype(np.float32) + 0.5
+    for i, d in enumerate(BOUNDARY_WIDTHS[dtype]):
+        x = (rng.standard_normal((n, d)) * 20).astype(dtype)
+        for op in ("sum", "mean", "max", "min"):
+            want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
+            got = host(g.send_recv(dev(x), op, out_size=n + 5 if (i + len(op)) % 2 else None))
+            if np.issubdtype(dtype, np.integer):
+                assert np.array_equal(got[:n], want), (d, op)
+            else:
+                np.testing.assert_allclose(got[:n], want, rtol=RTOL if dtype == np.float32 else 1e-12,
+                                           atol=(1e-5 if dtype == np.float32 else 1e-10) * np.abs(want).max(), err_msg="d=%d %s" % (d, op))
+            assert (got[n:] == 0).all()
+        if np.issubdtype(dtype, np.floating):
+            base = rng.standard_normal((n, d)).astype(dtype)
+            acc = dev(base.copy())
+            pgl.ops.aggregate(dev(x), csr, "sum", dst_scale=dev(ds), out=acc, accumulate=True)
+            want = base + R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "sum") * ds[:, None].astype(dtype)
+            np.testing.assert_allclose(host(acc), want, rtol=1e-5, atol=1e-5 * np.abs(want).max(), err_msg="accumulate d=%d" % d)
+
+
+@pytest.mark.parametrize("tdt", [torch.float16, torch.bfloat16])
+def test_send_recv_16bit_at_every_dispatch_boundary(pgl, tdt):
+    n, e = 3000, 60000
+    edges, rng = rand_graph(n, e, 4343, hub=15000)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    for d in (15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 136, 255, 256, 264):
+        x = torch.as_tensor(rng.standard_normal((n, d)).astype(np.float32)).to(tdt)
+        for op in ("sum", "mean", "max", "min"):
+            want = R.c_send_u_recv(x.float().numpy(), edges[:, 0], edges[:, 1], op)
+            got = g.send_recv(x.cuda(), op)
+            np.testing.assert_allclose(host(got.float()), want, rtol=2 ** -7 if tdt == torch.bfloat16 else 2 ** -10,
+                                       atol=1e-3 * np.abs(want).max(), err_msg="d=%d %s" % (d, op))
+
+
 @pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_narrow_segment_softmax_one_pass(pgl, d, dtype):
@@ -1182,7 +1231,7 @@ def test_chunk_size_stress_in_subprocess(pgl):
     for k in ("8", "4096"):
         env = dict(os.environ, PGLAMD_CHUNK=k)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
-                            "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute or narrow or softmax or group_rows"],
+                            "-k", "send_recv_widths or gat_fused_matches or send_ue_recv or segment_reduce or distgraph_compute or narrow or softmax or group_rows or dispatch_boundary"],
                            env=env, capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stdout[-2000:]
 
