@@ -260,6 +260,31 @@ def test_send_ue_recv(pgl, mop, rop, shape):
     close(got, want, scale=np.abs(want).max())
 
 
+UE_SHAPES = [((d,), (d,)) for d in (1, 2, 8, 15, 16, 17, 32, 33, 64, 65, 128, 130, 300)] + \
+            [((d,), (1,)) for d in (8, 16, 17, 32, 64, 128, 129)] + \
+            [((h, dd), (h, 1)) for h, dd in ((1, 16), (2, 8), (3, 5), (4, 32), (8, 16), (8, 32), (8, 3), (16, 8), (12, 4), (5, 64))]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_send_ue_recv_operand_layouts_and_widths(pgl, dtype):
+    """Edge operand as a full row, one scalar per edge, one weight per head (the GAT layout, heads <= 8 and > 8), across the
+    widths where the lane-per-edge / flat / generic kernels take over from each other; hubs and empty rows included."""
+    n, e = 2500, 40000
+    edges, rng = rand_graph(n, e, 5151, hub=9000)
+    edges[edges[:, 1] % 8 == 0, 1] = 5
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    ops_cycle = [("mul", "sum"), ("add", "mean"), ("mul", "max"), ("sub", "sum"), ("div", "mean"), ("add", "min")]
+    for i, (xs, ys) in enumerate(UE_SHAPES):
+        x = rng.standard_normal((n,) + xs).astype(dtype)
+        y = (rng.standard_normal((e,) + ys) + 3.0).astype(dtype)
+        for mop, rop in (ops_cycle[i % 6], ops_cycle[(i + 3) % 6]):
+            want = R.c_send_ue_recv(x, y, edges[:, 0], edges[:, 1], mop, rop)
+            got = host(g.send_ue_recv(dev(x), dev(y), mop, rop))
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got, want, rtol=RTOL if dtype == np.float32 else 1e-12,
+                                       atol=(1e-5 if dtype == np.float32 else 1e-10) * np.abs(want).max(), err_msg="%s %s %s %s" % (xs, ys, mop, rop))
+
+
 @pytest.mark.parametrize("mop", ["add", "sub", "mul", "div"])
 @pytest.mark.parametrize("shape", [((8,), (8,)), ((8, 16), (8, 1)), ((5,), (5,)), ((1,), (7,))])
 def test_send_uv(pgl, mop, shape):
