@@ -126,11 +126,11 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
     return PGLAMD_OK;
 }
 
-// float / double here; the other four storage types are instantiated in aggregate_more.hip
+// float here; the other storage types are instantiated in aggregate_f64.hip / aggregate_more.hip / aggregate_half.hip
 #define PGLAMD_AGG_ARGS const void*, int64_t, const void*, int64_t, const int32_t*, const int32_t*, const int32_t*, const int64_t*, \
                         int64_t, int64_t, int64_t, int64_t, int32_t, int32_t, const float*, const float*, int, void*, void*, size_t, hipStream_t
 template int32_t aggregate_typed<float>(PGLAMD_AGG_ARGS);
-template int32_t aggregate_typed<double>(PGLAMD_AGG_ARGS);
+extern template int32_t aggregate_typed<double>(PGLAMD_AGG_ARGS);
 extern template int32_t aggregate_typed<int32_t>(PGLAMD_AGG_ARGS);
 extern template int32_t aggregate_typed<int64_t>(PGLAMD_AGG_ARGS);
 extern template int32_t aggregate_typed<__half>(PGLAMD_AGG_ARGS);

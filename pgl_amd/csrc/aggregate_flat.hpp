@@ -1,6 +1,6 @@
 // aggregate_flat.hpp -- the flat aggregation kernels and their typed launcher as templates, so that the (many)
-// instantiations can be compiled in two translation units side by side: aggregate.hip (float, double + the C ABI)
-// and aggregate_more.hip (int32, int64, fp16, bf16).  Design notes: see the head of aggregate.hip.
+// instantiations can be compiled in four translation units side by side: aggregate.hip (float + the C ABI),
+// aggregate_f64.hip, aggregate_more.hip (int32, int64), aggregate_half.hip (fp16, bf16).  Design notes: see the head of aggregate.hip.
 #pragma once
 #include "aggregate.hpp"
 #include "aggregate_group.hpp"

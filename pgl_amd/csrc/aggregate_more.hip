@@ -1,5 +1,6 @@
-// aggregate_more.hip -- the flat aggregation kernels for the integer and 16-bit storage types (int32, int64, fp16, bf16),
-// compiled next to aggregate.hip (fp32, fp64) to halve the build's critical path.  Same templates: aggregate_flat.hpp.
+// aggregate_more.hip -- the aggregation kernels for the integer storage types (int32, int64).  One translation unit per pair
+// of types (aggregate.hip fp32 + the C ABI, aggregate_f64.hip, this one, aggregate_half.hip) keeps the build's critical path
+// at one type's worth of instantiations.  Same templates: aggregate_flat.hpp.
 #include "aggregate_flat.hpp"
 
 namespace pglamd {
@@ -8,7 +9,5 @@ namespace pglamd {
                         int64_t, int64_t, int64_t, int64_t, int32_t, int32_t, const float*, const float*, int, void*, void*, size_t, hipStream_t
 template int32_t aggregate_typed<int32_t>(PGLAMD_AGG_ARGS);
 template int32_t aggregate_typed<int64_t>(PGLAMD_AGG_ARGS);
-template int32_t aggregate_typed<__half>(PGLAMD_AGG_ARGS);
-template int32_t aggregate_typed<__hip_bfloat16>(PGLAMD_AGG_ARGS);
 
 }  // namespace pglamd
