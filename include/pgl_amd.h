@@ -220,9 +220,10 @@ int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const 
  *   grad_feature[u,h,:] = sum_{e=(u->v)} drop_e alpha_e grad_out[v,h,:]
  *   grad_attn_src[u,h]  = sum_{e=(u->v)} d pre_e          (both from ONE walk of the src-sorted CSR)
  *   grad_attn_dst[v,h]  = sum_{e=(u->v)} d pre_e          (one walk of the dst-sorted CSR)
- *   grad_pre (optional) : when non-NULL the src-sorted walk also writes d pre_e to grad_pre[E,H] (ORIGINAL edge
- *                         order) and the dst-sorted walk is skipped; the caller then takes grad_attn_dst as the segment
- *                         sum of grad_pre by destination (pglamd_aggregate with col = eid): 1.3 ms faster at C3 for
+ *   grad_pre (optional) : when non-NULL the src-sorted walk also writes d pre_e to grad_pre[E,H], row p = the p-th edge of
+ *                         the SRC-SORTED stream (src_row / src_col), and the dst-sorted walk is skipped; the caller then
+ *                         takes grad_attn_dst as the segment sum of grad_pre by destination (pglamd_aggregate over the
+ *                         dst-sorted CSR with col = the src-sorted position of each edge): 1.3 ms faster at C3 for
  *                         4*E*H bytes of scratch.  grad_attn_dst may be NULL in that case.
  *   d pre_e = alpha_e (drop_e <grad_out[v,h,:], feature[u,h,:]> - t[v,h]) * leaky_relu'(attn_src[u,h] + attn_dst[v,h])
  *   t[v,h]  = sum_d grad_out[v,h,d] * out[v,h,d]  (out = the forward's output; computed here).

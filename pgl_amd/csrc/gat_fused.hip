@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     const float* __restrict__ ss = p.stat_s;
     const float slope = p.slope;
     constexpr bool drop = DROP;
-    const bool need_eid = drop || (ATT && p.dpre != nullptr);     // original edge ids: dropout hash / d pre_e output
+    const bool need_eid = drop;                                   // original edge ids only feed the dropout hash
 
     float m = -INFINITY, s = 0.f, acc[VEC], acc_a = 0.f;
 #pragma unroll
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             if constexpr (MODE == 2) a_held = prow[(int64_t)cur * p.H + head];
             else p_held = pk[(int64_t)cur * p.H + head];
         }
-        auto consume_att = [&](int r, int ed, const V& xv, const F4& pc, float ac, const V& yo, const F4& po, float ao) {
+        auto consume_att = [&](int r, int ed, int pos, const V& xv, const F4& pc, float ac, const V& yo, const F4& po, float ao) {
             if (r != cur) {
                 if (head_open) store_partial(true); else store_final(cur);
                 head_open = false;
@@ -321,7 +321,9 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             const float dl = alpha * (df * dot - q.t);
             const float dp = pre > 0.f ? dl : slope * dl;
             acc_a += dp;
-            if (dpre_out && (lane & (lph - 1)) == 0 && act) dpre_out[(int64_t)ed * p.H + head] = dp;   // [E,H], original edge order
+            // [E,H] in the order of THIS walk (sequential 32-byte rows; written in original edge order it was one more random
+            // line per edge, and the caller's reduction by destination gathers through a permutation either way)
+            if (dpre_out && (lane & (lph - 1)) == 0 && act) dpre_out[(int64_t)pos * p.H + head] = dp;
         };
         auto load_att = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], F4 (&pc)[U], float (&ac)[U], V (&yo)[U],
                             F4 (&po)[U], float (&ao)[U]) {
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             const bool more = g + 1 < n_full;
             if (more) { load_idx(e + U, cB, rB, eB); load_att(cB, rB, xB, pcB, acB, yB, poB, aoB); }
 #pragma unroll
-            for (int i = 0; i < U; ++i) consume_att(rA[i], eA[i], xA[i], pcA[i], acA[i], yA[i], poA[i], aoA[i]);
+            for (int i = 0; i < U; ++i) consume_att(rA[i], eA[i], e + i, xA[i], pcA[i], acA[i], yA[i], poA[i], aoA[i]);
             if (more) {
 #pragma unroll
                 for (int i = 0; i < U; ++i) {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
                 if constexpr (MODE == 2) { pc = pk[(int64_t)cc * p.H + head]; ao = prow[(int64_t)r * p.H + head]; }
                 else { ac = pcol[(int64_t)cc * p.H + head]; po = pk[(int64_t)r * p.H + head]; }
             }
-            consume_att(r, ed, xv, pc, ac, yo, po, ao);
+            consume_att(r, ed, e, xv, pc, ac, yo, po, ao);
         }
     }
     const bool tail_open = e1 < p.E && rowp[e1] == cur;

@@ -59,7 +59,7 @@ def _prod(shape):
 class CSR(object):
     """Device-side result of csr_build: the reference's five int64 arrays + int32 engine copies."""
     __slots__ = ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr", "row32", "col32", "eid32",
-                 "num_nodes", "num_edges")
+                 "num_nodes", "num_edges", "_pos_by_dst")
 
 
 def csr_build(u, v, num_nodes, want_i64=True):
@@ -368,12 +368,29 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
                                          _ptr(csr_src.eid32), _ptr(csr_src.indptr), csr_dst.num_edges, n, _ptr(gf),
                                          _ptr(g_src), _ptr(g_dst), _ptr(gpre), _ptr(ws), ws.numel(), _stream(feature)), "gat_backward")
     if use_pre:
-        class _E(object):       # edge rows gathered through the original edge id
-            def __init__(self, c):
-                self.row32, self.col32, self.eid32, self.indptr = c.row32, c.eid32, c.eid32, c.indptr
+        class _E(object):       # rows of the src-sorted edge buffer gathered in dst-sorted order
+            def __init__(self, c, pos):
+                self.row32, self.col32, self.eid32, self.indptr = c.row32, pos, pos, c.indptr
                 self.num_edges, self.num_nodes = c.num_edges, c.num_nodes
-        g_dst = aggregate(gpre, _E(csr_dst), "sum", n)
+        g_dst = aggregate(gpre, _E(csr_dst, _src_pos_in_dst_order(csr_dst, csr_src)), "sum", n)
     return gf, g_src, g_dst
+
+
+def _src_pos_in_dst_order(csr_dst, csr_src):
+    """perm[p] = position in the src-sorted stream of the edge at position p of the dst-sorted one (cached on csr_src)."""
+    hit = getattr(csr_src, "_pos_by_dst", None)
+    if hit is not None and hit[0] is csr_dst:
+        return hit[1]
+    E, dev_ = csr_dst.num_edges, csr_dst.row32.device
+    ar = torch.arange(E, dtype=torch.int32, device=dev_)
+    if csr_src.eid32 is None:
+        inv = ar
+    else:
+        inv = torch.empty(E, dtype=torch.int32, device=dev_)
+        inv[csr_src.eid32.long()] = ar
+    perm = inv if csr_dst.eid32 is None else inv[csr_dst.eid32.long()].contiguous()
+    csr_src._pos_by_dst = (csr_dst, perm)
+    return perm
 
 
 def sddmm(x, y, csr):
