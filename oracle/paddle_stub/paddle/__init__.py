@@ -83,10 +83,27 @@ _orig_getitem = _t.Tensor.__getitem__
 def _getitem(self, idx):                  # paddle accepts int32 index tensors
     if isinstance(idx, _t.Tensor) and idx.dtype in (_t.int32, _t.int16, _t.int8):
         idx = idx.to(_t.int64)
+    elif isinstance(idx, _t.Tensor) and idx.is_floating_point():
+        # pgl/math.py:276-296 adds a float32 offset to an int64 argsort result and indexes with the sum: Paddle 2.x keeps the
+        # LEFT operand's dtype in mixed elementwise arithmetic (int64 there), torch promotes to float.  Integral values only.
+        assert (idx == idx.round()).all().item(), "float index tensor with non-integral values"
+        idx = idx.to(_t.int64)
     return _orig_getitem(self, idx)
 
 
 _t.Tensor.__getitem__ = _getitem
+_orig_index_select = _t.Tensor.index_select
+
+
+def _index_select_method(self, *a, **k):   # paddle: x.index_select(index, axis=0); torch: x.index_select(dim, index)
+    if (a and isinstance(a[0], _t.Tensor)) or "axis" in k:
+        index = a[0] if a else k["index"]
+        axis = a[1] if len(a) > 1 else k.get("axis", 0)
+        return _orig_index_select(self, axis, _idx(index))
+    return _orig_index_select(self, *a, **k)
+
+
+_t.Tensor.index_select = _index_select_method
 _orig_split = _t.Tensor.split
 
 

@@ -21,14 +21,11 @@ import ref_python  # noqa: E402
 # them (flaky in the reference itself); METIS is pinned by tests/golden/metis_*.npz instead.
 # Tests that cannot run on the stand-in, all OUTSIDE the message-passing path of SURVEY.md section 8:
 EXCLUDED = {
-    "test_math.MathTest.test_segment_topk": "top-k pooling; relies on Paddle's int64 + float32 -> int64 promotion",
-    "test_pool.PoolTest.test_sag_pool": "top-k pooling (same promotion rule)",
-    "test_pool.PoolTest.test_set2set": "LSTM read-out",
     "test_static_graph.StaticGraphOpTest.test_static_graph": "second half needs Paddle's static-graph executor; the dygraph "
                                                              "GCN stack of its first half is exercised by make_golden_layers.py",
 }
 MODULES = ["test_graph", "test_math", "test_graph_op", "test_conv", "test_bigraph", "test_pool", "test_hetergraph",
-           "test_static_graph"]
+           "test_static_graph", "test_transform"]
 
 
 def run(verbose=False):

@@ -3,8 +3,9 @@ from . import functional
 from .conv import GCNConv, GATConv, GraphSageConv
 from .conv_more import (GATv2Conv, APPNP, GCNII, TransformerConv, GINConv, SGCConv, LightGCNConv, PinSageConv, GPRConv,
                         RGCNConv, SSGCConv, NGCFConv, FAConv)
-from .pool import GraphPool, GraphNorm, GlobalAttention
+from .pool import GraphPool, GraphNorm, GlobalAttention, Set2Set, SAGPool
+from .gmt_pool import GraphMultisetTransformer
 
 __all__ = ["GCNConv", "GATConv", "GraphSageConv", "GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv",
            "LightGCNConv", "PinSageConv", "GPRConv", "RGCNConv", "SSGCConv", "NGCFConv", "FAConv", "GraphPool", "GraphNorm",
-           "GlobalAttention", "functional"]
+           "GlobalAttention", "Set2Set", "SAGPool", "GraphMultisetTransformer", "functional"]

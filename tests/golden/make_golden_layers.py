@@ -258,6 +258,62 @@ b.update({"param::" + k: v.detach().numpy().copy() for k, v in conv.state_dict()
 save("batched_graph", **b)
 
 # ---------------------------------------------------------------------------------------------------------
+# Read-outs beyond segment pooling (pgl/nn/pool.py Set2Set / SAGPool, pgl/nn/gmt_pool.py, pgl/math.py segment_topk /
+# segment_padding, pgl/utils/transform.py to_dense_batch / filter_adj) on the same batched graph
+# ---------------------------------------------------------------------------------------------------------
+from pgl.utils.transform import to_dense_batch, filter_adj  # noqa: E402
+
+r = {"sizes": np.array(sizes), "feat": feat}
+for k, m in enumerate(sizes):
+    r["edges_%d" % k] = gl[k].edges
+tf = paddle.to_tensor(feat)
+rngr = np.random.default_rng(17)
+
+
+def sd(prefix, layer):
+    return {prefix + "::" + k: v.detach().numpy().copy() for k, v in layer.state_dict().items()}
+
+
+paddle.seed(21)
+s2s = gnn.Set2Set(6, 3, 1)
+xs = paddle.to_tensor(feat); xs.stop_gradient = False
+o = s2s(bg, xs)
+ct = rngr.standard_normal(tuple(o.shape)).astype(np.float32)
+(o * paddle.to_tensor(ct)).sum().backward()
+r.update({"set2set": o.detach().numpy(), "set2set_ct": ct, "set2set_dx": xs.grad.numpy().copy()}); r.update(sd("s2s", s2s))
+
+for tag, kw in (("sag", {}), ("sagm", {"min_score": 0.06})):
+    paddle.seed(22)
+    sag = gnn.SAGPool(6, 0.5, gnn=gnn.GCNConv, **kw)          # (the reference's default gnn=None hits an unimported name)
+    xo, bo, go = sag(bg, tf)
+    r.update({tag + "_x": xo.detach().numpy(), tag + "_batch": bo.numpy(), tag + "_edges": go.edges.numpy().astype(np.int64),
+              tag + "_graph_node_id": go.graph_node_id.numpy()})
+    r.update(sd(tag, sag))
+
+for tag, kw in (("gmt", {}), ("gmtln", {"layer_norm": True})):
+    paddle.seed(23)
+    gmt = gnn.GraphMultisetTransformer(6, 8, 3, num_nodes=12, num_heads=2, **kw)
+    xs = paddle.to_tensor(feat); xs.stop_gradient = False
+    o = gmt(bg, xs)
+    ct = rngr.standard_normal(tuple(o.shape)).astype(np.float32)
+    (o * paddle.to_tensor(ct)).sum().backward()
+    r.update({tag: o.detach().numpy(), tag + "_ct": ct, tag + "_dx": xs.grad.numpy().copy()}); r.update(sd(tag, gmt))
+
+score = tf[:, 2]
+kept, perm = pgl.math.segment_topk(tf, score, bg.graph_node_id, 0.3, return_index=True)
+r.update({"topk_perm": perm.numpy().astype(np.int64), "topk_out": kept.numpy()})
+kept, perm = pgl.math.segment_topk(tf, score, bg.graph_node_id, 0.3, min_score=0.4, return_index=True)
+r.update({"topk_min_perm": perm.numpy().astype(np.int64)})
+pad, plen, pidx = pgl.math.segment_padding(tf, bg.graph_node_id)
+r.update({"pad": pad.numpy(), "pad_len": plen.numpy().astype(np.int64), "pad_index": pidx.numpy().astype(np.int64)})
+dense, dmask = to_dense_batch(tf, bg)
+r.update({"dense": dense.numpy(), "dense_mask": dmask.numpy()})
+keep_nodes = paddle.to_tensor(np.sort(rngr.choice(sum(sizes), 30, replace=False)).astype(np.int64))
+fe, _ = filter_adj(bg.edges, keep_nodes)
+r.update({"filter_perm": keep_nodes.numpy(), "filter_edges": fe.numpy().astype(np.int64)})
+save("readouts", **r)
+
+# ---------------------------------------------------------------------------------------------------------
 # Training trajectories of the reference's EXAMPLE models (examples/gcn/train.py GCN, examples/gat/train.py GAT), imported
 # unchanged from the reference tree and driven with the example's own train() step semantics (cross-entropy on the
 # training nodes, Adam(lr, weight_decay) as in the scripts); dropout 0 so the trajectory is deterministic.

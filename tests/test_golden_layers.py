@@ -30,7 +30,7 @@ def _dense_adj(edges, n):
 
 def test_fixtures_present():
     assert len(LAYER_FILES) == 28
-    for f in ("graph_ops.npz", "batched_graph.npz", "rgcn_full.npz", "rgcn_bases2.npz"):
+    for f in ("graph_ops.npz", "batched_graph.npz", "rgcn_full.npz", "rgcn_bases2.npz", "readouts.npz"):
         assert os.path.exists(os.path.join(HERE, "golden", "layers", f))
 
 
@@ -79,7 +79,7 @@ def test_committed_fixtures_are_what_the_reference_produces(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "make_golden_layers.py")], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     committed = sorted(glob.glob(os.path.join(HERE, "golden", "layers", "*.npz")))
-    assert len(committed) == len(list(tmp_path.glob("*.npz"))) == 35
+    assert len(committed) == len(list(tmp_path.glob("*.npz"))) == 36
     for f in committed:
         a, b = np.load(f), np.load(os.path.join(str(tmp_path), os.path.basename(f)))
         assert a.files == b.files, os.path.basename(f)
@@ -270,6 +270,80 @@ def test_batched_graph_matches_reference_python(pgl):
     with torch.no_grad():
         out = conv.cuda()(bg, feat)
     np.testing.assert_allclose(out.cpu().numpy(), z["gcn_on_batch"], rtol=5 * RTOL, atol=1e-6)
+
+
+def _readout_case(pgl):
+    z = np.load(os.path.join(HERE, "golden", "layers", "readouts.npz"))
+    sizes = z["sizes"].tolist()
+    bg = pgl.Graph.disjoint([pgl.Graph(edges=z["edges_%d" % k], num_nodes=m) for k, m in enumerate(sizes)]).tensor()
+    return z, bg, torch.as_tensor(z["feat"]).cuda()
+
+
+def _sub(z, prefix):
+    return {k[len(prefix) + 2:]: z[k] for k in z.files if k.startswith(prefix + "::")}
+
+
+def test_host_side_readout_helpers_match_reference_python():
+    """segment_padding, the ratio branch of segment_topk, to_dense_batch and filter_adj are index arithmetic (no kernel):
+    checked against the reference's outputs on CPU tensors."""
+    import pgl_amd
+    from pgl_amd.utils.transform import to_dense_batch, filter_adj
+    z = np.load(os.path.join(HERE, "golden", "layers", "readouts.npz"))
+    sizes = z["sizes"].tolist()
+    gid = torch.as_tensor(np.repeat(np.arange(len(sizes)), sizes))
+    feat = torch.as_tensor(z["feat"])
+    kept, perm = pgl_amd.math.segment_topk(feat, feat[:, 2], gid, 0.3, return_index=True)
+    assert np.array_equal(perm.numpy(), z["topk_perm"]) and np.array_equal(kept.numpy(), z["topk_out"])
+    pad, plen, pidx = pgl_amd.math.segment_padding(feat, gid)
+    assert np.array_equal(pad.numpy(), z["pad"]) and np.array_equal(plen.numpy(), z["pad_len"]) and np.array_equal(pidx.numpy(), z["pad_index"])
+
+    class _G(object):
+        graph_node_id = gid
+    dense, mask = to_dense_batch(feat, _G())
+    assert np.array_equal(dense.numpy(), z["dense"]) and np.array_equal(mask.numpy(), z["dense_mask"])
+    edges = np.concatenate([z["edges_%d" % k] + sum(sizes[:k]) for k in range(len(sizes))])
+    fe, _ = filter_adj(torch.as_tensor(edges), torch.as_tensor(z["filter_perm"]))
+    assert np.array_equal(fe.numpy(), z["filter_edges"])
+    # integer ratio: at most k rows per segment (the reference's own integer branch calls paddle.min with two tensors and fails)
+    _, perm3 = pgl_amd.math.segment_topk(feat, feat[:, 2], gid, 3, return_index=True)
+    assert np.bincount(gid[perm3].numpy(), minlength=len(sizes)).tolist() == [min(3, m) for m in sizes]
+
+
+@pytest.mark.gpu
+def test_readout_layers_match_reference_python(pgl):
+    """Set2Set, SAGPool (ratio and min_score), GraphMultisetTransformer (with and without LayerNorm) with the reference's
+    parameters: outputs, pooled graphs and input gradients as the reference's own layer code produced them."""
+    z, bg, feat = _readout_case(pgl)
+    # Set2Set (the stand-in's LSTM wrapper nests its torch module one level deeper: lstm.lstm.* -> lstm.*)
+    s2s = pgl.nn.Set2Set(6, 3, 1)
+    s2s.load_state_dict({k.replace("lstm.lstm.", "lstm."): torch.as_tensor(v) for k, v in _sub(z, "s2s").items()})
+    x = feat.clone().requires_grad_(True)
+    out = s2s.cuda()(bg, x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["set2set"], rtol=1e-4, atol=1e-5)
+    (out * torch.as_tensor(z["set2set_ct"]).cuda()).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), z["set2set_dx"], rtol=1e-3, atol=1e-5)
+    # SAGPool
+    for tag, kw in (("sag", {}), ("sagm", {"min_score": 0.06})):
+        sag = pgl.nn.SAGPool(6, 0.5, **kw)
+        _load_params(sag, _sub(z, tag))
+        with torch.no_grad():
+            xo, bo, go = sag.cuda()(bg, feat)
+        np.testing.assert_allclose(xo.cpu().numpy(), z[tag + "_x"], rtol=1e-4, atol=1e-6)
+        assert np.array_equal(bo.cpu().numpy(), z[tag + "_batch"])
+        assert np.array_equal(np.asarray(go.edges.cpu()), z[tag + "_edges"])
+        assert np.array_equal(np.asarray(go.graph_node_id.cpu()), z[tag + "_graph_node_id"]) and go.num_nodes == len(z[tag + "_x"])
+    # GraphMultisetTransformer
+    for tag, kw in (("gmt", {}), ("gmtln", {"layer_norm": True})):
+        gmt = pgl.nn.GraphMultisetTransformer(6, 8, 3, num_nodes=12, num_heads=2, **kw)
+        _load_params(gmt, _sub(z, tag))
+        x = feat.clone().requires_grad_(True)
+        out = gmt.cuda()(bg, x)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), z[tag], rtol=2e-4, atol=2e-5)
+        (out * torch.as_tensor(z[tag + "_ct"]).cuda()).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), z[tag + "_dx"], rtol=2e-3, atol=2e-5)
+    # segment_topk with a score threshold (segment max on the device)
+    _, perm = pgl.math.segment_topk(feat, feat[:, 2], bg.graph_node_id, 0.3, min_score=0.4, return_index=True)
+    assert np.array_equal(perm.cpu().numpy(), z["topk_min_perm"])
 
 
 @pytest.mark.gpu

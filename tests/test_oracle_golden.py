@@ -223,7 +223,7 @@ def test_csr_omp_equals_serial():
 
 def test_reference_unit_tests_pass_on_the_oracle():
     """The reference's OWN test files for this path (tests/test_graph.py, test_math.py, test_graph_op.py, test_conv.py,
-    test_bigraph.py, test_pool.py, test_hetergraph.py), executed unchanged from /root/reference with `paddle` = the
+    test_bigraph.py, test_pool.py, test_hetergraph.py, test_transform.py), executed unchanged from /root/reference with `paddle` = the
     oracle's stand-in: every assertion they make holds for the restatement.  Build container only."""
     import os
     import subprocess
@@ -234,4 +234,4 @@ def test_reference_unit_tests_pass_on_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "oracle", "run_reference_tests.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     ran = sum(int(line.split()[2]) for line in r.stdout.splitlines() if " ran " in line)
-    assert ran >= 40, r.stdout
+    assert ran >= 45, r.stdout

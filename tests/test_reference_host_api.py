@@ -92,6 +92,13 @@ with tempfile.TemporaryDirectory() as td:
     assert x.num_graph == y.num_graph == br.num_graph
     same(x.graph_node_id, br.graph_node_id, "ref loads my batch"); same(y.graph_node_id, br.graph_node_id, "mine loads ref batch")
     same(y.graph_edge_id, br.graph_edge_id, "mine loads ref batch (edges)")
+# graph transforms (pgl/utils/transform.py)
+from pgl.utils.transform import to_undirected as r_und, add_self_loops as r_loops
+from pgl_amd.utils.transform import to_undirected as m_und, add_self_loops as m_loops
+for rf, mf in ((r_und, m_und), (r_loops, m_loops)):
+    a, b = rf(gr), mf(gm)
+    same(a.edges, b.edges, rf.__name__); assert a.num_nodes == b.num_nodes
+    same(a.node_feat["h"], b.node_feat["h"], rf.__name__ + " feat")
 print("HOST_API_OK")
 '''
 
