@@ -282,10 +282,17 @@ ct = rngr.standard_normal(tuple(o.shape)).astype(np.float32)
 (o * paddle.to_tensor(ct)).sum().backward()
 r.update({"set2set": o.detach().numpy(), "set2set_ct": ct, "set2set_dx": xs.grad.numpy().copy()}); r.update(sd("s2s", s2s))
 
+# (self-loops on every node: a node without in-edges scores exactly the bias, and the order of tied scores in a top-k is
+#  unspecified in the reference -- argsort -- so the fixture keeps all scores distinct)
+gl_loops = [pgl.Graph(edges=np.concatenate([g_.edges, np.stack([np.arange(m), np.arange(m)], 1)]).astype(np.int64), num_nodes=m)
+            for g_, m in zip(gl, sizes)]
+bgl = pgl.Graph.disjoint(gl_loops).tensor()
+for k, m in enumerate(sizes):
+    r["loop_edges_%d" % k] = gl_loops[k].edges
 for tag, kw in (("sag", {}), ("sagm", {"min_score": 0.06})):
     paddle.seed(22)
     sag = gnn.SAGPool(6, 0.5, gnn=gnn.GCNConv, **kw)          # (the reference's default gnn=None hits an unimported name)
-    xo, bo, go = sag(bg, tf)
+    xo, bo, go = sag(bgl, tf)
     r.update({tag + "_x": xo.detach().numpy(), tag + "_batch": bo.numpy(), tag + "_edges": go.edges.numpy().astype(np.int64),
               tag + "_graph_node_id": go.graph_node_id.numpy()})
     r.update(sd(tag, sag))

@@ -310,11 +310,10 @@ def test_host_side_readout_helpers_match_reference_python():
 
 
 @pytest.mark.gpu
-def test_readout_layers_match_reference_python(pgl):
-    """Set2Set, SAGPool (ratio and min_score), GraphMultisetTransformer (with and without LayerNorm) with the reference's
-    parameters: outputs, pooled graphs and input gradients as the reference's own layer code produced them."""
+def test_set2set_matches_reference_python(pgl):
+    """Set2Set with the reference's parameters: output and input gradient as the reference's own layer code produced them
+    (the stand-in's LSTM wrapper nests its torch module one level deeper: lstm.lstm.* -> lstm.*)."""
     z, bg, feat = _readout_case(pgl)
-    # Set2Set (the stand-in's LSTM wrapper nests its torch module one level deeper: lstm.lstm.* -> lstm.*)
     s2s = pgl.nn.Set2Set(6, 3, 1)
     s2s.load_state_dict({k.replace("lstm.lstm.", "lstm."): torch.as_tensor(v) for k, v in _sub(z, "s2s").items()})
     x = feat.clone().requires_grad_(True)
@@ -322,26 +321,41 @@ def test_readout_layers_match_reference_python(pgl):
     np.testing.assert_allclose(out.detach().cpu().numpy(), z["set2set"], rtol=1e-4, atol=1e-5)
     (out * torch.as_tensor(z["set2set_ct"]).cuda()).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), z["set2set_dx"], rtol=1e-3, atol=1e-5)
-    # SAGPool
-    for tag, kw in (("sag", {}), ("sagm", {"min_score": 0.06})):
-        sag = pgl.nn.SAGPool(6, 0.5, **kw)
-        _load_params(sag, _sub(z, tag))
-        with torch.no_grad():
-            xo, bo, go = sag.cuda()(bg, feat)
-        np.testing.assert_allclose(xo.cpu().numpy(), z[tag + "_x"], rtol=1e-4, atol=1e-6)
-        assert np.array_equal(bo.cpu().numpy(), z[tag + "_batch"])
-        assert np.array_equal(np.asarray(go.edges.cpu()), z[tag + "_edges"])
-        assert np.array_equal(np.asarray(go.graph_node_id.cpu()), z[tag + "_graph_node_id"]) and go.num_nodes == len(z[tag + "_x"])
-    # GraphMultisetTransformer
-    for tag, kw in (("gmt", {}), ("gmtln", {"layer_norm": True})):
-        gmt = pgl.nn.GraphMultisetTransformer(6, 8, 3, num_nodes=12, num_heads=2, **kw)
-        _load_params(gmt, _sub(z, tag))
-        x = feat.clone().requires_grad_(True)
-        out = gmt.cuda()(bg, x)
-        np.testing.assert_allclose(out.detach().cpu().numpy(), z[tag], rtol=2e-4, atol=2e-5)
-        (out * torch.as_tensor(z[tag + "_ct"]).cuda()).sum().backward()
-        np.testing.assert_allclose(x.grad.cpu().numpy(), z[tag + "_dx"], rtol=2e-3, atol=2e-5)
-    # segment_topk with a score threshold (segment max on the device)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw", [("sag", {}), ("sagm", {"min_score": 0.06})])
+def test_sagpool_matches_reference_python(pgl, tag, kw):
+    """SAGPool (top ceil(ratio n) per graph / score threshold): kept features, graph ids, relabelled edges, pooled Graph."""
+    z, _, feat = _readout_case(pgl)
+    sizes = z["sizes"].tolist()
+    bg = pgl.Graph.disjoint([pgl.Graph(edges=z["loop_edges_%d" % k], num_nodes=m) for k, m in enumerate(sizes)]).tensor()
+    sag = pgl.nn.SAGPool(6, 0.5, **kw)
+    _load_params(sag, _sub(z, tag))
+    with torch.no_grad():
+        xo, bo, go = sag.cuda()(bg, feat)
+    assert np.array_equal(bo.cpu().numpy(), z[tag + "_batch"])
+    np.testing.assert_allclose(xo.cpu().numpy(), z[tag + "_x"], rtol=1e-4, atol=1e-6)
+    assert np.array_equal(np.asarray(go.edges.cpu()), z[tag + "_edges"])
+    assert np.array_equal(np.asarray(go.graph_node_id.cpu()), z[tag + "_graph_node_id"]) and go.num_nodes == len(z[tag + "_x"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,kw", [("gmt", {}), ("gmtln", {"layer_norm": True})])
+def test_graph_multiset_transformer_matches_reference_python(pgl, tag, kw):
+    z, bg, feat = _readout_case(pgl)
+    gmt = pgl.nn.GraphMultisetTransformer(6, 8, 3, num_nodes=12, num_heads=2, **kw)
+    _load_params(gmt, _sub(z, tag))
+    x = feat.clone().requires_grad_(True)
+    out = gmt.cuda()(bg, x)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z[tag], rtol=2e-4, atol=2e-5)
+    (out * torch.as_tensor(z[tag + "_ct"]).cuda()).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), z[tag + "_dx"], rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_segment_topk_with_score_threshold_matches_reference_python(pgl):
+    z, bg, feat = _readout_case(pgl)
     _, perm = pgl.math.segment_topk(feat, feat[:, 2], bg.graph_node_id, 0.3, min_score=0.4, return_index=True)
     assert np.array_equal(perm.cpu().numpy(), z["topk_min_perm"])
 
