@@ -85,7 +85,7 @@ def run_epoch(args, model, optim, graph_np, graph_dev, sampler, feature, labels,
         loss = F.cross_entropy(pred, y)
         if train:
             optim.zero_grad(); loss.backward(); optim.step()
-        tot_loss += float(loss) * len(nodes); tot_acc += float((pred.argmax(1) == y).sum()); tot += len(nodes)
+        tot_loss += loss.item() * len(nodes); tot_acc += int((pred.argmax(1) == y).sum().item()); tot += len(nodes)
     return tot_loss / tot, tot_acc / tot
 
 
