@@ -25,6 +25,20 @@ def test_library_exports_every_header_symbol():
     assert L.pglamd_abi_version() == 1
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/pgl_amd.h is bound in pgl_amd/_ffi.py with the same number of parameters (a silent
+    mismatch would shift every later argument of a call)."""
+    import pgl_amd
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pgl_amd.h")).read(), flags=re.S)
+    protos = re.findall(r"\b(pglamd_\w+)\s*\(([^;{]*?)\)\s*;", hdr)
+    assert len(protos) >= 30
+    for name, args in protos:
+        n = 0 if args.strip() in ("", "void") else len(args.split(","))
+        assert name in pgl_amd._ffi._SIGNATURES, name
+        assert len(pgl_amd._ffi._SIGNATURES[name][1]) == n, (name, n, len(pgl_amd._ffi._SIGNATURES[name][1]))
+    assert set(pgl_amd._ffi._SIGNATURES) == {n for n, _ in protos}
+
+
 def test_product_never_touches_the_oracle():
     """pgl_amd/ must not import, load or reference anything under oracle/."""
     bad = []
