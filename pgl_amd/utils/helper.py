@@ -60,3 +60,21 @@ def generate_segment_id_from_index(index):
     seg = np.zeros(int(index[-1]) + 1, dtype="int32")
     np.add.at(seg, index[:-1], 1)
     return (np.cumsum(seg)[:-1] - 1).astype("int32")
+
+
+def scatter(x, index, updates, overwrite=True, name=None):
+    """pgl/utils/helper.py:46-117 (paddle.scatter): rows of `x` named by `index` replaced by the rows of `updates`
+    (overwrite=True; with duplicate ids the LAST update wins here, the reference leaves the order unspecified) or first
+    zeroed and then summed over the duplicates (overwrite=False).  Out of place."""
+    index = torch.as_tensor(index, device=x.device).reshape(-1).long()
+    if overwrite:
+        out = x.clone()
+        # index_copy_ with duplicates is order-dependent on the device: resolve to the last occurrence explicitly
+        last = torch.full((x.shape[0],), -1, dtype=torch.int64, device=x.device)
+        last.scatter_reduce_(0, index, torch.arange(index.shape[0], device=x.device), "amax", include_self=True)
+        hit = last >= 0
+        out[hit] = updates[last[hit]].to(x.dtype)
+        return out
+    out = x.clone()
+    out[index] = 0
+    return out.index_add(0, index, updates.to(x.dtype))

@@ -1,4 +1,4 @@
-"""Mirror of pgl/utils/op.py: read_rows / RowReader / get_index_from_counts."""
+"""Mirror of pgl/utils/op.py: read_rows / RowReader / get_index_from_counts / all_reduce_sum_with_grad."""
 import numpy as np
 import torch
 
@@ -41,3 +41,34 @@ class RowReader(dict):
 
     def keys(self):
         return self.nfeat.keys()
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """Sum over the ranks of the default process group; the gradient of that sum w.r.t. each rank's contribution is the
+    sum of the ranks' output gradients (what Paddle's c_allreduce_sum registers as its backward)."""
+
+    @staticmethod
+    def forward(ctx, tensor, group):
+        import torch.distributed as dist
+        ctx.group = group
+        out = tensor.contiguous().clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        import torch.distributed as dist
+        g = grad.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def all_reduce_sum_with_grad(tensor, group=None):
+    """pgl/utils/op.py:90-122 (the collective behind the reference's DistGPUGraph): all-reduce(sum) that autograd can
+    differentiate.  Out of place; a single process (no initialised group) returns the tensor unchanged.
+    `DistGraph` / `FeatureShardedGraph` (pgl_amd/distributed.py) do not need it -- their layouts have no reduction
+    collective -- it is here for code written against the reference's edge-sharded scheme."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensor
+    return _AllReduceSum.apply(tensor, group)

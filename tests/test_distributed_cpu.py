@@ -169,3 +169,55 @@ def test_feature_sharded_layout_changes_gloo(world):
         assert np.array_equal(back, x[:, c0:c1]), "rows_to_cols"
         rows_seen += list(range(r0, r1)); cols_seen += list(range(c0, c1))
     assert sorted(rows_seen) == list(range(n)) and sorted(cols_seen) == list(range(d))
+
+
+# ------------------------------------------------------------------------------------------------
+# all_reduce_sum_with_grad (pgl/utils/op.py:90-122): the reference DistGPUGraph's collective, differentiable
+# ------------------------------------------------------------------------------------------------
+def _ars_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgl_amd.utils.op import all_reduce_sum_with_grad
+        x = (torch.arange(6, dtype=torch.float32).reshape(2, 3) + 10 * rank).requires_grad_(True)
+        w = torch.full((2, 3), float(rank + 1))
+        out = all_reduce_sum_with_grad(x)
+        (out * w).sum().backward()
+        q.put((rank, out.detach().numpy(), x.grad.numpy()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_reduce_sum_with_grad_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ars_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = np.arange(6, dtype=np.float32).reshape(2, 3)
+    for rank, out, grad in got:
+        assert np.array_equal(out, base * 2 + 10)            # x_0 + x_1 on every rank
+        assert np.array_equal(grad, np.full((2, 3), 3.0))    # d/dx_r of sum_q <w_q, x_0 + x_1> = w_0 + w_1
+
+
+def test_all_reduce_sum_with_grad_single_process_is_identity():
+    from pgl_amd.utils.op import all_reduce_sum_with_grad
+    x = torch.ones(3, requires_grad=True)
+    assert all_reduce_sum_with_grad(x) is x
+
+
+def test_helper_scatter_follows_the_reference_docstring():
+    """pgl/utils/helper.py:46-72."""
+    from pgl_amd.utils.helper import scatter
+    x = torch.tensor([[1., 1], [2, 2], [3, 3]]); index = torch.tensor([2, 1, 0, 1])
+    updates = torch.tensor([[1., 1], [2, 2], [3, 3], [4, 4]])
+    assert scatter(x, index, updates, overwrite=False).tolist() == [[3, 3], [6, 6], [1, 1]]
+    assert scatter(x, index, updates, overwrite=True).tolist() == [[3, 3], [4, 4], [1, 1]]       # last duplicate wins
+    assert x.tolist() == [[1, 1], [2, 2], [3, 3]]                                                 # out of place
