@@ -79,14 +79,19 @@ const char* pglamd_device_arch(void);
  *                   bit-identical to build_index (stable by original edge id)
  *   row32[E] col32[E] eid32[E]   optional (NULL to skip) int32 copies of sorted_u / sorted_v /
  *                   sorted_eid that the aggregation kernels read (halves index traffic)
+ *   range_flag      optional device int32[1] (caller zeroes it): set to 1 when a key lies outside
+ *                   [0, N) or a neighbour id outside [0, 2^31).  Offending keys are clamped to row 0
+ *                   so the call itself stays memory-safe; the call is asynchronous, the CALLER
+ *                   decides when to read the flag (pgl_amd.ops.csr_build raises ValueError, the
+ *                   error pglamd_build_index_host returns as PGLAMD_E_RANGE on the host side).
  * Limits: N < 2^31, E < 2^31 (PGLAMD_E_RANGE otherwise).
  * ---------------------------------------------------------------------------------------------- */
 size_t pglamd_csr_build_workspace_bytes(int64_t num_edges, int64_t num_nodes);
 int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const int64_t* v, int64_t v_stride,
                          int64_t num_edges, int64_t num_nodes, int64_t* degree, int64_t* sorted_v,
                          int64_t* sorted_u, int64_t* sorted_eid, int64_t* indptr, int32_t* row32,
-                         int32_t* col32, int32_t* eid32, void* workspace, size_t workspace_bytes,
-                         void* stream);
+                         int32_t* col32, int32_t* eid32, int32_t* range_flag, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* Replaces unique_segment(dst_sorted) = paddle.unique(return_inverse=True)
  * (pgl/utils/helper.py:156-160, cached by Graph.get_segment_ids, pgl/graph.py:1397-1407).
@@ -128,6 +133,9 @@ int32_t pglamd_narrow_i64(const int64_t* in, int64_t in_stride, int64_t n, int32
  *              combined (+ / max / min) with their existing contents, other rows are untouched --
  *              used to add the halo-source edges after the local-source edges of a partitioned
  *              graph (still deterministic: the two launches are ordered on the stream); not with MEAN.
+ *              2: rows that receive edges are OVERWRITTEN, other rows are untouched -- the boundary rows of a
+ *              partitioned graph are finished after the halo arrives, on top of the interior rows' launch
+ *              (max / min have no identity that an empty first launch could leave behind).
  * ---------------------------------------------------------------------------------------------- */
 size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t dout, int32_t dtype);
 int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t dx, const void* y,

@@ -21,7 +21,7 @@ _SIGNATURES = {
     "pglamd_device_arch": (ctypes.c_char_p, []),
     "pglamd_csr_build_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "pglamd_csr_build": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                  c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                  c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_unique_segment_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "pglamd_unique_segment": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_narrow_i64": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),

@@ -137,7 +137,7 @@ class _GatherRows(torch.autograd.Function):
         csr = ctx.index_csr() if callable(ctx.index_csr) else ctx.index_csr
         if csr is None:     # arbitrary index: key it on the fly
             iota = torch.arange(ctx.index.shape[0], device=grad.device, dtype=torch.int64)
-            csr = ops.csr_build(ctx.index.to(torch.int64), iota, ctx.n)
+            csr = ops.csr_build(ctx.index.to(torch.int64), iota, ctx.n, check_range=False)
         return ops.aggregate(grad.contiguous(), _edge_csr(csr), "sum", ctx.n), None, None
 
 

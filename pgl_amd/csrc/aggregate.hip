@@ -183,6 +183,7 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
 }
 
 extern "C" int32_t pglamd_profile_begin(void) {
+    std::lock_guard<std::mutex> lk(prof().mu);
     for (auto& pr : prof().ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     prof().ev.clear();
     prof().on = true;
@@ -191,6 +192,7 @@ extern "C" int32_t pglamd_profile_begin(void) {
 
 extern "C" int32_t pglamd_profile_end(double* total_ms, int64_t* launches) {
     prof().on = false;
+    std::lock_guard<std::mutex> lk(prof().mu);
     double tot = 0;
     int64_t n = 0;
     for (auto& pr : prof().ev) {
@@ -206,4 +208,9 @@ extern "C" int32_t pglamd_profile_end(double* total_ms, int64_t* launches) {
     return PGLAMD_OK;
 }
 
-extern "C" const char* pglamd_profile_last_kernel(void) { return prof().last_kernel.c_str(); }
+extern "C" const char* pglamd_profile_last_kernel(void) {
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(prof().mu);
+    copy = prof().last_kernel;
+    return copy.c_str();
+}

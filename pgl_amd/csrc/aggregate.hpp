@@ -1,6 +1,8 @@
 // aggregate.hpp -- launch parameters and device helpers shared by the aggregation kernels
 // (aggregate.hip: lanes across the feature dimension; aggregate_narrow.hip: one lane per edge).
 #pragma once
+#include <atomic>
+#include <mutex>
 #include "common.hpp"
 
 #include <string>
@@ -27,7 +29,7 @@ struct AggParams {
     int ypad;                             // YMODE 3: y row length rounded up to a power of two (<= 8); 0 = not applicable
     int mop, is_max, is_mean;
     int zvec;                             // vector width the zero-fill role may use (1, 2, 4)
-    int accumulate;                       // 1: combine with the existing out row instead of overwriting
+    int accumulate;                       // 0: write every row; 1: combine rows that receive edges with their old contents; 2: overwrite only those rows
     int align;                            // 1: never split rows of <= chunk edges (chunk_cut)
     int narrow_vec;                       // aggregate_narrow: rows may be moved with (<=16-byte) vector loads / stores
 };
@@ -90,7 +92,8 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
 // Optional in-library timing of the aggregation kernels (bench.py roofline leg): while enabled, every edge-kernel launch is
 // bracketed by a pair of HIP events on the launch stream.
 struct ProfileState {
-    bool on = false;
+    std::atomic<bool> on{false};     // read on every launch; everything else only under `mu` and only while on
+    std::mutex mu;                   // autograd backward threads launch concurrently with the main thread
     std::string last_kernel;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         if (r >= q->out_rows) return;
         T* dst = static_cast<T*>(q->out) + (int64_t)r * q->ldo;
         const float* dsp = q->dst_scale;
-        const bool is_mean = q->is_mean != 0, accumulate = q->accumulate != 0;
+        const bool is_mean = q->is_mean != 0, accumulate = q->accumulate == 1;
         float ds = 1.f;
         int64_t n = 1;
         if constexpr (RCLS == 0) {
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
                     }
                     ov[k] = v;
                 }
-                if (p.accumulate) {
+                if (p.accumulate == 1) {
                     const VO old = *reinterpret_cast<const VO*>(dst + j0[t]);
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) ov[k] = comb(to_acc<T>(old.v[k]), ov[k]);
@@ -571,9 +571,11 @@ __global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx
             else acc = m < acc ? m : acc;
         }
         if (additive && p.is_mean && t > s) acc = acc / (A)(t - s);
-        if (p.accumulate) {
+        if (p.accumulate == 1) {
             const A ol = to_acc<T>(out[j]);
             if (t > s) out[j] = from_acc<T>(additive ? ol + acc : (p.is_max == 1 ? (acc > ol ? acc : ol) : (acc < ol ? acc : ol)));
+        } else if (p.accumulate == 2) {
+            if (t > s) out[j] = from_acc<T>(acc);
         } else {
             out[j] = from_acc<T>(acc);
         }
@@ -599,10 +601,11 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
-    prof().last_kernel = kernel_name<T>(VEC, NT, RCLS, YMODE);
     if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof().on) {
+    const bool profiling = prof().on.load(std::memory_order_relaxed);
+    if (profiling) {
+        { std::lock_guard<std::mutex> lk(prof().mu); prof().last_kernel = kernel_name<T>(VEC, NT, RCLS, YMODE); }
         PGLAMD_HIP_CHECK(hipEventCreate(&e0));
         PGLAMD_HIP_CHECK(hipEventCreate(&e1));
         PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
@@ -634,8 +637,9 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     }
     PGLAMD_LAUNCH_CHECK();
 launched:
-    if (prof().on) {
+    if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
+        std::lock_guard<std::mutex> lk(prof().mu);
         prof().ev.emplace_back(e0, e1);
     }
     if (p.n_chunks > 1) {

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
                 }
             }
         }
-        if (q->accumulate != 0) {
+        if (q->accumulate == 1) {
             const V old = *reinterpret_cast<const V*>(dst);
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
@@ -220,18 +220,20 @@ int32_t launch_group_one(AggParams p, hipStream_t st) {
     const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (prof().on) {
+    const bool profiling = prof().on.load(std::memory_order_relaxed);
+    if (profiling) {
         char name[96];
         snprintf(name, sizeof(name), "agg_group_kernel<%d-byte elements, %d, %d, %d>", (int)sizeof(T), VEC, G, RCLS);
-        prof().last_kernel = name;
+        { std::lock_guard<std::mutex> lk(prof().mu); prof().last_kernel = name; }
         PGLAMD_HIP_CHECK(hipEventCreate(&ev0));
         PGLAMD_HIP_CHECK(hipEventCreate(&ev1));
         PGLAMD_HIP_CHECK(hipEventRecord(ev0, st));
     }
     hipLaunchKernelGGL((agg_group_kernel<T, VEC, G, RCLS>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
-    if (prof().on) {
+    if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(ev1, st));
+        std::lock_guard<std::mutex> lk(prof().mu);
         prof().ev.emplace_back(ev0, ev1);
     }
     return PGLAMD_OK;

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                     for (int k = 0; k < D; ++k) v[k] = flip(v[k]);
                 }
             }
-            if (p.accumulate) {
+            if (p.accumulate == 1) {
 #pragma unroll
                 for (int k = 0; k < D; ++k)
                     if (k < d) {
@@ -417,18 +417,20 @@ int32_t launch_one(AggParams p, int32_t dtype, hipStream_t st) {
     const int64_t zb = p.accumulate ? 0 : ceil_div(p.out_rows, kBlock);
     if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (prof().on) {
+    const bool profiling = prof().on.load(std::memory_order_relaxed);
+    if (profiling) {
         char name[96];
         snprintf(name, sizeof(name), "agg_narrow_kernel<%d-byte elements, %d, %d, %d>", (int)sizeof(T), D, RCLS, YMODE);
-        prof().last_kernel = name;
+        { std::lock_guard<std::mutex> lk(prof().mu); prof().last_kernel = name; }
         PGLAMD_HIP_CHECK(hipEventCreate(&ev0));
         PGLAMD_HIP_CHECK(hipEventCreate(&ev1));
         PGLAMD_HIP_CHECK(hipEventRecord(ev0, st));
     }
     hipLaunchKernelGGL((agg_narrow_kernel<T, D, RCLS, YMODE>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
-    if (prof().on) {
+    if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(ev1, st));
+        std::lock_guard<std::mutex> lk(prof().mu);
         prof().ev.emplace_back(ev0, ev1);
     }
     if (p.n_chunks > 1) return launch_fixup_cols(p, dtype, RCLS, st);

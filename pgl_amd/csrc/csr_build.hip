@@ -26,12 +26,20 @@ static int key_bits(int64_t n) {
 }
 
 __global__ __launch_bounds__(kBlock) void narrow_keys_kernel(const int64_t* __restrict__ u, int64_t u_stride, const int64_t* __restrict__ v,
-                                                             int64_t v_stride, int64_t n, int32_t* __restrict__ key,
-                                                             uint64_t* __restrict__ val) {
+                                                             int64_t v_stride, int64_t n, int64_t n_rows, int32_t* __restrict__ key,
+                                                             uint64_t* __restrict__ val, int32_t* __restrict__ range_flag) {
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        key[i] = (int32_t)u[i * u_stride];
-        val[i] = ((uint64_t)(uint32_t)v[i * v_stride] << 32) | (uint64_t)(uint32_t)i;       // (neighbour, original edge id)
+        int64_t k = u[i * u_stride];
+        const int64_t nb = v[i * v_stride];
+        // a key outside [0, N) would be sorted on its low bits only and then race in row_bounds_kernel; a neighbour that
+        // does not fit 31 bits would alias another node.  Both are clamped (memory-safe) and reported through range_flag.
+        if ((uint64_t)k >= (uint64_t)n_rows) { k = 0; bad = true; }
+        if ((uint64_t)nb > (uint64_t)INT32_MAX) bad = true;
+        key[i] = (int32_t)k;
+        val[i] = ((uint64_t)(uint32_t)nb << 32) | (uint64_t)(uint32_t)i;       // (neighbour, original edge id)
     }
+    if (range_flag && __any(bad)) { if ((threadIdx.x & (kWave - 1)) == 0) atomicOr(range_flag, 1); }
 }
 
 __global__ __launch_bounds__(kBlock) void narrow_i64_kernel(const int64_t* __restrict__ in, int64_t stride, int64_t n, int32_t* __restrict__ out) {
@@ -124,8 +132,8 @@ extern "C" size_t pglamd_csr_build_workspace_bytes(int64_t num_edges, int64_t nu
 extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const int64_t* v, int64_t v_stride,
                                     int64_t num_edges, int64_t num_nodes, int64_t* degree, int64_t* sorted_v,
                                     int64_t* sorted_u, int64_t* sorted_eid, int64_t* indptr, int32_t* row32,
-                                    int32_t* col32, int32_t* eid32, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
+                                    int32_t* col32, int32_t* eid32, int32_t* range_flag, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
     if (num_edges < 0 || num_nodes < 0 || num_edges >= INT32_MAX || num_nodes >= INT32_MAX)
         return fail(PGLAMD_E_RANGE, "csr_build: E=%lld N=%lld beyond the int32 engine range", (long long)num_edges, (long long)num_nodes);
     if (!indptr || !degree || (num_edges > 0 && (!u || !v))) return fail(PGLAMD_E_ARG, "csr_build: NULL pointer");
@@ -145,7 +153,7 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
     if (!cv.ok()) return fail(PGLAMD_E_WORKSPACE, "csr_build: workspace carve overflow");
 
     if (E > 0) {
-        hipLaunchKernelGGL(narrow_keys_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, u, u_stride, v, v_stride, E, key_in, val_in);
+        hipLaunchKernelGGL(narrow_keys_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, u, u_stride, v, v_stride, E, N, key_in, val_in, range_flag);
         PGLAMD_LAUNCH_CHECK();
         PGLAMD_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, key_in, rows, val_in, val_out, (size_t)E, 0u, (unsigned)bits, st));
     }

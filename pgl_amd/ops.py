@@ -62,11 +62,14 @@ class CSR(object):
                  "num_nodes", "num_edges", "_pos_by_dst")
 
 
-def csr_build(u, v, num_nodes, want_i64=True):
+def csr_build(u, v, num_nodes, want_i64=True, check_range=True):
     """EdgeIndex.from_edges (pgl/utils/edge_index.py:38-58) / build_index (graph_kernel.pyx:59-88).
     u, v: 1-D int64 CUDA tensors (may be strided views of the [E,2] edge tensor).
     want_i64=False skips the three int64 [E] outputs (sorted_v / sorted_u / sorted_eid stay None): the kernels only
-    read the int32 copies, and EdgeIndex widens them on first access -- 480 MB less to write and hold at |E| = 20 M."""
+    read the int32 copies, and EdgeIndex widens them on first access -- 480 MB less to write and hold at |E| = 20 M.
+    check_range: read back the library's range flag (one host sync; this is the once-per-graph setup path) and raise
+    ValueError for keys outside [0, num_nodes), as pglamd_build_index_host does on the host side.  Internal callers whose
+    ids are in range by construction (halo plans, sampled blocks) pass False and stay asynchronous."""
     _need_cuda(u, v)
     if u.dtype != torch.int64 or v.dtype != torch.int64:
         u, v = u.to(torch.int64), v.to(torch.int64)
@@ -85,10 +88,14 @@ def csr_build(u, v, num_nodes, want_i64=True):
     sv = v.stride(0) if E > 0 else 1
     nb = L.pglamd_csr_build_workspace_bytes(E, N)
     ws = _ws(nb, dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev) if (check_range and E > 0) else None
     with torch.cuda.device(dev):
         _ffi.check(L.pglamd_csr_build(_ptr(u), su, _ptr(v), sv, E, N, _ptr(c.degree), _ptr(c.sorted_v),
                                       _ptr(c.sorted_u), _ptr(c.sorted_eid), _ptr(c.indptr), _ptr(c.row32),
-                                      _ptr(c.col32), _ptr(c.eid32), _ptr(ws), ws.numel(), _stream(u)), "csr_build")
+                                      _ptr(c.col32), _ptr(c.eid32), _ptr(flag), _ptr(ws), ws.numel(), _stream(u)), "csr_build")
+    if flag is not None and int(flag.item()):
+        raise ValueError("pgl_amd csr_build: edge ids outside [0, num_nodes=%d) (or >= 2^31); the graph index would be "
+                         "garbage -- check num_nodes against the edge list" % N)
     return c
 
 
@@ -152,7 +159,9 @@ _PRESCALE_ROW_BYTES = int(os.environ.get("PGLAMD_PRESCALE_ROW_BYTES", "704"))
 def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None,
               out=None, accumulate=False):
     """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
-    graph's cached dst-CSR.  y (if given) is in ORIGINAL edge order, shape [E, ...]."""
+    graph's cached dst-CSR.  y (if given) is in ORIGINAL edge order, shape [E, ...].
+    accumulate: False / 0 write every row of `out`; True / 1 combine the rows that receive edges with their old contents;
+    2 overwrite only the rows that receive edges (include/pgl_amd.h)."""
     _need_cuda(x, y, src_scale, dst_scale)
     L = _ffi.lib()
     x = x.contiguous()
@@ -188,7 +197,7 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
         _ffi.check(L.pglamd_aggregate(_ptr(x), code, int(x.shape[0]), dx, _ptr(y), dy,
                                       _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
                                       _ptr(csr.indptr), csr.num_edges, csr.num_nodes, M, dout, MSG[message_op],
-                                      REDUCE[reduce_op], _ptr(src_scale), _ptr(dst_scale), int(bool(accumulate)), _ptr(out), _ptr(ws),
+                                      REDUCE[reduce_op], _ptr(src_scale), _ptr(dst_scale), int(accumulate), _ptr(out), _ptr(ws),
                                       ws.numel(), _stream(x)), "aggregate")
     return out
 

@@ -1,0 +1,181 @@
+"""GPU tests (-m gpu) added in round 2: range flag of the CSR build, the overwrite-only accumulate mode,
+the fused GAT kernels at BASELINE configs[2] size against the oracle, per-element fp64 error bounds."""
+import numpy as np
+import pytest
+import torch
+
+import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pgl():
+    import pgl_amd
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    assert pgl_amd._ffi.lib().pglamd_device_arch().decode().startswith("gfx950")
+    return pgl_amd
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_within_fp32_reassociation(got, want64, abs_terms64, n_terms, slack=4.0):
+    """Per-element bound against the fp64 result ("within fp32 reassociation bound of the fp64 result"):
+    any order of summing n fp32 terms t_i is within  n_terms * eps32 * sum|t_i|  of the exact sum (first-order bound,
+    Higham 4.4); `slack` covers the rounding of the terms themselves.  Unlike an atol tied to max|want| this bound
+    scales with each output element's own term magnitudes, so small outputs are held to a small absolute error."""
+    eps = np.finfo(np.float32).eps
+    bound = slack * np.maximum(n_terms, 1) * eps * abs_terms64 + np.finfo(np.float32).tiny
+    err = np.abs(got.astype(np.float64) - want64)
+    worst = np.unravel_index(np.argmax(err - bound), err.shape)
+    assert (err <= bound).all(), "element %s: |err| %.3e > bound %.3e (want %.6e)" % (worst, err[worst], bound[worst], want64[worst])
+
+
+# ------------------------------------------------------------------------------------------------
+# csr_build must not silently accept ids outside [0, num_nodes)
+# ------------------------------------------------------------------------------------------------
+def test_csr_build_rejects_out_of_range_ids(pgl):
+    u = dev(np.array([0, 1, 7, 2], np.int64)); v = dev(np.array([1, 2, 3, 0], np.int64))
+    with pytest.raises(ValueError, match="outside"):
+        pgl.ops.csr_build(u, v, 5)                               # key 7 >= num_nodes 5
+    with pytest.raises(ValueError, match="outside"):
+        pgl.ops.csr_build(dev(np.array([0, -1], np.int64)), dev(np.array([1, 1], np.int64)), 5)
+    with pytest.raises(ValueError, match="outside"):
+        pgl.Graph(edges=np.array([[0, 9]], np.int64), num_nodes=4).tensor().adj_dst_index
+    c = pgl.ops.csr_build(u.clamp(max=4), v, 5)                  # in range: fine, and the flag stays clear
+    assert int(c.indptr[-1]) == 4
+
+
+@pytest.mark.parametrize("d,op", [(128, "max"), (128, "min"), (8, "max"), (32, "min"), (128, "sum")])
+def test_accumulate_overwrite_only_rows_with_edges(pgl, d, op):
+    """accumulate=2: rows that receive edges are overwritten, every other row keeps its contents (the boundary rows of a
+    partitioned graph are finished on top of the interior rows' launch)."""
+    rng = np.random.default_rng(5)
+    n, e = 3000, 40000
+    src = rng.integers(0, n, e); dst = rng.integers(0, n // 2, e) * 2          # odd rows receive nothing
+    dst[rng.choice(e, 3000, replace=False)] = 10                                # a row longer than a chunk
+    x = rng.standard_normal((n, d)).astype(np.float32) - 3.0                     # all-negative maxima: 0 would be wrong
+    csr = pgl.ops.csr_build(dev(dst.astype(np.int64)), dev(src.astype(np.int64)), n)
+    before = rng.standard_normal((n, d)).astype(np.float32)
+    out = dev(before.copy())
+    pgl.ops.aggregate(dev(x), csr, op, out=out, accumulate=2)
+    want = R.c_send_u_recv(x, src.astype(np.int64), dst.astype(np.int64), op)
+    has = np.bincount(dst, minlength=n) > 0
+    got = host(out)
+    np.testing.assert_allclose(got[has], want[has], rtol=1e-5, atol=1e-5 * np.abs(want).max())
+    assert np.array_equal(got[~has], before[~has])
+
+
+# ------------------------------------------------------------------------------------------------
+# VERDICT r1 "weak" 2/3: the FUSED GAT kernels at BASELINE configs[2] size (RMAT scale 20, |E| = 20 M, H = 8, D = 16)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c3(pgl):
+    from pgl_amd.utils.rmat import rmat_edges
+    n, H, D = 1 << 20, 8, 16
+    edges = rmat_edges(20, 20_000_000, seed=42, device="cuda")
+    g = pgl.Graph(edges=edges, num_nodes=n)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    f = torch.randn(n, H * D, generator=gen, device="cuda").reshape(n, H, D)
+    gen.manual_seed(11)
+    a_s = torch.randn(n, H, generator=gen, device="cuda")
+    a_d = torch.randn(n, H, generator=gen, device="cuda")
+    return g, f, a_s, a_d
+
+
+def _dense_gat_fp64(edges, f, a_s, a_d, slope=0.2):
+    """The formula of pgl/nn/conv.py:331-339 written edge by edge in fp64 torch (autograd-able): an independent
+    formulation -- gather, scatter_reduce(amax), index_add -- that shares no code with the engine or the C port."""
+    src, dst = edges[:, 0], edges[:, 1]
+    n, H = a_d.shape
+    logit = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], slope)                       # [E, H]
+    m = torch.full((n, H), -float("inf"), dtype=logit.dtype, device=logit.device)
+    m = m.scatter_reduce(0, dst[:, None].expand(-1, H), logit.detach(), "amax", include_self=True)
+    p = torch.exp(logit - m[dst])
+    s = torch.zeros((n, H), dtype=logit.dtype, device=logit.device).index_add(0, dst, p)
+    alpha = p / s[dst]
+    out = torch.zeros_like(f).index_add(0, dst, alpha[:, :, None] * f[src])
+    return out, alpha
+
+
+def test_c3_fused_gat_forward_vs_oracle_and_fp64(pgl, c3):
+    g, f, a_s, a_d = c3
+    n, H, D = f.shape
+    out = pgl.ops.gat_aggregate(f, a_s, a_d, g.adj_dst_index.csr, 0.2)
+    e = host(g.edges)
+    indeg = np.bincount(e[:, 1], minlength=n)
+    # (1) the numpy ORACLE (restatement of conv.py:333-339) on the ten largest hubs + 1 200 seeded rows: the whole
+    #     neighbourhood of each selected destination is restated, so the softmax is the reference's, not a sample of it
+    rng = np.random.default_rng(3)
+    hubs = np.argsort(-indeg)[:10]
+    assert indeg[hubs[0]] > 10000                                     # these rows span dozens of chunks and the fix-up path
+    rows = np.unique(np.concatenate([hubs, rng.choice(np.nonzero(indeg)[0], 1200, replace=False)]))
+    sel = np.isin(e[:, 1], rows)
+    sub = e[sel]
+    fa, asa, ada = host(f), host(a_s), host(a_d)
+    logit = R.np_send_uv(asa, ada, sub[:, 0], sub[:, 1], "add")
+    logit = np.where(logit >= 0, logit, logit * np.float32(0.2))
+    alpha = R.np_edge_softmax(sub, n, logit).reshape(-1, H, 1)
+    want = R.np_send_ue_recv(fa, alpha, sub[:, 0], sub[:, 1], "mul", "sum")
+    got = host(out)
+    np.testing.assert_allclose(got[rows], want[rows], rtol=1e-5, atol=1e-5 * np.abs(want[rows]).max())
+    # (2) every row against the fp64 edge-by-edge formula, with a PER-ELEMENT reassociation bound
+    o64, al64 = _dense_gat_fp64(g.edges, f.double(), a_s.double(), a_d.double())
+    absterms = torch.zeros_like(o64).index_add(0, g.edges[:, 1], al64[:, :, None] * f.double()[g.edges[:, 0]].abs())
+    nterm = torch.as_tensor(indeg, device="cuda").double()[:, None, None] + 16.0     # + exp / logit roundings
+    assert_within_fp32_reassociation(got, host(o64), host(absterms), host(nterm))
+    assert float((out[torch.as_tensor(indeg == 0, device="cuda")]).abs().max()) == 0.0
+    # (3) the relative bar of north_star on the bulk: 1e-5 of the data scale
+    np.testing.assert_allclose(got, host(o64), rtol=1e-5, atol=1e-5 * float(o64.abs().max()))
+
+
+def test_c3_fused_gat_backward_vs_fp64_autograd(pgl, c3):
+    g, f, a_s, a_d = c3
+    n, H, D = f.shape
+    gen = torch.Generator(device="cuda"); gen.manual_seed(5)
+    w = torch.randn(n, H, D, generator=gen, device="cuda")
+    fx, sx, dx = (t.clone().requires_grad_(True) for t in (f, a_s, a_d))
+    out = g.gat_aggregate(fx, sx, dx, 0.2)
+    (out * w).sum().backward()
+    f64, s64, d64 = (t.double().requires_grad_(True) for t in (f, a_s, a_d))
+    o64, _ = _dense_gat_fp64(g.edges, f64, s64, d64)
+    (o64 * w.double()).sum().backward()
+    for name, got, want in (("d feature", fx.grad, f64.grad), ("d attn_src", sx.grad, s64.grad), ("d attn_dst", dx.grad, d64.grad)):
+        err = (got.double() - want).abs()
+        scale = float(want.abs().max())
+        # hub sources / destinations sum 1e5 terms of mixed sign: 1e-5 of the tensor's scale, and 1e-5 in the Frobenius norm
+        assert float(err.max()) <= 2e-5 * scale, "%s: max err %.3e vs scale %.3e" % (name, float(err.max()), scale)
+        assert float(err.norm() / want.norm()) <= 1e-5, name
+    # the sampled-rows check the verdict asked for, on the rows with the largest degree (the hardest ones)
+    indeg = torch.bincount(g.edges[:, 1], minlength=n); outdeg = torch.bincount(g.edges[:, 0], minlength=n)
+    for idx, got, want in ((torch.topk(outdeg, 10).indices, fx.grad, f64.grad), (torch.topk(indeg, 10).indices, dx.grad, d64.grad)):
+        rel = (got[idx].double() - want[idx]).abs().amax() / want[idx].abs().amax()
+        assert float(rel) <= 2e-5
+
+
+def test_c2_gcn_spmm_within_fp32_reassociation_bound_of_fp64(pgl):
+    """SURVEY 8(c) large-scale procedure, second half: the fp32 result is within the reassociation bound of the fp64 result
+    ELEMENT BY ELEMENT (an atol tied to max|want| would hide relative error on small outputs)."""
+    from pgl_amd.utils.rmat import rmat_edges
+    n, d = 1 << 20, 128
+    edges = rmat_edges(20, 20_000_000, seed=42, device="cuda")
+    g = pgl.Graph(edges=edges, num_nodes=n)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    x = torch.randn(n, d, generator=gen, device="cuda")
+    indeg = torch.bincount(edges[:, 1], minlength=n).double()[:, None]
+    want = torch.zeros(n, d, dtype=torch.float64, device="cuda")
+    absterms = torch.zeros(n, d, dtype=torch.float64, device="cuda")
+    for lo in range(0, edges.shape[0], 4_000_000):                     # fp64 gathers in slabs of 4 M edges (4 GB each)
+        s, t = edges[lo:lo + 4_000_000, 0], edges[lo:lo + 4_000_000, 1]
+        xs = x[s].double()
+        want.index_add_(0, t, xs); absterms.index_add_(0, t, xs.abs())
+    for op in ("sum", "mean"):
+        got = g.send_recv(x, op)
+        w, a = (want, absterms) if op == "sum" else (want / indeg.clamp(min=1), absterms / indeg.clamp(min=1))
+        assert_within_fp32_reassociation(host(got), host(w), host(a), host(indeg.expand(-1, d)) + (1 if op == "mean" else 0), slack=2.0)
