@@ -8,11 +8,16 @@ A "step" is ONE pass of Graph.send_recv(x, "sum") (= pglamd_aggregate through th
 whole synthetic graph with the feature matrix already resident in HBM.
 Workload (config.workload): BASELINE.json configs[1] -- RMAT (0.57,0.19,0.19,0.05) |V| = 2^20,
 |E| = 20 M, d = 128 fp32, graph seed 42, feature seed 7.
-N > 1: the SAME global graph and feature matrix (strong scaling), spread over the N ranks in one of two ways:
-  rows  row partition of the graph, one halo all-to-all-v (RCCL) per step overlapped with the interior rows (DistGraph);
+N > 1: the SAME global graph and feature matrix (strong scaling).  The headline layout is north_star's (--parallel rows,
+the default): METIS row partition (pgl.partition.metis_partition's METIS through the C ABI), one RCCL halo all-to-all-v
+per step overlapped with the local-source edges, per rank pair the cheaper of pull and push (DistGraph).  Two other
+layouts are timed for a few steps and reported as SECONDARY fields (halo.alternatives_ms_per_step):
   cols  the graph replicated on every GPU, the feature COLUMNS split: out[:, cols_r] = A x[:, cols_r] needs no data-path
-        collective at all (FeatureShardedGraph) -- the better fit for graphs no partitioner can cut (RMAT: 82 % edge cut).
---parallel auto (default) runs the warm-up steps of both and times the faster; value = global |E| / max-rank time.
+        collective at all (FeatureShardedGraph);
+  grid  2 row parts x N/2 column slices (GridShardedGraph).
+value = global |E| / max-rank time of the headline layout; halo bytes and the exchange-only time per rank ride along.
+N = 1 adds: roofline.no_reuse (permutation graph and uniform degree-19 graph: known bytes / event-timed kernel, a physical
+fraction <= 1 -> roofline.frac_no_reuse) and target_size (|E| = 100 M, north_star's size).
 
 Output: one JSON line on rank 0 with the driver's contract fields plus
   roofline     -- dominant kernel (agg_flat_kernel) algorithmic bytes / its HIP-event time vs 8 TB/s
@@ -186,12 +191,19 @@ def main():
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--partition", default="random", choices=["auto", "kway", "random"],
-                    help="row partition for N > 1.  RMAT has no locality for a k-way partitioner to find (measured at C2, P=8: 82 %% of edges cut vs 87.5 %% random, slowest-rank halo 268 k vs 251 k rows), so the balanced random assignment is the default; auto = build both, keep the smaller slowest-rank halo")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "rows", "cols"],
-                    help="N > 1: 'rows' = row partition + RCCL halo all-to-all-v per step (DistGraph); 'cols' = graph replicated, "
-                         "feature columns split over the ranks, no data-path collective (FeatureShardedGraph); 'auto' = run the "
-                         "warm-up steps of both and keep the faster (max over ranks), falling back to 'cols' if the halo path fails")
+    ap.add_argument("--partition", default="metis", choices=["metis", "kway", "random", "auto"],
+                    help="row partition for N > 1: 'metis' = the reference's METIS (pgl.partition.metis_partition, via "
+                         "pglamd_partition_metis; falls back to the engine's k-way partitioner when the helper library is absent), "
+                         "'kway' = the engine's own partitioner, 'random' = balanced random, 'auto' = metis vs random, keep the "
+                         "plan whose slowest rank receives fewer rows")
+    ap.add_argument("--parallel", default="rows", choices=["rows", "cols", "grid", "auto"],
+                    help="N > 1 headline layout: 'rows' (default, north_star) = METIS row partition + one RCCL halo all-to-all-v "
+                         "per step overlapped with the local edges (DistGraph); 'cols' = graph replicated, feature columns split, "
+                         "no data-path collective (FeatureShardedGraph); 'grid' = 2 row parts x N/2 column slices; 'auto' = time "
+                         "all three and report the fastest.  With 'rows' the others are still timed and reported as secondary fields")
+    ap.add_argument("--push", default="auto", choices=["auto", "never"],
+                    help="per rank pair: 'auto' = the cheaper of pulling source rows and pushing pre-aggregated destination rows")
+    ap.add_argument("--no-alternatives", action="store_true", help="N > 1: time only the headline layout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="N = 1: skip the no-reuse roofline legs and the |E| = 100 M target-size leg (profiling runs)")
@@ -234,27 +246,9 @@ def main():
         halo = None
     else:
         import torch.distributed as dist
-        from pgl_amd.distributed import DistGraph, FeatureShardedGraph
+        from pgl_amd.distributed import DistGraph, FeatureShardedGraph, GridShardedGraph
         sync = lambda: torch.cuda.synchronize()
         barrier = lambda: dist.barrier()
-        cand = {}
-        if args.parallel in ("cols", "auto"):
-            g = pgl.Graph(edges=edges, num_nodes=N)
-            g.adj_dst_index
-            fs = FeatureShardedGraph(g, rank, world)
-            x_cols = fs.take_cols(x)
-            cand["cols"] = (lambda: fs.send_recv(x_cols, "sum"), fs.stats(), (int(x_cols.shape[1]), N, E))
-        if args.parallel in ("rows", "auto"):
-            try:
-                dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev)
-                x_own = dg.take_owned(x)
-                st = dg.stats()
-                cand["rows"] = (lambda: dg.send_recv(x_own, "sum"), st, (d, st["local_rows"], st["local_edges"]))
-            except Exception as ex:                                  # noqa: BLE001 -- report and keep the other mode
-                if args.parallel == "rows":
-                    raise
-                print("[bench] row-partition mode unavailable on rank %d: %r" % (rank, ex), file=sys.stderr, flush=True)
-        del x
 
         def timed(fn, n):
             sync(); barrier(); sync()
@@ -266,29 +260,65 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
-        ok = torch.tensor([1 if "rows" in cand else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                    # every rank must have the same candidates
-        if not int(ok.item()):
-            cand.pop("rows", None)
-        trial = {}
-        for name in [k for k in ("cols", "rows") if k in cand]:      # the collective-free layout first
-            fn = cand[name][0]
-            good = 1
+        def build(name):
+            """-> (step, stats, (d_loc, n_loc, e_loc), extra)"""
+            if name == "rows":
+                dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push)
+                x_own = dg.take_owned(x)
+                st = dg.stats()
+                return (lambda: dg.send_recv(x_own, "sum")), st, (d, st["local_rows"], st["local_edges"]), (dg, x_own)
+            if name == "cols":
+                g = pgl.Graph(edges=edges, num_nodes=N)
+                g.adj_dst_index
+                fs = FeatureShardedGraph(g, rank, world)
+                x_cols = fs.take_cols(x)
+                return (lambda: fs.send_recv(x_cols, "sum")), fs.stats(), (int(x_cols.shape[1]), N, E), None
+            pr = 2 if world % 2 == 0 else 1                          # grid: 2 row parts x world/2 column slices
+            gg = GridShardedGraph(edges, N, rank, world, grid=(pr, world // pr), method=args.partition, device=dev, push=args.push)
+            blk = gg.take(x)
+            st = gg.stats()
+            return (lambda: gg.send_recv(blk, "sum")), st, (int(blk.shape[1]), st["local_rows"], st["local_edges"]), None
+
+        # The headline layout is north_star's: METIS row partition + halo all-to-all-v (--parallel rows).  The other layouts
+        # are timed for a few steps and reported as SECONDARY fields (halo.alternatives_ms_per_step); "auto" promotes the
+        # fastest one to the headline and says so in config.parallelism.
+        order = {"rows": ["rows", "cols", "grid"], "cols": ["cols"], "grid": ["grid"], "auto": ["rows", "cols", "grid"]}[args.parallel]
+        if args.no_alternatives:
+            order = order[:1]
+        built, trial = {}, {}
+        for name in order:
+            good, t_trial = 1, 0.0
             try:
+                built[name] = build(name)
+                fn = built[name][0]
                 fn(); fn()
-                t_trial = timed(fn, max(args.warmup, 3))
-            except Exception as ex:                                  # noqa: BLE001 -- a failing layout is dropped, not fatal
-                if len(cand) == 1:
+                t_trial = timed(fn, max(args.warmup, 3)) / max(args.warmup, 3) * 1e3
+            except Exception as ex:                                  # noqa: BLE001 -- only the headline layout is fatal
+                if name == order[0] and args.parallel != "auto":
                     raise
                 good = 0
                 print("[bench] layout %r failed on rank %d: %r" % (name, rank, ex), file=sys.stderr, flush=True)
             flag = torch.tensor([good], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # keep a layout only if it worked on every rank
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # a layout counts only if it worked on every rank
             if int(flag.item()):
                 trial[name] = t_trial
-        mode = min(trial, key=trial.get)
-        step, halo, (d_loc, n_loc, e_loc) = cand[mode]
-        halo = dict(halo, mode=mode, trial_ms_per_step={k: v / max(args.warmup, 3) * 1e3 for k, v in trial.items()})
+            else:
+                built.pop(name, None)
+        mode = min(trial, key=trial.get) if args.parallel == "auto" else order[0]
+        step, halo, (d_loc, n_loc, e_loc), extra = built[mode]
+        halo = dict(halo, mode=mode, alternatives_ms_per_step=trial)
+        if mode == "rows":
+            # exchange alone (pack kernel + all-to-all-v + wait, no aggregation) and its bytes, per rank and worst rank
+            dg, x_own = extra
+            t_x = timed(lambda: dg.exchange_only(x_own), max(args.warmup, 3)) / max(args.warmup, 3) * 1e3
+            allp = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+            allp[rank, 0], allp[rank, 1] = float(halo["recv_rows"]) * d * 4, float(halo["send_rows"]) * d * 4
+            dist.all_reduce(allp)                                    # (a sum of one-hot rows = an all-gather every backend has)
+            halo.update(exchange_only_ms=t_x, recv_bytes_per_rank=allp[:, 0].tolist(), send_bytes_per_rank=allp[:, 1].tolist())
+        for k in list(built):
+            if k != mode:
+                del built[k]
+        del x
 
     for _ in range(args.warmup):
         step()
@@ -323,7 +353,10 @@ def main():
                                    "via pglamd_aggregate (BASELINE configs[1])" % (args.scale, N, E, d),
                        "graph_seed": 42, "feature_seed": 7,
                        "parallelism": "single GPU" if world == 1 else
-                       ("row partition (%s) x%d + RCCL halo all-to-all-v" % (halo["partition"], world) if halo["mode"] == "rows" else
+                       ("row partition (%s) x%d + RCCL halo all-to-all-v (pull/push per pair: %d pairs push)"
+                        % (halo["partition"], world, halo.get("pushed_pairs", 0)) if halo["mode"] == "rows" else
+                        "grid %s: row partition (%s) x column slices, halo all-to-all-v inside each column group"
+                        % (halo.get("grid"), halo["partition"]) if halo["mode"] == "grid" else
                         "feature columns x%d (graph replicated, %d of %d columns per GPU, no data-path collective)" % (world, d_loc, d))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

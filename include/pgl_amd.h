@@ -44,6 +44,7 @@ extern "C" {
 #define PGLAMD_E_WORKSPACE (-4) /* workspace NULL or too small */
 #define PGLAMD_E_HIP (-5)       /* HIP runtime error (message has hipGetErrorString) */
 #define PGLAMD_E_ARG (-6)       /* NULL pointer / bad enum */
+#define PGLAMD_E_UNAVAILABLE (-7) /* optional helper library (METIS, RCCL) not present */
 
 /* element types */
 #define PGLAMD_F16 0
@@ -333,11 +334,18 @@ int32_t pglamd_reindex(const int64_t* nodes, int64_t num_nodes, const int64_t* n
  * pglamd_map_ids replaces graph_kernel.map_edges / map_nodes (pgl/graph_kernel.pyx:104-138):
  *     out[i] = value of key in[i] in the (keys -> vals) dictionary; missing key -> 0, like
  *     std::unordered_map::operator[] in the reference.
- * pglamd_partition_kway is the engine's own multilevel k-way partitioner standing in for
- * METIS_PartGraphKway as called by pgl.partition.metis_partition (pgl/partition.py:37-91,
- * pgl/graph_kernel.pyx:434-472).  Same inputs (CSR xadj/adjncy int64, optional positive int64
- * vertex / edge weights), same output (part[N] int64 in [0, nparts)); partition ids are NOT
- * bit-identical to METIS (METIS is not reimplemented) -- parity is on balance and edge cut.
+ * pglamd_partition_metis is pgl.partition.metis_partition's native call (pgl/partition.py:37-91 ->
+ * graph_kernel.metis_partition, pgl/graph_kernel.pyx:434-472): METIS_PartGraphKway of the reference's
+ * vendored METIS 5 (idx_t = int64), called exactly as the reference calls it (ncon = 1, vsize /
+ * tpwgts / ubvec / options = NULL), so part ids are BIT-IDENTICAL to the reference's.  The METIS
+ * code lives in the helper library libpglamd_metis.so (built from the reference checkout by
+ * pgl_amd/_build_metis.py, opened with dlopen from the directory of this library or from
+ * $PGLAMD_METIS_LIB); without it the call returns PGLAMD_E_UNAVAILABLE and
+ * pglamd_metis_available() returns 0.
+ * pglamd_partition_kway is the engine's own multilevel k-way partitioner: the documented fallback
+ * when the helper is absent or METIS does not fit in host memory.  Same inputs (CSR xadj/adjncy
+ * int64, optional positive int64 vertex / edge weights), same output (part[N] int64 in
+ * [0, nparts)); its ids are NOT METIS's -- parity there is on balance and edge cut.
  * ---------------------------------------------------------------------------------------------- */
 /* Host twin of pglamd_csr_build for numpy-mode graphs (Graph.indegree()/sorted_edges() before
  * Graph.tensor(), as examples/gcn/train.py:83 does): same outputs, same order, HOST pointers.
@@ -348,6 +356,10 @@ int32_t pglamd_build_index_host(const int64_t* u, int64_t u_stride, const int64_
                                 int64_t* sorted_eid, int64_t* indptr);
 int32_t pglamd_map_ids(const int64_t* keys, const int64_t* vals, int64_t n_keys, const int64_t* in,
                        int64_t n_in, int64_t* out);
+int32_t pglamd_metis_available(void);
+int32_t pglamd_partition_metis(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
+                               const int64_t* vwgt, const int64_t* adjwgt, int64_t nparts,
+                               int64_t* part, int64_t* edgecut);
 int32_t pglamd_partition_kway(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
                               const int64_t* vwgt, const int64_t* adjwgt, int64_t nparts,
                               uint64_t seed, int64_t* part, int64_t* edgecut);

@@ -81,14 +81,14 @@ def build(force=False, jobs=None):
             # setup.py builds these as C++ (language="c++", -std=c++11); METIS is plain C
             # and g++ -x c++ rejects some of its idioms only as warnings; use the same
             # front end the reference uses (distutils compiles .c files with the C compiler).
-            _run(["gcc", "-O2", "-fPIC", "-w", "-c", src, "-o", obj] + inc_flags)
+            _run(["gcc", "-O2", "-fwrapv", "-DNDEBUG", "-fPIC", "-w", "-c", src, "-o", obj] + inc_flags)      # distutils CFLAGS carry -DNDEBUG: METIS asserts are off in the reference build
         return obj
 
     with ThreadPoolExecutor(jobs) as ex:
         objs = list(ex.map(cc, c_srcs))
 
     gen_obj = os.path.join(OUT, "obj", "graph_kernel.o")
-    _run(["g++", "-O2", "-fPIC", "-w", "-std=c++11", "-c", gen_cpp, "-o", gen_obj] + inc_flags)
+    _run(["g++", "-O2", "-fwrapv", "-DNDEBUG", "-fPIC", "-w", "-std=c++11", "-c", gen_cpp, "-o", gen_obj] + inc_flags)
 
     # 3. link
     _run(["g++", "-shared", "-o", target, gen_obj] + objs + ["-lm"])

@@ -19,5 +19,6 @@ from . import sampling
 from .graph import Graph
 from .bigraph import BiGraph, HeterGraph
 from .message import Message
+from .distributed import DistGraph, DistGPUGraph
 
-__all__ = ["Graph", "BiGraph", "HeterGraph", "Message", "math", "message", "nn", "ops", "partition", "sampling"]
+__all__ = ["Graph", "BiGraph", "HeterGraph", "Message", "DistGraph", "DistGPUGraph", "math", "message", "nn", "ops", "partition", "sampling"]

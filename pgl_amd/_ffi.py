@@ -60,10 +60,12 @@ _SIGNATURES = {
     "pglamd_build_index_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pglamd_map_ids": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "pglamd_partition_kway": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_u64, c_vp, c_vp]),
+    "pglamd_metis_available": (c_i32, []),
+    "pglamd_partition_metis": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
 ABI_VERSION = 1
-_ERRORS = {-1: ValueError, -2: TypeError, -3: OverflowError, -4: RuntimeError, -5: RuntimeError, -6: ValueError}
+_ERRORS = {-1: ValueError, -2: TypeError, -3: OverflowError, -4: RuntimeError, -5: RuntimeError, -6: ValueError, -7: RuntimeError}
 
 
 class NativeLibraryMissing(RuntimeError):

@@ -17,6 +17,10 @@
 #include <numeric>
 #include <unordered_map>
 #include <vector>
+#include <mutex>
+#include <string>
+
+#include <dlfcn.h>
 
 #include "../../include/pgl_amd.h"
 
@@ -314,5 +318,64 @@ extern "C" int32_t pglamd_partition_kway(int64_t num_nodes, const int64_t* xadj,
     }
     for (int64_t v = 0; v < num_nodes; ++v) part[v] = cur[v];
     if (edgecut) *edgecut = edge_cut(levels[0], cur);
+    return PGLAMD_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// METIS (the reference's vendored library, built by pgl_amd/_build_metis.py into libpglamd_metis.so next to this library)
+// ------------------------------------------------------------------------------------------------
+namespace {
+typedef int (*metis_kway_fn)(int64_t* nvtxs, int64_t* ncon, int64_t* xadj, int64_t* adjncy, int64_t* vwgt, int64_t* vsize,
+                             int64_t* adjwgt, int64_t* nparts, float* tpwgts, float* ubvec, int64_t* options,
+                             int64_t* edgecut, int64_t* part);
+struct MetisLib {
+    std::once_flag once;
+    metis_kway_fn kway = nullptr;
+    std::string why;
+};
+MetisLib& metis_lib() { static MetisLib m; return m; }
+
+void load_metis() {
+    MetisLib& m = metis_lib();
+    std::string path;
+    if (const char* e = getenv("PGLAMD_METIS_LIB")) path = e;
+    else {
+        Dl_info info;
+        if (dladdr((void*)&load_metis, &info) && info.dli_fname) {
+            path = info.dli_fname;
+            const size_t k = path.find_last_of('/');
+            path = (k == std::string::npos ? std::string(".") : path.substr(0, k)) + "/libpglamd_metis.so";
+        }
+    }
+    void* h = path.empty() ? nullptr : dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { m.why = "cannot open " + path + (dlerror() ? std::string(": ") + dlerror() : std::string()); return; }
+    m.kway = (metis_kway_fn)dlsym(h, "METIS_PartGraphKway");
+    if (!m.kway) m.why = path + " has no METIS_PartGraphKway";
+}
+}  // namespace
+
+extern "C" int32_t pglamd_metis_available(void) {
+    std::call_once(metis_lib().once, load_metis);
+    return metis_lib().kway ? 1 : 0;
+}
+
+extern "C" int32_t pglamd_partition_metis(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy, const int64_t* vwgt,
+                                          const int64_t* adjwgt, int64_t nparts, int64_t* part, int64_t* edgecut) {
+    if (num_nodes < 0 || nparts < 1 || !part || (num_nodes > 0 && (!xadj || (xadj[num_nodes] > 0 && !adjncy))))
+        return pglamd::fail(PGLAMD_E_ARG, "partition_metis: bad argument");
+    std::call_once(metis_lib().once, load_metis);
+    if (!metis_lib().kway) return pglamd::fail(PGLAMD_E_UNAVAILABLE, "partition_metis: %s", metis_lib().why.c_str());
+    if (nparts == 1 || num_nodes == 0) {
+        std::fill(part, part + num_nodes, (int64_t)0);
+        if (edgecut) *edgecut = 0;
+        return PGLAMD_OK;
+    }
+    // exactly the reference's call (pgl/graph_kernel.pyx:468-471): ncon = 1, no vsize / tpwgts / ubvec, DEFAULT options
+    int64_t nv = num_nodes, ncon = 1, np_ = nparts, cut = -1;
+    const int rc = metis_lib().kway(&nv, &ncon, const_cast<int64_t*>(xadj), const_cast<int64_t*>(adjncy), const_cast<int64_t*>(vwgt),
+                                    nullptr, const_cast<int64_t*>(adjwgt), &np_, nullptr, nullptr, nullptr, &cut, part);
+    if (rc != 1) return pglamd::fail(PGLAMD_E_ARG, "partition_metis: METIS_PartGraphKway returned %d", rc);   // METIS_OK == 1
+    if (edgecut) *edgecut = cut;
     return PGLAMD_OK;
 }

@@ -1,25 +1,39 @@
-"""pgl_amd.distributed -- row-partitioned multi-GPU aggregation with halo exchange.
+"""pgl_amd.distributed -- row-partitioned multi-GPU message passing with halo exchange.
 
-Stands in for the reference's `DistGPUGraph` (pgl/graph.py:1410-1553), whose mechanism is
-"shard the EDGES by dst % world, replicate all node features, all-reduce-sum the full [N, d]
-output after every aggregation" (pgl/utils/op.py:121, NCCL ring, 512 MB per layer at C2).
-Only its SEMANTICS are kept (same results as single-GPU); the mechanism is replaced:
+Stands in for the reference's `DistGPUGraph` (pgl/graph.py:1410-1553), whose mechanism is "shard the EDGES by
+dst % world, replicate all node features, all-reduce-sum the full [N, d] output after every aggregation"
+(pgl/utils/op.py:121, NCCL ring, 512 MB per layer at C2).  Its SEMANTICS are kept -- the same methods
+(recv / indegree / outdegree / send_recv / send_u_recv / send_ue_recv), the same results as the single-GPU graph, and
+gradients flow through every one of them -- the mechanism is replaced:
 
-  * destination NODES (rows) are partitioned k-way (pgl_amd.partition, the analogue of
-    pgl/partition.py:37-91) and relabelled so each rank owns a contiguous id range
-    (apps/GNNAutoScale/graph_partition.py:70-101 `permutation, part` convention);
-  * rank p keeps the in-edges of its rows, its rows' features, and a column space
-    [owned | halo grouped by owner] (apps/GNNAutoScale/dataset.py:196-209 layout);
-  * per aggregation: pack the rows peers need (one gather kernel) -> ONE RCCL all-to-all-v of halo
-    rows over xGMI (every GPU pair has its own link, so all 7 links carry traffic at once), issued
-    asynchronously on the process group's stream, overlapped with the aggregation of the
-    edges whose source is local -> wait -> aggregation of the halo-source edges accumulates
-    into the same output (pglamd_aggregate accumulate=1).  No reduction collective.
+  * destination NODES (rows) are partitioned k-way (pgl_amd.partition = pgl/partition.py:37-91) and relabelled so each
+    rank owns a contiguous id range (apps/GNNAutoScale/graph_partition.py:70-101 `permutation, part` convention);
+  * rank p keeps the in-edges of its rows, its rows' features, and a column space [owned | received rows grouped by
+    peer] (apps/GNNAutoScale/dataset.py:196-209 layout);
+  * per aggregation: ONE kernel builds the send buffer -> ONE RCCL all-to-all-v over xGMI (every GPU pair has its own
+    link, so all 7 links carry traffic at once), issued asynchronously and overlapped with the aggregation of the edges
+    whose source is local -> wait -> the received rows are accumulated into the same output.  No reduction collective.
+  * per rank PAIR the cheaper direction is chosen (SURVEY 8e lever iv): PULL ships the distinct source rows the peer
+    needs; PUSH pre-aggregates this rank's sources into partial destination rows and ships those (valid for sum / mean,
+    fp32 re-association only).  Either way a send row is "a sum over a set of local rows", so the pack step is the same
+    aggregation kernel over a small index and the receive step is the same accumulate launch.
+  * max / min have no identity a first launch could leave behind: their rows are split into INTERIOR rows (all sources
+    local; aggregated while the exchange is in flight) and BOUNDARY rows (finished after the wait on top of the first
+    launch, accumulate mode 2) -- SURVEY 8e lever iii.
+  * backward = the same flow over the transposed indices with the send / receive splits swapped
+    (`_HaloAggregate`, `_HaloExtend`): multi-GPU layers train.
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL).  With a backend that lacks
-all-to-all (gloo, used by the CPU tests) the exchange falls back to paired isend/irecv.
+Two classes:
+  DistGraph      the engine's distributed graph: features are the OWNED rows ([n_own, ...]) -- nothing is replicated;
+                 pgl_amd.nn layers take it in place of a Graph.
+  DistGPUGraph   drop-in for the reference class of that name: replicated [N, ...] features in, replicated out
+                 (owned rows are computed as above and all-gathered instead of all-reducing [N, d] partial sums).
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL).  With a backend that lacks all-to-all (gloo, used by the
+CPU tests) the exchange falls back to paired isend/irecv.
 """
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -28,8 +42,22 @@ import torch.distributed as dist
 from . import ops
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# transport
+# ------------------------------------------------------------------------------------------------------------------
+class _Done(object):
+    def wait(self):
+        return None
+
+
+def _group_ready(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
 def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
     """all-to-all-v of rows.  Returns an object with .wait()."""
+    if not _group_ready(group):
+        return _Done()
     backend = dist.get_backend(group)
     if backend == "nccl":
         return dist.all_to_all_single(recv_buf, send_buf, list(recv_splits), list(send_splits), group=group, async_op=True)
@@ -44,13 +72,14 @@ def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
     reqs = []
     if recv_splits[rank]:                              # own block: a plain copy, as all_to_all_single does
         dst[ro[rank]:ro[rank + 1]] = src[so[rank]:so[rank + 1]]
+    peer = (lambda q: q) if group is None else (lambda q: dist.get_global_rank(group, q))
     for q in range(world):
         if q == rank:
             continue
         if recv_splits[q]:
-            reqs.append(dist.irecv(dst[ro[q]:ro[q + 1]], src=q, group=group))
+            reqs.append(dist.irecv(dst[ro[q]:ro[q + 1]], src=peer(q), group=group))
         if send_splits[q]:
-            reqs.append(dist.isend(src[so[q]:so[q + 1]].contiguous(), dst=q, group=group))
+            reqs.append(dist.isend(src[so[q]:so[q + 1]].contiguous(), dst=peer(q), group=group))
 
     class _W(object):
         def wait(self_inner):
@@ -61,56 +90,178 @@ def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
     return _W()
 
 
-class HaloPlan(object):
-    """Pure index bookkeeping for one rank (device-agnostic torch tensors)."""
+def _all_gather(tensor, group=None):
+    """-> list of every rank's `tensor` (same shape on all ranks).  gloo has no CUDA all-gather: staged through the host."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) != "nccl" and tensor.is_cuda:
+        parts = [torch.empty(tensor.shape, dtype=tensor.dtype) for _ in range(world)]
+        dist.all_gather(parts, tensor.cpu(), group=group)
+        return [p.to(tensor.device) for p in parts]
+    parts = [torch.empty_like(tensor) for _ in range(world)]
+    dist.all_gather(parts, tensor.contiguous(), group=group)
+    return parts
 
-    def __init__(self, edges, num_nodes, part, rank, world):
+
+def _all_reduce_sum(tensor, group=None):
+    if dist.get_backend(group) != "nccl" and tensor.is_cuda:
+        buf = tensor.cpu()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        tensor.copy_(buf)
+    else:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# compute backend: libpglamd through pgl_amd.ops.  (The multi-process CPU tests pass another object with the same three
+# methods as a test seam -- the product has only this one and it refuses CPU tensors.)
+# ------------------------------------------------------------------------------------------------------------------
+class _EngineBackend(object):
+    def index(self, rows, cols, n_rows):
+        return ops.csr_build(rows, cols, int(n_rows), want_i64=False, check_range=False)
+
+    def aggregate(self, x, index, reduce_op, n_rows, y=None, message_op="add", src_scale=None, dst_scale=None, out=None,
+                  accumulate=0):
+        return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate)
+
+    def gather_rows(self, x, idx):
+        return ops.gather_rows(x, idx)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plan: pure index bookkeeping for one rank
+# ------------------------------------------------------------------------------------------------------------------
+class HaloPlan(object):
+    """Index bookkeeping of one rank (device-agnostic torch tensors), built from the GLOBAL edge list and part vector --
+    every rank derives the same pair decisions, so no negotiation is needed.
+
+    Local edges (destination owned here), in this order -- also the order of local EDGE FEATURES (`edge_global`):
+        loc   both endpoints owned:           (loc_rows, loc_cols)   cols = local source row
+        hal   source owned by a peer:         (hal_rows, hal_cols)   cols = position among the distinct halo sources
+    Exchange (one all-to-all-v per aggregation), `push` = [world, world] bool matrix, push[p, q]: pair (dst owner p,
+    src owner q) ships partial destination rows instead of source rows (None / all False = pull everywhere):
+        send  (send_rows, send_cols), n_send  send_buf[i] = sum of x_own[cols] over the edges with rows == i
+                                              (pull row: one identity edge; push row: this rank's edges into one peer row)
+        recv  (recv_rows, recv_cols), n_recv  out[rows] += recv_buf[cols]   (pull: the halo edges; push: one edge per row)
+    """
+
+    def __init__(self, edges, num_nodes, part, rank, world, push=None):
         dev = edges.device
         part = torch.as_tensor(part, device=dev).to(torch.int64)
-        N = int(num_nodes)
+        N, P = int(num_nodes), int(world)
         order = torch.argsort(part, stable=True)                      # new id -> old id
         new_id = torch.empty_like(order)
         new_id[order] = torch.arange(N, device=dev)
-        counts = torch.bincount(part, minlength=world)
-        off = torch.zeros(world + 1, dtype=torch.int64, device=dev)
+        counts = torch.bincount(part, minlength=P)
+        off = torch.zeros(P + 1, dtype=torch.int64, device=dev)
         off[1:] = torch.cumsum(counts, 0)
         self.offsets = off.cpu().tolist()
         lo, hi = self.offsets[rank], self.offsets[rank + 1]
-        self.rank, self.world, self.num_nodes = rank, world, N
+        self.rank, self.world, self.num_nodes = int(rank), P, N
         self.n_own = hi - lo
         self.own_global = order[lo:hi]                                # local row -> original node id
 
+        E = int(edges.shape[0])
         src = new_id[edges[:, 0]]
         dst = new_id[edges[:, 1]]
-        mine = (dst >= lo) & (dst < hi)
-        ls, ld = src[mine], dst[mine] - lo
-        own_src = (ls >= lo) & (ls < hi)
-        self.loc_rows, self.loc_cols = ld[own_src], ls[own_src] - lo
-        hs = ls[~own_src]
+        eid = torch.arange(E, device=dev)
+        own_s = torch.searchsorted(off, src, right=True) - 1          # owner rank of every edge's source / destination
+        own_d = torch.searchsorted(off, dst, right=True) - 1
+        mine = own_d == rank
+        loc = mine & (own_s == rank)
+        inc = mine & (own_s != rank)                                  # incoming: my row, a peer's source
+        outg = (own_s == rank) & (own_d != rank)                      # outgoing: my source, a peer's row
+        self.loc_rows, self.loc_cols = dst[loc] - lo, src[loc] - lo
+        self.in_degree = torch.bincount(dst[mine] - lo, minlength=self.n_own)
+        self.out_degree = torch.bincount(src[own_s == rank] - lo, minlength=self.n_own)
+        self.local_edges = int(mine.sum())
+
+        # ---- pull view of the incoming edges: always kept (generic ops gather whole source rows) -------------------
+        hs, hd = src[inc], dst[inc] - lo
         halo_ids, inv = torch.unique(hs, sorted=True, return_inverse=True)
-        self.hal_rows, self.hal_cols = ld[~own_src], inv
+        self.hal_rows, self.hal_cols = hd, inv
         self.n_halo = int(halo_ids.shape[0])
-        self.halo_global = halo_ids                                   # new-id space, ascending
+        self.halo_global = halo_ids                                   # new-id space, ascending (= grouped by owner)
         bounds = torch.searchsorted(halo_ids, off)
-        self.recv_splits = (bounds[1:] - bounds[:-1]).cpu().tolist()
-        # rows of mine that each peer needs: (owner(dst), src) pairs over edges leaving my range
-        outgoing = (src >= lo) & (src < hi) & ~mine
-        owner = torch.searchsorted(off, dst[outgoing], right=True) - 1
-        key = torch.unique(owner * N + src[outgoing], sorted=True)
+        self.halo_splits = (bounds[1:] - bounds[:-1]).cpu().tolist()
+        self.edge_global = torch.cat([eid[loc], eid[inc]])            # original edge id of local edge k
+        # rows of mine that each peer pulls: distinct (peer, src) pairs over the outgoing edges, peer-major
+        key = torch.unique(own_d[outg] * N + src[outg], sorted=True)
         self.send_idx = (key % N) - lo
-        self.send_splits = torch.bincount(key // N, minlength=world).cpu().tolist()
-        self.in_degree = torch.bincount(ld, minlength=self.n_own)
-        self.local_edges = int(ld.shape[0])
+        self.pull_splits = torch.bincount(key // N, minlength=P).cpu().tolist()
+
+        # ---- exchange plan under the pull / push choice ------------------------------------------------------------
+        if push is None:
+            push = torch.zeros((P, P), dtype=torch.bool)
+        push = torch.as_tensor(push).to(torch.bool).cpu()
+        self.push = push
+        in_push = push[rank].to(dev)[own_s[inc]]                      # pair (me <- q) pushes
+        out_push = push[:, rank].to(dev)[own_d[outg]]                 # pair (p <- me) pushes
+        q_in, p_out = own_s[inc], own_d[outg]
+
+        def grouped(keys, n_groups):
+            """distinct keys (group-major), per-group counts, rank of each key inside its group's block."""
+            u, iv = torch.unique(keys, sorted=True, return_inverse=True)
+            cnt = torch.bincount(u // N, minlength=n_groups)
+            start = torch.cumsum(cnt, 0) - cnt
+            return u, iv, cnt, start
+
+        # receive side
+        u_pl, iv_pl, c_pl, s_pl = grouped(q_in[~in_push] * N + hs[~in_push], P)           # pulled sources
+        u_ps, iv_ps, c_ps, s_ps = grouped(q_in[in_push] * N + (hd[in_push] + lo), P)      # pushed partial rows (my dsts)
+        rcnt = c_pl + c_ps
+        roff = torch.cumsum(rcnt, 0) - rcnt
+        pos_pl = roff[u_pl // N] + (torch.arange(u_pl.shape[0], device=dev) - s_pl[u_pl // N])
+        pos_ps = roff[u_ps // N] + (torch.arange(u_ps.shape[0], device=dev) - s_ps[u_ps // N])
+        self.recv_rows = torch.cat([hd[~in_push], (u_ps % N) - lo])
+        self.recv_cols = torch.cat([pos_pl[iv_pl], pos_ps])
+        self.recv_splits = rcnt.cpu().tolist()
+        self.n_recv = int(rcnt.sum())
+        # send side
+        so_, do_ = src[outg] - lo, dst[outg]
+        v_pl, jv_pl, d_pl, t_pl = grouped(p_out[~out_push] * N + (so_[~out_push] + lo), P)  # rows peers pull
+        v_ps, jv_ps, d_ps, t_ps = grouped(p_out[out_push] * N + do_[out_push], P)           # partial rows I push
+        scnt = d_pl + d_ps
+        soff = torch.cumsum(scnt, 0) - scnt
+        spos_pl = soff[v_pl // N] + (torch.arange(v_pl.shape[0], device=dev) - t_pl[v_pl // N])
+        spos_ps = soff[v_ps // N] + (torch.arange(v_ps.shape[0], device=dev) - t_ps[v_ps // N])
+        self.send_rows = torch.cat([spos_pl, spos_ps[jv_ps]])
+        self.send_cols = torch.cat([(v_pl % N) - lo, so_[out_push]])
+        self.send_splits = scnt.cpu().tolist()
+        self.n_send = int(scnt.sum())
+        self.pushed_pairs = int(push.sum())
+
+    # ---- the pair decision, identical on every rank ----------------------------------------------------------------
+    @staticmethod
+    def pair_counts(edges, num_nodes, part, world):
+        """-> (pull, push): [world, world] int64, entry [p, q] = rows pair (dst owner p <- src owner q) would ship when it
+        pulls (distinct sources) / pushes (distinct destinations).  Diagonal = 0."""
+        dev = edges.device
+        part = torch.as_tensor(part, device=dev).to(torch.int64)
+        N, P = int(num_nodes), int(world)
+        ps, pd = part[edges[:, 0]], part[edges[:, 1]]
+        cut = ps != pd
+        pair = pd[cut] * P + ps[cut]
+        pull = torch.bincount(torch.unique(pair * N + edges[cut, 0]) // N, minlength=P * P).reshape(P, P)
+        push = torch.bincount(torch.unique(pair * N + edges[cut, 1]) // N, minlength=P * P).reshape(P, P)
+        return pull.cpu(), push.cpu()
+
+    @staticmethod
+    def choose_push(pull, push, bias=1.0):
+        """push[p, q] = True where shipping partial destination rows moves fewer rows than shipping source rows."""
+        return (push.to(torch.float64) * float(bias)) < pull.to(torch.float64)
 
 
-_PLAN_ARRAYS = ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "halo_global", "send_idx", "in_degree")
-_PLAN_META = ("rank", "world", "num_nodes", "n_own", "n_halo", "local_edges", "offsets", "recv_splits", "send_splits")
+_PLAN_ARRAYS = ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "halo_global", "send_idx", "in_degree",
+                "out_degree", "edge_global", "recv_rows", "recv_cols", "send_rows", "send_cols", "push")
+_PLAN_META = ("rank", "world", "num_nodes", "n_own", "n_halo", "local_edges", "offsets", "halo_splits", "pull_splits",
+              "recv_splits", "send_splits", "n_recv", "n_send", "pushed_pairs")
 
 
 def _plan_dump(plan, path):
-    """On-disk cache of one rank's share ("next" row f2): int64 .npy arrays + meta.json under
-    <path>/rank_<r>/, in the spirit of Graph.dump's .npy directory (pgl/graph.py:1177-1302), so the
-    partitioner and the plan construction are one-off costs for graphs at config 4/5 scale."""
+    """On-disk cache of one rank's share ("next" row f2): .npy arrays + meta.json under <path>/rank_<r>/, in the spirit
+    of Graph.dump's .npy directory (pgl/graph.py:1177-1302), so the partitioner and the plan construction are one-off
+    costs for graphs at config 4/5 scale."""
     import json
     d = os.path.join(path, "rank_%d" % plan.rank)
     os.makedirs(d, exist_ok=True)
@@ -128,183 +279,600 @@ def _plan_load(path, rank, device=None, mmap_mode=None):
         setattr(plan, k, v)
     for k in _PLAN_ARRAYS:
         t = torch.from_numpy(np.array(np.load(os.path.join(d, k + ".npy"), mmap_mode=mmap_mode)))
-        setattr(plan, k, t.to(device) if device is not None else t)
+        setattr(plan, k, t.to(device) if (device is not None and k != "push") else t)
     return plan
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# differentiable data flows
+# ------------------------------------------------------------------------------------------------------------------
+class _HaloAggregate(torch.autograd.Function):
+    """out[v] = dst_scale[v] * ( sum_{local u->v} x_own[u]  +  sum over the received rows ), one all-to-all-v, overlapped.
+    Backward: the transposed indices, splits swapped: gx = A_loc^T g' + S^T (exchange^T (R^T g')), g' = dst_scale * g."""
+
+    @staticmethod
+    def forward(ctx, x_own, dg, scale):
+        ctx.dg, ctx.scale = dg, scale
+        return dg._flow(x_own, scale, transposed=False)
+
+    @staticmethod
+    def backward(ctx, grad):
+        return ctx.dg._flow(grad.contiguous(), ctx.scale, transposed=True), None, None
+
+
+class _HaloExtend(torch.autograd.Function):
+    """x_own [n_own, ...] -> x_ext [n_own + n_halo, ...] = [owned rows | halo rows grouped by owner] (pull exchange).
+    Backward: the halo rows' gradients travel back to their owners and are added to the rows they came from."""
+
+    @staticmethod
+    def forward(ctx, x_own, dg):
+        ctx.dg = dg
+        return dg._extend(x_own)
+
+    @staticmethod
+    def backward(ctx, g_ext):
+        return ctx.dg._extend_backward(g_ext.contiguous()), None
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """Owned rows of every rank -> the replicated [N, ...] tensor in ORIGINAL node order (DistGPUGraph's output
+    convention).  Backward: every replica's gradient counts (they are summed, as the backward of the reference's
+    c_allreduce_sum does, pgl/utils/op.py:90-122), and this rank keeps the rows it owns."""
+
+    @staticmethod
+    def forward(ctx, x_own, dg):
+        ctx.dg = dg
+        return dg.gather_global(x_own)
+
+    @staticmethod
+    def backward(ctx, g):
+        dg = ctx.dg
+        g = g.contiguous().clone()
+        if _group_ready(dg.group):
+            _all_reduce_sum(g, dg.group)
+        return g[dg.plan.own_global.to(g.device)].contiguous(), None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the distributed graph
+# ------------------------------------------------------------------------------------------------------------------
 class DistGraph(object):
-    """One rank's share of a row-partitioned graph.  send_recv(x_own, reduce) == the rows this rank
-    owns of Graph.send_recv(x_global, reduce) on the whole graph (un-permute with own_global)."""
+    """One rank's share of a row-partitioned graph.  Every method takes / returns OWNED rows: `send_recv(x_own, op)` ==
+    the rows this rank owns of `Graph.send_recv(x_global, op)` on the whole graph (un-permute with `own_global`, or
+    `gather_global`).  Mirrors the method set of the reference's DistGPUGraph (pgl/graph.py:1509-1553) plus the engine
+    extensions pgl_amd.nn layers use (send_recv_scaled, gat_aggregate, send_uv, send / recv)."""
 
-    def __init__(self, plan, device=None, group=None, aggregate_fn=None):
+    def __init__(self, plan, device=None, group=None, backend=None, exchange_plan=None):
         self.plan, self.group = plan, group
+        self.xplan = exchange_plan if exchange_plan is not None else plan     # pull/push plan of send_recv(sum | mean)
         self.device = device if device is not None else plan.loc_rows.device
-        self._agg = aggregate_fn            # test seam (CPU gloo tests inject the oracle here)
-        self._csr_loc = self._csr_hal = self._csr_all = None
-        self._send_idx32 = None
+        self._b = backend if backend is not None else _EngineBackend()
+        self._idx = {}
+        self._buf = {}
+        self._local_graph = None
         self._inv_deg = None
-        self._recv_buf = None
+        self._all_ids = None
+        self.method = "given"
 
-    # ---- construction ------------------------------------------------------------------------
+    # ---- construction ----------------------------------------------------------------------------------------------
     @classmethod
-    def from_global(cls, edges, num_nodes, rank, world, method="kway", device=None, part=None, group=None,
-                    aggregate_fn=None, seed=0):
-        """Every rank holds the same global edge list (synthetic graphs are regenerated from the
-        seed on each rank); rank 0 partitions and broadcasts the part vector."""
+    def from_global(cls, edges, num_nodes, rank, world, method="metis", device=None, part=None, group=None, backend=None,
+                    seed=0, push="auto"):
+        """Every rank holds the same global edge list (synthetic graphs are regenerated from the seed on each rank);
+        rank 0 partitions and broadcasts the part vector.
+        method: "metis" (the reference's METIS through pgl_amd.partition, k-way fallback when the helper library is
+                absent), "kway" (the engine's own multilevel partitioner), "random", "mod" (node id % world, the
+                reference DistGPUGraph's rule), or "auto" (build metis and random, keep the plan whose slowest rank
+                receives fewer rows).
+        push:   "auto" = per rank pair the cheaper of pull / push for send_recv(sum | mean); "never" = pull everywhere."""
         edges = torch.as_tensor(edges)
         if device is not None:
             edges = edges.to(device)
-        if part is not None or method != "auto" or world == 1:
-            given = part is not None
-            if part is None:
-                part = cls.partition(edges, num_nodes, world, "kway" if method == "auto" else method, rank, group, seed)
-            dg = cls(HaloPlan(edges, num_nodes, part, rank, world), device=edges.device, group=group,
-                     aggregate_fn=aggregate_fn)
-            dg.method = "given" if given else method
-            return dg
-        # "auto": build both plans, keep the one whose slowest rank moves fewer halo rows.  Power-law
-        # (RMAT) graphs have almost no locality for a k-way partitioner to find, and then the
-        # perfectly balanced random assignment wins; graphs with community structure go k-way.
+        given = part is not None
+        methods = [method] if (given or method != "auto" or world == 1) else ["metis", "random"]
         best = None
-        for m in ("kway", "random"):
-            pt = cls.partition(edges, num_nodes, world, m, rank, group, seed)
+        for m in methods:
+            pt = part if given else cls.partition(edges, num_nodes, world, m, rank, group, seed)
             plan = HaloPlan(edges, num_nodes, pt, rank, world)
-            cost = torch.tensor([float(plan.n_halo + plan.local_edges / 16.0)], dtype=torch.float64)
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            xplan = plan
+            if push == "auto" and world > 1:
+                pull_c, push_c = HaloPlan.pair_counts(edges, num_nodes, pt, world)
+                choice = HaloPlan.choose_push(pull_c, push_c)
+                if bool(choice.any()):
+                    xplan = HaloPlan(edges, num_nodes, pt, rank, world, push=choice)
+            cost = torch.tensor([float(xplan.n_recv + plan.local_edges / 16.0)], dtype=torch.float64)
+            if len(methods) > 1 and _group_ready(group):
                 c = cost.to(edges.device) if dist.get_backend(group) == "nccl" else cost
                 dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
                 cost = c.cpu()
             if best is None or float(cost) < best[0]:
-                best = (float(cost), m, plan)
-        dg = cls(best[2], device=edges.device, group=group, aggregate_fn=aggregate_fn)
-        dg.method = best[1]
+                best = (float(cost), m, plan, xplan)
+        dg = cls(best[2], device=edges.device, group=group, backend=backend, exchange_plan=best[3])
+        dg.method = "given" if given else best[1]
         return dg
 
+    @classmethod
+    def from_graph(cls, graph, rank=None, world=None, **kw):
+        """From a whole pgl_amd.Graph held by every rank (what the reference's DistGPUGraph(graph) receives)."""
+        if rank is None:
+            rank = dist.get_rank() if _group_ready() else 0
+        if world is None:
+            world = dist.get_world_size() if _group_ready() else 1
+        return cls.from_global(torch.as_tensor(graph.edges), graph.num_nodes, rank, world, **kw)
+
     @staticmethod
-    def partition(edges, num_nodes, world, method="kway", rank=0, group=None, seed=0):
+    def partition(edges, num_nodes, world, method="metis", rank=0, group=None, seed=0):
         if world == 1:
             return torch.zeros(num_nodes, dtype=torch.int64)
+        ready = _group_ready(group)
         part = torch.empty(num_nodes, dtype=torch.int64)
-        if rank == 0:
+        if rank == 0 or not ready:               # without a process group every caller computes it: deterministic in `seed`
             e = edges.cpu().numpy()
-            if method == "random":
+            if method == "mod":                   # the reference's own sharding rule (dst % world, pgl/graph.py:1496)
+                p = np.arange(num_nodes, dtype=np.int64) % world
+            elif method == "random":
                 rng = np.random.default_rng(seed)
                 p = np.repeat(np.arange(world, dtype=np.int64), -(-num_nodes // world))[:num_nodes]
                 rng.shuffle(p)
             else:
-                # symmetrised adjacency (the reference warns METIS input should be undirected,
-                # pgl/partition.py:61); vertex weight = in-degree + 1 balances aggregation work
+                # symmetrised adjacency (the reference warns METIS input should be undirected, pgl/partition.py:61);
+                # vertex weight = in-degree + 1 balances aggregation work (node_weights, pgl/partition.py:76-79)
                 u = np.concatenate([e[:, 0], e[:, 1]]); v = np.concatenate([e[:, 1], e[:, 0]])
                 _, sv, _, _, ip = ops.host_build_index(u, v, num_nodes)
                 vw = np.bincount(e[:, 1], minlength=num_nodes).astype(np.int64) + 1
-                p, _ = ops.host_partition_kway(num_nodes, ip, sv, world, vw, None, seed)
-            part.copy_(torch.from_numpy(p))
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                p = None
+                if method == "metis":
+                    from . import partition as _pt
+                    p = _pt.metis_kway_csr(num_nodes, ip, sv, world, vw)       # None when the METIS helper is not built
+                if p is None:
+                    p, _ = ops.host_partition_kway(num_nodes, ip, sv, world, vw, None, seed)
+            part.copy_(torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)))
+        if ready:
             buf = part.to(edges.device) if dist.get_backend(group) == "nccl" else part
-            dist.broadcast(buf, src=0, group=group)
+            dist.broadcast(buf, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
             part = buf.cpu()
         return part
 
     def dump(self, path):
-        """Cache this rank's partition share + halo plan under <path>/rank_<r>/ (see _plan_dump)."""
+        """Cache this rank's partition share + both plans under <path>/rank_<r>/ (see _plan_dump)."""
         _plan_dump(self.plan, path)
+        if self.xplan is not self.plan:
+            _plan_dump(self.xplan, os.path.join(path, "exchange"))
 
     @classmethod
-    def load(cls, path, rank, device=None, group=None, aggregate_fn=None):
-        dg = cls(_plan_load(path, rank, device), device=device, group=group, aggregate_fn=aggregate_fn)
+    def load(cls, path, rank, device=None, group=None, backend=None):
+        plan = _plan_load(path, rank, device)
+        xdir = os.path.join(path, "exchange")
+        xplan = _plan_load(xdir, rank, device) if os.path.isdir(os.path.join(xdir, "rank_%d" % rank)) else None
+        dg = cls(plan, device=device, group=group, backend=backend, exchange_plan=xplan)
         dg.method = "cached"
         return dg
 
-    # ---- helpers -----------------------------------------------------------------------------
+    # ---- bookkeeping -----------------------------------------------------------------------------------------------
+    @property
+    def num_nodes(self):
+        """Owned rows (what layers use as the number of output rows)."""
+        return self.plan.n_own
+
+    @property
+    def num_edges(self):
+        return self.plan.local_edges
+
     def take_owned(self, x_global):
-        """Rows of a replicated [N, ...] tensor that this rank owns, in local row order."""
+        """Rows of a replicated [N, ...] tensor that this rank owns, in local row order (differentiable)."""
         return x_global[self.plan.own_global.to(x_global.device)].contiguous()
 
-    def stats(self):
+    def take_edges(self, y_global):
+        """Rows of a replicated [E, ...] edge tensor for this rank's local edges, in LOCAL edge order (differentiable):
+        the edge operand of send_ue_recv / the edge features of send stay with the destination's owner."""
+        return y_global[self.plan.edge_global.to(y_global.device)].contiguous()
+
+    def gather_global(self, x_own):
+        """Owned rows of all ranks -> replicated [N, ...] in original node order (one all-gather of N*d/P per rank)."""
         p = self.plan
-        return {"partition": getattr(self, "method", "given"), "local_rows": p.n_own, "local_edges": p.local_edges, "halo_rows": p.n_halo,
-                "send_rows": int(sum(p.send_splits)), "edges_local_src": int(p.loc_rows.shape[0]),
+        if not _group_ready(self.group):
+            out = torch.empty((p.num_nodes,) + tuple(x_own.shape[1:]), dtype=x_own.dtype, device=x_own.device)
+            out[p.own_global.to(x_own.device)] = x_own
+            return out
+        sizes = [p.offsets[r + 1] - p.offsets[r] for r in range(p.world)]
+        pad = max(sizes)
+        mine = torch.zeros((pad,) + tuple(x_own.shape[1:]), dtype=x_own.dtype, device=x_own.device)
+        mine[:p.n_own] = x_own
+        parts = _all_gather(mine, self.group)
+        if self._all_ids is None:                                      # every rank's owned node ids: exchanged once
+            mine_ids = torch.zeros(pad, dtype=torch.int64, device=x_own.device)
+            mine_ids[:p.n_own] = p.own_global.to(x_own.device)
+            self._all_ids = _all_gather(mine_ids, self.group)
+        ids = self._all_ids
+        out = torch.empty((p.num_nodes,) + tuple(x_own.shape[1:]), dtype=x_own.dtype, device=x_own.device)
+        for r in range(p.world):
+            out[ids[r][:sizes[r]]] = parts[r][:sizes[r]]
+        return out
+
+    def stats(self):
+        p, x = self.plan, self.xplan
+        return {"partition": self.method, "local_rows": p.n_own, "local_edges": p.local_edges, "halo_rows": p.n_halo,
+                "send_rows": int(x.n_send), "recv_rows": int(x.n_recv), "pull_only_recv_rows": p.n_halo,
+                "pushed_pairs": int(x.pushed_pairs), "edges_local_src": int(p.loc_rows.shape[0]),
                 "edges_halo_src": int(p.hal_rows.shape[0])}
 
-    def _ensure_device_state(self):
-        p = self.plan
-        if self._csr_loc is None:
-            self._csr_loc = ops.csr_build(p.loc_rows, p.loc_cols, p.n_own)
-            self._csr_hal = ops.csr_build(p.hal_rows, p.hal_cols, p.n_own)
-            self._send_idx32 = p.send_idx.to(torch.int32)
-            self._inv_deg = (1.0 / p.in_degree.clamp(min=1).to(torch.float32)).contiguous()
+    def indegree(self, nodes=None):
+        """pgl/graph.py:1524-1527 (global in-degree of the owned nodes; `nodes` = local row ids)."""
+        d = self.plan.in_degree
+        return d if nodes is None else d[torch.as_tensor(nodes, device=d.device).long()]
 
-    def _combined_csr(self):
-        if self._csr_all is None:
-            p = self.plan
-            rows = torch.cat([p.loc_rows, p.hal_rows])
-            cols = torch.cat([p.loc_cols, p.hal_cols + p.n_own])
-            self._csr_all = ops.csr_build(rows, cols, p.n_own)
-        return self._csr_all
+    def outdegree(self, nodes=None):
+        """pgl/graph.py:1529-1532 (global out-degree of the owned nodes, counted over ALL edges at plan time)."""
+        d = self.plan.out_degree
+        return d if nodes is None else d[torch.as_tensor(nodes, device=d.device).long()]
 
-    # ---- the hot path --------------------------------------------------------------------------
-    def send_recv(self, x_own, reduce_func="sum"):
-        """Distributed Graph.send_recv (pgl/graph.py:834-861 semantics; DistGPUGraph.send_recv
-        pgl/graph.py:1517-1531 role).  x_own: [n_own, d] features of the owned rows."""
-        assert reduce_func in ("sum", "mean", "max", "min"), \
-            "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
-        p = self.plan
-        x_own = x_own.contiguous()
-        d_tail = tuple(x_own.shape[1:])
-        if self._agg is not None:
-            return self._send_recv_with(self._agg, x_own, reduce_func)
-        self._ensure_device_state()
-        send_buf = self.pack(x_own)
-        if self._recv_buf is None or self._recv_buf.shape != (p.n_halo,) + d_tail or self._recv_buf.dtype != x_own.dtype:
-            self._recv_buf = torch.empty((p.n_halo,) + d_tail, dtype=x_own.dtype, device=x_own.device)
-        work = _exchange(send_buf, p.send_splits, self._recv_buf, p.recv_splits, self.group) if p.world > 1 else None
-        return self.aggregate_with_halo(x_own, self._recv_buf, reduce_func, work)
+    # ---- lazily built device state -----------------------------------------------------------------------------------
+    def _index(self, name):
+        """dst-keyed indices loc / recv / send / hal / int / bnd and their transposes (suffix _t), built on first use."""
+        hit = self._idx.get(name)
+        if hit is not None:
+            return hit
+        p, x = self.plan, self.xplan
+        base, t = (name[:-2], True) if name.endswith("_t") else (name, False)
+        if base == "loc":
+            rows, cols, nr, nc = p.loc_rows, p.loc_cols, p.n_own, p.n_own
+        elif base == "recv":
+            rows, cols, nr, nc = x.recv_rows, x.recv_cols, p.n_own, x.n_recv
+        elif base == "send":
+            rows, cols, nr, nc = x.send_rows, x.send_cols, x.n_send, p.n_own
+        elif base == "hal":
+            rows, cols, nr, nc = p.hal_rows, p.hal_cols, p.n_own, p.n_halo
+        elif base == "pull":                                          # send_buf[i] = x_own[send_idx[i]] as an index
+            rows, cols = torch.arange(p.send_idx.shape[0], device=p.send_idx.device), p.send_idx
+            nr, nc = int(p.send_idx.shape[0]), p.n_own
+        elif base in ("int", "bnd"):
+            boundary = torch.zeros(p.n_own, dtype=torch.bool, device=p.hal_rows.device)
+            boundary[p.hal_rows] = True
+            if base == "int":                                         # interior rows: every source is local
+                keep = ~boundary[p.loc_rows]
+                rows, cols = p.loc_rows[keep], p.loc_cols[keep]
+            else:                                                     # boundary rows: all their edges, ext column space
+                keep = boundary[p.loc_rows]
+                rows = torch.cat([p.loc_rows[keep], p.hal_rows])
+                cols = torch.cat([p.loc_cols[keep], p.hal_cols + p.n_own])
+            nr, nc = p.n_own, p.n_own + p.n_halo
+        else:
+            raise KeyError(name)
+        idx = self._b.index(cols, rows, nc) if t else self._b.index(rows, cols, nr)
+        self._idx[name] = idx
+        return idx
 
-    def pack(self, x_own):
-        """Rows of mine that peers need, grouped by destination rank (one gather kernel, K6)."""
-        self._ensure_device_state()
-        return ops.gather_rows(x_own, self._send_idx32)
+    def _buffer(self, name, shape, dtype, device):
+        b = self._buf.get(name)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype or b.device != device:
+            b = torch.empty(shape, dtype=dtype, device=device)
+            self._buf[name] = b
+        return b
 
-    def aggregate_with_halo(self, x_own, recv_buf, reduce_func="sum", work=None):
-        """Compute half of send_recv: local-source edges first (overlapping the in-flight exchange
-        `work`), then the halo-source edges accumulate into the same rows."""
-        self._ensure_device_state()
-        p = self.plan
-        if reduce_func in ("sum", "mean"):
-            scale = self._inv_deg if reduce_func == "mean" else None
-            if scale is not None and x_own.dtype != torch.float32:
-                scale = None
-            out = ops.aggregate(x_own, self._csr_loc, "sum", p.n_own, dst_scale=scale)      # overlaps the exchange
-            if work is not None:
-                work.wait()
-            if p.n_halo:
-                ops.aggregate(recv_buf, self._csr_hal, "sum", p.n_own, dst_scale=scale, out=out, accumulate=True)
-            if reduce_func == "mean" and scale is None:
-                out = out / p.in_degree.clamp(min=1).to(out.dtype).reshape((-1,) + (1,) * (out.dim() - 1))
-            return out
-        # max / min: a row's identity must not be 0, so both edge sets go through one launch
+    def _scale(self, reduce_func):
+        if reduce_func != "mean":
+            return None
+        if self._inv_deg is None:
+            self._inv_deg = (1.0 / self.plan.in_degree.clamp(min=1).to(torch.float32)).contiguous()
+        return self._inv_deg
+
+    # ---- sum / mean: the overlapped pull/push flow (forward and, with the indices transposed, backward) ---------------
+    def _flow(self, x, scale, transposed):
+        p, xp, B = self.plan, self.xplan, self._b
+        tail = tuple(x.shape[1:])
+        if scale is not None and x.dtype != torch.float32:            # kernel scales are fp32-only
+            post = scale.to(x.dtype).reshape((-1,) + (1,) * len(tail))
+            if transposed:
+                x = x * post
+            scale_k = None
+        else:
+            post, scale_k = None, scale
+        if not transposed:
+            first, second, n_out, n_in = "send", "recv", xp.n_send, xp.n_recv
+            out_splits, in_splits = xp.send_splits, xp.recv_splits
+            kw_first, kw_rest = {}, {"dst_scale": scale_k}
+        else:
+            first, second, n_out, n_in = "recv_t", "send_t", xp.n_recv, xp.n_send
+            out_splits, in_splits = xp.recv_splits, xp.send_splits
+            kw_first, kw_rest = {"src_scale": scale_k}, {"src_scale": None}
+        work, in_buf = None, None
+        if p.world > 1 and (n_out or n_in):
+            out_buf = B.aggregate(x, self._index(first), "sum", n_out, **kw_first) if n_out else x.new_empty((0,) + tail)
+            in_buf = self._buffer("in%d" % transposed, (n_in,) + tail, x.dtype, x.device)
+            work = _exchange(out_buf, out_splits, in_buf, in_splits, self.group)
+        if not transposed:
+            out = B.aggregate(x, self._index("loc"), "sum", p.n_own, **kw_rest)                   # overlaps the exchange
+        else:
+            out = B.aggregate(x, self._index("loc_t"), "sum", p.n_own, src_scale=scale_k)
         if work is not None:
             work.wait()
-        x_cat = torch.cat([x_own, recv_buf], 0)
-        return ops.aggregate(x_cat, self._combined_csr(), reduce_func, p.n_own)
+            if n_in:
+                B.aggregate(in_buf, self._index(second), "sum", p.n_own, out=out, accumulate=1, **kw_rest)
+        if post is not None and not transposed:
+            out = out * post
+        return out
 
-    def _send_recv_with(self, agg, x_own, reduce_func):
-        """Same data flow with an injected aggregation callable (used by the gloo CPU tests, which
-        pass the oracle): agg(x, rows, cols, n_rows, reduce) -> [n_rows, ...]."""
+    def _sum_like(self, x_own, reduce_func, extra_dst_scale=None):
+        scale = self._scale(reduce_func)
+        if extra_dst_scale is not None:
+            scale = extra_dst_scale if scale is None else scale * extra_dst_scale
+        x_own = x_own.contiguous()
+        if torch.is_grad_enabled() and x_own.requires_grad:
+            return _HaloAggregate.apply(x_own, self, scale)
+        return self._flow(x_own, scale, transposed=False)
+
+    # ---- halo extension (pull), differentiable ------------------------------------------------------------------------
+    def _extend(self, x_own, work_out=None):
+        p, B = self.plan, self._b
+        x_own = x_own.contiguous()
+        tail = tuple(x_own.shape[1:])
+        x_ext = torch.empty((p.n_own + p.n_halo,) + tail, dtype=x_own.dtype, device=x_own.device)
+        work = None
+        if p.world > 1 and (p.n_halo or p.send_idx.shape[0]):
+            send_buf = B.gather_rows(x_own, self._send_idx32())
+            work = _exchange(send_buf, p.pull_splits, x_ext[p.n_own:], p.halo_splits, self.group)
+        x_ext[:p.n_own].copy_(x_own)                                   # overlaps the exchange
+        if work_out is not None:
+            work_out.append(work)
+        elif work is not None:
+            work.wait()
+        return x_ext
+
+    def _extend_backward(self, g_ext):
+        p, B = self.plan, self._b
+        tail = tuple(g_ext.shape[1:])
+        gx = g_ext[:p.n_own].clone()
+        n_send = int(p.send_idx.shape[0])
+        if p.world > 1 and (p.n_halo or n_send):
+            g_send = self._buffer("gsend", (n_send,) + tail, g_ext.dtype, g_ext.device)
+            work = _exchange(g_ext[p.n_own:].contiguous(), p.halo_splits, g_send, p.pull_splits, self.group)
+            work.wait()
+            if n_send:
+                B.aggregate(g_send, self._index("pull_t"), "sum", p.n_own, out=gx, accumulate=1)
+        return gx
+
+    def _send_idx32(self):
+        s = self._idx.get("send_idx32")
+        if s is None:
+            s = self.plan.send_idx.to(torch.int32) if self.plan.send_idx.is_cuda else self.plan.send_idx
+            self._idx["send_idx32"] = s
+        return s
+
+    def halo_extend(self, x_own):
+        """[n_own, ...] -> [n_own + n_halo, ...]: owned rows followed by the halo rows this rank's edges read, grouped by
+        owner (one all-to-all-v).  Differentiable: the halo rows' gradients return to their owners."""
+        if torch.is_grad_enabled() and x_own.requires_grad:
+            return _HaloExtend.apply(x_own, self)
+        return self._extend(x_own)
+
+    @property
+    def local_graph(self):
+        """This rank's edges as a pgl_amd.Graph over the EXTENDED node space [owned | halo] (sources index it, destinations
+        are < n_own), edge order = local edge order.  Every single-GPU op of the engine applies to it after halo_extend."""
+        if self._local_graph is None:
+            from .graph import Graph
+            p = self.plan
+            src = torch.cat([p.loc_cols, p.hal_cols + p.n_own])
+            dst = torch.cat([p.loc_rows, p.hal_rows])
+            self._local_graph = Graph(edges=torch.stack([src, dst], 1).to(self.device), num_nodes=p.n_own + p.n_halo)
+        return self._local_graph
+
+    @property
+    def adj_dst_index(self):
+        """dst-keyed index of the local edges (every in-edge of an owned row is local, so per-destination ops such as
+        GF.edge_softmax(norm_by="dst") are exact on it)."""
+        return self.local_graph.adj_dst_index
+
+    def _edge_cols32(self):
+        return self.local_graph._edge_cols32()
+
+    # ---- the reference's method set (pgl/graph.py:1509-1553), on owned rows -----------------------------------------------
+    def send_recv(self, feature, reduce_func="sum", out_size=None):
+        """pgl/graph.py:1534-1538 role; Graph.send_recv semantics (pgl/graph.py:834-861).  feature: [n_own, ...]."""
+        assert reduce_func in ("sum", "mean", "max", "min"), \
+            "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
+        if out_size is not None and int(out_size) not in (0, self.plan.n_own):
+            raise ValueError("DistGraph: out_size must equal the number of owned rows (%d)" % self.plan.n_own)
+        if reduce_func in ("sum", "mean"):
+            return self._sum_like(feature, reduce_func)
+        if torch.is_grad_enabled() and feature.requires_grad:
+            return self.local_graph.send_recv(self.halo_extend(feature), reduce_func)[:self.plan.n_own]
+        return self._minmax(feature.contiguous(), reduce_func)
+
+    def send_u_recv(self, feature, reduce_op="sum", out_size=None):
+        """pgl/graph.py:1540-1544."""
+        return self.send_recv(feature, reduce_op, out_size)
+
+    def _minmax(self, x_own, reduce_func):
+        """Interior rows while the halo is in flight, boundary rows on top afterwards (no identity needed)."""
+        p, B = self.plan, self._b
+        pending = []
+        x_ext = self._extend(x_own, work_out=pending)
+        out = B.aggregate(x_own, self._index("int"), reduce_func, p.n_own)
+        if pending[0] is not None:
+            pending[0].wait()
+        if p.n_halo:
+            B.aggregate(x_ext, self._index("bnd"), reduce_func, p.n_own, out=out, accumulate=2)
+        return out
+
+    def send_ue_recv(self, feature, edge_feature, message_op="add", reduce_op="sum", out_size=None):
+        """pgl/graph.py:1546-1553 role; Graph.send_ue_recv semantics (pgl/graph.py:889-937).  feature: [n_own, ...];
+        edge_feature: [local_edges, ...] in local edge order (`take_edges`) -- the edge operand stays with the
+        destination's owner, only source rows travel."""
+        assert message_op in ("add", "sub", "mul", "div"), "Only support 'add', 'sub', 'max', 'min' build-in message functions."
+        assert reduce_op in ("sum", "mean", "max", "min"), "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
         p = self.plan
-        send_buf = x_own[p.send_idx]
-        recv_buf = torch.empty((p.n_halo,) + tuple(x_own.shape[1:]), dtype=x_own.dtype, device=x_own.device)
-        if p.world > 1:
-            _exchange(send_buf, p.send_splits, recv_buf, p.recv_splits, self.group).wait()
-        x_cat = torch.cat([x_own, recv_buf], 0)
-        rows = torch.cat([p.loc_rows, p.hal_rows])
-        cols = torch.cat([p.loc_cols, p.hal_cols + p.n_own])
-        return agg(x_cat, rows, cols, p.n_own, reduce_func)
+        if int(edge_feature.shape[0]) != p.local_edges:
+            raise ValueError("edge feature has %d rows, this rank holds %d edges" % (edge_feature.shape[0], p.local_edges))
+        needs_grad = torch.is_grad_enabled() and (feature.requires_grad or edge_feature.requires_grad)
+        if needs_grad or reduce_op not in ("sum", "mean"):
+            return self.local_graph.send_ue_recv(self.halo_extend(feature), edge_feature, message_op, reduce_op)[:p.n_own]
+        # forward-only sum / mean: local-source edges overlap the exchange, halo-source edges accumulate afterwards
+        B = self._b
+        feature, edge_feature = feature.contiguous(), edge_feature.contiguous()
+        n_loc = int(p.loc_rows.shape[0])
+        pending = []
+        x_ext = self._extend(feature, work_out=pending)
+        scale = self._scale(reduce_op)
+        if scale is not None and feature.dtype != torch.float32:
+            return self.local_graph.send_ue_recv(self.halo_extend(feature), edge_feature, message_op, reduce_op)[:p.n_own]
+        out = B.aggregate(feature, self._index("loc"), "sum", p.n_own, y=edge_feature[:n_loc], message_op=message_op,
+                          dst_scale=scale)
+        if pending[0] is not None:
+            pending[0].wait()
+        if p.n_halo:
+            B.aggregate(x_ext[p.n_own:], self._index("hal"), "sum", p.n_own, y=edge_feature[n_loc:], message_op=message_op,
+                        dst_scale=scale, out=out, accumulate=1)
+        return out
 
-    def indegree(self):
-        return self.plan.in_degree
+    def send_uv(self, src_feature, dst_feature, message_op="add"):
+        """Graph.send_uv (pgl/graph.py:939-966) over this rank's edges -> [local_edges, ...] in local edge order."""
+        return self.local_graph.send_uv(self.halo_extend(src_feature), dst_feature, message_op)
+
+    def send(self, message_func, src_feat=None, dst_feat=None, edge_feat=None, node_feat=None):
+        """Graph.send (pgl/graph.py:694-776) over this rank's edges: source features are extended with their halo rows
+        first (one exchange per key), destination and edge features are local."""
+        if (src_feat is not None or dst_feat is not None) and node_feat is not None:
+            raise ValueError("Can not use src/dst feat and node feat at the same time")
+        if node_feat is not None:
+            assert isinstance(node_feat, dict), "The input node_feat must be a dict"
+            src_feat, dst_feat = node_feat, node_feat
+        if src_feat is not None:
+            assert isinstance(src_feat, dict), "The input src_feat must be a dict"
+            src_feat = {k: self.halo_extend(v) for k, v in src_feat.items()}
+        return self.local_graph.send(message_func, src_feat=src_feat, dst_feat=dst_feat, edge_feat=edge_feat)
+
+    def recv(self, reduce_func, msg, recv_mode="dst"):
+        """pgl/graph.py:1517-1522 role; Graph.recv semantics (pgl/graph.py:778-832)."""
+        if recv_mode != "dst":
+            raise ValueError("Currently DistGPUGraph can only support recv_mode=='dst'")
+        return self.local_graph.recv(reduce_func, msg, recv_mode)[:self.plan.n_own]
+
+    # ---- engine extensions the pgl_amd.nn layers look for ---------------------------------------------------------------
+    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None):
+        """out[v] = dst_scale[v] * sum_{u->v} src_scale[u] * feature[u] (GCN's symmetric norm, pgl/nn/conv.py:242-250): the
+        source scale is applied to the owned rows before they travel, the destination scale inside the kernels."""
+        if src_scale is not None:
+            feature = feature * src_scale.reshape((-1,) + (1,) * (feature.dim() - 1)).to(feature.dtype)
+        ds = None if dst_scale is None else dst_scale.reshape(-1).to(torch.float32).contiguous()
+        return self._sum_like(feature, "sum", extra_dst_scale=ds)
+
+    def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2, attn_drop=0.0, seed=0):
+        """The fused GAT attention of Graph.gat_aggregate over the partitioned graph: a_src rides with the halo feature
+        rows, a_dst is local; the softmax of every owned destination sees all of its in-edges."""
+        p = self.plan
+        n, H, D = (int(v) for v in feature.shape)
+        packed = torch.cat([feature.reshape(n, H * D), attn_src.reshape(n, H)], 1)       # one exchange for both
+        ext = self.halo_extend(packed)
+        f_ext = ext[:, :H * D].reshape(-1, H, D).contiguous()
+        as_ext = ext[:, H * D:].contiguous()
+        ad_ext = torch.cat([attn_dst, attn_dst.new_zeros((p.n_halo, H))], 0)
+        return self.local_graph.gat_aggregate(f_ext, as_ext, ad_ext, negative_slope, attn_drop, seed)[:p.n_own]
+
+    def exchange_only(self, x_own):
+        """Measurement hook (bench.py): the pack kernel, the all-to-all-v and the wait of send_recv(sum), without the
+        aggregations -- the time the overlap has to hide."""
+        xp, B = self.xplan, self._b
+        tail = tuple(x_own.shape[1:])
+        if self.plan.world == 1 or not (xp.n_send or xp.n_recv):
+            return None
+        out_buf = B.aggregate(x_own, self._index("send"), "sum", xp.n_send) if xp.n_send else x_own.new_empty((0,) + tail)
+        in_buf = self._buffer("in0", (xp.n_recv,) + tail, x_own.dtype, x_own.device)
+        _exchange(out_buf, xp.send_splits, in_buf, xp.recv_splits, self.group).wait()
+        return in_buf
+
+    # ---- in-process simulation helpers (single-GPU tests of the compute path) ---------------------------------------------
+    def pack(self, x_own):
+        """Rows of mine that peers pull, grouped by destination rank (one gather kernel, K6)."""
+        return self._b.gather_rows(x_own.contiguous(), self._send_idx32())
+
+    def aggregate_with_halo(self, x_own, halo_rows, reduce_func="sum"):
+        """Compute half of send_recv given the already exchanged halo rows (pull layout)."""
+        p, B = self.plan, self._b
+        x_own = x_own.contiguous()
+        if reduce_func in ("sum", "mean"):
+            scale = self._scale(reduce_func)
+            post = None
+            if scale is not None and x_own.dtype != torch.float32:
+                post, scale = scale, None
+            out = B.aggregate(x_own, self._index("loc"), "sum", p.n_own, dst_scale=scale)
+            if p.n_halo:
+                B.aggregate(halo_rows, self._index("hal"), "sum", p.n_own, dst_scale=scale, out=out, accumulate=1)
+            return out if post is None else out * post.to(out.dtype).reshape((-1,) + (1,) * (out.dim() - 1))
+        out = B.aggregate(x_own, self._index("int"), reduce_func, p.n_own)
+        if p.n_halo:
+            B.aggregate(torch.cat([x_own, halo_rows], 0), self._index("bnd"), reduce_func, p.n_own, out=out, accumulate=2)
+        return out
 
 
+class DistGPUGraph(object):
+    """Drop-in for the reference's `pgl.DistGPUGraph(graph)` (pgl/graph.py:1410-1553): constructed from a whole Graph on
+    every rank, takes REPLICATED [N, ...] node features (and [E, ...] edge features in the original edge order) and
+    returns replicated results -- what the reference's tests/test_dist_graph.py exercise.  Underneath, each rank
+    computes only the rows it owns on a `DistGraph` and the rows are all-gathered (N*d/P per rank instead of the
+    reference's all-reduce of [N, d] partial sums).  Gradients: with every rank running the same replicated computation
+    (the reference's model: DataParallel averages parameter gradients over ranks), the sum over ranks of the input
+    gradients equals the reference's sum over ranks -- see `_AllGatherRows`."""
+
+    def __init__(self, graph, method=None, group=None):
+        warnings.warn("DistGPUGraph is an experimental API for Multi-GPU FullBatch Training.")
+        g = graph if graph.is_tensor() else graph.tensor()
+        if method is None:                        # graphs too small to be worth a partitioner: the reference's modulo rule
+            method = "metis" if g.num_nodes >= 4096 else "mod"
+        self.graph = g
+        self.dist = DistGraph.from_graph(g, method=method, group=group, device=g.edges.device)
+        self.node_feat, self.edge_feat = g.node_feat, g.edge_feat
+        self.num_nodes, self.num_edges, self.edges = g.num_nodes, g.num_edges, g.edges
+
+    def is_tensor(self):
+        return True
+
+    def tensor(self, inplace=True):
+        return self
+
+    def numpy(self, inplace=True):
+        raise ValueError("DistGPUGraph can't convert into numpy")
+
+    def _out(self, own):
+        if torch.is_grad_enabled() and own.requires_grad:
+            return _AllGatherRows.apply(own, self.dist)
+        return self.dist.gather_global(own)
+
+    def _deg(self, d, nodes):
+        full = self.dist.gather_global(d)
+        return full if nodes is None else full[torch.as_tensor(nodes, device=full.device).long()]
+
+    def indegree(self, nodes=None):
+        return self._deg(self.dist.plan.in_degree, nodes)
+
+    def outdegree(self, nodes=None):
+        return self._deg(self.dist.plan.out_degree, nodes)
+
+    def send(self, message_func, src_feat=None, dst_feat=None, edge_feat=None, node_feat=None):
+        take = lambda d, f: None if d is None else {k: f(v) for k, v in d.items()}
+        dg = self.dist
+        return dg.send(message_func, src_feat=take(src_feat, dg.take_owned), dst_feat=take(dst_feat, dg.take_owned),
+                       edge_feat=take(edge_feat, dg.take_edges), node_feat=take(node_feat, dg.take_owned))
+
+    def recv(self, reduce_func, msg, recv_mode="dst"):
+        if recv_mode != "dst":
+            raise ValueError("Currently DistGPUGraph can only support recv_mode=='dst'")
+        return self._out(self.dist.recv(reduce_func, msg, recv_mode))
+
+    def send_recv(self, feature, reduce_func="sum", out_size=None):
+        return self._out(self.dist.send_recv(self.dist.take_owned(feature), reduce_func))
+
+    def send_u_recv(self, feature, reduce_op="sum", out_size=None):
+        return self._out(self.dist.send_recv(self.dist.take_owned(feature), reduce_op))
+
+    def send_ue_recv(self, feature, edge_feature, message_op="add", reduce_op="sum", out_size=None):
+        dg = self.dist
+        return self._out(dg.send_ue_recv(dg.take_owned(feature), dg.take_edges(edge_feature), message_op, reduce_op))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# feature sharding and the rows x columns grid
+# ------------------------------------------------------------------------------------------------------------------
 def _balanced_ranges(n, world):
     """[lo, hi) of every rank for n items split as evenly as possible (the first n % world ranks get one more)."""
     base, extra = divmod(int(n), int(world))
@@ -323,7 +891,8 @@ class FeatureShardedGraph(object):
     where a dense layer mixes columns (rows_to_cols / cols_to_rows: one balanced all-to-all of N*d*(P-1)/P^2 elements
     per rank -- 56 MB at C2, P = 8, against 128 MB of halo rows for the row partition of the same RMAT graph, and
     independent of the graph's locality).  Power-law graphs without communities (RMAT: 82 % of the edges cut by any
-    8-way partition) are the case for it; graphs with locality keep DistGraph's row partition + halo exchange."""
+    8-way partition) are the case for it; graphs with locality keep DistGraph's row partition + halo exchange.
+    The two layout changes are each other's backward (`_LayoutChange`), so layers between them train."""
 
     def __init__(self, graph, rank, world, group=None):
         self.graph, self.rank, self.world, self.group = graph, int(rank), int(world), group
@@ -346,15 +915,13 @@ class FeatureShardedGraph(object):
     def send_ue_recv(self, x_cols, edge_feature, message_op="add", reduce_op="sum"):
         return self.graph.send_ue_recv(x_cols, edge_feature, message_op, reduce_op)
 
-    # ---- layout changes around dense layers -----------------------------------------------------
-    def cols_to_rows(self, x_cols, d):
-        """[N, d_r] (all rows, my columns) -> [n_r, d] (my rows, all columns)."""
+    # ---- layout changes around dense layers ----------------------------------------------------------------------------
+    def _cols_to_rows(self, x_cols, d):
         rows, cols = _balanced_ranges(self.num_nodes, self.world), _balanced_ranges(d, self.world)
         (r0, r1), me = rows[self.rank], self.rank
-        if self.world == 1:
-            return x_cols
-        send = torch.cat([x_cols[a:b].reshape(-1) for a, b in rows])                       # peer q gets its rows of my columns
-        send_splits = [(b - a) * (cols[me][1] - cols[me][0]) for a, b in rows]
+        w = cols[me][1] - cols[me][0]
+        send = x_cols.contiguous().reshape(-1)            # peer q's rows of my columns are a contiguous block already
+        send_splits = [(b - a) * w for a, b in rows]
         recv_splits = [(r1 - r0) * (c1 - c0) for c0, c1 in cols]
         recv = torch.empty(sum(recv_splits), dtype=x_cols.dtype, device=x_cols.device)
         _exchange(send, send_splits, recv, recv_splits, self.group).wait()
@@ -365,23 +932,87 @@ class FeatureShardedGraph(object):
             off += n
         return out
 
-    def rows_to_cols(self, x_rows):
-        """[n_r, d] (my rows, all columns) -> [N, d_r] (all rows, my columns)."""
+    def _rows_to_cols(self, x_rows):
         d = int(x_rows.shape[1])
         rows, cols = _balanced_ranges(self.num_nodes, self.world), _balanced_ranges(d, self.world)
         (c0, c1), me = cols[self.rank], self.rank
-        if self.world == 1:
-            return x_rows
-        send = torch.cat([x_rows[:, a:b].reshape(-1) for a, b in cols])                    # peer q gets its columns of my rows
-        send_splits = [(rows[me][1] - rows[me][0]) * (b - a) for a, b in cols]
+        n_me = rows[me][1] - rows[me][0]
+        send = torch.empty(n_me * d, dtype=x_rows.dtype, device=x_rows.device)
+        off = 0
+        for a, b in cols:                                 # peer q gets its columns of my rows: strided copies into one buffer
+            send[off:off + n_me * (b - a)].view(n_me, b - a).copy_(x_rows[:, a:b])
+            off += n_me * (b - a)
+        send_splits = [n_me * (b - a) for a, b in cols]
         recv_splits = [(b - a) * (c1 - c0) for a, b in rows]
         recv = torch.empty(sum(recv_splits), dtype=x_rows.dtype, device=x_rows.device)
         _exchange(send, send_splits, recv, recv_splits, self.group).wait()
-        return recv.reshape(self.num_nodes, c1 - c0)                                       # peers' row blocks arrive in rank order
+        return recv.reshape(self.num_nodes, c1 - c0)      # peers' row blocks arrive in rank order
+
+    def cols_to_rows(self, x_cols, d):
+        """[N, d_r] (all rows, my columns) -> [n_r, d] (my rows, all columns).  Differentiable."""
+        if self.world == 1:
+            return x_cols
+        if torch.is_grad_enabled() and x_cols.requires_grad:
+            return _LayoutChange.apply(x_cols, self, True, int(d))
+        return self._cols_to_rows(x_cols, int(d))
+
+    def rows_to_cols(self, x_rows):
+        """[n_r, d] (my rows, all columns) -> [N, d_r] (all rows, my columns).  Differentiable."""
+        if self.world == 1:
+            return x_rows
+        if torch.is_grad_enabled() and x_rows.requires_grad:
+            return _LayoutChange.apply(x_rows, self, False, int(x_rows.shape[1]))
+        return self._rows_to_cols(x_rows)
 
     def stats(self):
         return {"partition": "feature columns (graph replicated)", "local_rows": int(self.num_nodes),
-                "local_edges": int(self.graph.num_edges), "halo_rows": 0}
+                "local_edges": int(self.graph.num_edges), "halo_rows": 0, "recv_rows": 0}
+
+
+class _LayoutChange(torch.autograd.Function):
+    """cols_to_rows and rows_to_cols are permutations of the same elements across ranks: each is the other's backward."""
+
+    @staticmethod
+    def forward(ctx, x, fs, to_rows, d):
+        ctx.fs, ctx.to_rows, ctx.d = fs, to_rows, d
+        return fs._cols_to_rows(x, d) if to_rows else fs._rows_to_cols(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (ctx.fs._rows_to_cols(g) if ctx.to_rows else ctx.fs._cols_to_rows(g, ctx.d)), None, None, None
+
+
+class GridShardedGraph(object):
+    """Hybrid of the two layouts (third candidate): world = Pr x Pc ranks; the graph is row-partitioned Pr ways
+    and the feature columns are split Pc ways.  Rank (i, c) owns row part i and column slice c; halo rows travel only
+    between the Pr ranks that share a column slice, and are d / Pc wide -- Pc times fewer bytes per link than the pure
+    row partition, Pr times more columns per rank than pure feature sharding (whose narrow rows are line-rate bound)."""
+
+    def __init__(self, edges, num_nodes, rank, world, grid, method="metis", device=None, seed=0, push="auto", backend=None):
+        pr, pc = int(grid[0]), int(grid[1])
+        assert pr * pc == int(world), "grid %r does not tile %d ranks" % (grid, world)
+        self.grid, self.rank, self.world = (pr, pc), int(rank), int(world)
+        self.row_rank, self.col_rank = self.rank // pc, self.rank % pc
+        group = None
+        if _group_ready():
+            for c in range(pc):                                       # every rank creates every group, in the same order
+                g = dist.new_group([i * pc + c for i in range(pr)])
+                if c == self.col_rank:
+                    group = g
+        self.row_graph = DistGraph.from_global(edges, num_nodes, self.row_rank, pr, method=method, device=device, group=group,
+                                               seed=seed, push=push, backend=backend)
+
+    def take(self, x_global):
+        """[N, d] replicated -> this rank's [n_own, d / Pc] block."""
+        lo, hi = _balanced_ranges(int(x_global.shape[1]), self.grid[1])[self.col_rank]
+        return self.row_graph.take_owned(x_global)[:, lo:hi].contiguous()
+
+    def send_recv(self, x_block, reduce_func="sum"):
+        return self.row_graph.send_recv(x_block, reduce_func)
+
+    def stats(self):
+        return dict(self.row_graph.stats(), grid="%dx%d" % self.grid)
 
 
 def init_parallel_env(backend=None):

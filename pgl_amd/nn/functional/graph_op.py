@@ -34,6 +34,10 @@ def edge_softmax(graph, logits, norm_by="dst"):
     the scatter back to ORIGINAL edge order are fused (the reference makes ~12 passes)."""
     if norm_by not in ("src", "dst"):
         raise ValueError("norm_by should be in 'src' or 'dst'.")
+    if hasattr(graph, "local_graph"):      # DistGraph: a destination's in-edges are all local, a source's out-edges are not
+        if norm_by != "dst":
+            raise ValueError("edge_softmax on a DistGraph supports norm_by='dst' only")
+        graph = graph.local_graph
     ix = graph.adj_dst_index if norm_by == "dst" else graph.adj_src_index
     csr = ix.csr
     src32, dst32 = graph._edge_cols32()

@@ -605,3 +605,23 @@ def host_partition_kway(num_nodes, indptr, adjncy, nparts, node_weights=None, ed
                                                 _np_ptr(ew), int(nparts), int(seed), _np_ptr(part),
                                                 ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)), "partition_kway")
     return part, int(cut.value)
+
+
+def metis_available():
+    """True when the METIS helper library (pgl_amd/_build_metis.py) can be opened."""
+    return bool(_ffi.lib().pglamd_metis_available())
+
+
+def host_partition_metis(num_nodes, indptr, adjncy, nparts, node_weights=None, edge_weights=None):
+    """graph_kernel.metis_partition(..., recursive=False) (pgl/graph_kernel.pyx:434-472): the reference's vendored METIS,
+    called as the reference calls it -> part ids bit-identical to the reference's.  Raises RuntimeError when the helper
+    library is absent (callers fall back to host_partition_kway)."""
+    indptr = _np_i64(indptr); adjncy = _np_i64(adjncy)
+    vw = None if node_weights is None else _np_i64(node_weights)
+    ew = None if edge_weights is None else _np_i64(edge_weights)
+    part = np.empty(int(num_nodes), np.int64)
+    cut = ctypes.c_int64(0)
+    _ffi.check(_ffi.lib().pglamd_partition_metis(int(num_nodes), _np_ptr(indptr), _np_ptr(adjncy), _np_ptr(vw), _np_ptr(ew),
+                                                 int(nparts), _np_ptr(part), ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)),
+               "partition_metis")
+    return part, int(cut.value)

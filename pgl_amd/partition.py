@@ -1,10 +1,13 @@
 """pgl_amd.partition -- metis_partition / random_partition.  Mirrors pgl/partition.py:25-123.
 
-`metis_partition` keeps the reference's signature and pre-processing (dst-CSR input, min-max weight
-scaling to positive ints, K-way only) but calls the engine's own multilevel k-way partitioner
-(pglamd_partition_kway) -- METIS itself is third-party code of the reference and is not vendored
-here.  Results are valid, balanced k-way partitions; ids are not bit-identical to METIS.
+`metis_partition` keeps the reference's signature and pre-processing (dst-CSR input, min-max weight scaling to positive
+ints, K-way only) and calls the reference's vendored METIS through the C ABI (pglamd_partition_metis ->
+libpglamd_metis.so, built from the reference checkout by pgl_amd/_build_metis.py): part ids are bit-identical to
+pgl.partition.metis_partition's.  When that helper library is absent (or PGLAMD_PARTITIONER=kway) the engine's own
+multilevel k-way partitioner (pglamd_partition_kway) is the documented fallback: valid, balanced partitions, not METIS's
+ids.
 """
+import os
 import math
 import warnings
 
@@ -41,8 +44,26 @@ def metis_partition(graph, npart, node_weights=None, edge_weights=None, seed=0):
         if check_is_tensor(node_weights):
             node_weights = node_weights.detach().cpu().numpy()
         node_weights = _metis_weight_scale(node_weights)
-    part, _ = ops.host_partition_kway(graph.num_nodes, indptr, v, npart, node_weights, edge_weights, seed)
+    part = metis_kway_csr(graph.num_nodes, indptr, v, npart, node_weights, edge_weights)
+    if part is None:
+        part, _ = ops.host_partition_kway(graph.num_nodes, indptr, v, npart, node_weights, edge_weights, seed)
     return part
+
+
+def metis_kway_csr(num_nodes, indptr, adjncy, npart, node_weights=None, edge_weights=None):
+    """METIS_PartGraphKway on a CSR as graph_kernel.metis_partition calls it, or None (with a warning, once) when the METIS
+    helper library is not available and the caller should use the engine's own partitioner."""
+    global _warned
+    if os.environ.get("PGLAMD_PARTITIONER", "metis") != "kway" and ops.metis_available():
+        return ops.host_partition_metis(num_nodes, indptr, adjncy, npart, node_weights, edge_weights)[0]
+    if not _warned:
+        warnings.warn("pgl_amd.partition: METIS helper library not available (python -m pgl_amd._build_metis needs the "
+                      "reference checkout); using the engine's own k-way partitioner -- part ids will differ from METIS's")
+        _warned = True
+    return None
+
+
+_warned = False
 
 
 def random_partition(graph, npart):

@@ -1,8 +1,9 @@
-"""Multi-rank path on CPU: world_size-2 gloo processes + in-process plan consistency for 4 ranks.
+"""Multi-rank path on CPU: world_size-2 gloo processes + in-process plan consistency for 1 / 3 / 4 ranks.
 
-The HIP kernels cannot run here, so the aggregation callable is the ORACLE (test seam
-DistGraph(aggregate_fn=...)): what is under test is the partition -> relabel -> halo plan ->
-exchange -> un-permute data flow, which must reproduce the single-graph result exactly."""
+The HIP kernels cannot run here, so DistGraph's compute backend is the torch-CPU TEST SEAM of tests/dist_backend.py
+(DistGraph(backend=...)); the reference values come from the ORACLE (oracle/ref_ops).  What is under test is the
+partition -> relabel -> pull/push plan -> pack -> exchange -> accumulate data flow, its transposed (backward) form, the
+halo extension and the reference's DistGPUGraph method set -- all of which must reproduce the single-graph result."""
 import os
 import socket
 
@@ -13,18 +14,17 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import ref_ops as R
+from dist_backend import TorchBackend
 
 
-def _oracle_agg(x, rows, cols, n_rows, reduce):
-    out = R.c_send_u_recv(x.numpy(), cols.numpy(), rows.numpy(), reduce, out_size=n_rows)
-    return torch.from_numpy(out)
-
-
-def _graph(n=400, e=6000, seed=3):
+def _graph(n=400, e=6000, seed=3, d=12):
     rng = np.random.default_rng(seed)
     edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
-    edges[rng.choice(e, 500, replace=False), 1] = 11      # hub
-    x = rng.standard_normal((n, 12)).astype(np.float32)
+    edges[rng.choice(e, 500, replace=False), 1] = 11      # hub destination
+    edges[rng.choice(e, 300, replace=False), 0] = 7       # hub source
+    edges[: e // 2, 1] = rng.integers(0, 16, e // 2)       # half of the edges end in 16 nodes: pushing 16 partial rows beats
+    #                                                        pulling hundreds of source rows for the pairs that own them
+    x = rng.standard_normal((n, d)).astype(np.float32)
     return edges, x
 
 
@@ -33,95 +33,306 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, method, q):
+def _spawn(fn, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for g in got:
+        if isinstance(g, tuple) and len(g) == 2 and isinstance(g[1], str) and g[1].startswith("ERROR"):
+            raise AssertionError(g[1])
+    return sorted(got, key=lambda g: g[0])
+
+
+def _entry(fn, rank, world, port, q, *args):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from pgl_amd.distributed import DistGraph
-        edges, x = _graph()
-        n = x.shape[0]
-        dg = DistGraph.from_global(torch.from_numpy(edges), n, rank, world, method=method, aggregate_fn=_oracle_agg)
-        x_own = dg.take_owned(torch.from_numpy(x))
-        res = {}
-        for op in ("sum", "mean", "max"):
-            res[op] = dg.send_recv(x_own, op).numpy()
-        q.put((rank, dg.plan.own_global.numpy(), res, dg.stats()))
+        q.put(fn(rank, world, *args))
         dist.barrier()
+    except Exception:                                            # noqa: BLE001 -- report through the queue, then fail
+        import traceback
+        q.put((rank, "ERROR on rank %d:\n%s" % (rank, traceback.format_exc())))
+        raise
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("method", ["kway", "random", "auto"])
-def test_two_rank_gloo_matches_single_graph(method):
+# ------------------------------------------------------------------------------------------------
+# forward: every reduce op, every partitioner, pull-only and pull/push plans
+# ------------------------------------------------------------------------------------------------
+def _fwd_worker(rank, world, method, push):
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph()
+    n = x.shape[0]
+    dg = DistGraph.from_global(torch.from_numpy(edges), n, rank, world, method=method, backend=TorchBackend(), push=push)
+    x_own = dg.take_owned(torch.from_numpy(x))
+    res = {op: dg.send_recv(x_own, op).numpy() for op in ("sum", "mean", "max", "min")}
+    res["u_recv"] = dg.send_u_recv(x_own, "sum").numpy()
+    rng = np.random.default_rng(1)
+    y = rng.standard_normal((len(edges), 1)).astype(np.float32) + 3.0
+    for mop in ("mul", "add", "div"):
+        res["ue_" + mop] = dg.send_ue_recv(x_own, dg.take_edges(torch.from_numpy(y)), mop, "sum").numpy()
+    res["ue_mean"] = dg.send_ue_recv(x_own, dg.take_edges(torch.from_numpy(y)), "mul", "mean").numpy()
+    res["ext"] = dg.halo_extend(x_own).numpy()
+    res["halo_ids"] = dg.plan.halo_global.numpy()
+    res["global"] = dg.gather_global(torch.from_numpy(res["sum"])).numpy()
+    res["indeg"], res["outdeg"] = dg.indegree().numpy(), dg.outdegree().numpy()
+    res["indeg_sel"] = dg.indegree(nodes=[0, 1]).numpy()
+    return (rank, dg.plan.own_global.numpy(), res, dg.stats(), dg.plan.offsets)
+
+
+@pytest.mark.parametrize("method,push", [("metis", "auto"), ("kway", "never"), ("random", "auto"), ("auto", "auto")])
+def test_two_rank_gloo_matches_single_graph(method, push):
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, method, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    got = _spawn(_fwd_worker, world, method, push)
     edges, x = _graph()
     n = x.shape[0]
     owned = np.concatenate([g[1] for g in got])
     assert sorted(owned.tolist()) == list(range(n))                  # every node owned exactly once
-    for op in ("sum", "mean", "max"):
-        want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
-        full = np.zeros_like(want)
-        for _, own, res, _ in got:
-            full[own] = res[op]
-        np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())   # order of summation differs
+    y = np.random.default_rng(1).standard_normal((len(edges), 1)).astype(np.float32) + 3.0
+    want = {op: R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op) for op in ("sum", "mean", "max", "min")}
+    want["u_recv"] = want["sum"]
+    for mop in ("mul", "add", "div"):
+        want["ue_" + mop] = R.c_send_ue_recv(x, y, edges[:, 0], edges[:, 1], mop, "sum")
+    want["ue_mean"] = R.c_send_ue_recv(x, y, edges[:, 0], edges[:, 1], "mul", "mean")
+    for key, w in want.items():
+        full = np.zeros_like(w)
+        for _, own, res, _, _ in got:
+            full[own] = res[key]
+        if key in ("max", "min"):
+            assert np.array_equal(full, w), key                      # no arithmetic: exact
+        else:
+            np.testing.assert_allclose(full, w, rtol=1e-5, atol=1e-5 * np.abs(w).max(), err_msg=key)   # summation order differs
+    indeg, outdeg = np.bincount(edges[:, 1], minlength=n), np.bincount(edges[:, 0], minlength=n)
+    new_of_old = np.empty(n, np.int64); new_of_old[owned] = np.arange(n)
+    for _, own, res, st, offsets in got:
+        assert np.array_equal(res["global"], want["sum"].astype(np.float32)) or np.allclose(res["global"], want["sum"], rtol=1e-5, atol=1e-4)
+        assert np.array_equal(res["indeg"], indeg[own]) and np.array_equal(res["outdeg"], outdeg[own])
+        assert np.array_equal(res["indeg_sel"], indeg[own[:2]])
+        # halo extension = [owned rows | the halo rows in ascending relabelled id]
+        assert np.array_equal(res["ext"][:len(own)], x[own])
+        assert np.array_equal(res["ext"][len(own):], x[owned[res["halo_ids"]]])
+        assert st["recv_rows"] <= st["pull_only_recv_rows"]          # push only ever shrinks the exchange
+        if push == "never":
+            assert st["pushed_pairs"] == 0 and st["recv_rows"] == st["halo_rows"]
     assert sum(g[3]["local_edges"] for g in got) == len(edges)
+    if push == "auto" and method != "auto":
+        assert sum(g[3]["pushed_pairs"] for g in got) > 0              # the hub destination makes its pair push
 
 
+# ------------------------------------------------------------------------------------------------
+# backward: gradients through the exchange == gradients of the single-graph formulation
+# ------------------------------------------------------------------------------------------------
+def _dense(edges, n):
+    A = torch.zeros(n, n, dtype=torch.float64)
+    A.index_put_((torch.from_numpy(edges[:, 1]), torch.from_numpy(edges[:, 0])), torch.ones(len(edges), dtype=torch.float64), accumulate=True)
+    return A
+
+
+def _bwd_worker(rank, world, push):
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph(n=300, e=4000, seed=9, d=6)
+    n = x.shape[0]
+    dg = DistGraph.from_global(torch.from_numpy(edges), n, rank, world, method="random", backend=TorchBackend(), push=push)
+    w = torch.from_numpy(np.random.default_rng(2).standard_normal(x.shape).astype(np.float32))
+    out = {}
+    for op in ("sum", "mean"):
+        x_own = dg.take_owned(torch.from_numpy(x)).requires_grad_(True)
+        y = dg.send_recv(x_own, op)
+        assert y.grad_fn is not None
+        (y * dg.take_owned(w)).sum().backward()
+        out[op] = x_own.grad.numpy()
+    x_own = dg.take_owned(torch.from_numpy(x)).requires_grad_(True)
+    ext = dg.halo_extend(x_own)
+    c = torch.arange(ext.shape[0], dtype=torch.float32).reshape(-1, 1) + 1.0
+    (ext * c).sum().backward()
+    out["ext"] = x_own.grad.numpy()
+    out["ext_coeff_halo"] = (dg.plan.halo_global.numpy(), c[dg.plan.n_own:, 0].numpy())
+    # fused scales of GCN: out = ds * A (ss * x)
+    x_own = dg.take_owned(torch.from_numpy(x)).requires_grad_(True)
+    nrm = dg.indegree().clamp(min=1).float().pow(-0.5)
+    y = dg.send_recv_scaled(x_own, nrm, nrm)
+    (y * dg.take_owned(w)).sum().backward()
+    out["scaled"], out["scaled_fwd"] = x_own.grad.numpy(), y.detach().numpy()
+    return (rank, dg.plan.own_global.numpy(), out, dg.plan.offsets)
+
+
+@pytest.mark.parametrize("push", ["never", "auto"])
+def test_two_rank_gloo_gradients_match_single_graph(push):
+    world = 2
+    got = _spawn(_bwd_worker, world, push)
+    edges, x = _graph(n=300, e=4000, seed=9, d=6)
+    n = x.shape[0]
+    A = _dense(edges, n)
+    w = torch.from_numpy(np.random.default_rng(2).standard_normal(x.shape).astype(np.float32)).double()
+    deg = A.sum(1).clamp(min=1)
+    want = {"sum": (A.T @ w).numpy(), "mean": (A.T @ (w / deg[:, None])).numpy()}
+    nrm = deg.pow(-0.5)
+    want["scaled"] = (nrm[:, None] * (A.T @ (nrm[:, None] * w))).numpy()
+    want_fwd = (nrm[:, None] * (A @ (nrm[:, None] * torch.from_numpy(x).double()))).numpy()
+    owned = np.concatenate([g[1] for g in got])
+    for key in ("sum", "mean", "scaled"):
+        full = np.zeros((n, x.shape[1]))
+        for _, own, out, _ in got:
+            full[own] = out[key]
+        np.testing.assert_allclose(full, want[key], rtol=1e-5, atol=1e-5 * np.abs(want[key]).max(), err_msg=key)
+    full = np.zeros((n, x.shape[1]))
+    for _, own, out, _ in got:
+        full[own] = out["scaled_fwd"]
+    np.testing.assert_allclose(full, want_fwd, rtol=1e-5, atol=1e-5 * np.abs(want_fwd).max())
+    # halo_extend backward: d/dx_own[i] = own coefficient + the coefficients every peer put on its copy of row i
+    coeff = np.zeros(n)
+    for _, own, out, _ in got:
+        coeff[own] += np.arange(len(own)) + 1.0
+        ids, c = out["ext_coeff_halo"]
+        coeff[owned[ids]] += c
+    for _, own, out, _ in got:
+        np.testing.assert_allclose(out["ext"], np.repeat(coeff[own][:, None], x.shape[1], 1))
+
+
+# ------------------------------------------------------------------------------------------------
+# a two-rank TRAINING STEP: layers on owned rows, parameters replicated, gradients all-reduced
+# ------------------------------------------------------------------------------------------------
+def _model(seed=0, din=6, dh=8, dout=3):
+    torch.manual_seed(seed)
+    return torch.nn.ModuleList([torch.nn.Linear(din, dh), torch.nn.Linear(dh, dout)])
+
+
+def _train_worker(rank, world):
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph(n=300, e=4000, seed=9, d=6)
+    n = x.shape[0]
+    dg = DistGraph.from_global(torch.from_numpy(edges), n, rank, world, method="kway", backend=TorchBackend())
+    lins = _model()
+    opt = torch.optim.SGD(lins.parameters(), lr=0.05)
+    labels = dg.take_owned(torch.from_numpy(np.random.default_rng(4).integers(0, 3, n)))
+    x_own = dg.take_owned(torch.from_numpy(x))
+    nrm = dg.indegree().clamp(min=1).float().pow(-0.5)
+    losses = []
+    for _ in range(3):
+        h = torch.relu(dg.send_recv_scaled(lins[0](x_own), nrm, nrm))
+        logits = dg.send_recv(lins[1](h), "mean")
+        loss = torch.nn.functional.cross_entropy(logits, labels, reduction="sum") / n
+        opt.zero_grad()
+        loss.backward()
+        for p in lins.parameters():                                   # data-parallel: parameters replicated, grads summed
+            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM)
+        opt.step()
+        t = loss.detach().clone(); dist.all_reduce(t); losses.append(float(t))
+    return (rank, losses, [p.detach().numpy() for p in lins.parameters()])
+
+
+def test_two_rank_training_step_matches_single_process():
+    got = _spawn(_train_worker, 2)
+    edges, x = _graph(n=300, e=4000, seed=9, d=6)
+    n = x.shape[0]
+    A = _dense(edges, n).float()
+    deg = A.sum(1).clamp(min=1)
+    An = deg.pow(-0.5)[:, None] * A * deg.pow(-0.5)[None, :]
+    Am = A / deg[:, None]
+    lins = _model()
+    opt = torch.optim.SGD(lins.parameters(), lr=0.05)
+    labels = torch.from_numpy(np.random.default_rng(4).integers(0, 3, n))
+    xt = torch.from_numpy(x)
+    want = []
+    for _ in range(3):
+        logits = Am @ lins[1](torch.relu(An @ lins[0](xt)))
+        loss = torch.nn.functional.cross_entropy(logits, labels, reduction="sum") / n
+        opt.zero_grad(); loss.backward(); opt.step()
+        want.append(float(loss))
+    for _, losses, params in got:
+        np.testing.assert_allclose(losses, want, rtol=2e-5)
+        for p, q in zip(params, lins.parameters()):
+            np.testing.assert_allclose(p, q.detach().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# plans, all ranks in one process
+# ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("world", [1, 3, 4])
-def test_plan_consistency_in_process(world):
-    """All ranks' plans built in one process: peer send lists line up with halo lists, and a
-    simulated exchange reproduces the global aggregation."""
+@pytest.mark.parametrize("push", [False, True])
+def test_plan_consistency_in_process(world, push):
+    """All ranks' plans built in one process: send blocks line up with receive blocks pair by pair, and a simulated
+    exchange through the send / recv indices reproduces the global aggregation (pull-only and pull/push plans)."""
     from pgl_amd.distributed import HaloPlan
     edges, x = _graph(n=300, e=4000, seed=5)
     n = x.shape[0]
     part = np.random.default_rng(0).integers(0, world, n)
-    plans = [HaloPlan(torch.from_numpy(edges), n, part, r, world) for r in range(world)]
+    et = torch.from_numpy(edges)
+    choice = None
+    if push:
+        pull_c, push_c = HaloPlan.pair_counts(et, n, part, world)
+        choice = HaloPlan.choose_push(pull_c, push_c)
+        assert pull_c.diagonal().sum() == 0 and (world == 1 or bool(choice.any()))
+    plans = [HaloPlan(et, n, part, r, world, push=choice) for r in range(world)]
+    B = TorchBackend()
     xt = torch.from_numpy(x)
     want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "sum")
+    send_bufs = [B.aggregate(xt[p.own_global], B.index(p.send_rows, p.send_cols, p.n_send), "sum", p.n_send) for p in plans]
     full = np.zeros_like(want)
     for p in plans:
         assert p.send_splits[p.rank] == 0 and p.recv_splits[p.rank] == 0
-        x_own = xt[p.own_global]
-        # what peer q sends me, in q's send order, must be exactly my halo rows in my halo order
         recv = []
         for qr, pq in enumerate(plans):
             so = np.concatenate([[0], np.cumsum(pq.send_splits)])
-            idx = pq.send_idx[so[p.rank]:so[p.rank + 1]]
-            assert len(idx) == p.recv_splits[qr]
-            recv.append(xt[pq.own_global][idx])
+            blk = send_bufs[qr][so[p.rank]:so[p.rank + 1]]
+            assert len(blk) == p.recv_splits[qr]                      # what q sends me == what I expect from q
+            recv.append(blk)
         recv = torch.cat(recv, 0) if recv else xt[:0]
-        assert recv.shape[0] == p.n_halo
-        x_cat = torch.cat([x_own, recv], 0)
-        rows = torch.cat([p.loc_rows, p.hal_rows]); cols = torch.cat([p.loc_cols, p.hal_cols + p.n_own])
-        full[p.own_global.numpy()] = _oracle_agg(x_cat, rows, cols, p.n_own, "sum").numpy()
+        assert recv.shape[0] == p.n_recv
+        out = B.aggregate(xt[p.own_global], B.index(p.loc_rows, p.loc_cols, p.n_own), "sum", p.n_own)
+        if p.n_recv:
+            B.aggregate(recv, B.index(p.recv_rows, p.recv_cols, p.n_own), "sum", p.n_own, out=out, accumulate=1)
+        full[p.own_global.numpy()] = out.numpy()
         assert np.array_equal(p.in_degree.numpy(), np.bincount(edges[:, 1], minlength=n)[p.own_global.numpy()])
+        assert np.array_equal(p.out_degree.numpy(), np.bincount(edges[:, 0], minlength=n)[p.own_global.numpy()])
+        # local edge order: [local-source edges | halo-source edges], original edge ids kept
+        eg = p.edge_global.numpy()
+        assert len(eg) == p.local_edges and np.array_equal(np.sort(eg), np.nonzero(part[edges[:, 1]] == p.rank)[0])
+        if push:
+            assert p.n_recv <= p.n_halo
     np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())   # order of summation differs
 
 
+def test_partition_without_process_group_is_computed_on_every_rank():
+    """with world > 1 but no process group (in-process / dry-run use) every caller must get the real partition,
+    not an uninitialised buffer."""
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph(n=200, e=2000, seed=2)
+    et = torch.from_numpy(edges)
+    for method in ("random", "kway", "metis"):
+        parts = [DistGraph.partition(et, 200, 4, method, rank=r) for r in range(4)]
+        for p in parts:
+            assert torch.equal(p, parts[0]) and int(p.min()) == 0 and int(p.max()) == 3
+            assert int(torch.bincount(p, minlength=4).min()) > 0
+
+
 def test_plan_cache_roundtrip(tmp_path):
-    """f2: DistGraph.dump / load reproduce the plan (and therefore the aggregation) exactly."""
-    from pgl_amd.distributed import DistGraph, HaloPlan
+    """f2: DistGraph.dump / load reproduce both plans (and therefore the aggregation) exactly."""
+    from pgl_amd.distributed import DistGraph, HaloPlan, _PLAN_ARRAYS, _PLAN_META
     edges, x = _graph(n=250, e=3000, seed=8)
     n, world = x.shape[0], 3
     part = np.random.default_rng(1).integers(0, world, n)
+    et = torch.from_numpy(edges)
+    pull_c, push_c = HaloPlan.pair_counts(et, n, part, world)
+    choice = HaloPlan.choose_push(pull_c, push_c)
     for r in range(world):
-        dg = DistGraph(HaloPlan(torch.from_numpy(edges), n, part, r, world), aggregate_fn=_oracle_agg)
+        dg = DistGraph(HaloPlan(et, n, part, r, world), backend=TorchBackend(), exchange_plan=HaloPlan(et, n, part, r, world, push=choice))
         dg.dump(str(tmp_path))
-        back = DistGraph.load(str(tmp_path), r, aggregate_fn=_oracle_agg)
-        for k in ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "send_idx", "in_degree"):
-            assert torch.equal(getattr(dg.plan, k), getattr(back.plan, k)), k
-        assert back.plan.send_splits == dg.plan.send_splits and back.plan.recv_splits == dg.plan.recv_splits
-        assert back.stats()["partition"] == "cached" and back.plan.n_halo == dg.plan.n_halo
+        back = DistGraph.load(str(tmp_path), r, backend=TorchBackend())
+        for a, b in ((dg.plan, back.plan), (dg.xplan, back.xplan)):
+            for k in _PLAN_ARRAYS:
+                assert torch.equal(getattr(a, k), getattr(b, k)), k
+            for k in _PLAN_META:
+                assert getattr(a, k) == getattr(b, k), k
+        assert back.stats()["partition"] == "cached" and back.xplan is not back.plan
 
 
 # ------------------------------------------------------------------------------------------------
@@ -221,3 +432,28 @@ def test_helper_scatter_follows_the_reference_docstring():
     assert scatter(x, index, updates, overwrite=False).tolist() == [[3, 3], [6, 6], [1, 1]]
     assert scatter(x, index, updates, overwrite=True).tolist() == [[3, 3], [4, 4], [1, 1]]       # last duplicate wins
     assert x.tolist() == [[1, 1], [2, 2], [3, 3]]                                                 # out of place
+
+
+# ------------------------------------------------------------------------------------------------
+# rows x columns grid (hybrid layout): 4 ranks = 2 row parts x 2 column slices
+# ------------------------------------------------------------------------------------------------
+def _grid_worker(rank, world):
+    from pgl_amd.distributed import GridShardedGraph
+    edges, x = _graph(n=300, e=4000, seed=6, d=10)
+    gg = GridShardedGraph(torch.from_numpy(edges), x.shape[0], rank, world, grid=(2, 2), method="kway", backend=TorchBackend())
+    blk = gg.take(torch.from_numpy(x))
+    out = {op: gg.send_recv(blk, op).numpy() for op in ("sum", "max")}
+    return (rank, gg.row_graph.plan.own_global.numpy(), gg.col_rank, out, gg.stats())
+
+
+def test_grid_sharded_four_ranks_gloo():
+    got = _spawn(_grid_worker, 4)
+    edges, x = _graph(n=300, e=4000, seed=6, d=10)
+    for op in ("sum", "max"):
+        want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
+        full = np.full_like(want, np.nan)
+        for _, own, c, out, st in got:
+            lo, hi = (0, 5) if c == 0 else (5, 10)
+            full[np.ix_(own, np.arange(lo, hi))] = out[op]
+            assert st["grid"] == "2x2"
+        np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())

@@ -40,8 +40,28 @@ def test_map_ids_fixture():
 
 
 @pytest.mark.parametrize("k", [2, 4, 8])
-def test_partitioner_vs_metis_fixture(k):
+def test_metis_partition_bit_identical_to_reference_fixture(k):
+    """a14: pgl_amd.partition.metis_partition == the reference's pgl.partition.metis_partition (fixture produced by the
+    reference's compiled graph_kernel.metis_partition, tests/golden/make_*), id for id -- the same METIS, called the same
+    way, through the C ABI (pglamd_partition_metis -> libpglamd_metis.so)."""
     import pgl_amd
+    if not pgl_amd.ops.metis_available():
+        pytest.skip("libpglamd_metis.so not built (needs the reference checkout: python -m pgl_amd._build_metis)")
+    z = np.load(os.path.join(GOLD, "metis_k%d.npz" % k))
+    e, n = z["edges"], int(z["num_nodes"])
+    g = pgl_amd.Graph(edges=e, num_nodes=n)
+    with pytest.warns(UserWarning):
+        part = pgl_amd.partition.metis_partition(g, k)
+    assert part.dtype == np.int64 and np.array_equal(part, z["part"])
+    assert int((part[e[:, 0]] != part[e[:, 1]]).sum()) == int(z["cut"])
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_fallback_partitioner_vs_metis_fixture(k, monkeypatch):
+    """The documented fallback (engine's own k-way partitioner, PGLAMD_PARTITIONER=kway or helper absent): balanced, and
+    its cut within 1.5x of METIS's."""
+    import pgl_amd
+    monkeypatch.setenv("PGLAMD_PARTITIONER", "kway")
     z = np.load(os.path.join(GOLD, "metis_k%d.npz" % k))
     e, n = z["edges"], int(z["num_nodes"])
     g = pgl_amd.Graph(edges=e, num_nodes=n)

@@ -1360,6 +1360,10 @@ def test_bench_multi_rank_code_path_dry_run():
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["scaling"] == "strong"
     assert rec["halo"]["local_edges"] > 0 and "roofline" in rec
+    # the headline layout is north_star's: METIS row partition + halo exchange; the other layouts are secondary fields
+    assert rec["config"]["parallelism"].startswith("row partition (metis)") and rec["halo"]["mode"] == "rows"
+    assert set(rec["halo"]["alternatives_ms_per_step"]) >= {"rows", "cols"}
+    assert rec["halo"]["exchange_only_ms"] > 0 and len(rec["halo"]["recv_bytes_per_rank"]) == 2
 
 
 @pytest.mark.parametrize("H,D", [(4, 8), (8, 16), (1, 64), (3, 4)])

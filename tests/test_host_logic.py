@@ -150,10 +150,11 @@ def _sym_simple(n, e, seed, communities=0):
 
 
 @pytest.mark.parametrize("nparts", [2, 8])
-def test_partitioner_balance_and_cut_vs_metis(ref_native, nparts):
-    """Engine partitioner vs the reference's METIS (oracle/_ref) on a graph with planted communities:
-    valid ids, balanced within 10 %, edge cut within 1.5x of METIS and far below random."""
+def test_partitioner_balance_and_cut_vs_metis(ref_native, nparts, monkeypatch):
+    """Engine's own partitioner (the fallback) vs the reference's METIS (oracle/_ref) on a graph with planted
+    communities: valid ids, balanced within 10 %, edge cut within 1.5x of METIS and far below random."""
     import pgl_amd
+    monkeypatch.setenv("PGLAMD_PARTITIONER", "kway")
     n = 4000
     edges = _sym_simple(n, 40000, 4, communities=16)
     g = pgl_amd.Graph(edges=edges, num_nodes=n)
@@ -173,6 +174,30 @@ def test_partitioner_balance_and_cut_vs_metis(ref_native, nparts):
     # deterministic for a fixed seed
     with pytest.warns(UserWarning):
         assert np.array_equal(part, pgl_amd.partition.metis_partition(g, nparts))
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 8])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_metis_partition_equals_the_reference_module(ref_native, nparts, weighted):
+    """a14: the product's metis_partition against the reference's own compiled graph_kernel.metis_partition on the same
+    CSR (and the same min-max scaled weights): identical part ids."""
+    import pgl_amd
+    if not pgl_amd.ops.metis_available():
+        pytest.skip("libpglamd_metis.so not built")
+    n = 3000
+    edges = _sym_simple(n, 30000, 21 + nparts, communities=12)
+    g = pgl_amd.Graph(edges=edges, num_nodes=n)
+    ix = g.adj_dst_index
+    rng = np.random.default_rng(nparts)
+    nw = rng.random(n) if weighted else None
+    lo_, hi_ = np.minimum(edges[:, 0], edges[:, 1]), np.maximum(edges[:, 0], edges[:, 1])
+    ew = ((lo_ * 7919 + hi_ * 104729) % 1000 / 1000.0) if weighted else None      # symmetric: METIS checks w(u,v) == w(v,u)
+    with pytest.warns(UserWarning):
+        part = pgl_amd.partition.metis_partition(g, nparts, node_weights=nw, edge_weights=ew)
+    scale = pgl_amd.partition._metis_weight_scale
+    want = ref_native.metis_partition(n, ix._indptr, ix._sorted_v, nparts, None if nw is None else scale(nw),
+                                      None if ew is None else scale(ew[ix._sorted_eid]), False)
+    assert np.array_equal(part, want)
 
 
 def test_partition_weights_and_trivial_cases():
