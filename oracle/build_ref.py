@@ -95,6 +95,34 @@ def build(force=False, jobs=None):
     return target
 
 
+EXAMPLES = ("gcn/train.py", "gat/train.py", "graphsage/cpu_sample_version/train.py", "graphsage/cpu_sample_version/model.py",
+            "graphsage/cpu_sample_version/dataset.py")
+
+
+def examples_dir():
+    return os.path.join(OUT, "examples")
+
+
+def compile_examples(force=False):
+    """Byte-compiles the reference's three example programs (north_star: "drops into examples/gcn, gat and graphsage
+    unchanged") from the sources where they lie into oracle/_ref/examples/<same relative path>.pyc -- build outputs like
+    the .so above: git-ignored, never source, and they travel to the GPU box, where /root/reference does not exist.  The
+    GPU tests run these programs UNMODIFIED (python <...>/train.pyc; model.pyc / dataset.pyc are sourceless imports)
+    with `pgl` and `paddle` resolved to pgl_amd/compat, i.e. on the engine.  Returns the directory or None."""
+    import py_compile
+    root = os.path.join(REF, "examples")
+    out = examples_dir()
+    if not os.path.isdir(root):
+        return out if os.path.isdir(out) else None
+    for rel in EXAMPLES:
+        src, dst = os.path.join(root, rel), os.path.join(out, rel[:-3] + ".pyc")
+        if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            py_compile.compile(src, cfile=dst, dfile="<reference>/examples/" + rel, doraise=True)
+    return out
+
+
 if __name__ == "__main__":
+    compile_examples(force="--force" in sys.argv)
     p = build(force="--force" in sys.argv)
     print(p if p else "reference not present and no prebuilt module")
