@@ -38,6 +38,12 @@ def _device():
     return _t.device("cuda", _t.cuda.current_device()) if _t.cuda.is_available() else _t.device("cpu")
 
 
+# Paddle creates parameters and factory tensors on the current accelerator ("place") by default, and the reference's scripts
+# never move a model: make torch's factory functions do the same while this name layer is in use.
+if _t.cuda.is_available():
+    _t.set_default_device(_device())
+
+
 def get_default_dtype():
     return _default_dtype[0]
 
