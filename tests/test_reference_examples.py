@@ -154,16 +154,26 @@ def _example_module(rel):
     return mod
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["gcn", "gat", "sage"])
-def test_example_models_and_train_step_reproduce_the_reference_trajectory(tag):
-    """examples/gcn/train.py's GCN + train(), examples/gat/train.py's GAT + train(), examples/graphsage/.../model.py's
-    GraphSage: the reference's own classes and training step, executed on the engine through the compat names, against
-    the trajectory the same code produced in the reference environment (fixture)."""
+@pytest.fixture
+def paddle_names():
+    """install the compat names in THIS process and undo their one global side effect (torch's default device) afterwards."""
     import torch
     import pgl_amd.compat
     pgl_amd.compat.install()
     import paddle
+    torch.set_default_device(paddle._device())
+    yield paddle
+    torch.set_default_device("cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["gcn", "gat", "sage"])
+def test_example_models_and_train_step_reproduce_the_reference_trajectory(tag, paddle_names):
+    """examples/gcn/train.py's GCN + train(), examples/gat/train.py's GAT + train(), examples/graphsage/.../model.py's
+    GraphSage: the reference's own classes and training step, executed on the engine through the compat names, against
+    the trajectory the same code produced in the reference environment (fixture)."""
+    import torch
+    paddle = paddle_names
     import pgl
     z = np.load(os.path.join(HERE, "golden", "layers", "train_%s.npz" % tag))
     n, din, ncls = int(z["num_nodes"]), z["x"].shape[1], 5
