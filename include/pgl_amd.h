@@ -45,6 +45,7 @@ extern "C" {
 #define PGLAMD_E_HIP (-5)       /* HIP runtime error (message has hipGetErrorString) */
 #define PGLAMD_E_ARG (-6)       /* NULL pointer / bad enum */
 #define PGLAMD_E_UNAVAILABLE (-7) /* optional helper library (METIS, RCCL) not present */
+#define PGLAMD_E_RCCL (-8)      /* RCCL error (message has ncclGetErrorString) */
 
 /* element types */
 #define PGLAMD_F16 0
@@ -328,6 +329,56 @@ size_t pglamd_reindex_workspace_bytes(int64_t num_nodes, int64_t num_neighbors);
 int32_t pglamd_reindex(const int64_t* nodes, int64_t num_nodes, const int64_t* neighbors,
                        int64_t num_neighbors, int64_t* reindex_src, int64_t* out_nodes,
                        int64_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU exchange step of the row-partitioned path.  Replaces the collective of the reference's
+ * DistGPUGraph -- all_reduce_sum_with_grad of the whole [N, d] output after every aggregation
+ * (pgl/graph.py:1517-1553 -> pgl/utils/op.py:90-122, c_allreduce_sum) -- with one all-to-all-v of halo rows:
+ *   pglamd_comm_unique_id   rank 0 fills id_out[PGLAMD_COMM_ID_BYTES]; the caller hands it to every rank by any means
+ *                           (the reference's launcher broadcasts endpoints the same way: paddle.distributed.init_parallel_env)
+ *   pglamd_comm_init        one RCCL communicator per process + a library-owned side stream + two events
+ *   pglamd_halo_exchange_start   send_buf = rows for peer 0, 1, ... (send_rows[q] rows of row_bytes each), recv_buf
+ *                           likewise.  Everything already queued on compute_stream (the pack kernel) is ordered before
+ *                           the transfers by an event; the call returns at once, the caller keeps launching the
+ *                           local-source aggregation on compute_stream -- the overlap.
+ *   pglamd_halo_exchange_wait    makes compute_stream wait (on the GPU, no host sync) until recv_buf is complete.
+ * RCCL is opened with dlopen at the first call: PGLAMD_E_UNAVAILABLE without librccl.so, PGLAMD_E_RCCL on RCCL errors.
+ * The plan (which rows go where) is pglamd_halo_plan_* below.  pgl_amd.distributed uses torch.distributed's RCCL
+ * all_to_all_single by default and this transport with PGLAMD_TRANSPORT=abi; a caller without torch has only this one.
+ * ---------------------------------------------------------------------------------------------- */
+#define PGLAMD_COMM_ID_BYTES 128
+int32_t pglamd_comm_unique_id(void* id_out);
+int32_t pglamd_comm_init(int32_t rank, int32_t world, const void* unique_id, void** comm_out);
+int32_t pglamd_comm_destroy(void* comm);
+int32_t pglamd_halo_exchange_start(void* comm, const void* send_buf, const int64_t* send_rows,
+                                   void* recv_buf, const int64_t* recv_rows, int64_t row_bytes,
+                                   void* compute_stream);
+int32_t pglamd_halo_exchange_wait(void* comm, void* compute_stream);
+
+/* Halo plan of one rank (HOST pointers; every rank derives its own share from the global edge list and the part vector,
+ * so no negotiation is needed).  Relabelling and layout follow apps/GNNAutoScale/graph_partition.py:70-101 (owned ids
+ * contiguous per part, ascending original id inside a part) and apps/GNNAutoScale/dataset.py:196-209 ([owned | halo]).
+ *   pglamd_halo_plan_sizes  -> sizes[5] = n_own, n_local_source_edges, n_halo_source_edges, n_halo_rows, n_send_rows
+ *   pglamd_halo_plan_fill   offsets[world+1] first relabelled id of every part; own_global[n_own] original id of local row i;
+ *                           (loc_rows, loc_cols)[n_loc] local dst row / local src row of the edges with both ends owned;
+ *                           (hal_rows, hal_cols)[n_hal] local dst row / position in the halo block of the other in-edges;
+ *                           halo_global[n_halo] relabelled ids of the halo rows, ascending = grouped by owner;
+ *                           send_idx[n_send] owned rows to pack, grouped by destination rank; halo_splits / pull_splits[world]
+ *                           rows received from / sent to each rank (the recv_rows / send_rows of pglamd_halo_exchange_start);
+ *                           in_degree / out_degree[n_own] GLOBAL degrees of the owned nodes (DistGPUGraph.indegree/outdegree,
+ *                           pgl/graph.py:1524-1532); edge_global[n_loc + n_hal] original edge id of local edge k
+ *                           (order: local-source edges, then halo-source edges) -- where edge features are sliced.
+ *   Any output pointer except offsets / halo_splits / pull_splits may be NULL.  Bit-identical to pgl_amd.distributed.HaloPlan. */
+int32_t pglamd_halo_plan_sizes(const int64_t* src, int64_t src_stride, const int64_t* dst,
+                               int64_t dst_stride, int64_t num_edges, int64_t num_nodes,
+                               const int64_t* part, int32_t rank, int32_t world, int64_t* sizes);
+int32_t pglamd_halo_plan_fill(const int64_t* src, int64_t src_stride, const int64_t* dst,
+                              int64_t dst_stride, int64_t num_edges, int64_t num_nodes,
+                              const int64_t* part, int32_t rank, int32_t world, int64_t* offsets,
+                              int64_t* own_global, int64_t* loc_rows, int64_t* loc_cols,
+                              int64_t* hal_rows, int64_t* hal_cols, int64_t* halo_global,
+                              int64_t* send_idx, int64_t* halo_splits, int64_t* pull_splits,
+                              int64_t* in_degree, int64_t* out_degree, int64_t* edge_global);
 
 /* ------------------------------------------------------------------------------------------------
  * Host-side (CPU) helpers.  Pointers here are HOST pointers.

@@ -60,12 +60,19 @@ _SIGNATURES = {
     "pglamd_build_index_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pglamd_map_ids": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "pglamd_partition_kway": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_u64, c_vp, c_vp]),
+    "pglamd_comm_unique_id": (c_i32, [c_vp]),
+    "pglamd_comm_init": (c_i32, [c_i32, c_i32, c_vp, c_vp]),
+    "pglamd_comm_destroy": (c_i32, [c_vp]),
+    "pglamd_halo_exchange_start": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "pglamd_halo_exchange_wait": (c_i32, [c_vp, c_vp]),
+    "pglamd_halo_plan_sizes": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_vp]),
+    "pglamd_halo_plan_fill": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32] + [c_vp] * 13),
     "pglamd_metis_available": (c_i32, []),
     "pglamd_partition_metis": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
 ABI_VERSION = 1
-_ERRORS = {-1: ValueError, -2: TypeError, -3: OverflowError, -4: RuntimeError, -5: RuntimeError, -6: ValueError, -7: RuntimeError}
+_ERRORS = {-1: ValueError, -2: TypeError, -3: OverflowError, -4: RuntimeError, -5: RuntimeError, -6: ValueError, -7: RuntimeError, -8: RuntimeError}
 
 
 class NativeLibraryMissing(RuntimeError):

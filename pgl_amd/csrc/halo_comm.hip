@@ -1,0 +1,150 @@
+// halo_comm.hip -- the multi-GPU exchange step of the partitioned path behind the C ABI (comm_init,
+// halo_exchange_{start,wait}): one RCCL communicator per process, a library-owned side stream, ordering with the caller's
+// compute stream through HIP events.  Replaces the all-reduce of DistGPUGraph (pgl/graph.py:1517-1553 -> pgl/utils/op.py:121)
+// with ONE all-to-all-v of halo rows per aggregation: xGMI is point to point (7 links x ~153 GB/s per GPU), so every
+// rank pair's block travels on its own link and all links are busy at once -- expressed as a grouped ncclSend / ncclRecv
+// per peer, the pattern RCCL maps onto per-link transfers without a ring.
+//
+// RCCL itself is opened with dlopen (librccl.so of the ROCm installation, or $PGLAMD_RCCL_LIB): a process that never goes
+// multi-GPU does not load it, and a box without it gets PGLAMD_E_UNAVAILABLE from pglamd_comm_init -- never a link error.
+#include "common.hpp"
+
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace pglamd {
+namespace {
+
+struct Rccl {
+    std::once_flag once;
+    bool ok = false;
+    std::string why;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl& rccl() { static Rccl r; return r; }
+
+void load_rccl() {
+    Rccl& r = rccl();
+    const char* names[] = {getenv("PGLAMD_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) {
+        if (!n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) { r.why = "librccl.so not found (set PGLAMD_RCCL_LIB)"; return; }
+#define SYM(field, name)                                                   \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, name));         \
+    if (!r.field) { r.why = std::string("librccl.so lacks ") + name; return; }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    r.ok = true;
+}
+
+struct Comm {
+    ncclComm_t nccl = nullptr;
+    int rank = 0, world = 1;
+    hipStream_t side = nullptr;          // library-owned: the exchange never queues behind the caller's kernels
+    hipEvent_t ready = nullptr;          // compute stream -> side stream: the send buffer is complete
+    hipEvent_t done = nullptr;           // side stream -> compute stream: the receive buffer is complete
+    bool in_flight = false;
+};
+
+#define PGLAMD_NCCL_CHECK(expr)                                                                          \
+    do {                                                                                                 \
+        ncclResult_t _r = (expr);                                                                        \
+        if (_r != ncclSuccess)                                                                           \
+            return fail(PGLAMD_E_RCCL, "%s failed: %s", #expr, rccl().GetErrorString(_r));               \
+    } while (0)
+
+}  // namespace
+}  // namespace pglamd
+
+using namespace pglamd;
+
+extern "C" int32_t pglamd_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(PGLAMD_E_ARG, "comm_unique_id: NULL pointer");
+    std::call_once(rccl().once, load_rccl);
+    if (!rccl().ok) return fail(PGLAMD_E_UNAVAILABLE, "comm_unique_id: %s", rccl().why.c_str());
+    ncclUniqueId id;
+    PGLAMD_NCCL_CHECK(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == PGLAMD_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(id_out, &id, sizeof(id));
+    return PGLAMD_OK;
+}
+
+extern "C" int32_t pglamd_comm_init(int32_t rank, int32_t world, const void* unique_id, void** comm_out) {
+    if (!unique_id || !comm_out || world < 1 || rank < 0 || rank >= world) return fail(PGLAMD_E_ARG, "comm_init: bad argument");
+    std::call_once(rccl().once, load_rccl);
+    if (!rccl().ok) return fail(PGLAMD_E_UNAVAILABLE, "comm_init: %s", rccl().why.c_str());
+    Comm* c = new Comm();
+    c->rank = rank; c->world = world;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclResult_t r = rccl().CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(PGLAMD_E_RCCL, "ncclCommInitRank failed: %s", rccl().GetErrorString(r)); }
+    PGLAMD_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    PGLAMD_HIP_CHECK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+    PGLAMD_HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    *comm_out = c;
+    return PGLAMD_OK;
+}
+
+extern "C" int32_t pglamd_comm_destroy(void* comm) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c) return PGLAMD_OK;
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->done) (void)hipEventDestroy(c->done);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+    return PGLAMD_OK;
+}
+
+// send_buf: rows for peer 0, then peer 1, ... (send_rows[q] rows each); recv_buf likewise.  Rows are row_bytes wide.
+extern "C" int32_t pglamd_halo_exchange_start(void* comm, const void* send_buf, const int64_t* send_rows, void* recv_buf,
+                                              const int64_t* recv_rows, int64_t row_bytes, void* compute_stream) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c || !send_rows || !recv_rows || row_bytes <= 0) return fail(PGLAMD_E_ARG, "halo_exchange_start: bad argument");
+    if (c->in_flight) return fail(PGLAMD_E_ARG, "halo_exchange_start: the previous exchange has not been waited for");
+    hipStream_t cs = static_cast<hipStream_t>(compute_stream);
+    PGLAMD_HIP_CHECK(hipEventRecord(c->ready, cs));                   // everything queued so far (the pack kernel) ...
+    PGLAMD_HIP_CHECK(hipStreamWaitEvent(c->side, c->ready, 0));       // ... happens before the transfers
+    const char* sp = static_cast<const char*>(send_buf);
+    char* rp = static_cast<char*>(recv_buf);
+    PGLAMD_NCCL_CHECK(rccl().GroupStart());
+    for (int q = 0; q < c->world; ++q) {
+        const size_t sb = (size_t)send_rows[q] * (size_t)row_bytes, rb = (size_t)recv_rows[q] * (size_t)row_bytes;
+        if (q == c->rank) {                                           // own block (always empty for halo plans): a plain copy
+            if (sb) PGLAMD_HIP_CHECK(hipMemcpyAsync(rp, sp, sb, hipMemcpyDeviceToDevice, c->side));
+        } else {
+            if (sb) PGLAMD_NCCL_CHECK(rccl().Send(sp, sb, ncclInt8, q, c->nccl, c->side));
+            if (rb) PGLAMD_NCCL_CHECK(rccl().Recv(rp, rb, ncclInt8, q, c->nccl, c->side));
+        }
+        sp += sb; rp += rb;
+    }
+    PGLAMD_NCCL_CHECK(rccl().GroupEnd());
+    PGLAMD_HIP_CHECK(hipEventRecord(c->done, c->side));
+    c->in_flight = true;
+    return PGLAMD_OK;
+}
+
+extern "C" int32_t pglamd_halo_exchange_wait(void* comm, void* compute_stream) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c) return fail(PGLAMD_E_ARG, "halo_exchange_wait: NULL communicator");
+    if (!c->in_flight) return PGLAMD_OK;
+    PGLAMD_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(compute_stream), c->done, 0));   // no host sync
+    c->in_flight = false;
+    return PGLAMD_OK;
+}

@@ -54,11 +54,70 @@ def _group_ready(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+class AbiTransport(object):
+    """The library-owned RCCL transport of the C ABI (pglamd_comm_init / pglamd_halo_exchange_{start,wait}): its own
+    communicator and side stream, ordered against the caller's stream by HIP events -- what a caller without torch uses.
+    Selected for DistGraph with PGLAMD_TRANSPORT=abi (default: torch.distributed's RCCL all_to_all_single); the unique id
+    is handed out through the already initialised torch process group."""
+    _by_group = {}
+
+    def __init__(self, group=None):
+        import ctypes
+        from . import _ffi
+        self._ffi, self._ct = _ffi, ctypes
+        L = _ffi.lib()
+        ready = _group_ready(group)
+        self.rank = dist.get_rank(group) if ready else 0
+        self.world = dist.get_world_size(group) if ready else 1
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            _ffi.check(L.pglamd_comm_unique_id(ctypes.c_void_p(ident.data_ptr())), "comm_unique_id")
+        if ready:
+            buf = ident.cuda() if dist.get_backend(group) == "nccl" else ident
+            dist.broadcast(buf, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+            ident = buf.cpu()
+        self.comm = ctypes.c_void_p()
+        _ffi.check(L.pglamd_comm_init(self.rank, self.world, ctypes.c_void_p(ident.data_ptr()), ctypes.byref(self.comm)), "comm_init")
+
+    @classmethod
+    def get(cls, group=None):
+        if group not in cls._by_group:
+            cls._by_group[group] = cls(group)
+        return cls._by_group[group]
+
+    def exchange(self, send_buf, send_splits, recv_buf, recv_splits):
+        """splits are in ROWS of send_buf / recv_buf (leading dimension)."""
+        ct, L = self._ct, self._ffi.lib()
+        row_bytes = send_buf.element_size()
+        for s_ in send_buf.shape[1:]:
+            row_bytes *= int(s_)
+        sr = (ct.c_int64 * self.world)(*[int(v) for v in send_splits])
+        rr = (ct.c_int64 * self.world)(*[int(v) for v in recv_splits])
+        stream = ct.c_void_p(torch.cuda.current_stream(send_buf.device).cuda_stream)
+        self._ffi.check(L.pglamd_halo_exchange_start(self.comm, ct.c_void_p(send_buf.data_ptr()), sr, ct.c_void_p(recv_buf.data_ptr()),
+                                                     rr, row_bytes, stream), "halo_exchange_start")
+        keep = (send_buf, recv_buf)                    # the buffers must outlive the transfers
+        outer = self
+
+        class _W(object):
+            def wait(self_inner):
+                st = ct.c_void_p(torch.cuda.current_stream(keep[0].device).cuda_stream)
+                outer._ffi.check(L.pglamd_halo_exchange_wait(outer.comm, st), "halo_exchange_wait")
+        return _W()
+
+    def close(self):
+        if self.comm:
+            self._ffi.lib().pglamd_comm_destroy(self.comm)
+            self.comm = self._ct.c_void_p()
+
+
 def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
     """all-to-all-v of rows.  Returns an object with .wait()."""
     if not _group_ready(group):
         return _Done()
     backend = dist.get_backend(group)
+    if backend == "nccl" and os.environ.get("PGLAMD_TRANSPORT") == "abi":
+        return AbiTransport.get(group).exchange(send_buf, send_splits, recv_buf, recv_splits)
     if backend == "nccl":
         return dist.all_to_all_single(recv_buf, send_buf, list(recv_splits), list(send_splits), group=group, async_op=True)
     # gloo (CPU tests; single-GPU dry runs of the multi-rank code path): point-to-point, staged through host memory

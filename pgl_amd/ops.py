@@ -625,3 +625,28 @@ def host_partition_metis(num_nodes, indptr, adjncy, nparts, node_weights=None, e
                                                  int(nparts), _np_ptr(part), ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)),
                "partition_metis")
     return part, int(cut.value)
+
+
+def host_halo_plan(edges, num_nodes, part, rank, world):
+    """pglamd_halo_plan_sizes / _fill: one rank's pull plan as a dict of int64 numpy arrays (see include/pgl_amd.h)."""
+    e = np.asarray(edges)
+    if e.dtype != np.int64:
+        e = e.astype(np.int64)
+    part = _np_i64(part)
+    E, N = int(e.shape[0]), int(num_nodes)
+    st = e.strides[0] // 8 if E else 2
+    src, dst = (e[:, 0], e[:, 1]) if E else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    L = _ffi.lib()
+    sizes = np.zeros(5, np.int64)
+    args = (_np_ptr(src), st, _np_ptr(dst), st, E, N, _np_ptr(part), int(rank), int(world))
+    _ffi.check(L.pglamd_halo_plan_sizes(*args, _np_ptr(sizes)), "halo_plan_sizes")
+    n_own, n_loc, n_hal, n_halo, n_send = (int(v) for v in sizes)
+    out = {"offsets": np.zeros(world + 1, np.int64), "own_global": np.zeros(n_own, np.int64), "loc_rows": np.zeros(n_loc, np.int64),
+           "loc_cols": np.zeros(n_loc, np.int64), "hal_rows": np.zeros(n_hal, np.int64), "hal_cols": np.zeros(n_hal, np.int64),
+           "halo_global": np.zeros(n_halo, np.int64), "send_idx": np.zeros(n_send, np.int64), "halo_splits": np.zeros(world, np.int64),
+           "pull_splits": np.zeros(world, np.int64), "in_degree": np.zeros(n_own, np.int64), "out_degree": np.zeros(n_own, np.int64),
+           "edge_global": np.zeros(n_loc + n_hal, np.int64)}
+    order = ("offsets", "own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "halo_global", "send_idx", "halo_splits",
+             "pull_splits", "in_degree", "out_degree", "edge_global")
+    _ffi.check(L.pglamd_halo_plan_fill(*args, *[_np_ptr(out[k]) for k in order]), "halo_plan_fill")
+    return out

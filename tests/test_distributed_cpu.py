@@ -457,3 +457,25 @@ def test_grid_sharded_four_ranks_gloo():
             full[np.ix_(own, np.arange(lo, hi))] = out[op]
             assert st["grid"] == "2x2"
         np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_c_abi_halo_plan_is_identical_to_the_python_plan(world):
+    """pglamd_halo_plan_sizes / _fill (host side of the C ABI, what a caller without torch uses) == HaloPlan, array by array."""
+    from pgl_amd import ops
+    from pgl_amd.distributed import HaloPlan
+    edges, x = _graph(n=500, e=7000, seed=13)
+    n = x.shape[0]
+    part = np.random.default_rng(3).integers(0, world, n)
+    for r in range(world):
+        a = ops.host_halo_plan(edges, n, part, r, world)
+        b = HaloPlan(torch.from_numpy(edges), n, part, r, world)
+        for k in ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "halo_global", "send_idx", "in_degree", "out_degree",
+                  "edge_global"):
+            assert np.array_equal(a[k], getattr(b, k).numpy()), (r, k)
+        assert a["offsets"].tolist() == b.offsets and a["halo_splits"].tolist() == b.halo_splits
+        assert a["pull_splits"].tolist() == b.pull_splits
+    with pytest.raises(OverflowError):
+        ops.host_halo_plan(edges, n, part + world, 0, world)            # part ids out of range
+    e0 = ops.host_halo_plan(np.zeros((0, 2), np.int64), 4, np.array([0, 1, 0, 1]), 1, 2)
+    assert e0["own_global"].tolist() == [1, 3] and e0["edge_global"].size == 0

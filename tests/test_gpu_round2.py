@@ -179,3 +179,24 @@ def test_c2_gcn_spmm_within_fp32_reassociation_bound_of_fp64(pgl):
         got = g.send_recv(x, op)
         w, a = (want, absterms) if op == "sum" else (want / indeg.clamp(min=1), absterms / indeg.clamp(min=1))
         assert_within_fp32_reassociation(host(got), host(w), host(a), host(indeg.expand(-1, d)) + (1 if op == "mean" else 0), slack=2.0)
+
+
+def test_abi_rccl_transport_single_rank_plumbing(pgl):
+    """pglamd_comm_init / pglamd_halo_exchange_{start,wait} on the one GPU of the box: a world-1 communicator, the own
+    block is the copy the side stream performs -- this exercises RCCL loading, communicator creation, the side stream
+    and both event hand-overs (N > 1 needs an 8-GPU node: the driver's scaling run)."""
+    from pgl_amd.distributed import AbiTransport
+    tr = AbiTransport(None)
+    assert tr.world == 1 and tr.comm
+    x = torch.randn(1000, 64, device="cuda")
+    y = torch.empty_like(x)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # a non-default compute stream: ordering must come from the events
+        z = x * 2.0                                     # "pack kernel" queued before the exchange
+        w = tr.exchange(z, [1000], y, [1000])
+        w.wait()
+        out = y + 1.0                                   # consumer queued after the wait
+    side.synchronize()
+    assert torch.equal(out, x * 2.0 + 1.0)
+    w2 = tr.exchange(z[:0], [0], y[:0], [0]); w2.wait()
+    tr.close()
