@@ -393,6 +393,22 @@ class Graph(object):
             self._csr_views = (vd, vs)
         return self._csr_views
 
+    def edge_order(self, order="dst"):
+        """Engine extension: a view of this graph whose EDGE TENSORS ([E, ...]) are kept in destination-sorted (CSR)
+        order instead of original edge order.  In original order every pass over an [E, H] tensor that is keyed by
+        destination (edge_softmax, send_ue_recv's edge operand) reaches its rows through the eid permutation -- one
+        128-byte line per 32-byte row at H = 8; in this order the same passes are sequential.  A user-defined attention
+        layer opts in by producing its scores with `view.send_uv` / `view.sddmm`, normalising them with `view.edge_softmax`
+        and consuming them with `view.send_ue_recv` -- exactly what the built-in layers do internally; `to_order` /
+        `from_order` convert an original-order tensor when one has to cross (one permuted pass each)."""
+        if order != "dst":
+            raise ValueError("edge_order: only 'dst' is provided")
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        if getattr(self, "_edge_order_view", None) is None:
+            self._edge_order_view = _DstOrderedEdges(self)
+        return self._edge_order_view
+
     # ---- message passing (pgl/graph.py:694-966) -------------------------------------------------
     def send(self, message_func, src_feat=None, dst_feat=None, edge_feat=None, node_feat=None):
         """pgl/graph.py:694-776."""
@@ -524,6 +540,68 @@ class Graph(object):
             src32, dst32 = self._edge_cols32()
         return ag.aggregate(feature, self._csr_dst(), self._csr_src, reduce_op, out_size, edge_feature, message_op,
                             src32, dst32)
+
+
+class _DstOrderedEdges(object):
+    """Graph.edge_order("dst"): the graph's message-passing ops for [E, ...] tensors in destination-sorted order.
+    Position p of such a tensor is the edge (src[p], dst[p]) = (view.src, view.dst)[p], original id view.eid[p]."""
+
+    def __init__(self, graph):
+        self.graph = graph
+        self._cd, self._cs = graph._csr_order_views()
+        full = graph._csr_dst()
+        self.eid = full.eid32                                  # original edge id of position p
+        self.src, self.dst = full.col32, full.row32            # endpoints of position p (int32)
+        self.num_edges = full.num_edges
+        iota = torch.arange(full.num_edges, dtype=torch.int32, device=full.row32.device)
+        cdi = ops.CSR()                                        # dst-keyed view with an explicit identity edge map (for the
+        for k in ("degree", "indptr", "row32", "col32", "num_nodes", "num_edges"):     # gather-by-edge backward of send_uv)
+            setattr(cdi, k, getattr(self._cd, k))
+        cdi.sorted_v = cdi.sorted_u = cdi.sorted_eid = None
+        cdi.eid32 = iota
+        self._cd_iota = cdi
+        self._inv = None
+
+    def to_order(self, edge_tensor):
+        """original edge order -> this order (differentiable)."""
+        return ag.gather_rows(edge_tensor, self.eid)
+
+    def from_order(self, edge_tensor):
+        """this order -> original edge order (differentiable)."""
+        if self._inv is None:
+            inv = torch.empty(self.num_edges, dtype=torch.int32, device=self.eid.device)
+            inv[self.eid.long()] = torch.arange(self.num_edges, dtype=torch.int32, device=inv.device)
+            self._inv = inv
+        return ag.gather_rows(edge_tensor, self._inv)
+
+    def send_uv(self, src_feature, dst_feature, message_op="add"):
+        """Graph.send_uv (pgl/graph.py:939-966), result rows in this order."""
+        assert message_op in _MSGOP, "Only support 'add', 'sub', 'max', 'min' build-in message functions."
+        return ag.send_uv(src_feature, dst_feature, self.src, self.dst, message_op, lambda: self._cd_iota, lambda: self._cs)
+
+    def sddmm(self, src_feature, dst_feature):
+        """Graph.sddmm, result rows in this order."""
+        if (src_feature.dim() == 3 and src_feature.dtype == torch.float32 and dst_feature.dtype == torch.float32
+                and tuple(src_feature.shape[1:]) == tuple(dst_feature.shape[1:])
+                and ops.sddmm_supported(int(src_feature.shape[1]), int(src_feature.shape[2]))):
+            return ag.sddmm(src_feature.contiguous(), dst_feature.contiguous(), self._cd, lambda: self._cs)
+        return self.send_uv(src_feature, dst_feature, "mul").sum(-1)
+
+    def edge_softmax(self, logits):
+        """GF.edge_softmax(graph, logits, norm_by="dst") (pgl/nn/functional/graph_op.py:101-123) for logits in this order:
+        the segments are contiguous runs, no permutation is involved."""
+        cd = self._cd
+        return ag.segment_softmax(logits, ops.SegView(cd.indptr, cd.row32, cd.row32, None))
+
+    def send_ue_recv(self, feature, edge_feature, message_op="add", reduce_op="sum", out_size=None):
+        """Graph.send_ue_recv (pgl/graph.py:889-937) with the edge operand in this order."""
+        assert message_op in _MSGOP, "Only support 'add', 'sub', 'max', 'min' build-in message functions."
+        assert reduce_op in _REDUCE, "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
+        needs_grad = torch.is_grad_enabled() and (feature.requires_grad or edge_feature.requires_grad)
+        s32 = d32 = None
+        if needs_grad:
+            s32, d32 = self.src, self.dst
+        return ag.aggregate(feature, self._cd, lambda: self._cs, reduce_op, out_size, edge_feature, message_op, s32, d32)
 
 
 class _GraphRowReader(op.RowReader):

@@ -200,3 +200,42 @@ def test_abi_rccl_transport_single_rank_plumbing(pgl):
     assert torch.equal(out, x * 2.0 + 1.0)
     w2 = tr.exchange(z[:0], [0], y[:0], [0]); w2.wait()
     tr.close()
+
+
+def test_edge_order_dst_view_matches_the_original_order_api(pgl):
+    """Graph.edge_order("dst"): a user-defined attention chain written against the view (scores -> softmax -> weighted sum,
+    every [E,H] tensor in dst-sorted order) equals the same chain in original edge order, values and gradients."""
+    rng = np.random.default_rng(17)
+    n, e, H, D = 2500, 40000, 8, 16
+    src = rng.integers(0, n, e); dst = rng.integers(0, n, e)
+    dst[rng.choice(e, 5000, replace=False)] = 3
+    g = pgl.Graph(edges=np.stack([src, dst], 1).astype(np.int64), num_nodes=n).tensor()
+    view = g.edge_order("dst")
+    mk = lambda *s: dev(rng.standard_normal(s).astype(np.float32))
+    a_s, a_d, f = mk(n, H), mk(n, H), mk(n, H, D)
+    w = mk(n, H, D)
+
+    def chain(view_mode, a_s, a_d, f):
+        G = view if view_mode else g
+        score = torch.nn.functional.leaky_relu(G.send_uv(a_s, a_d, "add"), 0.2)
+        alpha = G.edge_softmax(score) if view_mode else pgl.nn.functional.edge_softmax(g, score)
+        return G.send_ue_recv(f, alpha.reshape(-1, H, 1), "mul", "sum"), alpha
+
+    outs = []
+    for mode in (False, True):
+        xs = [t.clone().requires_grad_(True) for t in (a_s, a_d, f)]
+        out, alpha = chain(mode, *xs)
+        (out * w).sum().backward()
+        outs.append((out.detach(), alpha.detach(), [t.grad for t in xs]))
+    (o0, al0, g0), (o1, al1, g1) = outs
+    np.testing.assert_allclose(host(o1), host(o0), rtol=1e-5, atol=1e-5 * float(o0.abs().max()))
+    np.testing.assert_allclose(host(view.from_order(al1)), host(al0), rtol=1e-5, atol=1e-7)
+    assert torch.equal(view.to_order(al0), al0[view.eid.long()])
+    for a, b in zip(g1, g0):
+        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+    # endpoints of the view's positions, and the dot-product score
+    ed = host(g.edges)
+    assert np.array_equal(host(view.src), ed[host(view.eid), 0]) and np.array_equal(host(view.dst), ed[host(view.eid), 1])
+    np.testing.assert_allclose(host(view.from_order(view.sddmm(f, w))), host(g.sddmm(f, w)), rtol=1e-5, atol=1e-4)
+    with pytest.raises(ValueError):
+        g.edge_order("src")
