@@ -331,6 +331,22 @@ int32_t pglamd_reindex(const int64_t* nodes, int64_t num_nodes, const int64_t* n
                        int64_t* num_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Layer epilogue (row f1, "SpMM -> GEMM epilogue fusion"): the element passes after the dense X.W of
+ * GraphSageConv (self + neigh + biases -> act -> F.normalize, pgl/nn/conv.py:99-115) and GCNConv (+ bias -> activation,
+ * pgl/nn/conv.py:250-254) as ONE row kernel forward and one backward.  float32, rows contiguous.
+ *   y[r,:] = normalize_L2( act( z[r,:] + bias ) )     act 0 none / 1 relu; normalize 0/1 (x / max(||x||, eps));
+ *            y may alias z; inv_norm[n_rows] (written when normalize) is what the backward needs besides y.
+ *   backward: dz = act'( normalize ? (dy - y <dy,y>) * inv_norm : dy ); col_partials[pglamd_row_epilogue_partials(n_rows), d]
+ *            (optional) receives per-wave column sums of dz -- summed over rows they are the bias gradient.
+ * ---------------------------------------------------------------------------------------------- */
+int64_t pglamd_row_epilogue_partials(int64_t n_rows);
+int32_t pglamd_row_epilogue(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act,
+                            int32_t normalize, float eps, float* y, float* inv_norm, void* stream);
+int32_t pglamd_row_epilogue_backward(const float* dy, const float* y, const float* inv_norm,
+                                     int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
+                                     float* dz, float* col_partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange step of the row-partitioned path.  Replaces the collective of the reference's
  * DistGPUGraph -- all_reduce_sum_with_grad of the whole [N, d] output after every aggregation
  * (pgl/graph.py:1517-1553 -> pgl/utils/op.py:90-122, c_allreduce_sum) -- with one all-to-all-v of halo rows:

@@ -381,3 +381,66 @@ def scatter_into_zeros(n_rows, index, x):
         return _ScatterRows.apply(n_rows, index, x)
     out = torch.zeros((n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     return ops.scatter_rows(out, index, x)
+
+
+class _RowEpilogue(torch.autograd.Function):
+    """y = normalize_L2(act(z + bias)): one kernel forward, one backward (which also yields the bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, z, bias, act, normalize):
+        y, inv = ops.row_epilogue(z, bias, act, normalize)
+        ctx.act, ctx.normalize, ctx.has_bias = act, normalize, bias is not None
+        ctx.save_for_backward(y, inv if inv is not None else y.new_zeros(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        dz, db = ops.row_epilogue_backward(dy, y, inv if ctx.normalize else None, ctx.act, ctx.normalize, want_b)
+        return dz, db, None, None
+
+
+def row_epilogue(z, bias=None, act=None, normalize=False):
+    if torch.is_grad_enabled() and (z.requires_grad or (bias is not None and bias.requires_grad)):
+        return _RowEpilogue.apply(z, bias, act, normalize)
+    return ops.row_epilogue(z, bias, act, normalize)[0]
+
+
+def _tall_wgrad(g, x):
+    """g^T x for [N, out] / [N, in] with N in the millions: the reduction over N split into 256 batched slabs (bmm -> sum); the
+    stock GEMM runs the whole reduction serially per output tile (1.9 ms vs 0.33 ms at N = 2^20, 128 x 128)."""
+    n = x.shape[0]
+    if n < 65536:
+        return g.t() @ x
+    split = 256
+    m = n // split * split
+    gw = torch.bmm(g[:m].view(split, m // split, -1).transpose(1, 2), x[:m].view(split, m // split, -1)).sum(0)
+    if m < n:
+        gw = gw + g[m:].t() @ x[m:]
+    return gw
+
+
+class _DualLinear(torch.autograd.Function):
+    """z = x Wa^T + y Wb^T: the second GEMM accumulates into the first one's output (beta = 1), so GraphSage's
+    `self_linear(x) + neigh_linear(agg)` (pgl/nn/conv.py:104-109) has no separate add pass; both biases go to the epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, y, wa, wb):
+        ctx.save_for_backward(x, y, wa, wb)
+        z = torch.nn.functional.linear(x, wa)
+        return z.addmm_(y, wb.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, wa, wb = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ wa if ctx.needs_input_grad[0] else None
+        gy = g @ wb if ctx.needs_input_grad[1] else None
+        gwa = _tall_wgrad(g, x) if ctx.needs_input_grad[2] else None
+        gwb = _tall_wgrad(g, y) if ctx.needs_input_grad[3] else None
+        return gx, gy, gwa, gwb
+
+
+def dual_linear(x, y, wa, wb):
+    return _DualLinear.apply(x, y, wa, wb)

@@ -12,6 +12,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as GF
+from .. import autograd as ag
+from .. import ops
 
 __all__ = ["GraphSageConv", "GCNConv", "GATConv"]
 
@@ -81,11 +83,18 @@ class GraphSageConv(nn.Module):
         self.normalize = normalize
         self.self_linear = _linear(input_size, hidden_size)
         self.neigh_linear = _linear(input_size, hidden_size)
+        self.fused = True        # False: the reference's op-by-op composition
 
     def forward(self, graph, feature, act=None):
         if isinstance(feature, torch.Tensor):
             feature = (feature, feature)
         neigh_feature = graph.send_recv(feature[0], self.aggr_func, out_size=feature[1].shape[0])
+        if act in (None, "relu") and ops.row_epilogue_supported(neigh_feature) and feature[1].dtype == torch.float32 \
+                and feature[1].is_cuda and self.fused:
+            # self_linear(x) + neigh_linear(agg) -> act -> F.normalize as two GEMMs (the second accumulating into the first)
+            # and ONE row kernel (both biases, the activation and the L2 normalisation); backward likewise one row kernel
+            z = ag.dual_linear(feature[1].contiguous(), neigh_feature, self.self_linear.weight, self.neigh_linear.weight)
+            return ag.row_epilogue(z, self.self_linear.bias + self.neigh_linear.bias, act, self.normalize)
         neigh_feature = self.neigh_linear(neigh_feature)
         self_feature = self.self_linear(feature[1])
         output = self_feature + neigh_feature
@@ -121,7 +130,12 @@ class GCNConv(nn.Module):
             # kernel as well and the bias rides in the GEMM epilogue: two [N, d] element passes fewer.
             output = graph.send_recv_scaled(feature, norm, norm)
             if self.input_size <= self.output_size:
-                output = _TallLinearFn.apply(output, self.linear.weight, self.bias) if (output.shape[0] >= 65536 and torch.is_grad_enabled()) \
+                tall = output.shape[0] >= 65536 and torch.is_grad_enabled()
+                if self.activation is F.relu and ops.row_epilogue_supported(output):
+                    # bias + relu as one row kernel; its backward also yields the bias gradient (no separate reduction)
+                    z = _TallLinearFn.apply(output, self.linear.weight, None) if tall else F.linear(output, self.linear.weight)
+                    return ag.row_epilogue(z, self.bias, "relu", False)
+                output = _TallLinearFn.apply(output, self.linear.weight, self.bias) if tall \
                     else F.linear(output, self.linear.weight, self.bias)
                 if self.activation is not None:
                     output = self.activation(output)
@@ -134,6 +148,8 @@ class GCNConv(nn.Module):
                 output = self.linear(output)
             if norm is not None:
                 output = output * norm
+        if self.activation is F.relu and ops.row_epilogue_supported(output):
+            return ag.row_epilogue(output, self.bias, "relu", False)
         output = output + self.bias
         if self.activation is not None:
             output = self.activation(output)

@@ -650,3 +650,43 @@ def host_halo_plan(edges, num_nodes, part, rank, world):
              "pull_splits", "in_degree", "out_degree", "edge_global")
     _ffi.check(L.pglamd_halo_plan_fill(*args, *[_np_ptr(out[k]) for k in order]), "halo_plan_fill")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# layer epilogue (row f1): bias + activation + L2 row normalisation in one pass each way
+# ------------------------------------------------------------------------------------------------
+def row_epilogue_supported(z):
+    d = int(z.shape[-1]) if z.dim() == 2 else 0
+    vec = 4 if d % 4 == 0 else 2 if d % 2 == 0 else 1
+    return z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 and 0 < d <= 64 * vec * 8
+
+
+def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12):
+    """y = normalize_L2(act(z + bias)) -> (y, inv_norm or None).  act: None | "relu".  GraphSageConv's epilogue
+    (pgl/nn/conv.py:109-115) and GCNConv's (pgl/nn/conv.py:250-254) in one kernel."""
+    _need_cuda(z, bias)
+    z = z.contiguous()
+    n, d = int(z.shape[0]), int(z.shape[1])
+    y = torch.empty_like(z)
+    inv = torch.empty(n, dtype=torch.float32, device=z.device) if normalize else None
+    if n:
+        with torch.cuda.device(z.device):
+            _ffi.check(_ffi.lib().pglamd_row_epilogue(_ptr(z), _ptr(None if bias is None else bias.contiguous()), n, d,
+                                                      1 if act == "relu" else 0, int(bool(normalize)), float(eps), _ptr(y), _ptr(inv),
+                                                      _stream(z)), "row_epilogue")
+    return y, inv
+
+
+def row_epilogue_backward(dy, y, inv_norm, act=None, normalize=False, want_bias=False):
+    """-> (dz, dbias or None) for row_epilogue."""
+    _need_cuda(dy, y, inv_norm)
+    dy = dy.contiguous()
+    n, d = int(dy.shape[0]), int(dy.shape[1])
+    dz = torch.empty_like(dy)
+    L = _ffi.lib()
+    part = torch.zeros((int(L.pglamd_row_epilogue_partials(n)), d), dtype=torch.float32, device=dy.device) if want_bias else None
+    if n:
+        with torch.cuda.device(dy.device):
+            _ffi.check(L.pglamd_row_epilogue_backward(_ptr(dy), _ptr(y), _ptr(inv_norm), n, d, 1 if act == "relu" else 0,
+                                                      int(bool(normalize)), _ptr(dz), _ptr(part), _stream(dy)), "row_epilogue_backward")
+    return dz, (part.sum(0) if want_bias else None)

@@ -239,3 +239,58 @@ def test_edge_order_dst_view_matches_the_original_order_api(pgl):
     np.testing.assert_allclose(host(view.from_order(view.sddmm(f, w))), host(g.sddmm(f, w)), rtol=1e-5, atol=1e-4)
     with pytest.raises(ValueError):
         g.edge_order("src")
+
+
+@pytest.mark.parametrize("d", [128, 64, 100, 7, 256, 1000])
+@pytest.mark.parametrize("act,normalize", [(None, True), ("relu", True), ("relu", False), (None, False)])
+def test_row_epilogue_forward_backward_vs_torch(pgl, d, act, normalize):
+    """y = normalize(act(z + bias)) (GraphSageConv / GCNConv epilogue, pgl/nn/conv.py:109-115, 250-254) against the torch
+    composition in fp64, values, input gradient and bias gradient; an all-zero row exercises the eps clamp."""
+    from pgl_amd import autograd as ag
+    rng = np.random.default_rng(d)
+    n = 3001
+    z = rng.standard_normal((n, d)).astype(np.float32); z[5] = 0.0
+    b = rng.standard_normal(d).astype(np.float32); 
+    if normalize:
+        b[:] = 0.0 if d == 7 else b                                   # keep one configuration where row 5 stays all-zero
+    w = rng.standard_normal((n, d)).astype(np.float32)
+    zt, bt = dev(z).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ag.row_epilogue(zt, bt, act, normalize)
+    (y * dev(w)).sum().backward()
+    z64, b64 = dev(z).double().requires_grad_(True), dev(b).double().requires_grad_(True)
+    t = z64 + b64
+    if act == "relu":
+        t = torch.relu(t)
+    if normalize:
+        t = torch.nn.functional.normalize(t, dim=1)
+    (t * dev(w).double()).sum().backward()
+    np.testing.assert_allclose(host(y), host(t), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(zt.grad), host(z64.grad), rtol=2e-5, atol=2e-5 * float(z64.grad.abs().max()))
+    np.testing.assert_allclose(host(bt.grad), host(b64.grad), rtol=1e-4, atol=1e-4 * float(b64.grad.abs().max()) + 1e-6)
+    with torch.no_grad():
+        assert torch.equal(ag.row_epilogue(zt, bt, act, normalize), y)
+
+
+def test_graphsage_fused_epilogue_equals_the_reference_composition(pgl):
+    torch.manual_seed(9)
+    n, e, d = 5000, 60000, 128
+    rng = np.random.default_rng(2)
+    g = pgl.Graph(edges=np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64), num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    w = dev(rng.standard_normal((n, 96)).astype(np.float32))
+    for act in (None, "relu"):
+        layer = pgl.nn.GraphSageConv(d, 96, "mean").cuda()
+        torch.nn.init.normal_(layer.self_linear.bias); torch.nn.init.normal_(layer.neigh_linear.bias)
+        res = []
+        for fused in (True, False):
+            layer.fused = fused
+            layer.zero_grad()
+            xs = x.clone().requires_grad_(True)
+            out = layer(g, xs, act=act)
+            (out * w).sum().backward()
+            res.append((out.detach(), xs.grad, [p.grad.clone() for p in layer.parameters()]))
+        (o1, gx1, gp1), (o0, gx0, gp0) = res
+        np.testing.assert_allclose(host(o1), host(o0), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=1e-4 * float(gx0.abs().max()))
+        for a, b in zip(gp1, gp0):
+            np.testing.assert_allclose(host(a), host(b), rtol=2e-4, atol=2e-4 * float(b.abs().max()))
