@@ -31,9 +31,16 @@ def _norm_propagate(graph, feature, norm):
 def _g_domain(graph, feature, norm):
     """True when k-hop propagation can iterate on g = norm (.) h: one hop of norm (.) A (norm (.) h) is then a single
     aggregation with dst_scale = norm^2 (plus an optional residual folded into the same launch) instead of
-    scale -> aggregate -> scale (-> axpby): fp32 features, one norm value per node, strictly positive."""
-    return (hasattr(graph, "propagate_step") and feature.dtype == torch.float32 and norm.dtype == torch.float32
-            and feature.dim() == 2 and norm.numel() == feature.shape[0])
+    scale -> aggregate -> scale (-> axpby): fp32 features, one norm value per node.  The g-domain result is divided by norm
+    at the end and norm enters the kernels as a gradient-free scale, so a caller-supplied norm must need no gradient and be
+    strictly positive (GF.degree_norm clamps the degree to >= 1, so the layers' own norm always is; the check costs one
+    reduction per forward, only for the layers that take a norm argument)."""
+    if not (hasattr(graph, "propagate_step") and feature.dtype == torch.float32 and norm.dtype == torch.float32
+            and feature.dim() == 2 and norm.numel() == feature.shape[0]):
+        return False
+    if norm.requires_grad and torch.is_grad_enabled():
+        return False
+    return getattr(norm, "_pglamd_positive", False) or bool((norm > 0).all())
 
 
 class LightGCNConv(nn.Module):

@@ -14,7 +14,9 @@ def degree_norm(graph, mode="indegree"):
         "The degree_norm mode should be in ['indegree', 'outdegree']. But recieve mode=%s" % mode
     degree = graph.indegree() if mode == "indegree" else graph.outdegree()
     dt = torch.get_default_dtype()
-    return ops.degree_norm(degree, dt if dt in (torch.float32, torch.float64) else torch.float32)
+    out = ops.degree_norm(degree, dt if dt in (torch.float32, torch.float64) else torch.float32)
+    out._pglamd_positive = True          # clip(degree, 1)^-0.5 > 0 by construction: lets the k-hop layers skip their check
+    return out
 
 
 def graph_pool(graph, feature, pool_type):

@@ -294,3 +294,25 @@ def test_graphsage_fused_epilogue_equals_the_reference_composition(pgl):
         np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=1e-4 * float(gx0.abs().max()))
         for a, b in zip(gp1, gp0):
             np.testing.assert_allclose(host(a), host(b), rtol=2e-4, atol=2e-4 * float(b.abs().max()))
+
+
+def test_khop_layers_with_caller_norm_zero_or_trainable_take_the_safe_path(pgl):
+    """APPNP / GCNII iterate on g = h * norm and divide by norm at the end only when norm is strictly positive and
+    needs no gradient; a caller-supplied norm with zeros (isolated nodes set to 0) or requires_grad uses the composition."""
+    rng = np.random.default_rng(4)
+    n, e, d = 600, 5000, 16
+    src = rng.integers(0, n - 50, e); dst = rng.integers(0, n - 50, e)            # the last 50 nodes are isolated
+    g = pgl.Graph(edges=np.stack([src, dst], 1).astype(np.int64), num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    deg = g.indegree().float()
+    norm0 = torch.where(deg > 0, deg.clamp(min=1).pow(-0.5), torch.zeros_like(deg)).reshape(-1, 1)     # zeros for isolated nodes
+    layer = pgl.nn.APPNP(alpha=0.2, k_hop=3)
+    out = layer(g, x, norm0)
+    assert torch.isfinite(out).all()
+    h = x
+    for _ in range(3):
+        h = 0.2 * x + 0.8 * (g.send_recv(h * norm0, "sum") * norm0)
+    np.testing.assert_allclose(host(out), host(h), rtol=1e-5, atol=1e-5)
+    nt = pgl.nn.functional.degree_norm(g).clone().requires_grad_(True)
+    layer(g, x, nt).sum().backward()
+    assert nt.grad is not None and float(nt.grad.abs().sum()) > 0
