@@ -3,9 +3,9 @@
 # exercises METIS at benchmark scale, the pull/push plans, all three layouts and the JSON line.  The times mean nothing.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O; cd $R
 for N in ${@:-2 8}; do
-  /usr/bin/time -v env PGLAMD_BENCH_DRYRUN=1 timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2973$N \
+  T0=$SECONDS; PGLAMD_BENCH_DRYRUN=1 timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 2973$N \
      bench.py --gpus $N --steps 3 --warmup 1 > $O/dryrun_n$N.json 2> $O/dryrun_n$N.err
-  echo "N=$N rc=$? wall=$(grep Elapsed $O/dryrun_n$N.err | awk '{print $NF}')"
+  echo "N=$N rc=$? wall=$((SECONDS-T0))s"
   grep "^{" $O/dryrun_n$N.json | python -c "
 import sys, json
 r = json.loads(sys.stdin.readline())
