@@ -10,8 +10,8 @@ Workload (config.workload): BASELINE.json configs[1] -- RMAT (0.57,0.19,0.19,0.0
 |E| = 20 M, d = 128 fp32, graph seed 42, feature seed 7.
 N > 1: the SAME global graph and feature matrix (strong scaling).  The headline layout is north_star's (--parallel rows,
 the default): METIS row partition (pgl.partition.metis_partition's METIS through the C ABI), one RCCL halo all-to-all-v
-per step overlapped with the local-source edges, per rank pair the cheaper of pull and push (DistGraph).  Two other
-layouts are timed for a few steps and reported as SECONDARY fields (halo.alternatives_ms_per_step):
+per step overlapped with the local-source edges, per rank pair the cheaper of pull and push (DistGraph).  The column layout
+is timed for a few steps and reported as a SECONDARY field (halo.alternatives_ms_per_step); --parallel auto also times the grid:
   cols  the graph replicated on every GPU, the feature COLUMNS split: out[:, cols_r] = A x[:, cols_r] needs no data-path
         collective at all (FeatureShardedGraph);
   grid  2 row parts x N/2 column slices (GridShardedGraph).
@@ -260,8 +260,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
+        t_setup = time.perf_counter()
+
+        def note(msg):
+            if rank == 0:                                            # progress to stderr: where the setup time of an N > 1 run goes
+                print("[bench %6.1fs] %s" % (time.perf_counter() - t_setup, msg), file=sys.stderr, flush=True)
+
         def build(name):
             """-> (step, stats, (d_loc, n_loc, e_loc), extra)"""
+            note("building layout %r" % name)
             if name == "rows":
                 dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push)
                 x_own = dg.take_owned(x)
@@ -282,28 +289,45 @@ def main():
         # The headline layout is north_star's: METIS row partition + halo all-to-all-v (--parallel rows).  The other layouts
         # are timed for a few steps and reported as SECONDARY fields (halo.alternatives_ms_per_step); "auto" promotes the
         # fastest one to the headline and says so in config.parallelism.
-        order = {"rows": ["rows", "cols", "grid"], "cols": ["cols"], "grid": ["grid"], "auto": ["rows", "cols", "grid"]}[args.parallel]
+        # (the grid costs a second METIS run -- about a minute at this scale -- so it is a candidate of --parallel auto / grid only)
+        order = {"rows": ["rows", "cols"], "cols": ["cols"], "grid": ["grid"], "auto": ["rows", "cols", "grid"]}[args.parallel]
         if args.no_alternatives:
             order = order[:1]
         built, trial = {}, {}
+
+        def agreed(ok):
+            """True only if the step succeeded on EVERY rank (a rank that failed must not leave the others waiting in a collective)."""
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(int(flag.item()))
+
         for name in order:
-            good, t_trial = 1, 0.0
+            err = None
             try:
                 built[name] = build(name)
+            except Exception as ex:                                  # noqa: BLE001
+                err = ex
+            if not agreed(err is None):                              # phase 1: every rank built the layout
+                built.pop(name, None)
+                print("[bench] layout %r not built (rank %d: %r)" % (name, rank, err), file=sys.stderr, flush=True)
+                if name == order[0] and args.parallel != "auto":
+                    raise err if err is not None else RuntimeError("layout %r failed on another rank" % name)
+                continue
+            t_trial = 0.0
+            try:
                 fn = built[name][0]
                 fn(); fn()
                 t_trial = timed(fn, max(args.warmup, 3)) / max(args.warmup, 3) * 1e3
-            except Exception as ex:                                  # noqa: BLE001 -- only the headline layout is fatal
-                if name == order[0] and args.parallel != "auto":
-                    raise
-                good = 0
-                print("[bench] layout %r failed on rank %d: %r" % (name, rank, ex), file=sys.stderr, flush=True)
-            flag = torch.tensor([good], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # a layout counts only if it worked on every rank
-            if int(flag.item()):
-                trial[name] = t_trial
-            else:
+            except Exception as ex:                                  # noqa: BLE001 -- (a failure inside a collective ends the job anyway)
+                err = ex
+            if not agreed(err is None):                              # phase 2: it ran on every rank
                 built.pop(name, None)
+                print("[bench] layout %r failed (rank %d: %r)" % (name, rank, err), file=sys.stderr, flush=True)
+                if name == order[0] and args.parallel != "auto":
+                    raise err if err is not None else RuntimeError("layout %r failed on another rank" % name)
+                continue
+            trial[name] = t_trial
+            note("layout %r: %.3f ms/step over %d trial steps" % (name, t_trial, max(args.warmup, 3)))
         mode = min(trial, key=trial.get) if args.parallel == "auto" else order[0]
         step, halo, (d_loc, n_loc, e_loc), extra = built[mode]
         halo = dict(halo, mode=mode, alternatives_ms_per_step=trial)
