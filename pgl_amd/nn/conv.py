@@ -123,7 +123,8 @@ class GCNConv(nn.Module):
         if self.input_size > self.output_size:
             feature = self.linear(feature)
         fuse = norm is not None and feature.dtype == torch.float32 and norm.dtype == torch.float32 \
-            and norm.numel() == feature.shape[0] and hasattr(graph, "send_recv_scaled")
+            and norm.numel() == feature.shape[0] and hasattr(graph, "send_recv_scaled") \
+            and not (norm.requires_grad and torch.is_grad_enabled())       # the fused scales carry no gradient
         if fuse:
             # (feature * norm) -> send_recv(sum) -> (* norm) as ONE pass over the edges.  Row scaling commutes with the
             # right-multiplication by W, so in the aggregate-first order the destination norm is applied inside the

@@ -23,7 +23,7 @@ __all__ = ["GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv
 def _norm_propagate(graph, feature, norm):
     """feature * norm -> send_recv(sum) -> * norm  (one kernel for fp32 features)."""
     if (feature.dtype == torch.float32 and norm.dtype == torch.float32 and norm.numel() == feature.shape[0]
-            and hasattr(graph, "send_recv_scaled")):
+            and hasattr(graph, "send_recv_scaled") and not (norm.requires_grad and torch.is_grad_enabled())):   # fused scales carry no gradient
         return graph.send_recv_scaled(feature, norm, norm)       # per-node scalar norm ([N] or [N,1]) only
     return graph.send_recv(feature * norm, "sum") * norm
 
