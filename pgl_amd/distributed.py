@@ -636,7 +636,11 @@ class DistGraph(object):
             kw_first, kw_rest = {"src_scale": scale_k}, {"src_scale": None}
         work, in_buf = None, None
         if p.world > 1 and (n_out or n_in):
-            out_buf = B.aggregate(x, self._index(first), "sum", n_out, **kw_first) if n_out else x.new_empty((0,) + tail)
+            # both exchange buffers persist across steps (no per-step allocation on the hot path); reuse is ordered by the
+            # stream: the pack launch below is queued after every earlier reader of the same buffer
+            out_buf = self._buffer("out%d" % transposed, (n_out,) + tail, x.dtype, x.device)
+            if n_out:
+                B.aggregate(x, self._index(first), "sum", n_out, out=out_buf, **kw_first)
             in_buf = self._buffer("in%d" % transposed, (n_in,) + tail, x.dtype, x.device)
             work = _exchange(out_buf, out_splits, in_buf, in_splits, self.group)
         if not transposed:
