@@ -231,15 +231,42 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
                 merge_in(take, tv, ts);
             };
             if constexpr (SM) {
-                // the softmax merge costs an exponential per step: six whole-wave steps (ds_bpermute) beat 4 + 3 here
+                // Two phases instead of an online-softmax scan (round 2; the scan paid an exponential and two ds_bpermutes per
+                // element per step, six steps -- the sequential case was compute-bound at ~0.5 ms for [20 M, 8]):
+                //   1. segmented MAX scan over the run (DPP row steps + 3 cross-row reads: VALU only), the run's maximum is
+                //      fetched from the run's LAST lane (one ds_bpermute per column);
+                //   2. p = exp(x - run max): ONE exponential per element, the accurate one -- these are the values the
+                //      normalisation divides by; segmented SUM scan of p (DPP again).
+                // Every lane then holds (run max, inclusive prefix sum relative to it): a valid softmax state for the carry /
+                // partial merges below, which keep the rescaling form.
+                auto seg_scan = [&](A (&val)[D], auto op, A idv) {
+                    auto step = [&](auto off_tag) {
+                        constexpr int OFF = decltype(off_tag)::value;
+                        const bool take = (lane & 15) >= OFF && lane - OFF >= start;
 #pragma unroll
-                for (int off = 1; off < kWave; off <<= 1) {
-                    const bool take = lane - off >= start;
-                    A tv[D], ts[D];
+                        for (int k = 0; k < D; ++k) { const A t = dpp_row_shr<OFF>(val[k]); val[k] = op(take ? t : idv, val[k]); }
+                    };
+                    step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+                    step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 8>{});
 #pragma unroll
-                    for (int k = 0; k < D; ++k) { tv[k] = shfl_up_t(v[k], off); ts[k] = shfl_up_t(sv[k], off); }
-                    merge_in(take, tv, ts);
+                    for (int rw = 1; rw < 4; ++rw) {
+                        const bool take = (lane >> 4) == rw && start < 16 * rw;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) { const A t = read_lane(val[k], 16 * rw - 1); val[k] = op(take ? t : idv, val[k]); }
+                    }
+                };
+                seg_scan(v, [](A a, A b) { return b > a ? b : a; }, Limits<A>::lo());
+                const unsigned long long above = lane == kWave - 1 ? 0ull : (hm >> (lane + 1));
+                const int tail = above ? lane + __builtin_ctzll(above) : kWave - 1;       // last lane of this lane's run
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const A xk = valid[b] ? to_acc<T>(raw[b][k]) : A(0);
+                    const A mk = shfl_t(v[k], tail);
+                    v[k] = mk;
+                    if constexpr (std::is_same_v<A, float>) sv[k] = valid[b] ? expf(xk - mk) : 0.f;
+                    else sv[k] = valid[b] ? exp(xk - mk) : A(0);
                 }
+                seg_scan(sv, [](A a, A b) { return a + b; }, A(0));
             } else {
             row_step(std::integral_constant<int, 1>{});
             row_step(std::integral_constant<int, 2>{});
