@@ -217,13 +217,16 @@ int32_t pglamd_segment_softmax(const void* data, int32_t dtype, int64_t num_rows
  * ---------------------------------------------------------------------------------------------- */
 size_t pglamd_gat_aggregate_workspace_bytes(int64_t num_edges, int64_t heads, int64_t head_dim);
 /* drop_p in [0,1): attention dropout applied to alpha (pgl/nn/conv.py:337-338) as a counter-based
- * hash of (seed, original edge id, head); needs eid (dst-sorted sorted_eid) when drop_p > 0. */
+ * hash of (seed, original edge id, head); needs eid (dst-sorted sorted_eid) when drop_p > 0.  *   out_pos, sum_pos   optional (both or neither; training): [out_rows, H*D] and [out_rows, H] positive-part statistics
+ *                      consumed by pglamd_gat_backward (see there).
+ */
 int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const float* attn_dst,
                              int64_t heads, int64_t head_dim, float negative_slope, float drop_p,
                              uint32_t seed, const int32_t* row, const int32_t* col,
                              const int32_t* eid, const int64_t* indptr, int64_t num_edges,
                              int64_t n_csr_rows, int64_t out_rows, float* out, float* row_max,
-                             float* row_sum, void* workspace, size_t workspace_bytes, void* stream);
+                             float* row_sum, float* out_pos, float* sum_pos, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* Backward of pglamd_gat_aggregate (row "next" f1: fused backward), alpha recomputed per edge from
  * the forward's statistics; nothing of size [E,H] or [E,H,D] is materialised:
@@ -235,6 +238,12 @@ int32_t pglamd_gat_aggregate(const float* feature, const float* attn_src, const 
  *                         takes grad_attn_dst as the segment sum of grad_pre by destination (pglamd_aggregate over the
  *                         dst-sorted CSR with col = the src-sorted position of each edge): 1.3 ms faster at C3 for
  *                         4*E*H bytes of scratch.  grad_attn_dst may be NULL in that case.
+ *   out_pos, sum_pos (optional, from pglamd_gat_aggregate): the forward's positive-part statistics -- out_pos[v,h,:] = the part
+ *                         of out[v] contributed by edges with pre_e > 0, sum_pos[v,h] = their softmax mass.  With them
+ *                         grad_attn_dst[v,h] = <g,out_pos> + slope <g,out - out_pos> - t (sum_pos + slope (1 - sum_pos)) is
+ *                         evaluated per (node, head) inside the pack kernel: no per-edge buffer (grad_pre is ignored) and
+ *                         no dst-sorted walk -- the round-2 default of pgl_amd (0.8 ms less at C3 for one more [N,H*D]
+ *                         tensor kept from the forward).
  *   d pre_e = alpha_e (drop_e <grad_out[v,h,:], feature[u,h,:]> - t[v,h]) * leaky_relu'(attn_src[u,h] + attn_dst[v,h])
  *   t[v,h]  = sum_d grad_out[v,h,d] * out[v,h,d]  (out = the forward's output; computed here).
  *   dst_* / src_*  the dst-sorted and src-sorted CSRs (int32 row / col / eid, int64 indptr).
@@ -251,7 +260,8 @@ int32_t pglamd_gat_backward(const float* grad_out, const float* feature, const f
                             const int32_t* src_row, const int32_t* src_col, const int32_t* src_eid,
                             const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
                             float* grad_feature, float* grad_attn_src, float* grad_attn_dst,
-                            float* grad_pre, void* workspace, size_t workspace_bytes, void* stream);
+                            float* grad_pre, const float* out_pos, const float* sum_pos,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Additive attention score over a sorted edge stream (GATv2Conv, pgl/nn/conv.py:421-424: send_uv(f, f, "add") ->
  * leaky_relu -> (alpha * attn).sum(-1), which materialises two [E,H,D] tensors):

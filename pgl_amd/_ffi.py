@@ -39,11 +39,11 @@ _SIGNATURES = {
     "pglamd_segment_softmax": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_gat_aggregate_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "pglamd_gat_aggregate": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_uint32,
-                                      c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                      c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_gat_backward_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
     "pglamd_gat_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_uint32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp,
-                                     c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_add_score": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_float, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "pglamd_add_score_chunks": (c_i64, [c_i64]),
     "pglamd_add_score_backward": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,

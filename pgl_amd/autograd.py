@@ -253,16 +253,18 @@ class _GatAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, feature, attn_src, attn_dst, csr_dst, csr_src_fn, slope, drop_p, seed):
-        out, mx, sm = ops.gat_aggregate(feature, attn_src, attn_dst, csr_dst, slope, None, True, drop_p, seed)
+        out, mx, sm, out_pos, s_pos = ops.gat_aggregate(feature, attn_src, attn_dst, csr_dst, slope, None, True, drop_p, seed)
         ctx.csr_dst, ctx.csr_src_fn, ctx.slope, ctx.drop_p, ctx.seed = csr_dst, csr_src_fn, slope, drop_p, seed
-        ctx.save_for_backward(feature, attn_src, attn_dst, out, mx, sm)
+        ctx.has_pos = out_pos is not None
+        ctx.save_for_backward(feature, attn_src, attn_dst, out, mx, sm, *((out_pos, s_pos) if ctx.has_pos else ()))
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        feature, a_s, a_d, out, mx, sm = ctx.saved_tensors
+        feature, a_s, a_d, out, mx, sm = ctx.saved_tensors[:6]
+        out_pos, s_pos = ctx.saved_tensors[6:] if ctx.has_pos else (None, None)
         gf, gs, gd = ops.gat_backward(grad, feature, out, a_s, a_d, mx, sm, ctx.csr_dst, ctx.csr_src_fn(), ctx.slope,
-                                      ctx.drop_p, ctx.seed)
+                                      ctx.drop_p, ctx.seed, out_pos, s_pos)
         return gf, gs, gd, None, None, None, None, None
 
 

@@ -41,6 +41,7 @@ struct GatParams {
     const float* stat_m; const float* stat_s;   // backward: softmax statistics of the dst node [N,H]
     float* out;
     float* row_max; float* row_sum;             // forward: optional statistics output [out_rows,H]
+    float* out_pos; float* sum_pos;             // forward, optional (training): out restricted to the edges with pre_e > 0 [out_rows,d], their softmax mass [out_rows,H]
     const int* row; const int* col; const int* eid; const int64_t* indptr;
     float* part_head; float* part_tail;         // [n_chunks, 3, d]: acc | m | s (forward) ; [n_chunks, d] (backward)
     int* long_count; int* long_list; int* long_list2;
@@ -88,10 +89,16 @@ __device__ __forceinline__ float drop_factor(unsigned seed, int eid, int head, f
 
 // MODE 0: forward (online softmax).  MODE 1: backward w.r.t. features only (additive, alpha recomputed).
 // MODE 2: MODE 1 + d a_src over the src-sorted stream.  MODE 3: d a_dst over the dst-sorted stream (no feature output).
-template <int VEC, int MODE, bool DROP>
+// POS (forward only): also accumulate the part of the row that comes from edges with pre_e > 0 (out_pos, and its softmax mass
+// sum_pos).  With them the backward gets d a_dst[v,h] = sum_e d pre_e WITHOUT any per-edge pass:
+//     sum_e alpha_e l'_e (drop_e <g,f_u> - t) = <g, out_pos> + slope <g, out - out_pos> - t (s_pos + slope (1 - s_pos)),
+// l'_e = 1 where pre_e > 0 and slope elsewhere -- a per-(node, head) formula evaluated in the pack kernel.  It replaces the
+// [E,H] d pre buffer of round 1 (0.64 GB written by the src-sorted walk, gathered back through a permutation by a 0.51 ms
+// segment sum) by one more [N, H*D] row written per destination in the forward.
+template <int VEC, int MODE, bool DROP, bool POS = false>
 __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     constexpr int U = 4;
-    constexpr int PW = MODE == 0 ? 3 : MODE == 2 ? 2 : 1;   // floats per column in a partial
+    constexpr int PW = MODE == 0 ? (POS ? 5 : 3) : MODE == 2 ? 2 : 1;   // floats per column in a partial
     constexpr bool ATT = MODE >= 2;                     // accumulates the attention-score gradient of the row node
     constexpr bool FEAT = MODE != 3;                    // accumulates / writes a feature row
     using V = FV<VEC>;
@@ -116,6 +123,10 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             if (FEAT && act) *reinterpret_cast<V*>(p.out + (r0 + l) * p.d + j0) = V{};
             if (ATT && lane < p.H) p.out_a[(r0 + l) * p.H + lane] = 0.f;
             if (MODE == 0 && p.row_max && lane < p.H) { p.row_max[(r0 + l) * p.H + lane] = 0.f; p.row_sum[(r0 + l) * p.H + lane] = 0.f; }
+            if constexpr (POS) {
+                if (act) *reinterpret_cast<V*>(p.out_pos + (r0 + l) * p.d + j0) = V{};
+                if (lane < p.H) p.sum_pos[(r0 + l) * p.H + lane] = 0.f;
+            }
         }
         return;
     }
@@ -139,8 +150,11 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     const bool need_eid = drop;                                   // original edge ids only feed the dropout hash
 
     float m = -INFINITY, s = 0.f, acc[VEC], acc_a = 0.f;
+    float accp[POS ? VEC : 1], sp = 0.f;
 #pragma unroll
     for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < (POS ? VEC : 1); ++k) accp[k] = 0.f;
     int cur = rowp[e0];
     bool head_open = e0 > 0 && rowp[e0 - 1] == cur;
 
@@ -163,6 +177,14 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = s;
                 *reinterpret_cast<V*>(dst + 2 * p.d + j0) = o;
+                if constexpr (POS) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o.v[k] = accp[k];
+                    *reinterpret_cast<V*>(dst + 3 * p.d + j0) = o;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) o.v[k] = sp;
+                    *reinterpret_cast<V*>(dst + 4 * p.d + j0) = o;
+                }
             }
         }
         if (!headp && lane == 0) p.long_list[atomicAdd(p.long_count, 1)] = c;
@@ -177,6 +199,12 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
         for (int k = 0; k < VEC; ++k) o.v[k] = acc[k] * inv;
         *reinterpret_cast<V*>(p.out + (int64_t)r * p.d + j0) = o;
         if (MODE == 0 && p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + head] = m; p.row_sum[(int64_t)r * p.H + head] = s; }
+        if constexpr (POS) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o.v[k] = accp[k] * inv;
+            *reinterpret_cast<V*>(p.out_pos + (int64_t)r * p.d + j0) = o;
+            if ((j0 % p.D) == 0) p.sum_pos[(int64_t)r * p.H + head] = sp * inv;
+        }
     };
     // the row node's scalar is fetched (asynchronously, with the batch) only for edges that may OPEN a row and held
     // in a register until the next row change: no stall on the change, no per-edge reload either.
@@ -186,9 +214,11 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             if (head_open) store_partial(true); else store_final(cur);
             head_open = false;
             cur = r;
-            m = -INFINITY; s = 0.f; acc_a = 0.f;
+            m = -INFINITY; s = 0.f; acc_a = 0.f; sp = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < (POS ? VEC : 1); ++k) accp[k] = 0.f;
             vr_held = vr;
         }
         const float pre = vc + vr_held;
@@ -204,6 +234,13 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             const float w = pe * df;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * sc + w * xv.v[k];
+            if constexpr (POS) {
+                const float pp = pre > 0.f ? 1.f : 0.f;
+                sp = sp * sc + pe * pp;
+                const float wp = w * pp;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) accp[k] = accp[k] * sc + wp * xv.v[k];
+            }
             m = up ? l : m;
         } else {
             const float alpha = expf(l - vm) / vs;   // alpha_e of the destination's softmax, recomputed
@@ -386,12 +423,15 @@ constexpr int kGatFixWaves = 16;
 constexpr int kGatFixGridShort = 2048;
 constexpr int kGatFixGridLong = 512;
 
-template <int VEC, bool LONG, int MODE>
+template <int VEC, bool LONG, int MODE, bool POS = false>
 __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixup_kernel(GatParams p) {
     using V = FV<VEC>;
     constexpr int NW = LONG ? kGatFixWaves : 1;
-    constexpr int PW = MODE == 0 ? 3 : MODE == 2 ? 2 : 1;
-    __shared__ float red[LONG ? kGatFixWaves : 1][3][LONG ? kWave * VEC : 1];
+    constexpr int PW = MODE == 0 ? (POS ? 5 : 3) : MODE == 2 ? 2 : 1;
+    // per-wave results of the LONG pass: the vectors (acc, and accp when POS) are VEC wide per lane, the scalars (m, s, sp)
+    // are one value per lane -- kept apart so that VEC = 4 with POS stays under 64 KiB of LDS
+    __shared__ float red_v[LONG ? kGatFixWaves : 1][POS ? 2 : 1][LONG ? kWave * VEC : 1];
+    __shared__ float red_s[LONG ? kGatFixWaves : 1][3][LONG ? kWave : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
     const cptr<int> rowp = as_const(p.row);
@@ -414,16 +454,23 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
                 continue;
             }
         }
-        float m = MODE == 0 ? -INFINITY : 0.f, s = 0.f, acc[VEC];
+        float m = MODE == 0 ? -INFINITY : 0.f, s = 0.f, sp = 0.f, acc[VEC], accp[POS ? VEC : 1];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-        auto merge_vals = [&](const V& va, float m2, float s2) {
+#pragma unroll
+        for (int k = 0; k < (POS ? VEC : 1); ++k) accp[k] = 0.f;
+        auto merge_vals = [&](const V& va, float m2, float s2, const V& vp, float sp2) {
             if constexpr (MODE == 0) {
                 const float mn = fmaxf(m, m2);
                 const float c1 = expf(m - mn), c2 = expf(m2 - mn);
                 s = s * c1 + s2 * c2;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * c1 + va.v[k] * c2;
+                if constexpr (POS) {
+                    sp = sp * c1 + sp2 * c2;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) accp[k] = accp[k] * c1 + vp.v[k] * c2;
+                }
                 m = mn;
             } else {                                   // additive modes: `m` doubles as the second component (MODE 2)
 #pragma unroll
@@ -433,9 +480,12 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
             }
         };
         auto merge = [&](const float* base) {
-            if constexpr (MODE == 0) merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], base[2 * p.d + j0]);
-            else if constexpr (MODE == 2) merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], 1.f);
-            else merge_vals(*reinterpret_cast<const V*>(base + j0), 0.f, 1.f);
+            if constexpr (MODE == 0) {
+                V vp{}; float sp2 = 0.f;
+                if constexpr (POS) { vp = *reinterpret_cast<const V*>(base + 3 * p.d + j0); sp2 = base[4 * p.d + j0]; }
+                merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], base[2 * p.d + j0], vp, sp2);
+            } else if constexpr (MODE == 2) merge_vals(*reinterpret_cast<const V*>(base + j0), base[p.d + j0], 1.f, V{}, 0.f);
+            else merge_vals(*reinterpret_cast<const V*>(base + j0), 0.f, 1.f, V{}, 0.f);
         };
         if constexpr (!LONG) {
             if (act) {
@@ -448,23 +498,31 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
                 for (int c = a + 1 + wib; c <= b; c += NW) merge(p.part_head + (int64_t)c * PW * p.d);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) red[wib][0][lane * VEC + k] = acc[k];
-            red[wib][1][lane * VEC] = m; red[wib][2][lane * VEC] = s;
+            for (int k = 0; k < VEC; ++k) {
+                red_v[wib][0][lane * VEC + k] = acc[k];
+                if constexpr (POS) red_v[wib][1][lane * VEC + k] = accp[k];
+            }
+            red_s[wib][0][lane] = m; red_s[wib][1][lane] = s; red_s[wib][2][lane] = sp;
             __syncthreads();
             if (wib != 0) continue;
             // wave 0: tail partial of chunk a first, then the wave results in wave order
-            m = MODE == 0 ? -INFINITY : 0.f; s = 0.f;
+            m = MODE == 0 ? -INFINITY : 0.f; s = 0.f; sp = 0.f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < (POS ? VEC : 1); ++k) accp[k] = 0.f;
             if (act) {
                 merge(p.part_tail + (int64_t)a * PW * p.d);
                 for (int w = 0; w < NW; ++w) {
-                    const float s2 = red[w][2][lane * VEC];
+                    const float s2 = red_s[w][1][lane];
                     if (s2 == 0.f) continue;                     // that wave had no partial
-                    V va;
+                    V va, vp{};
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) va.v[k] = red[w][0][lane * VEC + k];
-                    merge_vals(va, red[w][1][lane * VEC], s2);
+                    for (int k = 0; k < VEC; ++k) {
+                        va.v[k] = red_v[w][0][lane * VEC + k];
+                        if constexpr (POS) vp.v[k] = red_v[w][1][lane * VEC + k];
+                    }
+                    merge_vals(va, red_s[w][0][lane], s2, vp, red_s[w][2][lane]);
                 }
             }
         }
@@ -477,6 +535,12 @@ __global__ __launch_bounds__(LONG ? kGatFixWaves * kWave : kBlock) void gat_fixu
         for (int k = 0; k < VEC; ++k) o.v[k] = acc[k] * inv;
         *reinterpret_cast<V*>(p.out + (int64_t)r * p.d + j0) = o;
         if (MODE == 0 && p.row_max && (j0 % p.D) == 0) { p.row_max[(int64_t)r * p.H + j0 / p.D] = m; p.row_sum[(int64_t)r * p.H + j0 / p.D] = s; }
+        if constexpr (POS) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o.v[k] = accp[k] * inv;
+            *reinterpret_cast<V*>(p.out_pos + (int64_t)r * p.d + j0) = o;
+            if ((j0 % p.D) == 0) p.sum_pos[(int64_t)r * p.H + j0 / p.D] = sp * inv;
+        }
     }
 }
 
@@ -681,25 +745,37 @@ template <int LANES>
 __global__ __launch_bounds__(kBlock) void gat_pack_kernel(const float* __restrict__ a_dst, const float* __restrict__ m,
                                                          const float* __restrict__ sm, const float* __restrict__ g,
                                                          const float* __restrict__ out, int64_t n, int D,
-                                                         F4* __restrict__ packed) {
+                                                         F4* __restrict__ packed, const float* __restrict__ out_pos,
+                                                         const float* __restrict__ sum_pos, float slope,
+                                                         float* __restrict__ grad_a_dst) {
+    // with the forward's positive-part statistics the attention-score gradient of the DESTINATION is a per-(node, head)
+    // formula (see gat_flat_kernel, POS): u = <g, out_pos>, t = <g, out>  =>  d a_dst = u + slope (t - u) - t (sp + slope (1 - sp))
+    auto d_adst = [&](float t, float u, float spv) { return u + slope * (t - u) - t * (spv + slope * (1.f - spv)); };
     if constexpr (LANES == 0) {
         const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         if (i >= n) return;
-        float t = 0.f;
-        for (int k = 0; k < D; ++k) t += g[i * D + k] * out[i * D + k];
+        float t = 0.f, u = 0.f;
+        for (int k = 0; k < D; ++k) { t += g[i * D + k] * out[i * D + k]; if (out_pos) u += g[i * D + k] * out_pos[i * D + k]; }
         packed[i] = F4{a_dst[i], m[i], 1.f / sm[i], t};
+        if (out_pos) grad_a_dst[i] = d_adst(t, u, sum_pos[i]);
     } else {
         const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;          // float4 index into [n, D]
         const bool live = q < n * LANES;
-        float t = 0.f;
+        float t = 0.f, u = 0.f;
         if (live) {
             const float4 a = reinterpret_cast<const float4*>(g)[q], b = reinterpret_cast<const float4*>(out)[q];
             t = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+            if (out_pos) {
+                const float4 c = reinterpret_cast<const float4*>(out_pos)[q];
+                u = a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+            }
         }
         t = group_sum(t, LANES);
+        if (out_pos) u = group_sum(u, LANES);
         if (live && (q % LANES) == 0) {
             const int64_t i = q / LANES;
             packed[i] = F4{a_dst[i], m[i], 1.f / sm[i], t};
+            if (out_pos) grad_a_dst[i] = d_adst(t, u, sum_pos[i]);
         }
     }
 }
@@ -714,25 +790,31 @@ static int gat_chunk_edges() {
     return k;
 }
 
-template <int VEC, int MODE>
-static int32_t launch_gat(GatParams p, hipStream_t st) {
+template <int VEC, int MODE, bool POS>
+static int32_t launch_gat_pos(GatParams p, hipStream_t st) {
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     if (p.drop_p > 0.f)
-        hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+        hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, true, POS>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     else
-        hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+        hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, false, POS>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (p.n_chunks > 1) {
-        hipLaunchKernelGGL((gat_fixup_kernel<VEC, false, MODE>), dim3((unsigned)std::min<int64_t>(kGatFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, false, MODE, POS>), dim3((unsigned)std::min<int64_t>(kGatFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((gat_fixup_kernel<VEC, true, MODE>), dim3((unsigned)std::min<int64_t>(kGatFixGridLong, p.n_chunks)), dim3(kGatFixWaves * kWave), 0, st, p);
+        hipLaunchKernelGGL((gat_fixup_kernel<VEC, true, MODE, POS>), dim3((unsigned)std::min<int64_t>(kGatFixGridLong, p.n_chunks)), dim3(kGatFixWaves * kWave), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
     }
     return PGLAMD_OK;
+}
+
+template <int VEC, int MODE>
+static int32_t launch_gat(GatParams p, hipStream_t st) {
+    if constexpr (MODE == 0) { if (p.out_pos) return launch_gat_pos<VEC, 0, true>(p, st); }
+    return launch_gat_pos<VEC, MODE, false>(p, st);
 }
 
 // lane geometry: one 64-lane tile covers all H*D columns, VEC elements of ONE head per lane
@@ -765,7 +847,7 @@ using namespace pglamd;
 extern "C" size_t pglamd_gat_aggregate_workspace_bytes(int64_t num_edges, int64_t heads, int64_t head_dim) {
     if (num_edges <= 0) return 256;
     const int64_t n_chunks = ceil_div(num_edges, gat_chunk_edges());
-    return 2 * align_up((size_t)n_chunks * 3 * heads * head_dim * sizeof(float), 256) +
+    return 2 * align_up((size_t)n_chunks * 5 * heads * head_dim * sizeof(float), 256) +
            2 * align_up((size_t)(n_chunks + 64) * sizeof(int), 256) + 256;
 }
 
@@ -773,7 +855,8 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
                                         int64_t head_dim, float negative_slope, float drop_p, uint32_t seed,
                                         const int32_t* row, const int32_t* col, const int32_t* eid, const int64_t* indptr,
                                         int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, float* out, float* row_max,
-                                        float* row_sum, void* workspace, size_t workspace_bytes, void* stream) {
+                                        float* row_sum, float* out_pos, float* sum_pos, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
     if (!out || !indptr || heads <= 0 || head_dim <= 0 || out_rows < 0 || (num_edges > 0 && (!feature || !attn_src || !attn_dst || !row || !col)))
         return fail(PGLAMD_E_ARG, "gat_aggregate: bad argument");
     if ((row_max == nullptr) != (row_sum == nullptr)) return fail(PGLAMD_E_ARG, "gat_aggregate: row_max/row_sum must both be given or both NULL");
@@ -788,8 +871,14 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
             PGLAMD_HIP_CHECK(hipMemsetAsync(row_max, 0, (size_t)out_rows * heads * sizeof(float), st));
             PGLAMD_HIP_CHECK(hipMemsetAsync(row_sum, 0, (size_t)out_rows * heads * sizeof(float), st));
         }
+        if (out_pos) {
+            PGLAMD_HIP_CHECK(hipMemsetAsync(out_pos, 0, (size_t)out_rows * d * sizeof(float), st));
+            PGLAMD_HIP_CHECK(hipMemsetAsync(sum_pos, 0, (size_t)out_rows * heads * sizeof(float), st));
+        }
         return PGLAMD_OK;
     }
+    if ((out_pos == nullptr) != (sum_pos == nullptr) || (out_pos && reinterpret_cast<uintptr_t>(out_pos) % 16))
+        return fail(PGLAMD_E_ARG, "gat_aggregate: out_pos and sum_pos come together (out_pos 16-byte aligned)");
     const int vec = gat_vec(heads, head_dim, feature, out, workspace, false);
     if (vec == 0 || heads > kWave)
         return fail(PGLAMD_E_SHAPE, "gat_aggregate: heads*head_dim = %lld does not fit one 64-lane tile (max 256 with head_dim %% 4 == 0)", (long long)d);
@@ -797,12 +886,13 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
         return fail(PGLAMD_E_WORKSPACE, "gat_aggregate: workspace too small");
     GatParams p{};
     p.x = feature; p.p_col = attn_src; p.p_row = attn_dst; p.out = out; p.row_max = row_max; p.row_sum = row_sum;
+    p.out_pos = out_pos; p.sum_pos = sum_pos;
     p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
     p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)num_edges;
     p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
     p.d = (int)d; p.H = (int)heads; p.D = (int)head_dim; p.slope = negative_slope;
     p.drop_p = drop_p; p.drop_scale = 1.f / (1.f - drop_p); p.seed = seed;
-    gat_setup_partials(p, workspace, 3);
+    gat_setup_partials(p, workspace, out_pos ? 5 : 3);
     switch (vec) {
         case 1: return launch_gat<1, 0>(p, st);
         case 2: return launch_gat<2, 0>(p, st);
@@ -822,7 +912,11 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
                                        const int64_t* dst_indptr, const int32_t* src_row, const int32_t* src_col,
                                        const int32_t* src_eid, const int64_t* src_indptr, int64_t num_edges, int64_t num_nodes,
                                        float* grad_feature, float* grad_attn_src, float* grad_attn_dst, float* grad_pre,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
+                                       const float* out_pos, const float* sum_pos, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+    if ((out_pos == nullptr) != (sum_pos == nullptr) || (out_pos && (!grad_attn_dst || reinterpret_cast<uintptr_t>(out_pos) % 16)))
+        return fail(PGLAMD_E_ARG, "gat_backward: out_pos and sum_pos come together, with grad_attn_dst (out_pos 16-byte aligned)");
+    if (out_pos) grad_pre = nullptr;             // d a_dst comes out of the pack kernel: neither the edge buffer nor the dst-sorted walk
     if (heads <= 0 || head_dim <= 0 || num_nodes < 0 || num_edges < 0 || !grad_feature || !grad_attn_src || (!grad_attn_dst && !grad_pre) ||
         (num_edges > 0 && (!grad_out || !feature || !attn_src || !attn_dst || !row_max || !row_sum || !out || !dst_row || !dst_col ||
                            !dst_eid || !dst_indptr || !src_row || !src_col || !src_eid || !src_indptr)))
@@ -851,7 +945,8 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
         const int64_t pairs = num_nodes * heads;
         const int lanes = (head_dim % 4 == 0) ? (int)(head_dim / 4) : 0;
 #define PGLAMD_PACK(L) hipLaunchKernelGGL(gat_pack_kernel<L>, dim3((unsigned)ceil_div(pairs * (L ? L : 1), kBlock)), dim3(kBlock), 0, st, \
-                                          attn_dst, row_max, row_sum, grad_out, out, pairs, (int)head_dim, packed)
+                                          attn_dst, row_max, row_sum, grad_out, out, pairs, (int)head_dim, packed, out_pos, sum_pos, negative_slope, \
+                                          grad_attn_dst)
         switch (lanes) {
             case 1: PGLAMD_PACK(1); break;
             case 2: PGLAMD_PACK(2); break;
@@ -872,7 +967,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     int32_t rc;
     // (1) dst-sorted walk: row = v gathers f[u], a_src[u]; accumulates d a_dst[v].  Skipped when the caller takes
     //     d pre_e [E,H] from walk (2) instead and segment-sums it by destination itself (faster, 4*E*H bytes more memory).
-    if (!grad_pre) {
+    if (!grad_pre && !out_pos) {
         GatParams q = p;
         q.row = dst_row; q.col = dst_col; q.eid = dst_eid; q.indptr = dst_indptr;
         q.x = feature; q.p_col = attn_src; q.p_row = attn_dst; q.row_vec = grad_out; q.out = nullptr; q.out_a = grad_attn_dst;

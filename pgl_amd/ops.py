@@ -153,6 +153,7 @@ def _bcast(x, y):
 # aggregation (send_u_recv / send_ue_recv)
 # ------------------------------------------------------------------------------------------------
 _GAT_BWD_EDGE_BUFFER = os.environ.get("PGLAMD_GAT_BWD_EDGE_BUFFER", "1") != "0"
+_GAT_POS_STATS = os.environ.get("PGLAMD_GAT_POS_STATS", "1") != "0"
 _PRESCALE_ROW_BYTES = int(os.environ.get("PGLAMD_PRESCALE_ROW_BYTES", "704"))
 
 
@@ -339,22 +340,27 @@ def gat_aggregate(feature, attn_src, attn_dst, csr, negative_slope=0.2, out_size
         raise ValueError("gat_aggregate: attn_src/attn_dst must be [N, heads]")
     M = int(out_size) if (out_size is not None and int(out_size) > 0) else n
     out = torch.empty((M, H, D), dtype=torch.float32, device=feature.device)
-    mx = sm = None
+    mx = sm = out_pos = s_pos = None
     if return_stats:
         mx = torch.empty((M, H), dtype=torch.float32, device=feature.device)
         sm = torch.empty((M, H), dtype=torch.float32, device=feature.device)
+        if _GAT_POS_STATS:
+            # positive-part statistics: what the backward needs to form d a_dst per node instead of per edge
+            out_pos = torch.empty((M, H, D), dtype=torch.float32, device=feature.device)
+            s_pos = torch.empty((M, H), dtype=torch.float32, device=feature.device)
     L = _ffi.lib()
     ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), feature.device)
     with torch.cuda.device(feature.device):
         _ffi.check(L.pglamd_gat_aggregate(_ptr(feature), _ptr(attn_src), _ptr(attn_dst), H, D, float(negative_slope),
                                           float(drop_p), int(seed) & 0xFFFFFFFF, _ptr(csr.row32), _ptr(csr.col32),
                                           _ptr(csr.eid32), _ptr(csr.indptr), csr.num_edges, csr.num_nodes, M, _ptr(out),
-                                          _ptr(mx), _ptr(sm), _ptr(ws), ws.numel(), _stream(feature)), "gat_aggregate")
-    return (out, mx, sm) if return_stats else out
+                                          _ptr(mx), _ptr(sm), _ptr(out_pos), _ptr(s_pos), _ptr(ws), ws.numel(),
+                                          _stream(feature)), "gat_aggregate")
+    return (out, mx, sm, out_pos, s_pos) if return_stats else out
 
 
 def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, csr_dst, csr_src, negative_slope=0.2,
-                 drop_p=0.0, seed=0):
+                 drop_p=0.0, seed=0, out_pos=None, sum_pos=None):
     """Backward of gat_aggregate -> (grad_feature [N,H,D], grad_attn_src [N,H], grad_attn_dst [N,H])."""
     _need_cuda(grad_out, feature, out)
     grad_out = grad_out.contiguous(); feature = feature.contiguous()
@@ -364,7 +370,9 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     g_src = torch.empty((n, H), dtype=torch.float32, device=feature.device)
     # d a_dst either from a second (dst-sorted) walk inside the library, or -- 1.3 ms faster at C3, 4*E*H bytes of
     # scratch -- as the segment sum by destination of the d pre_e the src-sorted walk can emit
-    use_pre = _GAT_BWD_EDGE_BUFFER
+    # (round 2) with the forward's positive-part statistics d a_dst is a per-node formula inside the library's pack kernel:
+    # neither the edge buffer nor the second walk is needed
+    use_pre = _GAT_BWD_EDGE_BUFFER and out_pos is None
     g_dst = None if use_pre else torch.empty((n, H), dtype=torch.float32, device=feature.device)
     gpre = torch.empty((csr_dst.num_edges, H), dtype=torch.float32, device=feature.device) if use_pre else None
     L = _ffi.lib()
@@ -375,7 +383,8 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
                                          int(seed) & 0xFFFFFFFF, _ptr(csr_dst.row32), _ptr(csr_dst.col32),
                                          _ptr(csr_dst.eid32), _ptr(csr_dst.indptr), _ptr(csr_src.row32), _ptr(csr_src.col32),
                                          _ptr(csr_src.eid32), _ptr(csr_src.indptr), csr_dst.num_edges, n, _ptr(gf),
-                                         _ptr(g_src), _ptr(g_dst), _ptr(gpre), _ptr(ws), ws.numel(), _stream(feature)), "gat_backward")
+                                         _ptr(g_src), _ptr(g_dst), _ptr(gpre), _ptr(out_pos), _ptr(sum_pos), _ptr(ws), ws.numel(),
+                                         _stream(feature)), "gat_backward")
     if use_pre:
         class _E(object):       # rows of the src-sorted edge buffer gathered in dst-sorted order
             def __init__(self, c, pos):

@@ -564,7 +564,7 @@ def test_gat_fused_matches_unfused_and_oracle(pgl, H, D):
     a_s = (rng.standard_normal((n, H)) * 3).astype(np.float32)
     a_d = (rng.standard_normal((n, H)) * 3).astype(np.float32)
     g = pgl.Graph(edges=edges, num_nodes=n).tensor()
-    out, mx, sm = pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2, return_stats=True)
+    out, mx, sm, out_pos, s_pos = pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2, return_stats=True)
     # oracle (numpy restatement of conv.py:333-339)
     alpha = R.np_send_uv(a_s, a_d, edges[:, 0], edges[:, 1], "add")
     alpha = np.where(alpha >= 0, alpha, alpha * np.float32(0.2))
@@ -572,6 +572,11 @@ def test_gat_fused_matches_unfused_and_oracle(pgl, H, D):
     alpha = R.np_edge_softmax(edges, n, alpha).reshape(-1, H, 1)
     want = R.np_send_ue_recv(f, alpha, edges[:, 0], edges[:, 1], "mul", "sum")
     close(host(out), want, scale=np.abs(want).max())
+    # positive-part statistics (what the backward turns into d a_dst): the same sums restricted to edges with pre > 0
+    pos = (R.np_send_uv(a_s, a_d, edges[:, 0], edges[:, 1], "add") > 0).astype(np.float32).reshape(-1, H, 1)
+    close(host(out_pos), R.np_send_ue_recv(f, alpha * pos, edges[:, 0], edges[:, 1], "mul", "sum"), scale=np.abs(want).max())
+    want_sp = R.np_send_ue_recv(np.ones((n, H, 1), np.float32), alpha * pos, edges[:, 0], edges[:, 1], "mul", "sum").reshape(n, H)
+    close(host(s_pos), want_sp, scale=1.0)
     # unfused engine path
     al = torch.nn.functional.leaky_relu(g.send_uv(dev(a_s), dev(a_d), "add"), 0.2)
     al = pgl.nn.functional.edge_softmax(g, al).reshape(-1, H, 1)
@@ -1279,7 +1284,8 @@ def test_tall_linear_split_reduction_gradient(pgl):
 
 
 def test_gat_backward_variants_agree(pgl):
-    """d a_dst from the second (dst-sorted) walk == segment sum of the d pre_e buffer emitted by the src-sorted walk."""
+    """Three ways to d a_dst agree (with attention dropout): the per-node formula over the forward's positive-part statistics
+    (round-2 default), the segment sum of the d pre_e buffer emitted by the src-sorted walk, and the second (dst-sorted) walk."""
     n, e, H, D = 3000, 50000, 8, 16
     edges, rng = rand_graph(n, e, 321, hub=8000)
     g = pgl.Graph(edges=edges, num_nodes=n).tensor()
@@ -1287,17 +1293,18 @@ def test_gat_backward_variants_agree(pgl):
     a_s = dev(rng.standard_normal((n, H)).astype(np.float32)); a_d = dev(rng.standard_normal((n, H)).astype(np.float32))
     ct = dev(rng.standard_normal((n, H, D)).astype(np.float32))
     grads = []
-    keep = pgl.ops._GAT_BWD_EDGE_BUFFER
+    keep = (pgl.ops._GAT_BWD_EDGE_BUFFER, pgl.ops._GAT_POS_STATS)
     try:
-        for variant in (True, False):
-            pgl.ops._GAT_BWD_EDGE_BUFFER = variant
+        for pos, variant in ((True, True), (False, True), (False, False)):
+            pgl.ops._GAT_POS_STATS, pgl.ops._GAT_BWD_EDGE_BUFFER = pos, variant
             x, s, d = (t.clone().requires_grad_(True) for t in (f, a_s, a_d))
             (g.gat_aggregate(x, s, d, 0.2, 0.3, 1234) * ct).sum().backward()
             grads.append([host(t.grad) for t in (x, s, d)])
     finally:
-        pgl.ops._GAT_BWD_EDGE_BUFFER = keep
-    for a, b in zip(*grads):
-        close(a, b, scale=np.abs(b).max(), rtol=2e-5)
+        pgl.ops._GAT_BWD_EDGE_BUFFER, pgl.ops._GAT_POS_STATS = keep
+    for other in grads[1:]:
+        for a, b in zip(grads[0], other):
+            close(a, b, scale=np.abs(b).max(), rtol=2e-5)
 
 
 @pytest.mark.parametrize("H,D", [(4, 8), (8, 16), (2, 32), (3, 5)])
