@@ -587,7 +587,13 @@ def test_gat_fused_matches_unfused_and_oracle(pgl, H, D):
     want_max = R.np_segment(logits[np.argsort(edges[:, 1], kind="stable")], np.sort(edges[:, 1]), "max")
     assert np.array_equal(host(mx)[has], want_max[np.unique(edges[:, 1])][:, :]) or np.allclose(host(mx)[has], want_max[np.unique(edges[:, 1])])
     assert (host(out)[~has] == 0).all() and (host(sm)[~has] == 0).all()
-    assert torch.equal(out, pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2))   # reproducible
+    # bit-reproducible run to run, in both forms (inference, and training = with the statistics outputs: a different kernel
+    # instantiation whose fused multiply-adds may contract differently, so the two forms agree to rounding, not to the bit)
+    inf1 = pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2)
+    assert torch.equal(inf1, pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2))
+    again = pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2, return_stats=True)
+    assert all(torch.equal(a, b) for a, b in zip((out, mx, sm, out_pos, s_pos), again))
+    close(host(inf1), host(out), scale=float(out.abs().max()), rtol=1e-6)
 
 
 def test_gatconv_eval_uses_fused_path_and_matches_training_path(pgl):
