@@ -95,8 +95,8 @@ __device__ __forceinline__ float drop_factor(unsigned seed, int eid, int head, f
 // l'_e = 1 where pre_e > 0 and slope elsewhere -- a per-(node, head) formula evaluated in the pack kernel.  It replaces the
 // [E,H] d pre buffer of round 1 (0.64 GB written by the src-sorted walk, gathered back through a permutation by a 0.51 ms
 // segment sum) by one more [N, H*D] row written per destination in the forward.
-template <int VEC, int MODE, bool DROP, bool POS>
-__device__ __forceinline__ void gat_flat_body(const GatParams& p) {
+template <int VEC, int MODE, bool DROP, bool POS = false>
+__global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     constexpr int U = 4;
     constexpr int PW = MODE == 0 ? (POS ? 5 : 3) : MODE == 2 ? 2 : 1;   // floats per column in a partial
     constexpr bool ATT = MODE >= 2;                     // accumulates the attention-score gradient of the row node
@@ -235,9 +235,9 @@ __device__ __forceinline__ void gat_flat_body(const GatParams& p) {
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[k] = acc[k] * sc + w * xv.v[k];
             if constexpr (POS) {
-                const bool ps = l > 0.f;                    // pre > 0  <=>  leaky(pre) > 0 (slope > 0): `pre` need not stay live
-                sp = sp * sc + (ps ? pe : 0.f);
-                const float wp = ps ? w : 0.f;
+                const float pp = pre > 0.f ? 1.f : 0.f;
+                sp = sp * sc + pe * pp;
+                const float wp = w * pp;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) accp[k] = accp[k] * sc + wp * xv.v[k];
             }
@@ -411,17 +411,6 @@ __device__ __forceinline__ void gat_flat_body(const GatParams& p) {
     if (head_open) store_partial(true);
     else if (tail_open) store_partial(false);
     else store_final(cur);
-}
-
-template <int VEC, int MODE, bool DROP, bool POS = false>
-__global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) { gat_flat_body<VEC, MODE, DROP, POS>(p); }
-
-// The training forward (POS: two more accumulators per lane) lands at 82 VGPRs = 5 waves / SIMD where the inference forward
-// runs 7 (68 VGPRs), and the walk is latency-bound: 1.44 -> 1.83 ms.  Asking for 7 waves makes the register allocator
-// rematerialise addresses instead of holding them.
-template <int VEC, bool DROP>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8))) void gat_fwd_pos_kernel(GatParams p) {
-    gat_flat_body<VEC, 0, DROP, true>(p);
 }
 
 // merges the partials of the rows longer than a chunk (only those are split), from the work list
@@ -808,12 +797,7 @@ static int32_t launch_gat_pos(GatParams p, hipStream_t st) {
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
-    if constexpr (POS && VEC <= 2) {                               // (VEC = 4 does not fit 72 registers without spilling)
-        if (p.drop_p > 0.f)
-            hipLaunchKernelGGL((gat_fwd_pos_kernel<VEC, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-        else
-            hipLaunchKernelGGL((gat_fwd_pos_kernel<VEC, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-    } else if (p.drop_p > 0.f)
+    if (p.drop_p > 0.f)
         hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, true, POS>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     else
         hipLaunchKernelGGL((gat_flat_kernel<VEC, MODE, false, POS>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
