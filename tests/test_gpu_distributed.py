@@ -225,3 +225,25 @@ def test_distgraph_every_method_forward_backward_vs_single_gpu(world, method):
     assert sum(s["local_edges"] for s in stats) == 40000
     assert all(s["recv_rows"] <= s["pull_only_recv_rows"] for s in stats)
     assert sum(s["pushed_pairs"] for s in stats) > 0                  # the heavy destinations make some pairs push
+
+
+@pytest.mark.parametrize("model", ["sage", "gcn", "gat"])
+def test_distributed_full_batch_training_example_matches_one_gpu(model):
+    """examples/train_dist_fullbatch.py (BASELINE config 3's flow: METIS partition, halo exchange forward and backward, layers on
+    a DistGraph, parameter gradients all-reduced) launched with 2 ranks through torch.distributed.run reproduces the loss
+    trajectory of the same script on one GPU."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "examples", "train_dist_fullbatch.py")
+    args = ["--model", model, "--scale", "12", "--edges", "40000", "--dim", "32", "--hidden", "64", "--classes", "7", "--epochs", "6"]
+
+    def losses(cmd, env):
+        r = subprocess.run(cmd + [script] + args, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        line = [l for l in r.stdout.splitlines() if l.startswith("LOSSES")][-1]
+        return [float(v) for v in line.split()[1:]]
+    one = losses([sys.executable], dict(os.environ))
+    two = losses([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port())], dict(os.environ, PGLAMD_DRYRUN="1"))
+    assert one[-1] < one[0]
+    np.testing.assert_allclose(two, one, rtol=2e-4)
