@@ -448,6 +448,10 @@ class DistGraph(object):
                 best = (float(cost), m, plan, xplan)
         dg = cls(best[2], device=edges.device, group=group, backend=backend, exchange_plan=best[3])
         dg.method = "given" if given else best[1]
+        if dg.method == "metis" and world > 1:                       # say what actually ran (same answer on every rank)
+            from . import partition as _pt
+            if os.environ.get("PGLAMD_PARTITIONER", "metis") == "kway" or not ops.metis_available():
+                dg.method = "kway (METIS helper library absent)"
         return dg
 
     @classmethod
