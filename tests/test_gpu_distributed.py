@@ -165,6 +165,14 @@ def _api_worker(rank, world, method):
         both(lambda t: g.send_recv(t, op), lambda t: dg.send_recv(t, op), [x], what="send_recv " + op)
         with torch.no_grad():                                         # the overlapped forward-only flows
             _close(dg.send_recv(dg.take_owned(x), op), g.send_recv(x, op)[own], 2e-5, "no-grad " + op)
+    # fp16 / bf16 feature storage (BASELINE config 4: fp16 features, halo rows travel in the storage dtype, fp32 accumulation)
+    for tdt, tol in ((torch.float16, 4e-3), (torch.bfloat16, 3e-2)):
+        xh = x.to(tdt)
+        for op in ("sum", "mean", "max"):
+            with torch.no_grad():
+                got = dg.send_recv(dg.take_owned(xh), op)
+            assert got.dtype == tdt
+            _close(got.float(), g.send_recv(xh, op)[own].float(), tol, "%s storage %s" % (tdt, op))
     y = mk(e, 1) + 3.0
     for mop, rop in (("mul", "sum"), ("add", "mean"), ("div", "sum"), ("mul", "max")):
         both(lambda t, yy: g.send_ue_recv(t, yy, mop, rop), lambda t, yy: dg.send_ue_recv(t, yy, mop, rop), [x], [y],
