@@ -39,6 +39,16 @@ int chunk_edges() {
     return k;
 }
 
+// Edges per chunk for an edge stream of E edges.  256 is the optimum at benchmark size (20 M edges: 78 k chunks, ten waves per
+// wave slot of the chip); a stream of a few million edges -- one rank's share of a partitioned graph, a sampled block -- cut
+// at 256 gives barely one wave per slot and the launch ends with the slowest wave.  Measured on rank 0 of the 8-way row
+// partition of the benchmark graph (2.6 M edges in three launches): 0.384 ms at 256, 0.335 at 128, 0.301 at 64; at 10 M edges
+// 0.851 / 0.834.  PGLAMD_CHUNK pins one value (stress tests).
+int chunk_edges_for(int64_t num_edges) {
+    if (getenv("PGLAMD_CHUNK")) return chunk_edges();
+    return num_edges >= 12000000 ? 256 : num_edges >= 5000000 ? 128 : 64;
+}
+
 // Optional in-library timing of the dominant kernel (bench.py's roofline leg): while enabled,
 // every flat-kernel launch is bracketed by a pair of HIP events on the launch stream.
 ProfileState& prof() { static ProfileState s; return s; }
@@ -143,7 +153,7 @@ using namespace pglamd;
 extern "C" size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t dout, int32_t dtype) {
     size_t es = dtype_size(dtype);
     if (es == 0 || num_edges <= 0) return 256;
-    int64_t k = chunk_edges();
+    int64_t k = chunk_edges_for(num_edges);
     if ((int64_t)(dout * (int64_t)es) <= group_row_bytes()) k = std::min<int64_t>(k, group_chunk_edges(16));   // grouped kernel: shorter chunks
     const int64_t n_chunks = ceil_div(num_edges, k);
     const int64_t max_cols = 1024;                      // widest tile any (VEC, NT) pair covers

@@ -101,6 +101,7 @@ ProfileState& prof();      // defined once, in aggregate.hip
 
 // aggregate.hip: edges per chunk (256; PGLAMD_CHUNK overrides, used by the stress tests)
 int chunk_edges();
+int chunk_edges_for(int64_t num_edges);     // size-aware default (aggregate.hip)
 int narrow_chunk_edges();
 // aggregate.hip: combines the T[a] / H[c] partials the edge kernels leave for rows longer than a chunk
 // (tile_cols <= 64 columns, one column per lane).

@@ -779,7 +779,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         return fail(PGLAMD_E_ARG, "src_scale/dst_scale need a floating dtype and sum/mean");
 
     if (fast) {
-        const int K = chunk_edges();
+        const int K = chunk_edges_for(E);
         p.chunk = K;
         p.n_chunks = (int)ceil_div(E, K);
         const int max_cols = kWave * vec * max_tiles<T>(vec);
