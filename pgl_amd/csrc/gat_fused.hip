@@ -780,14 +780,18 @@ __global__ __launch_bounds__(kBlock) void gat_pack_kernel(const float* __restric
     }
 }
 
-static int gat_chunk_edges() {
-    static int k = [] {
+// edges per chunk: 256 at benchmark size, shorter for small edge streams so that the launch still fills the chip (same rule and
+// measurements as chunk_edges_for in aggregate.hip); PGLAMD_CHUNK pins one value (stress tests)
+static int gat_chunk_edges(int64_t num_edges) {
+    static const int pinned = [] {
         const char* s = getenv("PGLAMD_CHUNK");
-        int v = s ? atoi(s) : 256;
+        if (!s) return 0;
+        int v = atoi(s);
         if (v < 8) v = 8;
         return v / 8 * 8;
     }();
-    return k;
+    if (pinned) return pinned;
+    return num_edges >= 12000000 ? 256 : num_edges >= 5000000 ? 128 : 64;
 }
 
 template <int VEC, int MODE, bool POS>
@@ -846,7 +850,7 @@ using namespace pglamd;
 
 extern "C" size_t pglamd_gat_aggregate_workspace_bytes(int64_t num_edges, int64_t heads, int64_t head_dim) {
     if (num_edges <= 0) return 256;
-    const int64_t n_chunks = ceil_div(num_edges, gat_chunk_edges());
+    const int64_t n_chunks = ceil_div(num_edges, gat_chunk_edges(num_edges));
     return 2 * align_up((size_t)n_chunks * 5 * heads * head_dim * sizeof(float), 256) +
            2 * align_up((size_t)(n_chunks + 64) * sizeof(int), 256) + 256;
 }
@@ -889,7 +893,7 @@ extern "C" int32_t pglamd_gat_aggregate(const float* feature, const float* attn_
     p.out_pos = out_pos; p.sum_pos = sum_pos;
     p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
     p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)num_edges;
-    p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.chunk = gat_chunk_edges(num_edges); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
     p.d = (int)d; p.H = (int)heads; p.D = (int)head_dim; p.slope = negative_slope;
     p.drop_p = drop_p; p.drop_scale = 1.f / (1.f - drop_p); p.seed = seed;
     gat_setup_partials(p, workspace, out_pos ? 5 : 3);
@@ -961,7 +965,7 @@ extern "C" int32_t pglamd_gat_backward(const float* grad_out, const float* featu
     GatParams p{};
     p.H = (int)heads; p.D = (int)head_dim; p.d = (int)d; p.slope = negative_slope;
     p.drop_p = drop_p; p.drop_scale = 1.f / (1.f - drop_p); p.seed = seed;
-    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(num_edges); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
     p.packed = packed;
     p.out_rows = num_nodes; p.n_csr_rows = num_nodes;
     int32_t rc;
@@ -995,7 +999,7 @@ extern "C" int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, in
         return fail(PGLAMD_E_SHAPE, "sddmm: heads*head_dim = %lld needs one 64-lane tile and head_dim/VEC a power of two", (long long)(heads * head_dim));
     GatParams p{};
     p.H = (int)heads; p.D = (int)head_dim; p.d = (int)(heads * head_dim);
-    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(num_edges); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
     p.row = row; p.col = col; p.eid = eid; p.f = x_by_col; p.g = y_by_row; p.dpre = out;
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     p.n_blocks = (int)nb;
@@ -1009,7 +1013,7 @@ extern "C" int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, in
     return PGLAMD_OK;
 }
 
-extern "C" int64_t pglamd_add_score_chunks(int64_t num_edges) { return num_edges > 0 ? ceil_div(num_edges, gat_chunk_edges()) : 0; }
+extern "C" int64_t pglamd_add_score_chunks(int64_t num_edges) { return num_edges > 0 ? ceil_div(num_edges, gat_chunk_edges(num_edges)) : 0; }
 
 extern "C" int32_t pglamd_add_score(const float* x_by_col, const float* y_by_row, const float* w, int64_t heads, int64_t head_dim,
                                     float negative_slope, const int32_t* row, const int32_t* col, const int32_t* eid,
@@ -1023,7 +1027,7 @@ extern "C" int32_t pglamd_add_score(const float* x_by_col, const float* y_by_row
         return fail(PGLAMD_E_SHAPE, "add_score: heads*head_dim = %lld needs one 64-lane tile and head_dim/VEC a power of two", (long long)(heads * head_dim));
     GatParams p{};
     p.H = (int)heads; p.D = (int)head_dim; p.d = (int)(heads * head_dim); p.slope = negative_slope;
-    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(num_edges); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
     p.row = row; p.col = col; p.eid = eid; p.f = x_by_col; p.g = y_by_row; p.w = w; p.dpre = out;
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     p.n_blocks = (int)nb;
@@ -1061,7 +1065,7 @@ extern "C" int32_t pglamd_add_score_backward(const float* x_by_col, const float*
         return fail(PGLAMD_E_WORKSPACE, "add_score_backward: workspace too small");
     GatParams p{};
     p.H = (int)heads; p.D = (int)head_dim; p.d = (int)d; p.slope = negative_slope;
-    p.E = (int)num_edges; p.chunk = gat_chunk_edges(); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
+    p.E = (int)num_edges; p.chunk = gat_chunk_edges(num_edges); p.n_chunks = (int)ceil_div(num_edges, p.chunk);
     p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
     p.x = x_by_col; p.row_vec = y_by_row; p.w = w; p.ge = grad_score; p.out = grad_rows; p.part_w = grad_w_partials;
     p.out_rows = num_rows; p.n_csr_rows = num_rows;
