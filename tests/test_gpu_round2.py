@@ -316,3 +316,31 @@ def test_khop_layers_with_caller_norm_zero_or_trainable_take_the_safe_path(pgl):
     nt = pgl.nn.functional.degree_norm(g).clone().requires_grad_(True)
     layer(g, x, nt).sum().backward()
     assert nt.grad is not None and float(nt.grad.abs().sum()) > 0
+
+
+def test_200M_edge_shard_fp16_properties(pgl):
+    """Maximum size of the BASELINE list on one GPU (one rank's share of configs[4]: 2^24 rows, 200 M edges, d = 128, fp16 storage /
+    fp32 accumulation): int32 edge positions, chunking and the fix-up path at 10x the headline size.  Size-independent properties
+    plus sampled rows (hubs included) against an fp64 recomputation."""
+    from pgl_amd.utils.rmat import rmat_edges
+    scale, E, d = 24, 200_000_000, 128
+    N = 1 << scale
+    edges = rmat_edges(scale, E, seed=42, device="cuda")
+    g = pgl.Graph(edges=edges, num_nodes=N)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    x = torch.randn(N, d, generator=gen, device="cuda").half()
+    out = g.send_recv(x, "sum")
+    assert out.dtype == torch.float16 and torch.equal(out, g.send_recv(x, "sum"))          # bit-reproducible
+    indeg = torch.bincount(edges[:, 1], minlength=N)
+    assert float(out[indeg == 0].abs().max()) == 0.0                                        # rows without messages are exactly zero
+    outdeg = torch.bincount(edges[:, 0], minlength=N).double()
+    lhs = out.double().sum(0); rhs = (outdeg[:, None] * x.double()).sum(0)
+    assert float(((lhs - rhs).abs() / rhs.abs().clamp(min=1.0)).max()) < 2e-3              # fp16 outputs summed over 16 M rows
+    # sampled destination rows, the ten largest hubs included, recomputed in fp64 from the raw edge list
+    rows = torch.cat([torch.topk(indeg, 10).indices, torch.randint(0, N, (2000,), generator=gen, device="cuda")]).unique()
+    sel = torch.isin(edges[:, 1], rows)
+    sub = edges[sel]
+    want = torch.zeros(N, d, dtype=torch.float64, device="cuda").index_add_(0, sub[:, 1], x[sub[:, 0]].double())[rows]
+    got = out[rows].double()
+    tol = 2.0 ** -10 * want.abs() + 1e-2                                                    # fp16 rounding of the stored result
+    assert bool(((got - want).abs() <= tol).all())
