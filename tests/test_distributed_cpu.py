@@ -479,3 +479,41 @@ def test_c_abi_halo_plan_is_identical_to_the_python_plan(world):
         ops.host_halo_plan(edges, n, part + world, 0, world)            # part ids out of range
     e0 = ops.host_halo_plan(np.zeros((0, 2), np.int64), 4, np.array([0, 1, 0, 1]), 1, 2)
     assert e0["own_global"].tolist() == [1, 3] and e0["edge_global"].size == 0
+
+
+def test_degenerate_partitions_empty_ranks_and_no_cut_edges():
+    """Edge cases of the plan: a rank that owns nothing, a rank whose rows need no halo, a graph without edges."""
+    from pgl_amd.distributed import HaloPlan, DistGraph
+    B = TorchBackend()
+    edges, x = _graph(n=120, e=900, seed=21, d=5)
+    n = x.shape[0]
+    xt = torch.from_numpy(x)
+    want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "sum")
+    # every node on rank 1 of 3: ranks 0 and 2 own nothing, rank 1 has no halo at all
+    part = np.ones(n, np.int64)
+    for r in range(3):
+        dg = DistGraph(HaloPlan(torch.from_numpy(edges), n, part, r, 3), backend=B)
+        out = dg.send_recv(dg.take_owned(xt), "sum")
+        ext = dg.halo_extend(dg.take_owned(xt))
+        if r == 1:
+            assert dg.plan.n_own == n and dg.plan.n_halo == 0 and dg.xplan.n_send == 0
+            np.testing.assert_allclose(out.numpy()[np.argsort(dg.plan.own_global.numpy())], want, rtol=1e-5, atol=1e-5)
+            assert ext.shape[0] == n
+        else:
+            assert dg.plan.n_own == 0 and out.shape == (0, x.shape[1]) and ext.shape[0] == 0 and dg.plan.local_edges == 0
+        for op in ("max", "mean"):
+            assert dg.send_recv(dg.take_owned(xt), op).shape[0] == dg.plan.n_own
+    # two components, one per rank: both ranks own rows, nobody needs a halo row
+    half = n // 2
+    e2 = np.concatenate([edges[(edges[:, 0] < half) & (edges[:, 1] < half)], edges[(edges[:, 0] >= half) & (edges[:, 1] >= half)]])
+    part2 = (np.arange(n) >= half).astype(np.int64)
+    want2 = R.c_send_u_recv(x, e2[:, 0], e2[:, 1], "sum")
+    for r in range(2):
+        p = HaloPlan(torch.from_numpy(e2), n, part2, r, 2)
+        assert p.n_halo == 0 and sum(p.recv_splits) == 0 and sum(p.send_splits) == 0
+        dg = DistGraph(p, backend=B)
+        np.testing.assert_allclose(dg.send_recv(dg.take_owned(xt), "sum").numpy(), want2[p.own_global.numpy()], rtol=1e-5, atol=1e-5)
+    # no edges at all
+    p0 = HaloPlan(torch.zeros((0, 2), dtype=torch.int64), 6, np.array([0, 1, 0, 1, 0, 1]), 0, 2)
+    dg0 = DistGraph(p0, backend=B)
+    assert float(dg0.send_recv(torch.ones(3, 4), "sum").abs().sum()) == 0.0 and dg0.indegree().tolist() == [0, 0, 0]

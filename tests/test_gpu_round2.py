@@ -344,3 +344,28 @@ def test_200M_edge_shard_fp16_properties(pgl):
     got = out[rows].double()
     tol = 2.0 ** -10 * want.abs() + 1e-2                                                    # fp16 rounding of the stored result
     assert bool(((got - want).abs() <= tol).all())
+
+
+def test_distgraph_degenerate_partitions_on_the_engine(pgl):
+    """A rank that owns nothing / a rank without halo rows / max-min with an empty boundary: the plan's empty index sets must go
+    through csr_build and the kernels (no process group: the exchange is a no-op)."""
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    rng = np.random.default_rng(8)
+    n, e, d = 500, 4000, 32
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    part = np.ones(n, np.int64)                                    # everything on rank 1 of 3
+    for r in range(3):
+        dg = DistGraph(HaloPlan(dev(edges), n, part, r, 3))
+        xo = dg.take_owned(x)
+        for op in ("sum", "mean", "max", "min"):
+            out = dg.send_recv(xo, op)
+            assert out.shape[0] == dg.plan.n_own
+            if r == 1:
+                want = g.send_recv(x, op)[dg.plan.own_global]
+                np.testing.assert_allclose(host(out), host(want), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+        xr = xo.clone().requires_grad_(True)
+        dg.send_recv(xr, "sum").sum().backward()
+        assert xr.grad.shape == xo.shape
+        assert dg.halo_extend(xo).shape[0] == dg.plan.n_own
