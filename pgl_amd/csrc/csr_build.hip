@@ -136,7 +136,7 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
                                     size_t workspace_bytes, void* stream) {
     if (num_edges < 0 || num_nodes < 0 || num_edges >= INT32_MAX || num_nodes >= INT32_MAX)
         return fail(PGLAMD_E_RANGE, "csr_build: E=%lld N=%lld beyond the int32 engine range", (long long)num_edges, (long long)num_nodes);
-    if (!indptr || !degree || (num_edges > 0 && (!u || !v))) return fail(PGLAMD_E_ARG, "csr_build: NULL pointer");
+    if (!indptr || (num_nodes > 0 && !degree) || (num_edges > 0 && (!u || !v))) return fail(PGLAMD_E_ARG, "csr_build: NULL pointer");   // (an empty degree array has no address)
     if (!workspace || workspace_bytes < pglamd_csr_build_workspace_bytes(num_edges, num_nodes))
         return fail(PGLAMD_E_WORKSPACE, "csr_build: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
