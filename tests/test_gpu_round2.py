@@ -369,3 +369,11 @@ def test_distgraph_degenerate_partitions_on_the_engine(pgl):
         dg.send_recv(xr, "sum").sum().backward()
         assert xr.grad.shape == xo.shape
         assert dg.halo_extend(xo).shape[0] == dg.plan.n_own
+        # the generic ops (local graph over the extended node space) on an empty / halo-free share
+        ye = dg.take_edges(dev(rng.standard_normal((e, 1)).astype(np.float32)))
+        assert ye.shape[0] == dg.plan.local_edges
+        assert dg.send_ue_recv(xo.clone().requires_grad_(True), ye, "mul", "sum").shape[0] == dg.plan.n_own
+        assert dg.send_uv(xo, xo, "add").shape[0] == dg.plan.local_edges
+        f = xo.reshape(-1, 4, 8)
+        a = xo[:, :4].contiguous()
+        assert dg.gat_aggregate(f, a, a, 0.2).shape == f.shape
