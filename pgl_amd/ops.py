@@ -348,6 +348,8 @@ def gat_aggregate(feature, attn_src, attn_dst, csr, negative_slope=0.2, out_size
             # positive-part statistics: what the backward needs to form d a_dst per node instead of per edge
             out_pos = torch.empty((M, H, D), dtype=torch.float32, device=feature.device)
             s_pos = torch.empty((M, H), dtype=torch.float32, device=feature.device)
+    if M == 0:                                             # an empty share of a partitioned graph: nothing to launch
+        return (out, mx, sm, out_pos, s_pos) if return_stats else out
     L = _ffi.lib()
     ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), feature.device)
     with torch.cuda.device(feature.device):
@@ -375,6 +377,8 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     use_pre = _GAT_BWD_EDGE_BUFFER and out_pos is None
     g_dst = None if use_pre else torch.empty((n, H), dtype=torch.float32, device=feature.device)
     gpre = torch.empty((csr_dst.num_edges, H), dtype=torch.float32, device=feature.device) if use_pre else None
+    if n == 0:
+        return gf, g_src, (g_dst if g_dst is not None else torch.empty((0, H), dtype=torch.float32, device=feature.device))
     L = _ffi.lib()
     ws = _ws(L.pglamd_gat_backward_workspace_bytes(csr_dst.num_edges, n, H, D), feature.device)
     with torch.cuda.device(feature.device):
