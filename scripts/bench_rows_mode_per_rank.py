@@ -12,8 +12,21 @@ from pgl_amd.utils.rmat import rmat_edges
 dev = torch.device("cuda:0")
 scale, E, d = 20, 20_000_000, 128
 N = 1 << scale
-edges = rmat_edges(scale, E, seed=42, device=dev)
 gen = torch.Generator(device=dev); gen.manual_seed(7)
+if os.environ.get("GRAPH", "rmat") == "community":
+    # a graph a partitioner CAN cut (what configs 3/4 look like): 256 communities of 4096 nodes, 90 % of the edges stay inside
+    # their source's community, node ids randomly permuted so that nothing is contiguous by accident
+    C = 256
+    src = torch.randint(0, N, (E,), generator=gen, device=dev)
+    inside = torch.rand(E, generator=gen, device=dev) < 0.9
+    dst = torch.where(inside, (src // (N // C)) * (N // C) + torch.randint(0, N // C, (E,), generator=gen, device=dev),
+                      torch.randint(0, N, (E,), generator=gen, device=dev))
+    perm = torch.randperm(N, generator=gen, device=dev)
+    edges = torch.stack([perm[src], perm[dst]], 1)
+    print("graph: 256 planted communities, 90 % intra-community edges, ids permuted")
+else:
+    edges = rmat_edges(scale, E, seed=42, device=dev)
+    print("graph: RMAT scale 20 (the benchmark graph)")
 x = torch.randn(N, d, generator=gen, device=dev)
 g = pgl.Graph(edges=edges, num_nodes=N); g.adj_dst_index
 def t(fn, it=20, warm=5):
@@ -28,6 +41,7 @@ LINK_GBS = 153.0
 for P in (int(a) for a in (sys.argv[1:] or ["2", "4", "8"])):
     t0 = time.time()
     part = DistGraph.partition(edges, N, P, "metis", rank=0)
+    print("   edge cut %.3f" % float((part[edges[:, 0].cpu()] != part[edges[:, 1].cpu()]).float().mean()))
     pull_c, push_c = HaloPlan.pair_counts(edges, N, part, P)
     choice = HaloPlan.choose_push(pull_c, push_c)
     tp = time.time() - t0
