@@ -147,6 +147,30 @@ int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t
                          const float* src_scale, const float* dst_scale, int32_t accumulate, void* out,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* K1x  pglamd_aggregate with what a ROW-PARTITIONED graph needs (pgl_amd/distributed.py; the reference's multi-GPU graph,
+ * pgl/graph.py:1475-1553, all-reduces [N, d] partial sums instead).  Every argument shared with pglamd_aggregate means the same;
+ * there is no src_scale (a caller scales owned rows before they travel).  The additions:
+ *   x2, x_split     second source table: a column id c >= x_split reads row (c - x_split) of x2, c < x_split reads row c of x.
+ *                   x = the rows this rank owns, x2 = the rows received from its peers: the boundary rows of a partition
+ *                   aggregate straight from the two buffers, nothing is copied into an [owned | halo] matrix first.
+ *                   x2 NULL: one table, as pglamd_aggregate.  Same dtype and row length (dx == dout) for both.
+ *   zero_indptr     [n_csr_rows+1] or NULL (= indptr).  With accumulate 0 a row r is zero-filled iff
+ *                   zero_indptr[r] == zero_indptr[r+1]; rows that are empty in THIS index but not in zero_indptr are left
+ *                   untouched.  The interior launch of a partition passes the indptr of ALL local edges: it writes interior
+ *                   rows and truly empty rows, the boundary launch (accumulate 2) writes the rest -- every output row is
+ *                   written exactly once across the two launches.
+ *   max_row_edges   longest row of the index, or 0 when unknown.  No row of <= chunk edges is ever split between waves, so a
+ *                   launcher that sees max_row_edges <= its chunk skips the counter reset and both fix-up launches
+ *                   (pack indices of a halo plan: every row has one edge).
+ * ---------------------------------------------------------------------------------------------- */
+int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx,
+                             const void* y, int64_t dy, const int32_t* eid, const int32_t* row,
+                             const int32_t* col, const int64_t* indptr, const int64_t* zero_indptr,
+                             int64_t max_row_edges, int64_t num_edges, int64_t n_csr_rows,
+                             int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
+                             const float* dst_scale, int32_t accumulate, void* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* Measurement hook for the dominant kernel (bench.py roofline leg): between profile_begin and
  * profile_end every launch of the flat aggregation kernel is bracketed by HIP events on its own
  * launch stream; profile_end synchronises them and returns the summed kernel time (host out). */
@@ -311,6 +335,12 @@ int32_t pglamd_gather_rows(const void* x, int64_t d, int32_t elem_bytes, const v
                            int32_t index_i64, int64_t n_index, void* out, void* stream);
 int32_t pglamd_scatter_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index,
                             int32_t index_i64, int64_t n_index, void* out, void* stream);
+
+/* K6w  row gather with a dtype change -- the wire pack / unpack of the halo exchange (16-bit wire for fp32 features):
+ *   out[i, :] = cast(x[index[i], :]),  index int32 [n_index] or NULL (identity: a row-wise conversion of n_index rows).
+ *   (x_dtype, out_dtype): F32 -> F16 | BF16 | F32, F16 | BF16 -> F32.  Stands where the reference would paddle.gather + cast. */
+int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64_t d, const int32_t* index,
+                                int64_t n_index, void* out, int32_t out_dtype, void* stream);
 
 /* K9  degree_norm.  Replaces cast/clip/pow in GF.degree_norm (pgl/nn/functional/graph_op.py:46-55):
  *     out[i] = max((float)degree[i], 1) ** -0.5      out F32 (out_f64 = 0) or F64 (= 1)           */

@@ -137,8 +137,6 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 }
 
 // float here; the other storage types are instantiated in aggregate_f64.hip / aggregate_more.hip / aggregate_half.hip
-#define PGLAMD_AGG_ARGS const void*, int64_t, const void*, int64_t, const int32_t*, const int32_t*, const int32_t*, const int64_t*, \
-                        int64_t, int64_t, int64_t, int64_t, int32_t, int32_t, const float*, const float*, int, void*, void*, size_t, hipStream_t
 template int32_t aggregate_typed<float>(PGLAMD_AGG_ARGS);
 extern template int32_t aggregate_typed<double>(PGLAMD_AGG_ARGS);
 extern template int32_t aggregate_typed<int32_t>(PGLAMD_AGG_ARGS);
@@ -162,13 +160,11 @@ extern "C" size_t pglamd_aggregate_workspace_bytes(int64_t num_edges, int64_t do
     return 2 * align_up((size_t)n_chunks * tile * es, 256) + 2 * align_up((size_t)(n_chunks + 64) * sizeof(int), 256) + 256;
 }
 
-extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t dx, const void* y,
-                                    int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
-                                    const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
-                                    int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
-                                    const float* src_scale, const float* dst_scale, int32_t accumulate, void* out,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-    (void)n_x_rows;
+static int32_t aggregate_entry(const void* x, int32_t dtype, int64_t dx, const void* y, int64_t dy, const int32_t* eid,
+                               const int32_t* row, const int32_t* col, const int64_t* indptr, int64_t num_edges,
+                               int64_t n_csr_rows, int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
+                               const float* src_scale, const float* dst_scale, int32_t accumulate, void* out, void* workspace,
+                               size_t workspace_bytes, const AggExtra& ex, void* stream) {
     if (!out || !indptr || (num_edges > 0 && (!x || !row))) return fail(PGLAMD_E_ARG, "aggregate: NULL pointer");
     if (num_edges < 0 || num_edges > kMaxEdges || n_csr_rows >= INT32_MAX || out_rows >= INT32_MAX)
         return fail(PGLAMD_E_RANGE, "aggregate: sizes beyond int32 engine range");
@@ -177,9 +173,10 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
                     (long long)dx, (long long)dy, (long long)dout);
     if (reduce_op < 0 || reduce_op > 3 || (y && (message_op < 0 || message_op > 3)))
         return fail(PGLAMD_E_ARG, "aggregate: bad op enum");
+    if (ex.x2 && (ex.x_split < 0 || ex.x_split >= INT32_MAX)) return fail(PGLAMD_E_RANGE, "aggregate_ext: x_split out of range");
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define CALL(T) aggregate_typed<T>(x, dx, y, dy, eid, row, col, indptr, num_edges, n_csr_rows, out_rows, dout, \
-                                   message_op, reduce_op, src_scale, dst_scale, accumulate, out, workspace, workspace_bytes, st)
+                                   message_op, reduce_op, src_scale, dst_scale, accumulate, out, workspace, workspace_bytes, ex, st)
     switch (dtype) {
         case PGLAMD_F32: return CALL(float);
         case PGLAMD_F64: return CALL(double);
@@ -190,6 +187,29 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
         default: return fail(PGLAMD_E_DTYPE, "aggregate: dtype %d not supported", dtype);
     }
 #undef CALL
+}
+
+extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t dx, const void* y,
+                                    int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
+                                    const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
+                                    int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
+                                    const float* src_scale, const float* dst_scale, int32_t accumulate, void* out,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    (void)n_x_rows;
+    return aggregate_entry(x, dtype, dx, y, dy, eid, row, col, indptr, num_edges, n_csr_rows, out_rows, dout, message_op, reduce_op,
+                           src_scale, dst_scale, accumulate, out, workspace, workspace_bytes, AggExtra{}, stream);
+}
+
+extern "C" int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx, const void* y,
+                                        int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
+                                        const int64_t* indptr, const int64_t* zero_indptr, int64_t max_row_edges,
+                                        int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, int64_t dout,
+                                        int32_t message_op, int32_t reduce_op, const float* dst_scale, int32_t accumulate,
+                                        void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    AggExtra ex;
+    ex.x2 = x2; ex.x_split = x_split; ex.zero_indptr = zero_indptr; ex.max_row_edges = max_row_edges;
+    return aggregate_entry(x, dtype, dx, y, dy, eid, row, col, indptr, num_edges, n_csr_rows, out_rows, dout, message_op, reduce_op,
+                           nullptr, dst_scale, accumulate, out, workspace, workspace_bytes, ex, stream);
 }
 
 extern "C" int32_t pglamd_profile_begin(void) {

@@ -14,6 +14,8 @@ namespace pglamd {
 
 struct AggParams {
     const void* x; const void* y; void* out;
+    const void* x2;                       // second source table, ALREADY rebased: source row c >= x_split is read at x2 + c * ldx
+    const int64_t* zero_indptr;           // rows r with zero_indptr[r] == zero_indptr[r+1] are the ones the zero-fill role clears
     const int* row; const int* col; const int* eid;
     const int64_t* indptr;
     const float* src_scale; const float* dst_scale;
@@ -32,7 +34,15 @@ struct AggParams {
     int accumulate;                       // 0: write every row; 1: combine rows that receive edges with their old contents; 2: overwrite only those rows
     int align;                            // 1: never split rows of <= chunk edges (chunk_cut)
     int narrow_vec;                       // aggregate_narrow: rows may be moved with (<=16-byte) vector loads / stores
+    int x_split;                          // INT32_MAX when there is no second table
+    int max_row_edges;                    // host-side hint: longest row of the index (0 = unknown).  Rows of <= chunk edges are never
+                                          // split (chunk_cut), so when it is <= chunk no partial exists and the fix-up launches are skipped
 };
+
+// true when this launch can leave split-row partials behind (=> the counter reset and the two fix-up launches are needed)
+inline bool needs_fixups(const AggParams& p) {
+    return p.n_chunks > 1 && !(p.align && p.max_row_edges > 0 && p.max_row_edges <= p.chunk);
+}
 
 template <typename T, int VEC> struct alignas(sizeof(T) * VEC) VecT { T v[VEC]; };
 
@@ -72,7 +82,7 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
     if (r0 >= p.out_rows) return;
     const int64_t r = r0 + lane;
     bool empty = false;
-    if (r < p.out_rows) empty = (r >= p.n_csr_rows) || (p.indptr[r] == p.indptr[r + 1]);
+    if (r < p.out_rows) empty = (r >= p.n_csr_rows) || (p.zero_indptr[r] == p.zero_indptr[r + 1]);
     unsigned long long m = __ballot(empty);
     T* out = static_cast<T*>(p.out) + p.j_base;
     while (m) {

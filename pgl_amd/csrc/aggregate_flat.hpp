@@ -45,6 +45,11 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     const cptr<int> eidp = as_const(p.eid);
     const T* __restrict__ x = static_cast<const T*>(p.x);
     const T* __restrict__ y = static_cast<const T*>(p.y);
+    // second source table (rows received from peers, pgl_amd.distributed): column ids >= x_split address it.  x2 arrives
+    // rebased by -x_split rows, so the address arithmetic is the same and the choice is one scalar select per edge.
+    const T* __restrict__ x2 = static_cast<const T*>(p.x2);
+    const int xs = p.x_split;
+    auto src_row = [&](int cc) -> const T* { return (cc < xs ? x : x2) + (int64_t)cc * p.ldx; };
     constexpr bool has_ss = SS;       // per-source scale compiled in only where asked for (keeps 16 SGPRs free otherwise)
     const bool is_max = p.is_max != 0;
 
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         if constexpr (has_ss) sv = sscale_v[cl];
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-            const T* xr = x + (int64_t)cc[i] * p.ldx;
+            const T* xr = src_row(cc[i]);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (act[t]) vx[i][t] = *reinterpret_cast<const V*>(xr + j0[t]);
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
 #pragma unroll
             for (int i = 0; i < UB; ++i) {
                 const int cc = __builtin_amdgcn_readlane(cv, i);
-                if (act[0]) vx[i][0] = *reinterpret_cast<const V*>(x + (int64_t)cc * p.ldx + j0[0]);
+                if (act[0]) vx[i][0] = *reinterpret_cast<const V*>(src_row(cc) + j0[0]);
             }
         };
         const int n_fullv = (e1 - e0) / UB;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         int cc = colp ? colp[e] : e;
         float s = has_ss ? scale_of(cc) : 1.f;
         V vx[NT], vy[NT];
-        const T* xr = x + (int64_t)cc * p.ldx;
+        const T* xr = src_row(cc);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (act[t]) vx[t] = *reinterpret_cast<const V*>(xr + j0[t]);
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(kBlock) void agg_generic_kernel(AggParams p, int gx
         A acc = A(0);
         for (int64_t q = s; q < t; ++q) {
             const int cc = p.col ? p.col[q] : (int)q;
-            A m = to_acc<T>(x[(int64_t)cc * p.ldx + j / gx]);
+            A m = to_acc<T>((cc < p.x_split ? x : static_cast<const T*>(p.x2))[(int64_t)cc * p.ldx + j / gx]);
             if (y) {
                 const int64_t yy = p.eid ? p.eid[q] : q;
                 m = apply_mop(m, to_acc<T>(y[yy * p.ldy + j / p.gy]), p.mop);
@@ -601,7 +606,8 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
-    if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
+    const bool fixups = needs_fixups(p);
+    if (fixups) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool profiling = prof().on.load(std::memory_order_relaxed);
     if (profiling) {
@@ -642,7 +648,7 @@ launched:
         std::lock_guard<std::mutex> lk(prof().mu);
         prof().ev.emplace_back(e0, e1);
     }
-    if (p.n_chunks > 1) {
+    if (fixups) {
         hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), dim3((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
         hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), dim3((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks)), dim3(kFixWaves * kWave), 0, st, p);
@@ -725,19 +731,39 @@ template <typename T> int max_vec() { return sizeof(T) == 2 ? 8 : sizeof(T) == 4
 // columns one launch covers: 64 lanes x VEC x NT(max)
 template <typename T> int max_tiles(int vec) { return (sizeof(T) == 2 && vec == 8) ? 2 : 4; }
 
+// What pglamd_aggregate_ext adds to pglamd_aggregate (include/pgl_amd.h): a second source table for column ids >= x_split
+// (x2 = NULL: none), the indptr that decides which rows the zero-fill clears (NULL: the launch's own), and the longest row of
+// the index as a hint (0 = unknown) that lets the launcher skip the split-row fix-up when no row can be split.
+struct AggExtra {
+    const void* x2 = nullptr; int64_t x_split = 0; const int64_t* zero_indptr = nullptr; int64_t max_row_edges = 0;
+};
+
+// argument list of aggregate_typed<T> for the explicit instantiations (aggregate*.hip)
+#define PGLAMD_AGG_ARGS const void*, int64_t, const void*, int64_t, const int32_t*, const int32_t*, const int32_t*, const int64_t*, \
+                        int64_t, int64_t, int64_t, int64_t, int32_t, int32_t, const float*, const float*, int, void*, void*, size_t, \
+                        const AggExtra&, hipStream_t
+
 template <typename T>
 int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, const int32_t* eid,
                                const int32_t* row, const int32_t* col, const int64_t* indptr, int64_t E,
                                int64_t n_csr_rows, int64_t out_rows, int64_t dout, int32_t mop, int32_t rop,
                                const float* src_scale, const float* dst_scale, int accumulate, void* out, void* ws,
-                               size_t ws_bytes, hipStream_t st) {
+                               size_t ws_bytes, const AggExtra& ex, hipStream_t st) {
     int32_t rc = PGLAMD_OK;
     if (accumulate && rop == PGLAMD_MEAN)
         return fail(PGLAMD_E_ARG, "aggregate: accumulate with MEAN is undefined (use SUM with dst_scale = 1/degree)");
-    if (E == 0) return accumulate ? PGLAMD_OK : zero_empty_rows(indptr, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
+    const int64_t* zip = ex.zero_indptr ? ex.zero_indptr : indptr;
+    if (E == 0) return accumulate ? PGLAMD_OK : zero_empty_rows(zip, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
 
     AggParams p{};
     p.x = x; p.y = y; p.out = out; p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
+    p.zero_indptr = zip;
+    // the second table is rebased by -x_split rows here, so that the kernels address both tables with the same column id
+    p.x2 = ex.x2 ? static_cast<const char*>(ex.x2) - ex.x_split * dx * (int64_t)sizeof(T) : x;
+    p.x_split = ex.x2 ? (int)ex.x_split : INT32_MAX;
+    p.max_row_edges = (int)std::min<int64_t>(ex.max_row_edges, INT32_MAX);
+    if (ex.x2 && (src_scale || dout != dx))
+        return fail(PGLAMD_E_ARG, "aggregate_ext: a second source table excludes src_scale and source-side broadcasting");
     p.src_scale = src_scale; p.dst_scale = dst_scale;
     p.ldx = dx; p.ldy = dy; p.ldo = dout; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)E;
     p.mop = mop; p.is_mean = rop == PGLAMD_MEAN; p.is_max = rop == PGLAMD_MAX; p.accumulate = accumulate;

@@ -80,6 +80,8 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
     const int j0 = gl * VEC;
     const bool act = j0 < p.tile_cols;
     const T* __restrict__ x = static_cast<const T*>(p.x) + p.j_base + j0;
+    const T* __restrict__ x2 = static_cast<const T*>(p.x2) + p.j_base + j0;     // second source table (see aggregate_flat.hpp)
+    const int xs = p.x_split;
 
     A acc[VEC];
     auto reset = [&]() {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
 #pragma unroll
             for (int i = 0; i < UB; ++i) {
                 const int cc = __shfl(cv[i / G], gbase + (i % G), kWave);
-                if (act && eb + i < e1) vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc * p.ldx);
+                if (act && eb + i < e1) vx[i] = *reinterpret_cast<const V*>((cc < xs ? x : x2) + (int64_t)cc * p.ldx);
             }
         }
     };
@@ -218,7 +220,7 @@ int32_t launch_group_one(AggParams p, hipStream_t st) {
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
-    if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
+    if (needs_fixups(p)) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool profiling = prof().on.load(std::memory_order_relaxed);
     if (profiling) {
@@ -258,7 +260,7 @@ int32_t launch_group_vec(AggParams p, int rcls, int32_t dtype, char* ws, size_t 
         p.long_list2 = reinterpret_cast<int*>(ws + 2 * half + lst);
         *handled = true;
         const int32_t rc = rcls == 0 ? launch_group_one<T, VEC, G, 0>(p, st) : launch_group_one<T, VEC, G, 1>(p, st);
-        if (rc != PGLAMD_OK || p.n_chunks <= 1) return rc;
+        if (rc != PGLAMD_OK || !needs_fixups(p)) return rc;
         return launch_fixup_cols(p, dtype, rcls, st);
     }
     return PGLAMD_OK;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
         if (p.accumulate || RCLS == 2) return;
         const int64_t r = ((int64_t)blockIdx.x - p.n_grid_chunks) * kBlock + threadIdx.x;
         if (r >= p.out_rows) return;
-        if (r < p.n_csr_rows && p.indptr[r] != p.indptr[r + 1]) return;
+        if (r < p.n_csr_rows && p.zero_indptr[r] != p.zero_indptr[r + 1]) return;
         T* dst = out + r * p.ldo;
         if (exact) {
 #pragma unroll
@@ -116,6 +116,8 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
     const int* __restrict__ colp = p.col;
     const int* __restrict__ eidp = p.eid;
     const T* __restrict__ x = static_cast<const T*>(p.x);
+    const T* __restrict__ x2 = static_cast<const T*>(p.x2);     // second source table (see aggregate_flat.hpp)
+    const int xs = p.x_split;
     const T* __restrict__ y = static_cast<const T*>(p.y);
     const float* __restrict__ sscale = p.src_scale;
 
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const T* xr = x + (int64_t)cc[b] * p.ldx;
+            const T* xr = (cc[b] < xs ? x : x2) + (int64_t)cc[b] * p.ldx;
             if (valid[b]) {
                 if (exact) {
 #pragma unroll
@@ -442,7 +444,7 @@ int32_t launch_one(AggParams p, int32_t dtype, hipStream_t st) {
     p.n_blocks = (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(p.out_rows, kBlock);
-    if (p.n_chunks > 1) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
+    if (needs_fixups(p)) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool profiling = prof().on.load(std::memory_order_relaxed);
     if (profiling) {
@@ -460,7 +462,7 @@ int32_t launch_one(AggParams p, int32_t dtype, hipStream_t st) {
         std::lock_guard<std::mutex> lk(prof().mu);
         prof().ev.emplace_back(ev0, ev1);
     }
-    if (p.n_chunks > 1) return launch_fixup_cols(p, dtype, RCLS, st);
+    if (needs_fixups(p)) return launch_fixup_cols(p, dtype, RCLS, st);
     return PGLAMD_OK;
 }
 
@@ -515,6 +517,7 @@ int32_t narrow_softmax_stats(const void* data, int32_t dtype, int64_t num_rows, 
     if (ws_bytes < narrow_softmax_workspace_bytes(num_rows, d, dtype, chunk)) return fail(PGLAMD_E_WORKSPACE, "softmax statistics: workspace too small");
     AggParams p{};
     p.x = data; p.out = stats; p.row = row32; p.col = perm32; p.indptr = seg_ptr;
+    p.x2 = data; p.x_split = INT32_MAX; p.zero_indptr = seg_ptr;
     p.ldx = d; p.ldo = 2 * d; p.out_rows = n_seg; p.n_csr_rows = n_seg; p.E = (int)num_rows;
     p.chunk = chunk; p.n_chunks = (int)ceil_div(num_rows, chunk); p.align = 1;
     p.tile_cols = (int)d; p.j_base = 0;

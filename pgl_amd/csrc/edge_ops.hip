@@ -301,6 +301,63 @@ extern "C" int32_t pglamd_gather_rows(const void* x, int64_t d, int32_t elem_byt
     return move_rows<false>(x, d, elem_bytes, index, index_i64, n_index, out, static_cast<hipStream_t>(stream));
 }
 
+// ------------------------------------------------------------------------------------------------
+// K6w  row gather with a dtype change: the wire pack / unpack of the halo exchange (pgl_amd.distributed, 16-bit wire for
+// fp32 features).  out[i, :] = cast(x[index[i], :])  (index NULL: identity = a plain row-wise conversion).
+// One thread moves 4 elements (16 bytes of fp32 in or out), rows are contiguous.
+// ------------------------------------------------------------------------------------------------
+namespace {
+template <typename T> __device__ __forceinline__ float wire_to_f32(T v);
+template <> __device__ __forceinline__ float wire_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float wire_to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float wire_to_f32<__hip_bfloat16>(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T wire_from_f32(float v);
+template <> __device__ __forceinline__ float wire_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half wire_from_f32<__half>(float v) { return __float2half(v); }
+template <> __device__ __forceinline__ __hip_bfloat16 wire_from_f32<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+
+template <typename TI, typename TO, int VEC>
+__global__ __launch_bounds__(kBlock) void gather_cast_kernel(const TI* __restrict__ x, int64_t d, const int32_t* __restrict__ index,
+                                                             int64_t n_index, TO* __restrict__ out) {
+    struct alignas(sizeof(TI) * VEC) VI { TI v[VEC]; };
+    struct alignas(sizeof(TO) * VEC) VO { TO v[VEC]; };
+    const int64_t per = d / VEC, total = n_index * per;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / per, j = (i - r * per) * VEC;
+        const int64_t s = index ? (int64_t)index[r] : r;
+        const VI a = *reinterpret_cast<const VI*>(x + s * d + j);
+        VO o;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o.v[k] = wire_from_f32<TO>(wire_to_f32<TI>(a.v[k]));
+        *reinterpret_cast<VO*>(out + r * d + j) = o;
+    }
+}
+
+template <typename TI, typename TO>
+int32_t gather_cast(const void* x, int64_t d, const int32_t* index, int64_t n, void* out, hipStream_t st) {
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out);
+    if (d % 4 == 0 && al % 16 == 0)
+        hipLaunchKernelGGL((gather_cast_kernel<TI, TO, 4>), dim3(grid_for(n * (d / 4))), dim3(kBlock), 0, st, static_cast<const TI*>(x), d, index, n, static_cast<TO*>(out));
+    else
+        hipLaunchKernelGGL((gather_cast_kernel<TI, TO, 1>), dim3(grid_for(n * d)), dim3(kBlock), 0, st, static_cast<const TI*>(x), d, index, n, static_cast<TO*>(out));
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+}  // namespace
+
+extern "C" int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64_t d, const int32_t* index, int64_t n_index,
+                                           void* out, int32_t out_dtype, void* stream) {
+    if (n_index < 0 || d < 0 || (n_index > 0 && d > 0 && (!x || !out))) return fail(PGLAMD_E_ARG, "gather_rows_cast: bad argument");
+    if (n_index == 0 || d == 0) return PGLAMD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_F16) return gather_cast<float, __half>(x, d, index, n_index, out, st);
+    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_BF16) return gather_cast<float, __hip_bfloat16>(x, d, index, n_index, out, st);
+    if (x_dtype == PGLAMD_F16 && out_dtype == PGLAMD_F32) return gather_cast<__half, float>(x, d, index, n_index, out, st);
+    if (x_dtype == PGLAMD_BF16 && out_dtype == PGLAMD_F32) return gather_cast<__hip_bfloat16, float>(x, d, index, n_index, out, st);
+    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_F32) return gather_cast<float, float>(x, d, index, n_index, out, st);
+    return fail(PGLAMD_E_DTYPE, "gather_rows_cast: F32 <-> F16 / BF16 only (got %d -> %d)", x_dtype, out_dtype);
+}
+
 extern "C" int32_t pglamd_scatter_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index, int32_t index_i64,
                                        int64_t n_index, void* out, void* stream) {
     if (n_index < 0 || d < 0 || (n_index > 0 && d > 0 && (!x || !index || !out))) return fail(PGLAMD_E_ARG, "scatter_rows: bad argument");

@@ -349,7 +349,11 @@ void load_metis() {
         }
     }
     void* h = path.empty() ? nullptr : dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!h) { m.why = "cannot open " + path + (dlerror() ? std::string(": ") + dlerror() : std::string()); return; }
+    if (!h) {
+        const char* err = dlerror();               // ONE call: dlerror() clears the message it returns
+        m.why = "cannot open " + path + (err ? std::string(": ") + err : std::string());
+        return;
+    }
     m.kway = (metis_kway_fn)dlsym(h, "METIS_PartGraphKway");
     if (!m.kway) m.why = path + " has no METIS_PartGraphKway";
 }

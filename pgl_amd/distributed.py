@@ -176,15 +176,26 @@ def _all_reduce_sum(tensor, group=None):
 # methods as a test seam -- the product has only this one and it refuses CPU tensors.)
 # ------------------------------------------------------------------------------------------------------------------
 class _EngineBackend(object):
-    def index(self, rows, cols, n_rows):
-        return ops.csr_build(rows, cols, int(n_rows), want_i64=False, check_range=False)
+    def index(self, rows, cols, n_rows, edge_ids=None):
+        """CSR of the (rows, cols) pairs.  edge_ids: the LOCAL edge id of every pair (edge operands of send_ue_recv are in
+        local edge order); None = pair k is edge k.  The longest row rides along (`max_row`: one host read at plan set-up),
+        so launches over an index no row of which can be split skip the fix-up kernels."""
+        c = ops.csr_build(rows, cols, int(n_rows), want_i64=False, check_range=False)
+        if edge_ids is not None and c.num_edges:
+            c.eid32 = edge_ids.to(torch.int32)[c.eid32.long()].contiguous()
+        c.max_row = int(c.degree.max().item()) if c.num_edges else 0
+        return c
 
     def aggregate(self, x, index, reduce_op, n_rows, y=None, message_op="add", src_scale=None, dst_scale=None, out=None,
-                  accumulate=0):
-        return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate)
+                  accumulate=0, x2=None, zero_indptr=None):
+        return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
+                             x2=x2, zero_indptr=zero_indptr)
 
     def gather_rows(self, x, idx):
         return ops.gather_rows(x, idx)
+
+    def gather_rows_cast(self, x, idx, dtype, out=None):
+        return ops.gather_rows_cast(x, idx, dtype, out)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -412,6 +423,10 @@ class DistGraph(object):
         self._inv_deg = None
         self._all_ids = None
         self.method = "given"
+        # halo rows of fp32 features travel as fp16 / bf16 when set (half the xGMI bytes; ~1e-3 relative error on the
+        # remote contributions, so OFF by default: north_star's 1e-5 parity holds only with the features' own dtype);
+        # PGLAMD_WIRE=fp16|bf16 sets the default
+        self.wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}.get(os.environ.get("PGLAMD_WIRE", ""), None)
 
     # ---- construction ----------------------------------------------------------------------------------------------
     @classmethod
@@ -434,16 +449,21 @@ class DistGraph(object):
             pt = part if given else cls.partition(edges, num_nodes, world, m, rank, group, seed)
             plan = HaloPlan(edges, num_nodes, pt, rank, world)
             xplan = plan
-            if push == "auto" and world > 1:
+            pull_c = push_c = choice = None
+            if world > 1 and (push == "auto" or len(methods) > 1):
                 pull_c, push_c = HaloPlan.pair_counts(edges, num_nodes, pt, world)
+            if push == "auto" and world > 1:
                 choice = HaloPlan.choose_push(pull_c, push_c)
                 if bool(choice.any()):
                     xplan = HaloPlan(edges, num_nodes, pt, rank, world, push=choice)
-            cost = torch.tensor([float(xplan.n_recv + plan.local_edges / 16.0)], dtype=torch.float64)
-            if len(methods) > 1 and _group_ready(group):
-                c = cost.to(edges.device) if dist.get_backend(group) == "nccl" else cost
-                dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
-                cost = c.cpu()
+            cost = 0.0
+            if len(methods) > 1:
+                # the SAME number on every rank, with or without a process group: rows received by the slowest rank (from the
+                # global pair counts) + its edges / 16 -- every rank derives it from the global edge list
+                rows_in = (torch.where(choice, push_c, pull_c) if choice is not None else pull_c).sum(1).to(torch.float64)
+                ptd = torch.as_tensor(pt, device=edges.device).to(torch.int64)[edges[:, 1]]
+                edges_in = torch.bincount(ptd, minlength=world).to(torch.float64).cpu()
+                cost = float((rows_in + edges_in / 16.0).max())
             if best is None or float(cost) < best[0]:
                 best = (float(cost), m, plan, xplan)
         dg = cls(best[2], device=edges.device, group=group, backend=backend, exchange_plan=best[3])
@@ -504,6 +524,8 @@ class DistGraph(object):
 
     @classmethod
     def load(cls, path, rank, device=None, group=None, backend=None):
+        if device is None and backend is None and torch.cuda.is_available():
+            device = torch.device("cuda", torch.cuda.current_device())      # the engine's kernels need the plan on the GPU
         plan = _plan_load(path, rank, device)
         xdir = os.path.join(path, "exchange")
         xplan = _plan_load(xdir, rank, device) if os.path.isdir(os.path.join(xdir, "rank_%d" % rank)) else None
@@ -571,39 +593,86 @@ class DistGraph(object):
 
     # ---- lazily built device state -----------------------------------------------------------------------------------
     def _index(self, name):
-        """dst-keyed indices loc / recv / send / hal / int / bnd and their transposes (suffix _t), built on first use."""
+        """Indices of this rank, built on first use.  <k> = "x" (the pull/push exchange plan of sum / mean) or "p" (the pull
+        plan: max / min and everything that needs whole source rows).  Column space of the two-table indices: [owned rows |
+        rows received in the exchange], i.e. column n_own + i is row i of the receive buffer.
+          <k>send     send_buf[i] = sum of owned rows (one identity edge for a pulled row, this rank's edges into one
+                      destination row for a pushed one)                                  rows: n_send      cols: owned
+          <k>int      INTERIOR rows -- every source local -- with their edges            rows: n_own       cols: owned
+          <k>bnd      BOUNDARY rows -- at least one received source -- with ALL their edges                cols: owned | received
+          <k>recv_t   transposed flow (gradients): what travels back, recv_buf_t[i] = sum of g over the rows that read
+                      received row i                                                     rows: n_recv      cols: owned
+          <k>int_t    owned rows no peer reads, with their transposed local edges        rows: n_own       cols: owned
+          <k>bnd_t    owned rows that were sent, with their transposed local edges and the rows coming back
+          loc / hal / pull (+ _t)   the plain local-source / halo-source / pack indices of the pull plan (generic ops)
+        """
         hit = self._idx.get(name)
         if hit is not None:
             return hit
-        p, x = self.plan, self.xplan
-        base, t = (name[:-2], True) if name.endswith("_t") else (name, False)
-        if base == "loc":
-            rows, cols, nr, nc = p.loc_rows, p.loc_cols, p.n_own, p.n_own
-        elif base == "recv":
-            rows, cols, nr, nc = x.recv_rows, x.recv_cols, p.n_own, x.n_recv
-        elif base == "send":
-            rows, cols, nr, nc = x.send_rows, x.send_cols, x.n_send, p.n_own
-        elif base == "hal":
-            rows, cols, nr, nc = p.hal_rows, p.hal_cols, p.n_own, p.n_halo
-        elif base == "pull":                                          # send_buf[i] = x_own[send_idx[i]] as an index
-            rows, cols = torch.arange(p.send_idx.shape[0], device=p.send_idx.device), p.send_idx
-            nr, nc = int(p.send_idx.shape[0]), p.n_own
-        elif base in ("int", "bnd"):
-            boundary = torch.zeros(p.n_own, dtype=torch.bool, device=p.hal_rows.device)
-            boundary[p.hal_rows] = True
-            if base == "int":                                         # interior rows: every source is local
-                keep = ~boundary[p.loc_rows]
-                rows, cols = p.loc_rows[keep], p.loc_cols[keep]
-            else:                                                     # boundary rows: all their edges, ext column space
-                keep = boundary[p.loc_rows]
-                rows = torch.cat([p.loc_rows[keep], p.hal_rows])
-                cols = torch.cat([p.loc_cols[keep], p.hal_cols + p.n_own])
-            nr, nc = p.n_own, p.n_own + p.n_halo
+        p = self.plan
+        eids = None
+        if name in ("loc", "loc_t", "hal", "hal_t", "pull", "pull_t"):
+            base, t = (name[:-2], True) if name.endswith("_t") else (name, False)
+            if base == "loc":
+                rows, cols, nr, nc = p.loc_rows, p.loc_cols, p.n_own, p.n_own
+            elif base == "hal":
+                rows, cols, nr, nc = p.hal_rows, p.hal_cols, p.n_own, p.n_halo
+            else:                                                     # send_buf[i] = x_own[send_idx[i]] as an index
+                rows, cols = torch.arange(p.send_idx.shape[0], device=p.send_idx.device), p.send_idx
+                nr, nc = int(p.send_idx.shape[0]), p.n_own
+            if t:
+                rows, cols, nr = cols, rows, nc
         else:
-            raise KeyError(name)
-        idx = self._b.index(cols, rows, nc) if t else self._b.index(rows, cols, nr)
+            k, base = name[0], name[1:]
+            xp = self.xplan if k == "x" else p
+            if k not in ("x", "p"):
+                raise KeyError(name)
+            n_loc = int(p.loc_rows.shape[0])
+            if base == "send":
+                rows, cols, nr = xp.send_rows, xp.send_cols, xp.n_send
+            elif base == "recv_t":
+                rows, cols, nr = xp.recv_cols, xp.recv_rows, xp.n_recv
+            elif base in ("int", "bnd"):
+                boundary = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
+                boundary[xp.recv_rows] = True
+                keep = boundary[p.loc_rows] if base == "bnd" else ~boundary[p.loc_rows]
+                rows, cols = p.loc_rows[keep], p.loc_cols[keep]
+                sel = torch.nonzero(keep).reshape(-1)
+                if base == "bnd":
+                    rows = torch.cat([rows, xp.recv_rows])
+                    cols = torch.cat([cols, xp.recv_cols + p.n_own])
+                    # local edge ids (edge operands): the halo edges follow the local-source ones in local edge order; only
+                    # meaningful for the pull plan, whose received edges ARE the halo edges
+                    sel = torch.cat([sel, n_loc + torch.arange(int(xp.recv_rows.shape[0]), device=sel.device)])
+                if k == "p":
+                    eids = sel
+                nr = p.n_own
+            elif base in ("int_t", "bnd_t"):
+                sent = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
+                sent[xp.send_cols] = True
+                keep = sent[p.loc_cols] if base == "bnd_t" else ~sent[p.loc_cols]
+                rows, cols = p.loc_cols[keep], p.loc_rows[keep]
+                if base == "bnd_t":
+                    rows = torch.cat([rows, xp.send_cols])
+                    cols = torch.cat([cols, xp.send_rows + p.n_own])
+                nr = p.n_own
+            else:
+                raise KeyError(name)
+        idx = self._b.index(rows, cols, nr, eids) if eids is not None else self._b.index(rows, cols, nr)
         self._idx[name] = idx
         return idx
+
+    def _zero_indptr(self, transposed):
+        """indptr over ALL edges that end (transposed: start) in an owned row -- what decides which rows the interior launch
+        zero-fills: rows empty here are written by nobody else (include/pgl_amd.h, pglamd_aggregate_ext)."""
+        key = "zin_t" if transposed else "zin"
+        z = self._idx.get(key)
+        if z is None:
+            deg = self.plan.out_degree if transposed else self.plan.in_degree
+            z = torch.zeros(self.plan.n_own + 1, dtype=torch.int64, device=deg.device)
+            z[1:] = torch.cumsum(deg, 0)
+            self._idx[key] = z
+        return z
 
     def _buffer(self, name, shape, dtype, device):
         b = self._buf.get(name)
@@ -619,43 +688,86 @@ class DistGraph(object):
             self._inv_deg = (1.0 / self.plan.in_degree.clamp(min=1).to(torch.float32)).contiguous()
         return self._inv_deg
 
-    # ---- sum / mean: the overlapped pull/push flow (forward and, with the indices transposed, backward) ---------------
-    def _flow(self, x, scale, transposed):
-        p, xp, B = self.plan, self.xplan, self._b
+    def _wire(self, dtype):
+        """dtype the halo rows travel in: `wire_dtype` (fp16 / bf16) for fp32 features when set, else the features' own."""
+        w = self.wire_dtype
+        return w if (w is not None and dtype == torch.float32 and w in (torch.float16, torch.bfloat16)) else dtype
+
+    # ---- the exchange: pack -> all-to-all-v (asynchronous) ------------------------------------------------------------
+    def _start_exchange(self, x, kind, transposed):
+        """-> (work, in_buf, unpack) or None when this plan moves nothing.  Pack = ONE launch: a row gather straight into
+        the wire buffer (in the wire dtype) when every send row is a single owned row, otherwise the aggregation kernel over
+        the send index (pushed partial rows; the transposed flow's pre-summed gradients) followed by the wire cast."""
+        p, B = self.plan, self._b
+        xp = self.xplan if kind == "x" else p
+        if transposed:
+            first, n_out, n_in, out_splits, in_splits = kind + "recv_t", xp.n_recv, xp.n_send, xp.recv_splits, xp.send_splits
+        else:
+            first, n_out, n_in, out_splits, in_splits = kind + "send", xp.n_send, xp.n_recv, xp.send_splits, xp.recv_splits
+        if p.world == 1 or not (n_out or n_in):
+            return None
         tail = tuple(x.shape[1:])
-        if scale is not None and x.dtype != torch.float32:            # kernel scales are fp32-only
-            post = scale.to(x.dtype).reshape((-1,) + (1,) * len(tail))
-            if transposed:
-                x = x * post
+        wire = self._wire(x.dtype)
+        tag = "%s%d" % (kind, transposed)
+        out_buf = self._buffer("out" + tag, (n_out,) + tail, wire, x.device)
+        if n_out:
+            plain = (not transposed) and int(xp.pushed_pairs) == 0
+            if plain and wire != x.dtype:
+                B.gather_rows_cast(x, self._send_cols32(kind), wire, out_buf)
+            elif plain:
+                out_buf = B.gather_rows(x, self._send_cols32(kind))
+            else:
+                acc = out_buf if wire == x.dtype else self._buffer("acc" + tag, (n_out,) + tail, x.dtype, x.device)
+                B.aggregate(x, self._index(first), "sum", n_out, out=acc)
+                if wire != x.dtype:
+                    B.gather_rows_cast(acc, None, wire, out_buf)
+        # the receive buffer persists across steps; its reuse is ordered by the stream (the previous step's boundary launch
+        # is queued before this exchange)
+        in_wire = self._buffer("in" + tag, (n_in,) + tail, wire, x.device)
+        work = _exchange(out_buf, out_splits, in_wire, in_splits, self.group)
+        if wire == x.dtype:
+            return work, in_wire, None
+        in_buf = self._buffer("inw" + tag, (n_in,) + tail, x.dtype, x.device)
+        return work, in_buf, (lambda: B.gather_rows_cast(in_wire, None, x.dtype, in_buf) if n_in else None)
+
+    def _send_cols32(self, kind):
+        key = "send_cols32" + kind
+        s = self._idx.get(key)
+        if s is None:
+            c = (self.xplan if kind == "x" else self.plan).send_cols
+            s = c.to(torch.int32) if c.is_cuda else c
+            self._idx[key] = s
+        return s
+
+    # ---- the overlapped two-phase flow (forward and, with the indices transposed, backward) --------------------------------
+    def _flow(self, x, scale, transposed, reduce="sum", kind="x"):
+        """out[v] = scale[v] * REDUCE over ALL in-edges of owned row v (transposed: the gradient of that).  SURVEY 8e steps
+        1-4: pack -> all-to-all-v on the side stream -> INTERIOR rows (every source local) while the rows travel -> wait ->
+        BOUNDARY rows from the two tables [owned | received].  Every output row is written exactly once: by the interior
+        launch (which also zero-fills rows without any edge) or by the boundary launch -- nothing is read-modify-written."""
+        p, B = self.plan, self._b
+        xp = self.xplan if kind == "x" else p
+        tail = tuple(x.shape[1:])
+        post, scale_k = None, scale
+        if scale is not None and transposed:                         # gradients are scaled before they travel
+            x = x * scale.to(x.dtype).reshape((-1,) + (1,) * len(tail))
             scale_k = None
-        else:
-            post, scale_k = None, scale
-        if not transposed:
-            first, second, n_out, n_in = "send", "recv", xp.n_send, xp.n_recv
-            out_splits, in_splits = xp.send_splits, xp.recv_splits
-            kw_first, kw_rest = {}, {"dst_scale": scale_k}
-        else:
-            first, second, n_out, n_in = "recv_t", "send_t", xp.n_recv, xp.n_send
-            out_splits, in_splits = xp.recv_splits, xp.send_splits
-            kw_first, kw_rest = {"src_scale": scale_k}, {"src_scale": None}
-        work, in_buf = None, None
-        if p.world > 1 and (n_out or n_in):
-            # both exchange buffers persist across steps (no per-step allocation on the hot path); reuse is ordered by the
-            # stream: the pack launch below is queued after every earlier reader of the same buffer
-            out_buf = self._buffer("out%d" % transposed, (n_out,) + tail, x.dtype, x.device)
-            if n_out:
-                B.aggregate(x, self._index(first), "sum", n_out, out=out_buf, **kw_first)
-            in_buf = self._buffer("in%d" % transposed, (n_in,) + tail, x.dtype, x.device)
-            work = _exchange(out_buf, out_splits, in_buf, in_splits, self.group)
-        if not transposed:
-            out = B.aggregate(x, self._index("loc"), "sum", p.n_own, **kw_rest)                   # overlaps the exchange
-        else:
-            out = B.aggregate(x, self._index("loc_t"), "sum", p.n_own, src_scale=scale_k)
-        if work is not None:
+        elif scale is not None and x.dtype != torch.float32:          # kernel scales are fp32-only
+            post, scale_k = scale.to(x.dtype).reshape((-1,) + (1,) * len(tail)), None
+        sfx = "_t" if transposed else ""
+        started = self._start_exchange(x, kind, transposed)
+        n_in = (xp.n_send if transposed else xp.n_recv) if started is not None else 0
+        out = B.aggregate(x, self._index(kind + "int" + sfx), reduce, p.n_own, dst_scale=scale_k,
+                          zero_indptr=self._zero_indptr(transposed) if n_in else None)        # overlaps the exchange
+        if started is not None:
+            work, in_buf, unpack = started
             work.wait()
             if n_in:
-                B.aggregate(in_buf, self._index(second), "sum", p.n_own, out=out, accumulate=1, **kw_rest)
-        if post is not None and not transposed:
+                if unpack is not None:
+                    unpack()
+                B.aggregate(x, self._index(kind + "bnd" + sfx), reduce, p.n_own, dst_scale=scale_k, out=out, accumulate=2,
+                            x2=in_buf)
+        if post is not None:
             out = out * post
         return out
 
@@ -751,16 +863,9 @@ class DistGraph(object):
         return self.send_recv(feature, reduce_op, out_size)
 
     def _minmax(self, x_own, reduce_func):
-        """Interior rows while the halo is in flight, boundary rows on top afterwards (no identity needed)."""
-        p, B = self.plan, self._b
-        pending = []
-        x_ext = self._extend(x_own, work_out=pending)
-        out = B.aggregate(x_own, self._index("int"), reduce_func, p.n_own)
-        if pending[0] is not None:
-            pending[0].wait()
-        if p.n_halo:
-            B.aggregate(x_ext, self._index("bnd"), reduce_func, p.n_own, out=out, accumulate=2)
-        return out
+        """Interior rows while the halo is in flight, boundary rows afterwards from [owned | received] (pull plan: max / min
+        need whole source rows; no identity element is needed because every row is written once)."""
+        return self._flow(x_own, None, False, reduce=reduce_func, kind="p")
 
     def send_ue_recv(self, feature, edge_feature, message_op="add", reduce_op="sum", out_size=None):
         """pgl/graph.py:1546-1553 role; Graph.send_ue_recv semantics (pgl/graph.py:889-937).  feature: [n_own, ...];
@@ -774,22 +879,25 @@ class DistGraph(object):
         needs_grad = torch.is_grad_enabled() and (feature.requires_grad or edge_feature.requires_grad)
         if needs_grad or reduce_op not in ("sum", "mean"):
             return self.local_graph.send_ue_recv(self.halo_extend(feature), edge_feature, message_op, reduce_op)[:p.n_own]
-        # forward-only sum / mean: local-source edges overlap the exchange, halo-source edges accumulate afterwards
+        scale = self._scale(reduce_op)
+        if scale is not None and feature.dtype != torch.float32:      # (checked BEFORE any exchange is started)
+            return self.local_graph.send_ue_recv(self.halo_extend(feature), edge_feature, message_op, reduce_op)[:p.n_own]
+        # forward-only sum / mean: interior rows overlap the exchange, boundary rows follow from [owned | received]; the
+        # edge operand is addressed by LOCAL edge id through the indices' edge maps
         B = self._b
         feature, edge_feature = feature.contiguous(), edge_feature.contiguous()
-        n_loc = int(p.loc_rows.shape[0])
-        pending = []
-        x_ext = self._extend(feature, work_out=pending)
-        scale = self._scale(reduce_op)
-        if scale is not None and feature.dtype != torch.float32:
-            return self.local_graph.send_ue_recv(self.halo_extend(feature), edge_feature, message_op, reduce_op)[:p.n_own]
-        out = B.aggregate(feature, self._index("loc"), "sum", p.n_own, y=edge_feature[:n_loc], message_op=message_op,
-                          dst_scale=scale)
-        if pending[0] is not None:
-            pending[0].wait()
-        if p.n_halo:
-            B.aggregate(x_ext[p.n_own:], self._index("hal"), "sum", p.n_own, y=edge_feature[n_loc:], message_op=message_op,
-                        dst_scale=scale, out=out, accumulate=1)
+        started = self._start_exchange(feature, "p", False)
+        n_in = p.n_halo if started is not None else 0
+        out = B.aggregate(feature, self._index("pint"), "sum", p.n_own, y=edge_feature, message_op=message_op, dst_scale=scale,
+                          zero_indptr=self._zero_indptr(False) if n_in else None)
+        if started is not None:
+            work, in_buf, unpack = started
+            work.wait()
+            if n_in:
+                if unpack is not None:
+                    unpack()
+                B.aggregate(feature, self._index("pbnd"), "sum", p.n_own, y=edge_feature, message_op=message_op, dst_scale=scale,
+                            out=out, accumulate=2, x2=in_buf)
         return out
 
     def send_uv(self, src_feature, dst_feature, message_op="add"):
@@ -837,15 +945,15 @@ class DistGraph(object):
         return self.local_graph.gat_aggregate(f_ext, as_ext, ad_ext, negative_slope, attn_drop, seed)[:p.n_own]
 
     def exchange_only(self, x_own):
-        """Measurement hook (bench.py): the pack kernel, the all-to-all-v and the wait of send_recv(sum), without the
-        aggregations -- the time the overlap has to hide."""
-        xp, B = self.xplan, self._b
-        tail = tuple(x_own.shape[1:])
-        if self.plan.world == 1 or not (xp.n_send or xp.n_recv):
+        """Measurement hook (bench.py): the pack kernel, the all-to-all-v, the wait and the wire unpack of send_recv(sum),
+        without the aggregations -- the time the overlap has to hide."""
+        started = self._start_exchange(x_own.contiguous(), "x", False)
+        if started is None:
             return None
-        out_buf = B.aggregate(x_own, self._index("send"), "sum", xp.n_send) if xp.n_send else x_own.new_empty((0,) + tail)
-        in_buf = self._buffer("in0", (xp.n_recv,) + tail, x_own.dtype, x_own.device)
-        _exchange(out_buf, xp.send_splits, in_buf, xp.recv_splits, self.group).wait()
+        work, in_buf, unpack = started
+        work.wait()
+        if unpack is not None:
+            unpack()
         return in_buf
 
     # ---- in-process simulation helpers (single-GPU tests of the compute path) ---------------------------------------------
@@ -854,22 +962,20 @@ class DistGraph(object):
         return self._b.gather_rows(x_own.contiguous(), self._send_idx32())
 
     def aggregate_with_halo(self, x_own, halo_rows, reduce_func="sum"):
-        """Compute half of send_recv given the already exchanged halo rows (pull layout)."""
+        """Compute half of send_recv given the already exchanged halo rows (pull layout): the interior / boundary launches
+        of `_flow` with `halo_rows` standing where the receive buffer would be."""
         p, B = self.plan, self._b
         x_own = x_own.contiguous()
-        if reduce_func in ("sum", "mean"):
-            scale = self._scale(reduce_func)
-            post = None
-            if scale is not None and x_own.dtype != torch.float32:
-                post, scale = scale, None
-            out = B.aggregate(x_own, self._index("loc"), "sum", p.n_own, dst_scale=scale)
-            if p.n_halo:
-                B.aggregate(halo_rows, self._index("hal"), "sum", p.n_own, dst_scale=scale, out=out, accumulate=1)
-            return out if post is None else out * post.to(out.dtype).reshape((-1,) + (1,) * (out.dim() - 1))
-        out = B.aggregate(x_own, self._index("int"), reduce_func, p.n_own)
+        scale = self._scale(reduce_func)
+        op = "sum" if reduce_func in ("sum", "mean") else reduce_func
+        post = None
+        if scale is not None and x_own.dtype != torch.float32:
+            post, scale = scale, None
+        out = B.aggregate(x_own, self._index("pint"), op, p.n_own, dst_scale=scale,
+                          zero_indptr=self._zero_indptr(False) if p.n_halo else None)
         if p.n_halo:
-            B.aggregate(torch.cat([x_own, halo_rows], 0), self._index("bnd"), reduce_func, p.n_own, out=out, accumulate=2)
-        return out
+            B.aggregate(x_own, self._index("pbnd"), op, p.n_own, dst_scale=scale, out=out, accumulate=2, x2=halo_rows.contiguous())
+        return out if post is None else out * post.to(out.dtype).reshape((-1,) + (1,) * (out.dim() - 1))
 
 
 class DistGPUGraph(object):

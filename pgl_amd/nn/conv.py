@@ -89,7 +89,8 @@ class GraphSageConv(nn.Module):
         if isinstance(feature, torch.Tensor):
             feature = (feature, feature)
         neigh_feature = graph.send_recv(feature[0], self.aggr_func, out_size=feature[1].shape[0])
-        if act in (None, "relu") and ops.row_epilogue_supported(neigh_feature) and feature[1].dtype == torch.float32 \
+        if act in (None, "relu") and ops.row_epilogue_supported(neigh_feature, self.self_linear.out_features) \
+                and feature[1].dtype == torch.float32 and self.self_linear.weight.dtype == torch.float32 \
                 and feature[1].is_cuda and self.fused:
             # self_linear(x) + neigh_linear(agg) -> act -> F.normalize as two GEMMs (the second accumulating into the first)
             # and ONE row kernel (both biases, the activation and the L2 normalisation); backward likewise one row kernel
@@ -132,7 +133,8 @@ class GCNConv(nn.Module):
             output = graph.send_recv_scaled(feature, norm, norm)
             if self.input_size <= self.output_size:
                 tall = output.shape[0] >= 65536 and torch.is_grad_enabled()
-                if self.activation is F.relu and ops.row_epilogue_supported(output):
+                if self.activation is F.relu and ops.row_epilogue_supported(output, self.output_size) \
+                        and self.linear.weight.dtype == torch.float32:
                     # bias + relu as one row kernel; its backward also yields the bias gradient (no separate reduction)
                     z = _TallLinearFn.apply(output, self.linear.weight, None) if tall else F.linear(output, self.linear.weight)
                     return ag.row_epilogue(z, self.bias, "relu", False)

@@ -59,7 +59,7 @@ def _prod(shape):
 class CSR(object):
     """Device-side result of csr_build: the reference's five int64 arrays + int32 engine copies."""
     __slots__ = ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr", "row32", "col32", "eid32",
-                 "num_nodes", "num_edges", "_pos_by_dst")
+                 "num_nodes", "num_edges", "_pos_by_dst", "max_row")
 
 
 def csr_build(u, v, num_nodes, want_i64=True, check_range=True):
@@ -77,6 +77,7 @@ def csr_build(u, v, num_nodes, want_i64=True, check_range=True):
     L = _ffi.lib()
     c = CSR()
     c.num_nodes, c.num_edges = N, E
+    c.max_row = 0                      # longest row when a caller has measured it (halo plans), 0 = unknown
     i64 = dict(dtype=torch.int64, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
     c.degree = torch.empty(N, **i64); c.indptr = torch.empty(N + 1, **i64)
@@ -158,14 +159,23 @@ _PRESCALE_ROW_BYTES = int(os.environ.get("PGLAMD_PRESCALE_ROW_BYTES", "704"))
 
 
 def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None,
-              out=None, accumulate=False):
+              out=None, accumulate=False, x2=None, zero_indptr=None):
     """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
     graph's cached dst-CSR.  y (if given) is in ORIGINAL edge order, shape [E, ...].
     accumulate: False / 0 write every row of `out`; True / 1 combine the rows that receive edges with their old contents;
-    2 overwrite only the rows that receive edges (include/pgl_amd.h)."""
-    _need_cuda(x, y, src_scale, dst_scale)
+    2 overwrite only the rows that receive edges (include/pgl_amd.h).
+    x2 / zero_indptr (pglamd_aggregate_ext, row-partitioned graphs): column ids >= x.shape[0] read row (id - x.shape[0]) of
+    x2 (the rows received from peers); rows are zero-filled where zero_indptr -- not the index's own indptr -- says they
+    have no edge.  An index carrying `max_row` (longest row) lets the library skip the split-row fix-up launches."""
+    _need_cuda(x, y, src_scale, dst_scale, x2, zero_indptr)
     L = _ffi.lib()
     x = x.contiguous()
+    max_row = int(getattr(csr, "max_row", 0) or 0)
+    ext = x2 is not None or zero_indptr is not None or max_row > 0
+    if x2 is not None:
+        x2 = x2.contiguous()
+        if x2.dtype != x.dtype or tuple(x2.shape[1:]) != tuple(x.shape[1:]) or src_scale is not None:
+            raise ValueError("aggregate: x2 must have x's dtype and row shape, and excludes src_scale")
     if src_scale is not None and y is None and x.dim() >= 2 and x.is_floating_point() \
             and _prod(x.shape[1:]) * x.element_size() <= _PRESCALE_ROW_BYTES and src_scale.numel() == x.shape[0]:
         # The fused per-source scale costs one random 4-byte access per EDGE (+0.25 ms at 20 M edges, any row width);
@@ -194,6 +204,14 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
         return out
     code = _code(x.dtype)
     ws = _ws(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
+    if ext and src_scale is None:
+        with torch.cuda.device(x.device):
+            _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, _ptr(y), dy,
+                                              _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
+                                              _ptr(csr.indptr), _ptr(zero_indptr), max_row, csr.num_edges, csr.num_nodes, M, dout,
+                                              MSG[message_op], REDUCE[reduce_op], _ptr(dst_scale), int(accumulate), _ptr(out),
+                                              _ptr(ws), ws.numel(), _stream(x)), "aggregate_ext")
+        return out
     with torch.cuda.device(x.device):
         _ffi.check(L.pglamd_aggregate(_ptr(x), code, int(x.shape[0]), dx, _ptr(y), dy,
                                       _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
@@ -491,6 +509,28 @@ def gather_rows(x, index):
     return out
 
 
+def gather_rows_cast(x, index, out_dtype, out=None):
+    """out[i] = cast(x[index[i]]) (index None: a row-wise conversion) -- pglamd_gather_rows_cast, the wire pack / unpack of the
+    halo exchange.  fp32 <-> fp16 / bf16."""
+    _need_cuda(x, index)
+    x = x.contiguous()
+    n = int(x.shape[0]) if index is None else int(index.shape[0])
+    if index is not None:
+        index = index.contiguous()
+        if index.dtype != torch.int32:
+            index = index.to(torch.int32)
+    d = _prod(x.shape[1:])
+    if out is None:
+        out = torch.empty((n,) + tuple(x.shape[1:]), dtype=out_dtype, device=x.device)
+    elif tuple(out.shape) != (n,) + tuple(x.shape[1:]) or out.dtype != out_dtype or not out.is_contiguous():
+        raise ValueError("gather_rows_cast: out must be a contiguous %s tensor of dtype %s" % ((n,) + tuple(x.shape[1:]), out_dtype))
+    if n and d:
+        with torch.cuda.device(x.device):
+            _ffi.check(_ffi.lib().pglamd_gather_rows_cast(_ptr(x), _code(x.dtype), d, _ptr(index), n, _ptr(out), _code(out_dtype),
+                                                          _stream(x)), "gather_rows_cast")
+    return out
+
+
 def scatter_rows(out, index, x):
     """paddle.scatter(out, index, x, overwrite=True) with unique indices, in place on `out`
     (pgl/graph.py:828-830)."""
@@ -668,16 +708,31 @@ def host_halo_plan(edges, num_nodes, part, rank, world):
 # ------------------------------------------------------------------------------------------------
 # layer epilogue (row f1): bias + activation + L2 row normalisation in one pass each way
 # ------------------------------------------------------------------------------------------------
-def row_epilogue_supported(z):
-    d = int(z.shape[-1]) if z.dim() == 2 else 0
+def row_epilogue_width_ok(d):
+    """Row widths pglamd_row_epilogue covers (one wave per row, <= 8 vectors per lane)."""
+    d = int(d)
     vec = 4 if d % 4 == 0 else 2 if d % 2 == 0 else 1
-    return z.is_cuda and z.dtype == torch.float32 and z.dim() == 2 and 0 < d <= 64 * vec * 8
+    return 0 < d <= 64 * vec * 8
+
+
+def row_epilogue_supported(z, width=None):
+    """True when the fused epilogue can run on a tensor shaped / typed like `z` whose rows are `width` wide (default: z's own
+    width).  Layers gate on the tensor the kernel PROCESSES -- the GEMM output, `width` = hidden / output size -- not on the
+    GEMM's input."""
+    if not (z.is_cuda and z.dtype == torch.float32 and z.dim() == 2):
+        return False
+    return row_epilogue_width_ok(z.shape[-1] if width is None else width)
 
 
 def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12):
     """y = normalize_L2(act(z + bias)) -> (y, inv_norm or None).  act: None | "relu".  GraphSageConv's epilogue
     (pgl/nn/conv.py:109-115) and GCNConv's (pgl/nn/conv.py:250-254) in one kernel."""
     _need_cuda(z, bias)
+    if z.dtype != torch.float32 or z.dim() != 2 or (bias is not None and bias.dtype != torch.float32):
+        raise TypeError("row_epilogue: float32 [n, d] rows and a float32 bias (got %s / %s)"
+                        % (z.dtype, None if bias is None else bias.dtype))
+    if not row_epilogue_width_ok(z.shape[1]):
+        raise ValueError("row_epilogue: rows of %d elements are wider than the kernel covers" % z.shape[1])
     z = z.contiguous()
     n, d = int(z.shape[0]), int(z.shape[1])
     y = torch.empty_like(z)

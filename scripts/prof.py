@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""scripts/prof.py -- every measurement helper of this repository behind one entry point (run on the GPU box through gpurun).
+
+    python scripts/prof.py diag                      box state a bandwidth number depends on (clocks, partition modes, VRAM)
+    python scripts/prof.py rows  [--scale 20 --edges 20000000 --parts 8 --partition kway|metis|random|FILE.npy]
+                                                     per-rank COMPUTE of the row-partitioned layout on ONE GPU, phase by phase,
+                                                     next to the bytes each rank receives and what they cost on xGMI
+    python scripts/prof.py ops                       one line per op of SURVEY 8(a) at C2 / C3 sizes (bench_ops)
+    python scripts/prof.py csr                       CSR build (a1) at C2 / C2' / sampled-block sizes
+    python scripts/prof.py layers ...                per-kernel time of a layer's forward / training step
+
+Each subcommand prints plain text; the GPU session scripts (scripts/gpu_*.sh) redirect it into gpurun_out/, and what is quoted in
+DESIGN.md is copied to profiles/rNN/.
+"""
+import argparse
+import glob
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _t(fn, it=20, warm=5):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(it):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / it
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def cmd_diag(args):
+    """What differs between a box where random 512-byte gathers over 8.6 GB run at 5.7 TB/s and one where they run at 4.9."""
+    def sh(cmd):
+        try:
+            return subprocess.run(cmd, shell=True, capture_output=True, text=True, timeout=60).stdout.strip()
+        except Exception as ex:                                      # noqa: BLE001
+            return "(%r)" % ex
+    print("== rocm-smi clocks / power / partitions")
+    print(sh("rocm-smi --showclocks --showpower --showmemuse --showcomputepartition --showmemorypartition 2>&1 | grep -v '^$' | head -60"))
+    print("== amdgpu module parameters that shape the GPU page tables")
+    for name in ("vm_fragment_size", "vm_block_size", "vm_size", "vm_update_mode", "noretry", "mtype_local", "sched_policy"):
+        p = "/sys/module/amdgpu/parameters/" + name
+        print("  %-18s %s" % (name, open(p).read().strip() if os.path.exists(p) else "(absent)"))
+    print("== VRAM / GTT (bytes)")
+    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+        for f in ("mem_info_vram_total", "mem_info_vram_used", "mem_info_vis_vram_total", "mem_info_gtt_used", "current_compute_partition",
+                  "current_memory_partition", "pp_dpm_mclk", "pp_dpm_fclk", "pp_dpm_sclk"):
+            p = os.path.join(dev, f)
+            if os.path.exists(p):
+                try:
+                    print("  %s/%s: %s" % (dev.split("/")[4], f, " | ".join(open(p).read().split("\n")).strip(" |")))
+                except Exception as ex:                              # noqa: BLE001
+                    print("  %s/%s: (%r)" % (dev.split("/")[4], f, ex))
+    print("== host")
+    print(sh("uname -r; nproc; cat /sys/kernel/mm/transparent_hugepage/enabled 2>/dev/null; uptime"))
+    print("== kfd topology: first GPU node's properties")
+    for n in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
+        txt = open(n).read()
+        if "simd_count 0" in txt:
+            continue
+        keep = [l for l in txt.split("\n") if l.split(" ")[0] in ("simd_count", "array_count", "cu_per_simd_array", "max_engine_clk_fcompute",
+                                                                    "local_mem_size", "num_xcc", "gfx_target_version", "sdma_fw_version")]
+        print("  " + n.split("/")[-2] + ": " + ", ".join(keep))
+        break
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def cmd_rows(args):
+    """Per-rank compute of DistGraph.send_recv(sum) on one GPU: the pack launch, the interior launch and the boundary launch
+    run on their real sizes with no process group (only the all-to-all-v itself is absent: the receive buffer holds stale
+    values; timing only).  `ideal` = this rank's edges / the single-GPU rate of the same graph."""
+    import numpy as np
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    scale, E, d = args.scale, args.edges, args.dim
+    N = 1 << scale
+    edges = rmat_edges(scale, E, seed=42, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, d, generator=gen, device=dev)
+    g = pgl.Graph(edges=edges, num_nodes=N); g.adj_dst_index
+    t1 = _t(lambda: g.send_recv(x, "sum"))
+    print("graph: RMAT scale %d, %d edges, d=%d fp32; 1 GPU: %.3f ms / step = %.2f G edges/s" % (scale, E, d, t1, E / t1 / 1e6), flush=True)
+    LINK = 153.0
+    for P in args.parts:
+        t0 = time.time()
+        if args.partition.endswith(".npy"):
+            part = torch.from_numpy(np.load(args.partition.replace("{P}", str(P))).astype(np.int64))
+            how = os.path.basename(args.partition.replace("{P}", str(P)))
+        else:
+            part = DistGraph.partition(edges, N, P, args.partition, rank=0)
+            how = args.partition
+        tp = time.time() - t0
+        pc = part.to(dev)
+        cut = float((pc[edges[:, 0]] != pc[edges[:, 1]]).float().mean())
+        pull_c, push_c = HaloPlan.pair_counts(edges, N, part, P)
+        choice = HaloPlan.choose_push(pull_c, push_c) if args.push == "auto" else torch.zeros((P, P), dtype=torch.bool)
+        print("P=%d partition %s (%.1f s), edge cut %.3f, %d of %d pairs push, wire %s" % (P, how, tp, cut, int(choice.sum()), P * (P - 1), args.wire or "fp32"))
+        worst, rows = {"compute": 0.0, "pair_mb": 0.0, "ratio": 0.0}, []
+        for r in range(P):
+            plan = HaloPlan(edges, N, part, r, P)
+            xplan = HaloPlan(edges, N, part, r, P, push=choice) if bool(choice.any()) else plan
+            dg = DistGraph(plan, device=dev, exchange_plan=xplan)
+            if args.wire:
+                dg.wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.wire]
+            x_own = dg.take_owned(x)
+            ms = _t(lambda: dg.send_recv(x_own, "sum"), it=10, warm=3)
+            # phases on their own (each between its own pair of events)
+            B = dg._b
+            pk = _t(lambda: dg._start_exchange(x_own, "x", False), it=10, warm=2)
+            zi = dg._zero_indptr(False)
+            it_ = _t(lambda: B.aggregate(x_own, dg._index("xint"), "sum", plan.n_own, zero_indptr=zi), it=10, warm=2)
+            out = torch.empty_like(x_own)
+            in_buf = dg._buffer("inx0" if not args.wire else "inwx0", (xplan.n_recv, d), torch.float32, dev)
+            bd = _t(lambda: B.aggregate(x_own, dg._index("xbnd"), "sum", plan.n_own, out=out, accumulate=2, x2=in_buf), it=10, warm=2) if xplan.n_recv else 0.0
+            wb = 2 if args.wire else 4
+            ideal = plan.local_edges / (E / t1)
+            e_int, e_bnd = dg._index("xint").num_edges, dg._index("xbnd").num_edges
+            pair_mb = max(xplan.recv_splits) * d * wb / 1e6
+            rows.append((r, plan.n_own, plan.local_edges, e_int, e_bnd, xplan.n_send, xplan.n_recv, ms, pk, it_, bd, ideal, pair_mb))
+            worst["compute"] = max(worst["compute"], ms); worst["pair_mb"] = max(worst["pair_mb"], pair_mb)
+            worst["ratio"] = max(worst["ratio"], ms / ideal)
+            del dg, plan, xplan, x_own, out
+        for r, n_own, le, ei, eb, ns, nr, ms, pk, it_, bd, ideal, pmb in rows:
+            print("   rank %d: %7d rows %9d edges (interior %8d, boundary %9d) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms = pack %.3f + interior %.3f + boundary %.3f (+gaps) | ideal %.3f ms -> x%.2f"
+                  % (r, n_own, le, ei, eb, ns, nr, pmb, ms, pk, it_, bd, ideal, ms / ideal))
+        t_link = worst["pair_mb"] / 1e3 / LINK * 1e3
+        print("   slowest rank compute %.3f ms (worst compute/ideal x%.2f; ideal = E/P at the 1-GPU rate = %.3f ms) | exchange >= %.3f ms (largest pair block at %.0f GB/s per link)"
+              % (worst["compute"], worst["ratio"], t1 / P, t_link, LINK))
+        print("   predicted step: max(compute, exchange) = %.3f ms = %.2fx of one GPU; compute + exchange = %.3f ms = %.2fx"
+              % (max(worst["compute"], t_link), t1 / max(worst["compute"], t_link), worst["compute"] + t_link, t1 / (worst["compute"] + t_link)), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _run_script(name, argv):
+    """Subcommands whose bodies still live in their own files."""
+    path = os.path.join(ROOT, "scripts", name)
+    sys.argv = [path] + list(argv)
+    import runpy
+    runpy.run_path(path, run_name="__main__")
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    sub.add_parser("diag")
+    r = sub.add_parser("rows")
+    r.add_argument("--scale", type=int, default=20)
+    r.add_argument("--edges", type=int, default=20_000_000)
+    r.add_argument("--dim", type=int, default=128)
+    r.add_argument("--parts", type=lambda s: [int(v) for v in s.split(",")], default=[2, 4, 8])
+    r.add_argument("--partition", default="kway", help="kway | metis | random | path/with{P}.npy")
+    r.add_argument("--push", default="auto", choices=["auto", "never"])
+    r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
+    for name in ("ops", "csr", "layers"):
+        s_ = sub.add_parser(name)
+        s_.add_argument("rest", nargs=argparse.REMAINDER)
+    args = ap.parse_args()
+    if args.cmd == "diag":
+        cmd_diag(args)
+    elif args.cmd == "rows":
+        cmd_rows(args)
+    elif args.cmd == "ops":
+        _run_script("bench_ops.py", args.rest)
+    elif args.cmd == "layers":
+        _run_script("prof_layers.py", args.rest)
+    else:
+        raise SystemExit("subcommand %r is not wired up yet" % args.cmd)
+
+
+if __name__ == "__main__":
+    main()

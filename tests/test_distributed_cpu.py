@@ -128,6 +128,43 @@ def test_two_rank_gloo_matches_single_graph(method, push):
 
 
 # ------------------------------------------------------------------------------------------------
+# 16-bit wire for fp32 features: same flow, the halo rows travel as fp16 / bf16
+# ------------------------------------------------------------------------------------------------
+def _wire_worker(rank, world, wire):
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph()
+    dg = DistGraph.from_global(torch.from_numpy(edges), x.shape[0], rank, world, method="random", backend=TorchBackend(), push="auto")
+    dg.wire_dtype = wire
+    x_own = dg.take_owned(torch.from_numpy(x))
+    xg = x_own.clone().requires_grad_(True)
+    out = dg.send_recv(xg, "sum")
+    out.sum().backward()
+    return (rank, dg.plan.own_global.numpy(), {"sum": dg.send_recv(x_own, "sum").numpy(), "max": dg.send_recv(x_own, "max").numpy(),
+                                                 "train": out.detach().numpy(), "grad": xg.grad.numpy()})
+
+
+@pytest.mark.parametrize("wire", [torch.float16, torch.bfloat16])
+def test_two_rank_gloo_16bit_wire(wire):
+    got = _spawn(_wire_worker, 2, wire)
+    edges, x = _graph()
+    n = x.shape[0]
+    tol = 2e-3 if wire == torch.float16 else 1.6e-2             # half-precision rounding of the REMOTE contributions only
+    for key, op in (("sum", "sum"), ("train", "sum"), ("max", "max")):
+        w = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
+        full = np.full_like(w, np.nan)
+        for _, own, res in got:
+            full[own] = res[key]
+        assert np.isfinite(full).all(), key
+        err = np.abs(full - w).max() / np.abs(w).max()
+        assert 0 < err < tol, (key, err)                        # > 0: the 16-bit wire really was used
+    grad = np.full((n, x.shape[1]), np.nan, np.float32)
+    for _, own, res in got:
+        grad[own] = res["grad"]
+    outdeg = np.bincount(edges[:, 0], minlength=n).astype(np.float32)
+    np.testing.assert_allclose(grad, np.repeat(outdeg[:, None], x.shape[1], 1), rtol=tol)   # d/dx of sum(out) = out-degree
+
+
+# ------------------------------------------------------------------------------------------------
 # backward: gradients through the exchange == gradients of the single-graph formulation
 # ------------------------------------------------------------------------------------------------
 def _dense(edges, n):

@@ -267,3 +267,33 @@ def test_bench_and_entry_scripts_import_cleanly():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as ge
     assert callable(ge.build) and callable(ge.smoke)
+
+
+def test_missing_metis_helper_falls_back_without_crashing(tmp_path):
+    """with the helper library absent load_metis() used to call dlerror() twice and crash the interpreter.  A
+    fresh process (the loader result is cached per process) pointed at a path that does not exist must report 'unavailable' and
+    partition through the engine's own partitioner with a warning."""
+    import subprocess
+    import sys
+    code = r'''
+import warnings, numpy as np
+import pgl_amd
+from pgl_amd import ops
+assert ops.metis_available() is False
+try:
+    ops.host_partition_metis(4, np.array([0, 1, 2, 3, 4]), np.array([1, 0, 3, 2]), 2)
+    raise SystemExit("host_partition_metis did not raise")
+except RuntimeError as ex:
+    assert "cannot open" in str(ex), ex
+g = pgl_amd.Graph(edges=np.array([[0, 1], [1, 0], [2, 3], [3, 2], [1, 2], [2, 1]]), num_nodes=4)
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    part = pgl_amd.partition.metis_partition(g, 2)
+assert any("METIS helper library not available" in str(m.message) for m in w), [str(m.message) for m in w]
+assert sorted(np.bincount(part, minlength=2).tolist()) == [2, 2]
+print("fallback ok")
+'''
+    env = dict(os.environ, PGLAMD_METIS_LIB=str(tmp_path / "no_such_libmetis.so"))
+    env.pop("PGLAMD_PARTITIONER", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
+    assert r.returncode == 0 and "fallback ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
