@@ -161,10 +161,9 @@ def gcn_norm_leg(pgl, g, x, E, steps=10, warmup=3):
             "unfused_ms": tu["median_ms"], "unfused_p95_ms": tu["p95_ms"], "unfused_edges_per_s": E / (tu["median_ms"] * 1e-3)}
 
 
-def target_size_leg(pgl, dev, d, steps=10, warmup=3):
+def target_size_leg(pgl, dev, d, scale=22, E=100_000_000, steps=10, warmup=3):
     """north_star's target size (SURVEY 8d C2'): RMAT scale 22, |E| = 100 M, same seeds, same op."""
     from pgl_amd.utils.rmat import rmat_edges
-    scale, E = 22, 100_000_000
     N = 1 << scale
     edges = rmat_edges(scale, E, seed=42, device=dev)
     gen = torch.Generator(device=dev); gen.manual_seed(7)
@@ -174,7 +173,7 @@ def target_size_leg(pgl, dev, d, steps=10, warmup=3):
     B = algorithmic_bytes(E, N, d, 4)
     tb, tsrc = recorded_traffic("scale%d_e%d_d%d_f32" % (scale, E, d), kname)
     dist_ = step_distribution(lambda: g.send_recv(x, "sum"), n=30, warm=2)
-    rec = {"workload": "RMAT scale 22 |V|=%d |E|=%d d=%d fp32 (north_star target size, SURVEY 8d C2')" % (N, E, d),
+    rec = {"workload": "RMAT scale %d |V|=%d |E|=%d d=%d fp32 (north_star target size, SURVEY 8d C2')" % (scale, N, E, d),
            "value": E / (ms * 1e-3), "unit": "edges/s", "ms_per_step": ms, "steps": steps, "median_ms": dist_["median_ms"],
            "p95_ms": dist_["p95_ms"], "kernel_ms": kms, "kernel": kname,
            "model_bytes_per_launch": B, "model_bytes_over_kernel_time_GBs": B / (kms * 1e-3) / 1e9,
@@ -183,6 +182,40 @@ def target_size_leg(pgl, dev, d, steps=10, warmup=3):
            "traffic": tb, "traffic_source": tsrc,
            "traffic_frac_of_peak": (tb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None}
     del g, x, edges
+    torch.cuda.empty_cache()
+    return rec
+
+
+def target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note, steps=10):
+    """The |E| = 100 M graph of target_size_leg, row-partitioned over the N ranks of this run (same flow as the headline)."""
+    import torch.distributed as dist
+    from pgl_amd.distributed import DistGraph
+    from pgl_amd.utils.rmat import rmat_edges
+    scale, E = args.target_scale, args.target_edges
+    N = 1 << scale
+    note("target size: generating RMAT scale %d, %d edges" % (scale, E))
+    edges = rmat_edges(scale, E, seed=42, device=dev)
+    t0 = time.perf_counter()
+    dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push)
+    t_plan = time.perf_counter() - t0
+    note("target size: partition + plan %.1f s" % t_plan)
+    del edges
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x_own = dg.take_owned(torch.randn(N, d, generator=gen, device=dev, dtype=torch.float32))
+    fn = lambda: dg.send_recv(x_own, "sum")
+    fn(); fn(); fn()
+    t = timed(fn, steps) / steps * 1e3
+    t_x = timed(lambda: dg.exchange_only(x_own), 5) / 5 * 1e3
+    st = dg.stats()
+    allp = torch.zeros((world, 3), dtype=torch.float64, device=dev)
+    allp[rank, 0], allp[rank, 1], allp[rank, 2] = float(st["recv_rows"]) * d * 4, float(st["local_edges"]), float(st["local_rows"])
+    dist.all_reduce(allp)
+    rec = {"workload": "RMAT scale %d |V|=%d |E|=%d d=%d fp32 (north_star target size, SURVEY 8d C2'), row partition (%s) x%d"
+                       % (scale, N, E, d, st["partition"], world),
+           "value": E / (t * 1e-3), "unit": "edges/s", "ms_per_step": t, "steps": steps, "exchange_only_ms": t_x,
+           "partition_and_plan_s": t_plan, "pushed_pairs": st["pushed_pairs"], "recv_bytes_per_rank": allp[:, 0].tolist(),
+           "edges_per_rank": allp[:, 1].tolist(), "rows_per_rank": allp[:, 2].tolist()}
+    del dg, x_own
     torch.cuda.empty_cache()
     return rec
 
@@ -255,11 +288,11 @@ def main():
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--partition", default="metis", choices=["metis", "kway", "random", "auto"],
-                    help="row partition for N > 1: 'metis' = the reference's METIS (pgl.partition.metis_partition, via "
-                         "pglamd_partition_metis; falls back to the engine's k-way partitioner when the helper library is absent), "
-                         "'kway' = the engine's own partitioner, 'random' = balanced random, 'auto' = metis vs random, keep the "
-                         "plan whose slowest rank receives fewer rows")
+    ap.add_argument("--partition", default="kway", choices=["kway", "metis", "random", "auto"],
+                    help="row partition for N > 1: 'kway' (default) = the engine's own multilevel partitioner (pglamd_partition_edges, "
+                         "balanced on in-degree + 1 and on rows), 'metis' = the reference's METIS as an opt-in comparison (helper library "
+                         "built from the reference checkout; k-way when absent), 'random' = balanced random, 'auto' = kway vs random, "
+                         "keep the plan whose slowest rank receives fewer rows")
     ap.add_argument("--parallel", default="rows", choices=["rows", "cols", "grid", "auto"],
                     help="N > 1 headline layout: 'rows' (default, north_star) = METIS row partition + one RCCL halo all-to-all-v "
                          "per step overlapped with the local edges (DistGraph); 'cols' = graph replicated, feature columns split, "
@@ -268,6 +301,8 @@ def main():
     ap.add_argument("--push", default="auto", choices=["auto", "never"],
                     help="per rank pair: 'auto' = the cheaper of pulling source rows and pushing pre-aggregated destination rows")
     ap.add_argument("--no-alternatives", action="store_true", help="N > 1: time only the headline layout")
+    ap.add_argument("--target-scale", type=int, default=22, help="target_size leg: RMAT scale (north_star: 22)")
+    ap.add_argument("--target-edges", type=int, default=100_000_000, help="target_size leg: edges (north_star: 100 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="N = 1: skip the no-reuse roofline legs and the |E| = 100 M target-size leg (profiling runs)")
@@ -426,6 +461,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1: north_star's target size (|E| = 100 M, SURVEY 8d C2') through the same partitioned flow -- every rank regenerates the
+    # graph from the seed, rank 0 partitions it with the engine's partitioner (seconds), all ranks time the same steps
+    target_rec = None
+    if world > 1 and mode == "rows" and not args.no_extra_legs:
+        target_rec = target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note)
+
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = E * args.steps / dt
@@ -464,6 +505,8 @@ def main():
                            "kernel": kname, "headline_workload": head}
         if halo is not None:
             rec["halo"] = halo
+        if world > 1 and target_rec is not None:
+            rec["target_size"] = target_rec
         if world == 1:
             rec["timing"] = step_distribution(step)                  # median / p95 over 100 event-timed runs
             rec["gcn_norm"] = gcn_norm_leg(pgl, g, x, E)             # send_recv with both degree norms, fused and unfused
@@ -480,7 +523,7 @@ def main():
                 "what": "agg_flat_kernel (the headline kernel, d=128 fp32 sum) on the uniform in-degree-19 graph over 2^24 rows: known "
                         "gathered bytes (discounted by the largest possible cache-hit share) / HIP-event kernel time, measured in this run",
                 "no_reuse": legs, "frac_permutation": legs["permutation"]["frac"]})
-            rec["target_size"] = target_size_leg(pgl, dev, d)
+            rec["target_size"] = target_size_leg(pgl, dev, d, args.target_scale, args.target_edges)
         elif world == 1:
             rec["roofline"]["what"] = "--no-extra-legs: the known-bytes leg was skipped, so no physical fraction is reported in this run"
             edges_cpu, x_cpu = edges.cpu(), x.cpu()

@@ -470,6 +470,20 @@ int32_t pglamd_partition_metis(int64_t num_nodes, const int64_t* xadj, const int
 int32_t pglamd_partition_kway(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
                               const int64_t* vwgt, const int64_t* adjwgt, int64_t nparts,
                               uint64_t seed, int64_t* part, int64_t* edgecut);
+/* The same partitioner with what a row-partitioned aggregation needs: a SECOND balance constraint (vwgt2, e.g. 1 per row next to
+ * vwgt = in-degree + 1: a rank's time follows its edges, its row-wise kernels and its memory follow its rows), explicit imbalance
+ * bounds ub / ub2 (<= 1: 1.03) and a thread count (0: $PGLAMD_THREADS, else min(cores, 16)).  Parallel and deterministic: the
+ * parts depend on (graph, weights, nparts, seed) only, not on the thread count.  pglamd_partition_edges takes the DIRECTED edge
+ * list as it is (strided int64 src / dst) and builds the symmetrised adjacency itself, in parallel. */
+int32_t pglamd_partition_kway2(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
+                               const int64_t* vwgt, const int64_t* vwgt2, const int64_t* adjwgt,
+                               int64_t nparts, double ub, double ub2, uint64_t seed, int32_t threads,
+                               int64_t* part, int64_t* edgecut);
+int32_t pglamd_partition_edges(const int64_t* src, int64_t src_stride, const int64_t* dst,
+                               int64_t dst_stride, int64_t num_edges, int64_t num_nodes,
+                               const int64_t* vwgt, const int64_t* vwgt2, int64_t nparts, double ub,
+                               double ub2, uint64_t seed, int32_t threads, int64_t* part,
+                               int64_t* edgecut);
 
 #ifdef __cplusplus
 }

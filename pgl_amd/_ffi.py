@@ -63,6 +63,10 @@ _SIGNATURES = {
     "pglamd_build_index_host": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pglamd_map_ids": (c_i32, [c_vp, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "pglamd_partition_kway": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_u64, c_vp, c_vp]),
+    "pglamd_partition_kway2": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_double, ctypes.c_double, c_u64, c_i32,
+                                        c_vp, c_vp]),
+    "pglamd_partition_edges": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_i64, ctypes.c_double, ctypes.c_double,
+                                        c_u64, c_i32, c_vp, c_vp]),
     "pglamd_row_epilogue_partials": (c_i64, [c_i64]),
     "pglamd_row_epilogue": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.c_float, c_vp, c_vp, c_vp]),
     "pglamd_row_epilogue_backward": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),

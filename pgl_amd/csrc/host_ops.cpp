@@ -1,17 +1,14 @@
-// host_ops.cpp -- CPU-side helpers of libpglamd (HOST pointers): id relabel and the engine's own
-// multilevel k-way graph partitioner.
+// host_ops.cpp -- CPU-side helpers of libpglamd (HOST pointers): the host CSR build, id relabel, the opt-in METIS bridge and
+// the halo plan of a row-partitioned graph.  (The engine's own partitioner lives in partition.cpp.)
 //
-// pglamd_map_ids      <- graph_kernel.map_edges / map_nodes (pgl/graph_kernel.pyx:104-138)
-// pglamd_partition_kway <- METIS_PartGraphKway as driven by pgl.partition.metis_partition
-//                        (pgl/partition.py:37-91 -> pgl/graph_kernel.pyx:434-472).
-//
-// The reference vendors METIS 5.1 (pgl/third_party/metis, third-party C).  It is NOT copied or
-// linked here; the partitioner below is a from-scratch implementation of the same published
-// scheme (Karypis & Kumar multilevel k-way: heavy-edge matching coarsening, greedy graph-growing
-// initial partition, greedy boundary k-way refinement with a balance constraint).  Its output is
-// therefore not bit-identical to METIS; the test-suite compares balance and edge cut against the real
-// METIS (built from the reference tree as test infrastructure only).  Partitioning is one-off host setup.
+// pglamd_build_index_host <- graph_kernel.build_index (pgl/graph_kernel.pyx:59-88)
+// pglamd_map_ids          <- graph_kernel.map_edges / map_nodes (pgl/graph_kernel.pyx:104-138)
+// pglamd_partition_metis  <- METIS_PartGraphKway as driven by pgl.partition.metis_partition (pgl/partition.py:37-91 ->
+//                            pgl/graph_kernel.pyx:434-472): the reference's vendored METIS in a helper library, opt-in.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
@@ -27,193 +24,6 @@
 namespace pglamd {
 int32_t fail(int32_t code, const char* fmt, ...);
 }
-
-namespace {
-
-struct Rng {   // splitmix64 / xorshift: deterministic for a given seed
-    uint64_t s;
-    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull) {}
-    uint64_t next() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
-    uint64_t below(uint64_t n) { return next() % n; }
-};
-
-struct G {
-    int64_t n = 0;
-    std::vector<int64_t> xadj;     // n+1
-    std::vector<int32_t> adj;      // neighbours
-    std::vector<int64_t> ew;       // edge weights
-    std::vector<int64_t> vw;       // vertex weights
-    int64_t tvw = 0;
-};
-
-void shuffle_perm(std::vector<int32_t>& p, Rng& rng) {
-    for (int64_t i = (int64_t)p.size() - 1; i > 0; --i) std::swap(p[i], p[rng.below((uint64_t)i + 1)]);
-}
-
-// heavy-edge matching; returns coarse graph + cmap (fine -> coarse)
-bool coarsen(const G& g, int64_t maxvw, Rng& rng, G& c, std::vector<int32_t>& cmap) {
-    const int64_t n = g.n;
-    std::vector<int32_t> match(n, -1), perm(n);
-    std::iota(perm.begin(), perm.end(), 0);
-    shuffle_perm(perm, rng);
-    // visit low-degree vertices first (helps power-law graphs): bucket by degree class
-    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) {
-        const int64_t da = g.xadj[a + 1] - g.xadj[a], db = g.xadj[b + 1] - g.xadj[b];
-        auto cls = [](int64_t d) { int c = 0; while (d > 1) { d >>= 1; ++c; } return c; };
-        return cls(da) < cls(db);
-    });
-    int64_t nc = 0;
-    cmap.assign(n, -1);
-    for (int64_t ii = 0; ii < n; ++ii) {
-        const int32_t v = perm[ii];
-        if (match[v] >= 0) continue;
-        int32_t best = -1; int64_t bw = -1;
-        for (int64_t p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-            const int32_t u = g.adj[p];
-            if (u == v || match[u] >= 0) continue;
-            if (g.vw[v] + g.vw[u] > maxvw) continue;
-            if (g.ew[p] > bw) { bw = g.ew[p]; best = u; }
-        }
-        if (best < 0) { match[v] = v; cmap[v] = (int32_t)nc++; }
-        else { match[v] = best; match[best] = v; cmap[v] = cmap[best] = (int32_t)nc++; }
-    }
-    if (nc > n * 0.95) return false;   // stalled
-    c.n = nc; c.xadj.assign(nc + 1, 0); c.vw.assign(nc, 0); c.tvw = g.tvw;
-    c.adj.clear(); c.ew.clear();
-    c.adj.reserve(g.adj.size()); c.ew.reserve(g.adj.size());
-    std::vector<int64_t> slot(nc, -1);
-    std::vector<int32_t> first(nc, -1);
-    for (int64_t v = 0; v < n; ++v) if (first[cmap[v]] < 0) first[cmap[v]] = (int32_t)v;
-    for (int64_t cv = 0; cv < nc; ++cv) {
-        const int32_t v = first[cv];
-        const int32_t m = match[v];
-        const int64_t start = (int64_t)c.adj.size();
-        const int32_t members[2] = {v, m};
-        const int cntm = (m == v) ? 1 : 2;
-        for (int k = 0; k < cntm; ++k) {
-            const int32_t f = members[k];
-            c.vw[cv] += g.vw[f];
-            for (int64_t p = g.xadj[f]; p < g.xadj[f + 1]; ++p) {
-                const int32_t cu = cmap[g.adj[p]];
-                if (cu == cv) continue;
-                if (slot[cu] < 0) { slot[cu] = (int64_t)c.adj.size(); c.adj.push_back(cu); c.ew.push_back(g.ew[p]); }
-                else c.ew[slot[cu]] += g.ew[p];
-            }
-        }
-        for (int64_t p = start; p < (int64_t)c.adj.size(); ++p) slot[c.adj[p]] = -1;
-        c.xadj[cv + 1] = (int64_t)c.adj.size();
-    }
-    return true;
-}
-
-int64_t edge_cut(const G& g, const std::vector<int32_t>& part) {
-    int64_t cut = 0;
-    for (int64_t v = 0; v < g.n; ++v)
-        for (int64_t p = g.xadj[v]; p < g.xadj[v + 1]; ++p)
-            if (part[g.adj[p]] != part[v]) cut += g.ew[p];
-    return cut / 2;
-}
-
-// greedy graph growing: parts are grown one after the other from a random seed, always absorbing
-// the frontier vertex most strongly connected to the growing part.
-void initial_partition(const G& g, int k, Rng& rng, std::vector<int32_t>& part) {
-    const int64_t n = g.n;
-    part.assign(n, -1);
-    std::vector<int64_t> conn(n, 0);
-    int64_t assigned_w = 0;
-    std::vector<int32_t> frontier;
-    for (int p = 0; p < k - 1; ++p) {
-        const int64_t target = (g.tvw - assigned_w) / (k - p);
-        int64_t w = 0;
-        frontier.clear();
-        // seed: random unassigned vertex
-        int32_t seed = -1;
-        for (int tries = 0; tries < 64 && seed < 0; ++tries) { int32_t v = (int32_t)rng.below((uint64_t)n); if (part[v] < 0) seed = v; }
-        if (seed < 0) for (int64_t v = 0; v < n; ++v) if (part[v] < 0) { seed = (int32_t)v; break; }
-        if (seed < 0) break;
-        auto absorb = [&](int32_t v) {
-            part[v] = p; w += g.vw[v];
-            for (int64_t q = g.xadj[v]; q < g.xadj[v + 1]; ++q) {
-                const int32_t u = g.adj[q];
-                if (part[u] >= 0) continue;
-                if (conn[u] == 0) frontier.push_back(u);
-                conn[u] += g.ew[q];
-            }
-        };
-        absorb(seed);
-        while (w < target) {
-            // pick the frontier vertex with max connection (linear scan: coarsest graph is small)
-            int64_t bi = -1, bc = -1;
-            for (int64_t i = 0; i < (int64_t)frontier.size(); ++i) {
-                const int32_t u = frontier[i];
-                if (part[u] >= 0) { frontier[i] = frontier.back(); frontier.pop_back(); --i; continue; }
-                if (conn[u] > bc) { bc = conn[u]; bi = i; }
-            }
-            int32_t nxt = -1;
-            if (bi >= 0) { nxt = frontier[bi]; frontier[bi] = frontier.back(); frontier.pop_back(); }
-            else { for (int64_t v = 0; v < n; ++v) if (part[v] < 0) { nxt = (int32_t)v; break; } }
-            if (nxt < 0) break;
-            if (w + g.vw[nxt] > target && w > target * 0.9) break;
-            absorb(nxt);
-        }
-        for (int32_t u : frontier) conn[u] = 0;
-        for (int64_t v = 0; v < n; ++v) if (part[v] < 0) conn[v] = 0;
-        assigned_w += w;
-    }
-    for (int64_t v = 0; v < n; ++v) if (part[v] < 0) part[v] = k - 1;
-}
-
-// greedy k-way boundary refinement with balance constraint
-void refine(const G& g, int k, int64_t maxpw, int passes, Rng& rng, std::vector<int32_t>& part) {
-    const int64_t n = g.n;
-    std::vector<int64_t> pw(k, 0);
-    for (int64_t v = 0; v < n; ++v) pw[part[v]] += g.vw[v];
-    std::vector<int64_t> conn(k, 0);
-    std::vector<int32_t> touched;
-    std::vector<int32_t> perm(n);
-    std::iota(perm.begin(), perm.end(), 0);
-    for (int pass = 0; pass < passes; ++pass) {
-        shuffle_perm(perm, rng);
-        int64_t moves = 0;
-        for (int64_t ii = 0; ii < n; ++ii) {
-            const int32_t v = perm[ii];
-            const int32_t own = part[v];
-            touched.clear();
-            bool boundary = false;
-            for (int64_t p = g.xadj[v]; p < g.xadj[v + 1]; ++p) {
-                const int32_t q = part[g.adj[p]];
-                if (conn[q] == 0) touched.push_back(q);
-                conn[q] += g.ew[p];
-                if (q != own) boundary = true;
-            }
-            const bool over = pw[own] > maxpw;
-            if (boundary || over) {
-                const int64_t cown = conn[own];
-                int32_t best = -1; int64_t bgain = over ? INT64_MIN : 0; int64_t bpw = 0;
-                for (int32_t q : touched) {
-                    if (q == own) continue;
-                    if (pw[q] + g.vw[v] > maxpw) continue;
-                    const int64_t gain = conn[q] - cown;
-                    if (gain > bgain || (gain == bgain && best >= 0 && pw[q] < bpw) ||
-                        (gain == 0 && best < 0 && !over && pw[q] + g.vw[v] < pw[own])) {
-                        best = q; bgain = gain; bpw = pw[q];
-                    }
-                }
-                if (best < 0 && over) {   // overweight interior vertex: push to the lightest part
-                    int32_t lq = (int32_t)(std::min_element(pw.begin(), pw.end()) - pw.begin());
-                    if (lq != own && pw[lq] + g.vw[v] <= maxpw) best = lq;
-                }
-                if (best >= 0 && (bgain > 0 || over || pw[best] + g.vw[v] < pw[own])) {
-                    part[v] = best; pw[own] -= g.vw[v]; pw[best] += g.vw[v]; ++moves;
-                }
-            }
-            for (int32_t q : touched) conn[q] = 0;
-        }
-        if (moves == 0) break;
-    }
-}
-
-}  // namespace
 
 extern "C" int32_t pglamd_build_index_host(const int64_t* u, int64_t u_stride, const int64_t* v, int64_t v_stride,
                                            int64_t num_edges, int64_t num_nodes, int64_t* degree, int64_t* sorted_v,
@@ -255,72 +65,6 @@ extern "C" int32_t pglamd_map_ids(const int64_t* keys, const int64_t* vals, int6
     }
     return PGLAMD_OK;
 }
-
-extern "C" int32_t pglamd_partition_kway(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
-                                         const int64_t* vwgt, const int64_t* adjwgt, int64_t nparts, uint64_t seed,
-                                         int64_t* part, int64_t* edgecut) {
-    if (num_nodes < 0 || nparts < 1 || (num_nodes > 0 && (!xadj || !part)))
-        return pglamd::fail(PGLAMD_E_ARG, "partition_kway: bad argument");
-    if (num_nodes >= INT32_MAX) return pglamd::fail(PGLAMD_E_RANGE, "partition_kway: too many nodes");
-    if (num_nodes == 0) { if (edgecut) *edgecut = 0; return PGLAMD_OK; }
-    const int k = (int)std::min<int64_t>(nparts, num_nodes);
-    if (k == 1) { std::fill(part, part + num_nodes, 0); if (edgecut) *edgecut = 0; return PGLAMD_OK; }
-
-    Rng rng(seed + 1);
-    std::vector<G> levels(1);
-    G& g0 = levels[0];
-    g0.n = num_nodes;
-    g0.xadj.assign(xadj, xadj + num_nodes + 1);
-    const int64_t m = xadj[num_nodes];
-    if (m > 0 && !adjncy) return pglamd::fail(PGLAMD_E_ARG, "partition_kway: adjncy NULL");
-    g0.adj.resize(m); g0.ew.resize(m);
-    for (int64_t i = 0; i < m; ++i) { g0.adj[i] = (int32_t)adjncy[i]; g0.ew[i] = adjwgt ? adjwgt[i] : 1; }
-    g0.vw.resize(num_nodes);
-    for (int64_t i = 0; i < num_nodes; ++i) { g0.vw[i] = vwgt ? vwgt[i] : 1; g0.tvw += g0.vw[i]; }
-
-    // ---- coarsening
-    const int64_t coarsen_to = std::max<int64_t>(40 * k, 400);
-    std::vector<std::vector<int32_t>> cmaps;
-    while (levels.back().n > coarsen_to && levels.size() < 40) {
-        const G& g = levels.back();
-        const int64_t maxvw = std::max<int64_t>(1, (int64_t)(1.5 * g.tvw / coarsen_to));
-        G c; std::vector<int32_t> cmap;
-        if (!coarsen(g, maxvw, rng, c, cmap)) break;
-        levels.push_back(std::move(c));
-        cmaps.push_back(std::move(cmap));
-    }
-
-    // ---- initial partition on the coarsest graph (best of a few trials)
-    const double ub = 1.03;
-    const G& gc = levels.back();
-    std::vector<int32_t> best_part; int64_t best_cut = -1;
-    auto max_pw = [&](const G& g) {
-        int64_t mx = 0; for (int64_t v = 0; v < g.n; ++v) mx = std::max(mx, g.vw[v]);
-        return std::max<int64_t>((int64_t)(ub * g.tvw / k) + 1, (g.tvw + k - 1) / k + mx / 2);
-    };
-    for (int trial = 0; trial < 8; ++trial) {
-        std::vector<int32_t> p;
-        initial_partition(gc, k, rng, p);
-        refine(gc, k, max_pw(gc), 10, rng, p);
-        const int64_t cut = edge_cut(gc, p);
-        if (best_cut < 0 || cut < best_cut) { best_cut = cut; best_part = p; }
-    }
-
-    // ---- uncoarsen + refine
-    std::vector<int32_t> cur = std::move(best_part);
-    for (int64_t lv = (int64_t)levels.size() - 2; lv >= 0; --lv) {
-        const G& g = levels[lv];
-        std::vector<int32_t> fine(g.n);
-        const std::vector<int32_t>& cmap = cmaps[lv];
-        for (int64_t v = 0; v < g.n; ++v) fine[v] = cur[cmap[v]];
-        cur.swap(fine);
-        refine(g, k, max_pw(g), lv == 0 ? 6 : 8, rng, cur);
-    }
-    for (int64_t v = 0; v < num_nodes; ++v) part[v] = cur[v];
-    if (edgecut) *edgecut = edge_cut(levels[0], cur);
-    return PGLAMD_OK;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // METIS (the reference's vendored library, built by pgl_amd/_build_metis.py into libpglamd_metis.so next to this library)

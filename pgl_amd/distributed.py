@@ -430,20 +430,20 @@ class DistGraph(object):
 
     # ---- construction ----------------------------------------------------------------------------------------------
     @classmethod
-    def from_global(cls, edges, num_nodes, rank, world, method="metis", device=None, part=None, group=None, backend=None,
+    def from_global(cls, edges, num_nodes, rank, world, method="kway", device=None, part=None, group=None, backend=None,
                     seed=0, push="auto"):
         """Every rank holds the same global edge list (synthetic graphs are regenerated from the seed on each rank);
         rank 0 partitions and broadcasts the part vector.
-        method: "metis" (the reference's METIS through pgl_amd.partition, k-way fallback when the helper library is
-                absent), "kway" (the engine's own multilevel partitioner), "random", "mod" (node id % world, the
-                reference DistGPUGraph's rule), or "auto" (build metis and random, keep the plan whose slowest rank
-                receives fewer rows).
+        method: "kway" (default: the engine's own multilevel partitioner, balanced on aggregation work -- in-degree + 1 -- and
+                on rows), "metis" (opt-in comparison: the reference's METIS through pgl_amd.partition, k-way when its helper
+                library is absent), "random", "mod" (node id % world, the reference DistGPUGraph's rule), or "auto" (build
+                kway and random, keep the plan whose slowest rank receives fewer rows).
         push:   "auto" = per rank pair the cheaper of pull / push for send_recv(sum | mean); "never" = pull everywhere."""
         edges = torch.as_tensor(edges)
         if device is not None:
             edges = edges.to(device)
         given = part is not None
-        methods = [method] if (given or method != "auto" or world == 1) else ["metis", "random"]
+        methods = [method] if (given or method != "auto" or world == 1) else ["kway", "random"]
         best = None
         for m in methods:
             pt = part if given else cls.partition(edges, num_nodes, world, m, rank, group, seed)
@@ -468,10 +468,8 @@ class DistGraph(object):
                 best = (float(cost), m, plan, xplan)
         dg = cls(best[2], device=edges.device, group=group, backend=backend, exchange_plan=best[3])
         dg.method = "given" if given else best[1]
-        if dg.method == "metis" and world > 1:                       # say what actually ran (same answer on every rank)
-            from . import partition as _pt
-            if os.environ.get("PGLAMD_PARTITIONER", "metis") == "kway" or not ops.metis_available():
-                dg.method = "kway (METIS helper library absent)"
+        if dg.method == "metis" and world > 1 and not ops.metis_available():   # say what actually ran (same answer on every rank)
+            dg.method = "kway (METIS helper library absent)"
         return dg
 
     @classmethod
@@ -484,7 +482,7 @@ class DistGraph(object):
         return cls.from_global(torch.as_tensor(graph.edges), graph.num_nodes, rank, world, **kw)
 
     @staticmethod
-    def partition(edges, num_nodes, world, method="metis", rank=0, group=None, seed=0):
+    def partition(edges, num_nodes, world, method="kway", rank=0, group=None, seed=0):
         if world == 1:
             return torch.zeros(num_nodes, dtype=torch.int64)
         ready = _group_ready(group)
@@ -498,17 +496,19 @@ class DistGraph(object):
                 p = np.repeat(np.arange(world, dtype=np.int64), -(-num_nodes // world))[:num_nodes]
                 rng.shuffle(p)
             else:
-                # symmetrised adjacency (the reference warns METIS input should be undirected, pgl/partition.py:61);
-                # vertex weight = in-degree + 1 balances aggregation work (node_weights, pgl/partition.py:76-79)
-                u = np.concatenate([e[:, 0], e[:, 1]]); v = np.concatenate([e[:, 1], e[:, 0]])
-                _, sv, _, _, ip = ops.host_build_index(u, v, num_nodes)
+                # vertex weight = in-degree + 1 balances aggregation work (node_weights, pgl/partition.py:76-79); the adjacency is
+                # symmetrised (the reference warns METIS input should be undirected, pgl/partition.py:61)
                 vw = np.bincount(e[:, 1], minlength=num_nodes).astype(np.int64) + 1
                 p = None
-                if method == "metis":
-                    from . import partition as _pt
-                    p = _pt.metis_kway_csr(num_nodes, ip, sv, world, vw)       # None when the METIS helper is not built
+                if method == "metis" and ops.metis_available():       # opt-in comparison: the reference's METIS
+                    u = np.concatenate([e[:, 0], e[:, 1]]); v = np.concatenate([e[:, 1], e[:, 0]])
+                    _, sv, _, _, ip = ops.host_build_index(u, v, num_nodes)
+                    p = ops.host_partition_metis(num_nodes, ip, sv, world, vw)[0]
                 if p is None:
-                    p, _ = ops.host_partition_kway(num_nodes, ip, sv, world, vw, None, seed)
+                    # the engine's partitioner on the directed edge list (symmetrised inside, in parallel); second constraint =
+                    # rows, kept loose: on power-law graphs hubs and leaves cannot be spread evenly under a tight row bound,
+                    # and the isolated vertices, placed last, level the row counts anyway
+                    p, _ = ops.host_partition_edges(e, num_nodes, world, vw, np.ones(num_nodes, np.int64), 1.03, 1.6, seed)
             part.copy_(torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)))
         if ready:
             buf = part.to(edges.device) if dist.get_backend(group) == "nccl" else part
@@ -991,7 +991,7 @@ class DistGPUGraph(object):
         warnings.warn("DistGPUGraph is an experimental API for Multi-GPU FullBatch Training.")
         g = graph if graph.is_tensor() else graph.tensor()
         if method is None:                        # graphs too small to be worth a partitioner: the reference's modulo rule
-            method = "metis" if g.num_nodes >= 4096 else "mod"
+            method = "kway" if g.num_nodes >= 4096 else "mod"
         self.graph = g
         self.dist = DistGraph.from_graph(g, method=method, group=group, device=g.edges.device)
         self.node_feat, self.edge_feat = g.node_feat, g.edge_feat
@@ -1162,7 +1162,7 @@ class GridShardedGraph(object):
     between the Pr ranks that share a column slice, and are d / Pc wide -- Pc times fewer bytes per link than the pure
     row partition, Pr times more columns per rank than pure feature sharding (whose narrow rows are line-rate bound)."""
 
-    def __init__(self, edges, num_nodes, rank, world, grid, method="metis", device=None, seed=0, push="auto", backend=None):
+    def __init__(self, edges, num_nodes, rank, world, grid, method="kway", device=None, seed=0, push="auto", backend=None):
         pr, pc = int(grid[0]), int(grid[1])
         assert pr * pc == int(world), "grid %r does not tile %d ranks" % (grid, world)
         self.grid, self.rank, self.world = (pr, pc), int(rank), int(world)

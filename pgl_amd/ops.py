@@ -660,6 +660,39 @@ def host_partition_kway(num_nodes, indptr, adjncy, nparts, node_weights=None, ed
     return part, int(cut.value)
 
 
+def host_partition_kway2(num_nodes, indptr, adjncy, nparts, node_weights=None, node_weights2=None, edge_weights=None,
+                         ub=1.03, ub2=1.03, seed=0, threads=0):
+    """pglamd_partition_kway2: the engine's partitioner with a second balance constraint and explicit imbalance bounds."""
+    indptr = _np_i64(indptr); adjncy = _np_i64(adjncy)
+    vw = None if node_weights is None else _np_i64(node_weights)
+    vw2 = None if node_weights2 is None else _np_i64(node_weights2)
+    ew = None if edge_weights is None else _np_i64(edge_weights)
+    part = np.empty(int(num_nodes), np.int64)
+    cut = ctypes.c_int64(0)
+    _ffi.check(_ffi.lib().pglamd_partition_kway2(int(num_nodes), _np_ptr(indptr), _np_ptr(adjncy), _np_ptr(vw), _np_ptr(vw2),
+                                                 _np_ptr(ew), int(nparts), float(ub), float(ub2), int(seed), int(threads),
+                                                 _np_ptr(part), ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)), "partition_kway2")
+    return part, int(cut.value)
+
+
+def host_partition_edges(edges, num_nodes, nparts, node_weights=None, node_weights2=None, ub=1.03, ub2=1.03, seed=0, threads=0):
+    """pglamd_partition_edges: partition the graph of a DIRECTED [E, 2] int64 edge list (symmetrised inside the library)."""
+    e = np.asarray(edges)
+    if e.dtype != np.int64:
+        e = e.astype(np.int64)
+    E = int(e.shape[0])
+    st = e.strides[0] // 8 if E else 2
+    src, dst = (e[:, 0], e[:, 1]) if E else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    vw = None if node_weights is None else _np_i64(node_weights)
+    vw2 = None if node_weights2 is None else _np_i64(node_weights2)
+    part = np.empty(int(num_nodes), np.int64)
+    cut = ctypes.c_int64(0)
+    _ffi.check(_ffi.lib().pglamd_partition_edges(_np_ptr(src), st, _np_ptr(dst), st, E, int(num_nodes), _np_ptr(vw), _np_ptr(vw2),
+                                                 int(nparts), float(ub), float(ub2), int(seed), int(threads), _np_ptr(part),
+                                                 ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)), "partition_edges")
+    return part, int(cut.value)
+
+
 def metis_available():
     """True when the METIS helper library (pgl_amd/_build_metis.py) can be opened."""
     return bool(_ffi.lib().pglamd_metis_available())

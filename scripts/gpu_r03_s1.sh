@@ -8,9 +8,9 @@ timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu_s1.log 2>&1; ech
 tail -4 $O/pytest_gpu_s1.log
 timeout 600 python bench.py > $O/bench_n1_s1.json 2> $O/bench_n1_s1.err; echo "bench rc=$?"
 head -c 1500 $O/bench_n1_s1.json; echo
-timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 2,4,8 --partition "scratch/parts/rmat20_e20000000_p{P}_kway_r2.npy" > $O/rows_c2_s1.txt 2>&1
+timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 2,4,8 --partition "scratch/parts/rmat20_e20000000_p{P}_kway.npy" > $O/rows_c2_s1.txt 2>&1
 tail -30 $O/rows_c2_s1.txt
-if [ -f scratch/parts/rmat22_e100000000_p8_kway_r2.npy ]; then
-  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "scratch/parts/rmat22_e100000000_p{P}_kway_r2.npy" > $O/rows_c2p_s1.txt 2>&1
+if [ -f scratch/parts/rmat22_e100000000_p8_kway.npy ]; then
+  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "scratch/parts/rmat22_e100000000_p{P}_kway.npy" > $O/rows_c2p_s1.txt 2>&1
   tail -14 $O/rows_c2p_s1.txt
 fi

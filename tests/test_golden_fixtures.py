@@ -40,11 +40,13 @@ def test_map_ids_fixture():
 
 
 @pytest.mark.parametrize("k", [2, 4, 8])
-def test_metis_partition_bit_identical_to_reference_fixture(k):
-    """a14: pgl_amd.partition.metis_partition == the reference's pgl.partition.metis_partition (fixture produced by the
-    reference's compiled graph_kernel.metis_partition, tests/golden/make_*), id for id -- the same METIS, called the same
-    way, through the C ABI (pglamd_partition_metis -> libpglamd_metis.so)."""
+def test_metis_partition_bit_identical_to_reference_fixture(k, monkeypatch):
+    """The OPT-IN METIS bridge (PGLAMD_PARTITIONER=metis): pgl_amd.partition.metis_partition == the reference's
+    pgl.partition.metis_partition (fixture produced by the reference's compiled graph_kernel.metis_partition,
+    tests/golden/make_*), id for id -- the same METIS, called the same way, through pglamd_partition_metis ->
+    libpglamd_metis.so.  It is the comparison partner, not the product default."""
     import pgl_amd
+    monkeypatch.setenv("PGLAMD_PARTITIONER", "metis")
     if not pgl_amd.ops.metis_available():
         pytest.skip("libpglamd_metis.so not built (needs the reference checkout: python -m pgl_amd._build_metis)")
     z = np.load(os.path.join(GOLD, "metis_k%d.npz" % k))
@@ -57,19 +59,59 @@ def test_metis_partition_bit_identical_to_reference_fixture(k):
 
 
 @pytest.mark.parametrize("k", [2, 4, 8])
-def test_fallback_partitioner_vs_metis_fixture(k, monkeypatch):
-    """The documented fallback (engine's own k-way partitioner, PGLAMD_PARTITIONER=kway or helper absent): balanced, and
-    its cut within 1.5x of METIS's."""
+def test_engine_partitioner_vs_metis_fixture(k, monkeypatch):
+    """a14, the product default: the engine's own partitioner (csrc/partition.cpp) against what the reference's METIS produced
+    on the same graph (fixture): cut <= 1.05x METIS's, parts within 1.03 of even (VERDICT r2 item 3's bar), for several seeds."""
     import pgl_amd
-    monkeypatch.setenv("PGLAMD_PARTITIONER", "kway")
+    monkeypatch.delenv("PGLAMD_PARTITIONER", raising=False)
     z = np.load(os.path.join(GOLD, "metis_k%d.npz" % k))
     e, n = z["edges"], int(z["num_nodes"])
     g = pgl_amd.Graph(edges=e, num_nodes=n)
-    with pytest.warns(UserWarning):
-        part = pgl_amd.partition.metis_partition(g, k)
-    cut = int((part[e[:, 0]] != part[e[:, 1]]).sum())
-    assert np.bincount(part, minlength=k).max() <= 1.10 * n / k
-    assert cut <= 1.5 * int(z["cut"]) + 50, (cut, int(z["cut"]))
+    for seed in range(4):
+        with pytest.warns(UserWarning):
+            part = pgl_amd.partition.metis_partition(g, k, seed=seed)
+        assert part.dtype == np.int64 and part.min() >= 0 and part.max() == k - 1
+        cut = int((part[e[:, 0]] != part[e[:, 1]]).sum())
+        assert np.bincount(part, minlength=k).max() <= 1.03 * n / k + 1e-9, np.bincount(part, minlength=k)
+        assert cut <= 1.05 * int(z["cut"]), (seed, cut, int(z["cut"]))
+
+
+def test_engine_partitioner_on_the_benchmark_graph_vs_committed_metis_numbers():
+    """RMAT-20 (the benchmark graph) at P = 8 with the weights DistGraph uses (in-degree + 1, rows as second constraint) against
+    the numbers the reference's METIS produced on the same graph and weights (tests/golden/metis_rmat20_p8.json, 42 s on one
+    core): cut <= 1.05x, weight balance <= 1.03, rows far better spread (METIS leaves them at 2.5x), and seconds, not a minute."""
+    import json
+    import time
+    import torch
+    import pgl_amd
+    from pgl_amd.utils.rmat import rmat_edges
+    ref = json.load(open(os.path.join(GOLD, "metis_rmat20_p8.json")))
+    N, P = 1 << 20, 8
+    e = rmat_edges(20, 20_000_000, seed=42, device=torch.device("cpu")).numpy()
+    vw = np.bincount(e[:, 1], minlength=N).astype(np.int64) + 1
+    t0 = time.time()
+    part, cut = pgl_amd.ops.host_partition_edges(e, N, P, vw, np.ones(N, np.int64), 1.03, 1.6, 0)
+    dt = time.time() - t0
+    directed = int((part[e[:, 0]] != part[e[:, 1]]).sum())
+    w = np.bincount(part, weights=vw, minlength=P)
+    rows = np.bincount(part, minlength=P)
+    assert directed <= 1.05 * ref["metis_directed_cut_edges"], (directed, ref["metis_directed_cut_edges"])
+    assert w.max() / w.mean() <= 1.0305 and rows.max() / rows.mean() <= 1.3, (w.max() / w.mean(), rows.max() / rows.mean())
+    assert dt < max(10.0, ref["metis_seconds_1_core"] / 4), dt          # ~3 s on 8 threads; bound loose for a loaded test host
+    print("engine partitioner: %.1f s, directed cut %d = %.3fx METIS (%d, %.0f s)" % (dt, directed, directed / ref["metis_directed_cut_edges"],
+                                                                                     ref["metis_directed_cut_edges"], ref["metis_seconds_1_core"]))
+
+
+def test_engine_partitioner_is_independent_of_the_thread_count():
+    """Deterministic in (graph, weights, k, seed): ranks that partition on their own (no process group) must agree."""
+    import pgl_amd
+    rng = np.random.default_rng(5)
+    n = 20000
+    e = np.stack([rng.integers(0, n, 200000), (rng.integers(0, n, 200000) ** 2 // n)], 1).astype(np.int64)   # skewed destinations
+    vw = np.bincount(e[:, 1], minlength=n).astype(np.int64) + 1
+    parts = [pgl_amd.ops.host_partition_edges(e, n, 6, vw, np.ones(n, np.int64), 1.03, 1.6, 3, threads=t)[0] for t in (1, 3, 8)]
+    assert np.array_equal(parts[0], parts[1]) and np.array_equal(parts[0], parts[2])
+    assert not np.array_equal(parts[0], pgl_amd.ops.host_partition_edges(e, n, 6, vw, np.ones(n, np.int64), 1.03, 1.6, 4)[0])
 
 
 @pytest.mark.gpu
