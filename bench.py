@@ -298,8 +298,10 @@ def main():
                          "per step overlapped with the local edges (DistGraph); 'cols' = graph replicated, feature columns split, "
                          "no data-path collective (FeatureShardedGraph); 'grid' = 2 row parts x N/2 column slices; 'auto' = time "
                          "all three and report the fastest.  With 'rows' the others are still timed and reported as secondary fields")
-    ap.add_argument("--push", default="auto", choices=["auto", "never"],
-                    help="per rank pair: 'auto' = the cheaper of pulling source rows and pushing pre-aggregated destination rows")
+    ap.add_argument("--push", default="never", choices=["never", "auto"],
+                    help="'never' (default) = halo source rows are pulled, every edge is aggregated by its destination's owner (what the "
+                         "partitioner balanced); 'auto' = per rank pair the cheaper of pulling source rows and pushing pre-aggregated "
+                         "destination rows (fewer bytes, but it moves edge work between ranks)")
     ap.add_argument("--no-alternatives", action="store_true", help="N > 1: time only the headline layout")
     ap.add_argument("--target-scale", type=int, default=22, help="target_size leg: RMAT scale (north_star: 22)")
     ap.add_argument("--target-edges", type=int, default=100_000_000, help="target_size leg: edges (north_star: 100 M)")

@@ -4,8 +4,11 @@
 //
 // Plan (all HBM-bound integer work, ~28 B/edge algorithmic):
 //   1. narrow the int64 keys (strided: a column of the [E,2] edge array) to int32, eid = iota;
-//   2. stable LSD radix sort of (key32, eid32) over ceil(log2 N) key bits only
-//      (rocPRIM device radix sort, the AMD-native primitive: onesweep passes tuned for gfx9);
+//   2. stable LSD radix sort over ceil(log2 N) key bits only -- HAND-WRITTEN for this job (round 3; rounds 1-2 called
+//      rocPRIM's radix_sort_pairs: three onesweep passes at 0.09 of the byte model): ceil(bits / 11) passes of <= 11 bits,
+//      i.e. TWO passes up to 4 M rows, each pass = block histograms -> scan -> stable scatter (see "the sort" below);
+//      the first pass reads the caller's int64 (u, v) columns directly and the last one writes the int32 (row, col, eid)
+//      arrays the kernels read, so the narrow and unpack passes of the library version are gone;
 //      stability == ascending eid inside equal keys == the reference's order by construction;
 //   3. indptr from row boundaries in the sorted keys (no atomics, no scan): every position p with
 //      key[p] != key[p-1] writes indptr for the rows in (key[p-1], key[p]];  degree = diff;
@@ -98,17 +101,239 @@ __global__ __launch_bounds__(kBlock) void seg_ids_kernel(const int64_t* __restri
         seg[p] = rank[sorted_u[p]];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The sort.  One pass moves (key32, value64) pairs by one digit of BITS bits, stably:
+//   hist      every 1024-thread block counts the digits of its tile of 16 384 items (LDS atomics) -> hist[digit][block]
+//   scan      exclusive scan of hist in (digit, block) order: one block per digit scans its row, one small kernel scans the
+//             row totals -> the global position of the first item of every (digit, block)
+//   scatter   the block reloads its tile; wave w owns items [w * 1024, (w + 1) * 1024) of it and walks them 64 at a time IN
+//             ORDER.  Inside a 64-item step the lanes holding the same digit find each other with BITS ballots (peers = AND
+//             of ballot(bit) or its complement), rank = popcount of the peers below the lane, and the lowest peer bumps the
+//             wave's own 16-bit digit counter in LDS by the group size -- no atomics, and the order inside a wave is the
+//             item order.  A 16-step pass over the wave counters turns them into exclusive prefixes over the waves, so
+//             position = hist offset + prefix over earlier waves + count in earlier steps of this wave + rank: stable.
+//   Every lane writes its own pair; a (block, digit) run is 16 consecutive slots on average at 10 bits (64-byte key runs,
+//   128-byte value runs), and neighbouring blocks -- resident at the same time -- extend each other's runs in L2.
+// Nothing here is graph specific except FIRST (keys / values come from the caller's strided int64 columns, ids are range
+// checked) and LAST (the outputs are the CSR arrays).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSortThreads = 1024;
+constexpr int kSortWaves = kSortThreads / kWave;
+constexpr int kSortItems = 16;
+constexpr int kSortTile = kSortThreads * kSortItems;
+constexpr int kSortMaxBits = 11;
+
+struct SortArgs {
+    const int64_t* u; int64_t us; const int64_t* v; int64_t vs;      // FIRST: strided int64 key / neighbour columns
+    const int32_t* key_in; const uint64_t* val_in;                   // otherwise
+    int32_t* key_out; uint64_t* val_out;                             // not LAST
+    int32_t* row32; int32_t* col32; int32_t* eid32;                  // LAST (any may be NULL)
+    int64_t* sorted_u; int64_t* sorted_v; int64_t* sorted_eid;       // LAST, optional int64 copies (the reference's arrays)
+    uint32_t* hist;                                                  // [bins][nblk]
+    uint32_t* dbase;                                                 // [bins]
+    int32_t* range_flag;
+    int64_t n, n_rows;
+    int shift, nblk;
+};
+
+template <bool FIRST>
+__device__ __forceinline__ int32_t sort_key(const SortArgs& a, int64_t idx, bool& bad) {
+    if constexpr (FIRST) {
+        int64_t k = a.u[idx * a.us];
+        if ((uint64_t)k >= (uint64_t)a.n_rows) { k = 0; bad = true; }   // clamped (memory-safe) and reported
+        return (int32_t)k;
+    } else {
+        return a.key_in[idx];
+    }
+}
+
+template <int BITS, bool FIRST>
+__global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(SortArgs a) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t h[BINS];
+    for (int i = threadIdx.x; i < BINS; i += kSortThreads) h[i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < kSortItems; ++i) {
+        const int64_t idx = base + (int64_t)i * kSortThreads + threadIdx.x;
+        if (idx < a.n) atomicAdd(&h[(sort_key<FIRST>(a, idx, bad) >> a.shift) & (BINS - 1)], 1u);
+    }
+    if (FIRST && a.range_flag && __any(bad)) { if ((threadIdx.x & (kWave - 1)) == 0) atomicOr(a.range_flag, 1); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < BINS; i += kSortThreads) a.hist[(int64_t)i * a.nblk + blockIdx.x] = h[i];
+}
+
+// one block per digit: exclusive scan of its row of block counts, row total -> totals[digit]
+__global__ __launch_bounds__(kBlock) void sort_scan_rows_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals, int nblk) {
+    __shared__ uint32_t part[kBlock];
+    uint32_t* row = hist + (int64_t)blockIdx.x * nblk;
+    const int per = (nblk + kBlock - 1) / kBlock;
+    const int b = min((int)threadIdx.x * per, nblk), e = min(b + per, nblk);
+    uint32_t s = 0;
+    for (int i = b; i < e; ++i) s += row[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {             // inclusive Hillis-Steele over the 256 partial sums
+        const uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = b; i < e; ++i) { const uint32_t c = row[i]; row[i] = run; run += c; }
+    if (threadIdx.x == kBlock - 1) totals[blockIdx.x] = part[kBlock - 1];
+}
+
+__global__ __launch_bounds__(kBlock) void sort_scan_totals_kernel(const uint32_t* __restrict__ totals, uint32_t* __restrict__ dbase, int bins) {
+    __shared__ uint32_t part[kBlock];
+    const int per = (bins + kBlock - 1) / kBlock;
+    const int b = min((int)threadIdx.x * per, bins), e = min(b + per, bins);
+    uint32_t s = 0;
+    for (int i = b; i < e; ++i) s += totals[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+        const uint32_t add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = b; i < e; ++i) { dbase[i] = run; run += totals[i]; }
+}
+
+template <int BITS, bool FIRST, bool LAST>
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ uint32_t gb[BINS];                         // global position of this block's first item of every digit
+    __shared__ uint16_t cnt[kSortWaves][BINS];            // per-wave digit counts, then exclusive prefixes over the waves
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
+    for (int i = tid; i < BINS; i += kSortThreads) gb[i] = a.dbase[i] + a.hist[(int64_t)i * a.nblk + blockIdx.x];
+    {
+        uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0]);
+        for (int i = tid; i < kSortWaves * BINS / 2; i += kSortThreads) z[i] = 0;
+    }
+    __syncthreads();
+    const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)w * (kWave * kSortItems);
+    int32_t key[kSortItems];
+    uint64_t val[kSortItems];
+    uint16_t pos[kSortItems];
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s) {
+        const int64_t idx = wbase + s * kWave + lane;
+        key[s] = 0; val[s] = 0;
+        if (idx < a.n) {
+            key[s] = sort_key<FIRST>(a, idx, bad);
+            if constexpr (FIRST) {
+                const int64_t nb = a.v[idx * a.vs];
+                if ((uint64_t)nb > (uint64_t)INT32_MAX) bad = true;
+                val[s] = ((uint64_t)(uint32_t)nb << 32) | (uint64_t)(uint32_t)idx;        // (neighbour, original edge id)
+            } else {
+                val[s] = a.val_in[idx];
+            }
+        }
+    }
+    if (FIRST && a.range_flag && __any(bad)) { if (lane == 0) atomicOr(a.range_flag, 1); }
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s) {
+        const bool valid = wbase + s * kWave + lane < a.n;
+        const int d = (key[s] >> a.shift) & (BINS - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < BITS; ++b) {
+            const bool bit = (d >> b) & 1;
+            const unsigned long long m = __ballot(valid && bit);
+            peers &= bit ? m : ~m;
+        }
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0));
+        const int leader = __builtin_ctzll(peers | (1ull << 63));
+        int old = 0;
+        if (valid && rank == 0) { old = cnt[w][d]; cnt[w][d] = (uint16_t)(old + __popcll(peers)); }
+        old = __shfl(old, leader, kWave);
+        pos[s] = (uint16_t)(old + rank);
+    }
+    __syncthreads();
+    for (int d = tid; d < BINS; d += kSortThreads) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < kSortWaves; ++ww) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s) {
+        if (wbase + s * kWave + lane >= a.n) continue;
+        const int d = (key[s] >> a.shift) & (BINS - 1);
+        const int64_t dest = (int64_t)gb[d] + cnt[w][d] + pos[s];
+        if constexpr (LAST) {
+            const int32_t nb = (int32_t)(uint32_t)(val[s] >> 32), e = (int32_t)(uint32_t)val[s];
+            if (a.row32) a.row32[dest] = key[s];
+            if (a.col32) a.col32[dest] = nb;
+            if (a.eid32) a.eid32[dest] = e;
+            if (a.sorted_u) a.sorted_u[dest] = key[s];
+            if (a.sorted_v) a.sorted_v[dest] = nb;
+            if (a.sorted_eid) a.sorted_eid[dest] = e;
+        } else {
+            a.key_out[dest] = key[s];
+            a.val_out[dest] = val[s];
+        }
+    }
+}
+
+static int sort_max_bits() {
+    static int v = [] { const char* e = getenv("PGLAMD_SORT_MAXBITS"); int b = e ? atoi(e) : kSortMaxBits; return b < 6 ? 6 : b > kSortMaxBits ? kSortMaxBits : b; }();
+    return v;
+}
+
+template <int BITS, bool FIRST, bool LAST>
+static int32_t sort_pass_launch(const SortArgs& a, uint32_t* totals, hipStream_t st) {
+    hipLaunchKernelGGL((sort_hist_kernel<BITS, FIRST>), dim3((unsigned)a.nblk), dim3(kSortThreads), 0, st, a);
+    PGLAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(1u << BITS), dim3(kBlock), 0, st, a.hist, totals, a.nblk);
+    PGLAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(kBlock), 0, st, totals, a.dbase, 1 << BITS);
+    PGLAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL((sort_scatter_kernel<BITS, FIRST, LAST>), dim3((unsigned)a.nblk), dim3(kSortThreads), 0, st, a);
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+template <bool FIRST, bool LAST>
+static int32_t sort_pass(int bits, const SortArgs& a, uint32_t* totals, hipStream_t st) {
+    switch (bits) {
+        case 6: return sort_pass_launch<6, FIRST, LAST>(a, totals, st);
+        case 7: return sort_pass_launch<7, FIRST, LAST>(a, totals, st);
+        case 8: return sort_pass_launch<8, FIRST, LAST>(a, totals, st);
+        case 9: return sort_pass_launch<9, FIRST, LAST>(a, totals, st);
+        case 10: return sort_pass_launch<10, FIRST, LAST>(a, totals, st);
+        default: return sort_pass_launch<11, FIRST, LAST>(a, totals, st);
+    }
+}
+
+// digits of the passes for keys of `bits` bits: as few passes as the widest digit allows, digits of (nearly) equal width >= 6
+static int sort_plan(int bits, int (&width)[8]) {
+    const int mb = sort_max_bits();
+    int passes = (bits + mb - 1) / mb;
+    if (passes < 1) passes = 1;
+    int left = bits;
+    for (int p = 0; p < passes; ++p) {
+        int w = (left + (passes - p) - 1) / (passes - p);
+        if (w < 6) w = 6;
+        width[p] = w;
+        left -= w;
+        if (left < 0) left = 0;
+    }
+    return passes;
+}
+
+static size_t sort_hist_entries(int64_t E) { return ((size_t)1 << kSortMaxBits) * (size_t)ceil_div(E > 0 ? E : 1, (int64_t)kSortTile); }
+
 static unsigned grid_for(int64_t n) {
     int64_t g = ceil_div(n > 0 ? n : 1, kBlock);
     return (unsigned)(g < 256 * 16 ? g : 256 * 16);
-}
-
-static size_t sort_temp_bytes(int64_t E, int bits) {
-    size_t bytes = 0;
-    int32_t* k = nullptr;
-    uint64_t* w = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, w, w, (size_t)(E > 0 ? E : 1), 0u, (unsigned)bits, (hipStream_t)0);
-    return bytes;
 }
 
 static size_t scan_temp_bytes(int64_t N) {
@@ -125,8 +350,10 @@ using namespace pglamd;
 
 extern "C" size_t pglamd_csr_build_workspace_bytes(int64_t num_edges, int64_t num_nodes) {
     const int64_t E = num_edges > 0 ? num_edges : 1;
-    // key_in, row32 (when the caller does not keep it), packed values in / out, sort temp
-    return 2 * align_up((size_t)E * 4, 256) + 2 * align_up((size_t)E * 8, 256) + align_up(sort_temp_bytes(E, key_bits(num_nodes)), 256) + 1024;
+    // two (key32, value64) ping-pong buffers, row32 when the caller does not keep it, block histograms + digit totals / bases
+    (void)num_nodes;
+    return 3 * align_up((size_t)E * 4, 256) + 2 * align_up((size_t)E * 8, 256) + align_up(sort_hist_entries(E) * 4, 256) +
+           2 * align_up(((size_t)1 << kSortMaxBits) * 4, 256) + 1024;
 }
 
 extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const int64_t* v, int64_t v_stride,
@@ -142,30 +369,43 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t E = num_edges, N = num_nodes;
     Carver cv(workspace, workspace_bytes);
-    int32_t* key_in = cv.take<int32_t>(E > 0 ? E : 1);
+    int32_t* key_a = cv.take<int32_t>(E > 0 ? E : 1);
+    int32_t* key_b = cv.take<int32_t>(E > 0 ? E : 1);
     int32_t* row_tmp = cv.take<int32_t>(E > 0 ? E : 1);
-    uint64_t* val_in = cv.take<uint64_t>(E > 0 ? E : 1);
-    uint64_t* val_out = cv.take<uint64_t>(E > 0 ? E : 1);
-    int32_t* rows = row32 ? row32 : row_tmp;
-    const int bits = key_bits(N);
-    size_t temp_bytes = sort_temp_bytes(E, bits);
-    void* temp = cv.take<char>(temp_bytes);
+    uint64_t* val_a = cv.take<uint64_t>(E > 0 ? E : 1);
+    uint64_t* val_b = cv.take<uint64_t>(E > 0 ? E : 1);
+    uint32_t* hist = cv.take<uint32_t>(sort_hist_entries(E));
+    uint32_t* totals = cv.take<uint32_t>((size_t)1 << kSortMaxBits);
+    uint32_t* dbase = cv.take<uint32_t>((size_t)1 << kSortMaxBits);
     if (!cv.ok()) return fail(PGLAMD_E_WORKSPACE, "csr_build: workspace carve overflow");
+    int32_t* rows = row32 ? row32 : row_tmp;
 
     if (E > 0) {
-        hipLaunchKernelGGL(narrow_keys_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, u, u_stride, v, v_stride, E, N, key_in, val_in, range_flag);
-        PGLAMD_LAUNCH_CHECK();
-        PGLAMD_HIP_CHECK(rocprim::radix_sort_pairs(temp, temp_bytes, key_in, rows, val_in, val_out, (size_t)E, 0u, (unsigned)bits, st));
+        int width[8];
+        const int passes = sort_plan(key_bits(N), width);
+        SortArgs a{};
+        a.u = u; a.us = u_stride; a.v = v; a.vs = v_stride; a.range_flag = range_flag;
+        a.hist = hist; a.dbase = dbase; a.n = E; a.n_rows = N; a.nblk = (int)ceil_div(E, (int64_t)kSortTile);
+        int shift = 0;
+        for (int p = 0; p < passes; ++p) {
+            const bool first = p == 0, last = p == passes - 1;
+            a.shift = shift;
+            a.key_in = (p & 1) ? key_a : key_b; a.val_in = (p & 1) ? val_a : val_b;      // pass 0 writes A, pass 1 reads A ...
+            a.key_out = (p & 1) ? key_b : key_a; a.val_out = (p & 1) ? val_b : val_a;
+            if (last) { a.row32 = rows; a.col32 = col32; a.eid32 = eid32; a.sorted_u = sorted_u; a.sorted_v = sorted_v; a.sorted_eid = sorted_eid; }
+            int32_t rc;
+            if (first && last) rc = sort_pass<true, true>(width[p], a, totals, st);
+            else if (first) rc = sort_pass<true, false>(width[p], a, totals, st);
+            else if (last) rc = sort_pass<false, true>(width[p], a, totals, st);
+            else rc = sort_pass<false, false>(width[p], a, totals, st);
+            if (rc != PGLAMD_OK) return rc;
+            shift += width[p];
+        }
     }
     hipLaunchKernelGGL(row_bounds_kernel<int32_t>, dim3(grid_for(E + 1)), dim3(kBlock), 0, st, rows, E, N, indptr);
     PGLAMD_LAUNCH_CHECK();
     if (N > 0) {
         hipLaunchKernelGGL(degree_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st, indptr, N, degree);
-        PGLAMD_LAUNCH_CHECK();
-    }
-    if (E > 0) {
-        hipLaunchKernelGGL(finish_csr_kernel, dim3(grid_for(E)), dim3(kBlock), 0, st, rows, val_out, E,
-                           sorted_v, sorted_u, sorted_eid, col32, eid32);
         PGLAMD_LAUNCH_CHECK();
     }
     return PGLAMD_OK;

@@ -176,13 +176,15 @@ def _all_reduce_sum(tensor, group=None):
 # methods as a test seam -- the product has only this one and it refuses CPU tensors.)
 # ------------------------------------------------------------------------------------------------------------------
 class _EngineBackend(object):
-    def index(self, rows, cols, n_rows, edge_ids=None):
+    def index(self, rows, cols, n_rows, edge_ids=None, n_edge_rows=0):
         """CSR of the (rows, cols) pairs.  edge_ids: the LOCAL edge id of every pair (edge operands of send_ue_recv are in
-        local edge order); None = pair k is edge k.  The longest row rides along (`max_row`: one host read at plan set-up),
+        local edge order, n_edge_rows of them); None = pair k is edge k.  The longest row rides along (`max_row`: one host read at plan set-up),
         so launches over an index no row of which can be split skip the fix-up kernels."""
         c = ops.csr_build(rows, cols, int(n_rows), want_i64=False, check_range=False)
-        if edge_ids is not None and c.num_edges:
-            c.eid32 = edge_ids.to(torch.int32)[c.eid32.long()].contiguous()
+        if edge_ids is not None:
+            if c.num_edges:
+                c.eid32 = edge_ids.to(torch.int32)[c.eid32.long()].contiguous()
+            c.y_rows = int(n_edge_rows) if n_edge_rows else 0
         c.max_row = int(c.degree.max().item()) if c.num_edges else 0
         return c
 
@@ -431,14 +433,17 @@ class DistGraph(object):
     # ---- construction ----------------------------------------------------------------------------------------------
     @classmethod
     def from_global(cls, edges, num_nodes, rank, world, method="kway", device=None, part=None, group=None, backend=None,
-                    seed=0, push="auto"):
+                    seed=0, push="never"):
         """Every rank holds the same global edge list (synthetic graphs are regenerated from the seed on each rank);
         rank 0 partitions and broadcasts the part vector.
         method: "kway" (default: the engine's own multilevel partitioner, balanced on aggregation work -- in-degree + 1 -- and
                 on rows), "metis" (opt-in comparison: the reference's METIS through pgl_amd.partition, k-way when its helper
                 library is absent), "random", "mod" (node id % world, the reference DistGPUGraph's rule), or "auto" (build
                 kway and random, keep the plan whose slowest rank receives fewer rows).
-        push:   "auto" = per rank pair the cheaper of pull / push for send_recv(sum | mean); "never" = pull everywhere."""
+        push:   "never" (default) = pull everywhere: every edge is aggregated by its DESTINATION's owner, which is what the
+                partitioner balanced; "auto" = per rank pair the cheaper of pull / push for send_recv(sum | mean) -- 3-10 % fewer
+                rows on the wire on RMAT, but a pushing rank pre-aggregates edges the partitioner gave to someone else
+                (measured, profiles/r03: the slowest rank's compute grows by a third)."""
         edges = torch.as_tensor(edges)
         if device is not None:
             edges = edges.to(device)
@@ -600,6 +605,7 @@ class DistGraph(object):
                       destination row for a pushed one)                                  rows: n_send      cols: owned
           <k>int      INTERIOR rows -- every source local -- with their edges            rows: n_own       cols: owned
           <k>bnd      BOUNDARY rows -- at least one received source -- with ALL their edges                cols: owned | received
+          <k>all      every row with all its edges (taken instead of int + bnd when almost nothing is interior)
           <k>recv_t   transposed flow (gradients): what travels back, recv_buf_t[i] = sum of g over the rows that read
                       received row i                                                     rows: n_recv      cols: owned
           <k>int_t    owned rows no peer reads, with their transposed local edges        rows: n_own       cols: owned
@@ -632,13 +638,14 @@ class DistGraph(object):
                 rows, cols, nr = xp.send_rows, xp.send_cols, xp.n_send
             elif base == "recv_t":
                 rows, cols, nr = xp.recv_cols, xp.recv_rows, xp.n_recv
-            elif base in ("int", "bnd"):
+            elif base in ("int", "bnd", "all"):
                 boundary = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
                 boundary[xp.recv_rows] = True
-                keep = boundary[p.loc_rows] if base == "bnd" else ~boundary[p.loc_rows]
+                keep = torch.ones_like(boundary[p.loc_rows]) if base == "all" else \
+                    boundary[p.loc_rows] if base == "bnd" else ~boundary[p.loc_rows]
                 rows, cols = p.loc_rows[keep], p.loc_cols[keep]
                 sel = torch.nonzero(keep).reshape(-1)
-                if base == "bnd":
+                if base != "int":
                     rows = torch.cat([rows, xp.recv_rows])
                     cols = torch.cat([cols, xp.recv_cols + p.n_own])
                     # local edge ids (edge operands): the halo edges follow the local-source ones in local edge order; only
@@ -647,18 +654,18 @@ class DistGraph(object):
                 if k == "p":
                     eids = sel
                 nr = p.n_own
-            elif base in ("int_t", "bnd_t"):
+            elif base in ("int_t", "bnd_t", "all_t"):
                 sent = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
                 sent[xp.send_cols] = True
-                keep = sent[p.loc_cols] if base == "bnd_t" else ~sent[p.loc_cols]
+                keep = torch.ones_like(sent[p.loc_cols]) if base == "all_t" else sent[p.loc_cols] if base == "bnd_t" else ~sent[p.loc_cols]
                 rows, cols = p.loc_cols[keep], p.loc_rows[keep]
-                if base == "bnd_t":
+                if base != "int_t":
                     rows = torch.cat([rows, xp.send_cols])
                     cols = torch.cat([cols, xp.send_rows + p.n_own])
                 nr = p.n_own
             else:
                 raise KeyError(name)
-        idx = self._b.index(rows, cols, nr, eids) if eids is not None else self._b.index(rows, cols, nr)
+        idx = self._b.index(rows, cols, nr, eids, p.local_edges) if eids is not None else self._b.index(rows, cols, nr)
         self._idx[name] = idx
         return idx
 
@@ -757,19 +764,48 @@ class DistGraph(object):
         sfx = "_t" if transposed else ""
         started = self._start_exchange(x, kind, transposed)
         n_in = (xp.n_send if transposed else xp.n_recv) if started is not None else 0
-        out = B.aggregate(x, self._index(kind + "int" + sfx), reduce, p.n_own, dst_scale=scale_k,
-                          zero_indptr=self._zero_indptr(transposed) if n_in else None)        # overlaps the exchange
-        if started is not None:
+        if n_in and self._fold(kind, transposed):
+            # (almost) no interior -- a power-law graph cut 8 ways: one launch over every row after the wait instead of an
+            # interior launch with nothing to overlap (a launch costs ~10 us of GPU time whatever it carries)
             work, in_buf, unpack = started
             work.wait()
-            if n_in:
-                if unpack is not None:
-                    unpack()
-                B.aggregate(x, self._index(kind + "bnd" + sfx), reduce, p.n_own, dst_scale=scale_k, out=out, accumulate=2,
-                            x2=in_buf)
+            if unpack is not None:
+                unpack()
+            out = B.aggregate(x, self._index(kind + "all" + sfx), reduce, p.n_own, dst_scale=scale_k, x2=in_buf)
+        else:
+            out = B.aggregate(x, self._index(kind + "int" + sfx), reduce, p.n_own, dst_scale=scale_k,
+                              zero_indptr=self._zero_indptr(transposed) if n_in else None)    # overlaps the exchange
+            if started is not None:
+                work, in_buf, unpack = started
+                work.wait()
+                if n_in:
+                    if unpack is not None:
+                        unpack()
+                    B.aggregate(x, self._index(kind + "bnd" + sfx), reduce, p.n_own, dst_scale=scale_k, out=out, accumulate=2,
+                                x2=in_buf)
         if post is not None:
             out = out * post
         return out
+
+    def _fold(self, kind, transposed):
+        """True when the interior of this flow holds so few edges (< PGLAMD_FOLD_INTERIOR, default 3 %, of the local ones) that
+        overlapping them with the exchange buys less than their launch costs.  Decided once per (plan, direction) from the
+        plan's own counts -- no index is built for the decision."""
+        key = ("fold", kind, transposed)
+        hit = self._idx.get(key)
+        if hit is None:
+            p = self.plan
+            xp = self.xplan if kind == "x" else p
+            mark = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
+            if transposed:
+                mark[xp.send_cols] = True
+                e_int = int((~mark[p.loc_cols]).sum())
+            else:
+                mark[xp.recv_rows] = True
+                e_int = int((~mark[p.loc_rows]).sum())
+            hit = e_int < float(os.environ.get("PGLAMD_FOLD_INTERIOR", "0.03")) * max(p.local_edges, 1)
+            self._idx[key] = hit
+        return hit
 
     def _sum_like(self, x_own, reduce_func, extra_dst_scale=None):
         scale = self._scale(reduce_func)

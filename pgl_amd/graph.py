@@ -271,14 +271,16 @@ class Graph(object):
     def adj_src_index(self):
         """pgl/graph.py:1307-1316."""
         if self._adj_src_index is None:
-            self._adj_src_index = EdgeIndex.from_edges(u=self._edges[:, 0], v=self._edges[:, 1], num_nodes=self._num_nodes)
+            self._adj_src_index = EdgeIndex.from_edges(u=self._edges[:, 0], v=self._edges[:, 1], num_nodes=self._num_nodes,
+                                                       check_range=not getattr(self, "_ids_in_range", False))
         return self._adj_src_index
 
     @property
     def adj_dst_index(self):
         """pgl/graph.py:1319-1328 (u = dst, v = src)."""
         if self._adj_dst_index is None:
-            self._adj_dst_index = EdgeIndex.from_edges(u=self._edges[:, 1], v=self._edges[:, 0], num_nodes=self._num_nodes)
+            self._adj_dst_index = EdgeIndex.from_edges(u=self._edges[:, 1], v=self._edges[:, 0], num_nodes=self._num_nodes,
+                                                       check_range=not getattr(self, "_ids_in_range", False))
         return self._adj_dst_index
 
     def sorted_edges(self, sort_by="src"):

@@ -59,7 +59,7 @@ def _prod(shape):
 class CSR(object):
     """Device-side result of csr_build: the reference's five int64 arrays + int32 engine copies."""
     __slots__ = ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr", "row32", "col32", "eid32",
-                 "num_nodes", "num_edges", "_pos_by_dst", "max_row")
+                 "num_nodes", "num_edges", "_pos_by_dst", "max_row", "y_rows")
 
 
 def csr_build(u, v, num_nodes, want_i64=True, check_range=True):
@@ -97,6 +97,24 @@ def csr_build(u, v, num_nodes, want_i64=True, check_range=True):
     if flag is not None and int(flag.item()):
         raise ValueError("pgl_amd csr_build: edge ids outside [0, num_nodes=%d) (or >= 2^31); the graph index would be "
                          "garbage -- check num_nodes against the edge list" % N)
+    return c
+
+
+def csr_from_sorted(u_sorted, v, num_nodes):
+    """The index of edges ALREADY grouped by key (u non-decreasing) -- the blocks a neighbour sampler emits
+    (pgl/sampling/sage.py:144-147: `reindex_graph` returns the destinations as repeat_interleave(arange, count)): indptr from
+    the run boundaries (pglamd_seg_ptr_from_ids), eid = position, no sort.  The result equals csr_build(u, v) because a stable
+    sort leaves a sorted sequence where it is."""
+    _need_cuda(u_sorted, v)
+    E, N, dev = int(u_sorted.shape[0]), int(num_nodes), u_sorted.device
+    c = CSR()
+    c.num_nodes, c.num_edges, c.max_row = N, E, 0
+    c.sorted_v = c.sorted_u = c.sorted_eid = None
+    c.row32 = narrow_i64(u_sorted) if u_sorted.dtype == torch.int64 else u_sorted.to(torch.int32).contiguous()
+    c.col32 = narrow_i64(v) if v.dtype == torch.int64 else v.to(torch.int32).contiguous()
+    c.eid32 = torch.arange(E, dtype=torch.int32, device=dev)
+    c.indptr = seg_ptr_from_ids(c.row32, N)
+    c.degree = c.indptr[1:] - c.indptr[:-1]
     return c
 
 
@@ -186,8 +204,11 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     if y is not None:
         if y.dtype != x.dtype:
             y = y.to(x.dtype)
-        if int(y.shape[0]) != csr.num_edges:
-            raise ValueError("edge feature has %d rows, graph has %d edges" % (y.shape[0], csr.num_edges))
+        # (an index over a SUBSET of a graph's edges -- the interior / boundary indices of a partition -- addresses the operand
+        #  by the graph's own edge ids and says how many rows that is in `y_rows`)
+        n_y = int(getattr(csr, "y_rows", 0) or csr.num_edges)
+        if int(y.shape[0]) != n_y:
+            raise ValueError("edge feature has %d rows, graph has %d edges" % (y.shape[0], n_y))
         x, y, tail = _bcast(x, y)
         dy = _prod(y.shape[1:])
     else:

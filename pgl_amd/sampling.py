@@ -7,6 +7,7 @@ import torch
 
 from . import ops
 from .graph import Graph
+from .utils.edge_index import EdgeIndex
 
 
 class NeighborSampler(object):
@@ -26,7 +27,12 @@ class NeighborSampler(object):
             self._seed += 1
             neighbors, count = ops.sample_neighbors(self.csr, nodes, size, self._seed)
             edge_src, edge_dst, sample_index = ops.reindex_graph(nodes, neighbors, count)
-            block = Graph(num_nodes=int(sample_index.shape[0]), edges=torch.stack([edge_src, edge_dst], 1))
+            # reindex_graph returns the destinations as repeat_interleave(arange, count): the block IS dst-sorted, so its dst
+            # index needs no sort (round 2 re-sorted every block of every step through the full radix sort)
+            n_blk = int(sample_index.shape[0])
+            block = Graph(num_nodes=n_blk, edges=torch.stack([edge_src, edge_dst], 1),
+                          adj_dst_index=EdgeIndex.from_sorted(edge_dst, edge_src, n_blk))
+            block._ids_in_range = True        # ids come from reindex_graph: the src index (backward) is built without the range read-back
             graph_list.append((block, int(nodes.shape[0])))
             nodes = sample_index
         return graph_list[::-1], nodes

@@ -58,15 +58,24 @@ class EdgeIndex(object):
 
     # ---- construction ------------------------------------------------------------------------
     @classmethod
-    def from_edges(cls, u, v, num_nodes):
+    def from_edges(cls, u, v, num_nodes, check_range=True):
         self = cls()
         self._is_tensor = check_is_tensor(u, v)
         if self._is_tensor:
-            c = ops.csr_build(u, v, int(num_nodes), want_i64=False)
+            c = ops.csr_build(u, v, int(num_nodes), want_i64=False, check_range=check_range)
             self._adopt(c)
         else:
             self._degree, self._sorted_v, self._sorted_u, self._sorted_eid, self._indptr = \
                 ops.host_build_index(u, v, int(num_nodes))
+        return self
+
+    @classmethod
+    def from_sorted(cls, u, v, num_nodes):
+        """Tensor-mode index of edges whose keys `u` are ALREADY non-decreasing (sampled blocks): no sort, the caller vouches
+        for the order.  Same arrays as from_edges(u, v) would produce."""
+        self = cls()
+        self._is_tensor = True
+        self._adopt(ops.csr_from_sorted(u, v, int(num_nodes)))
         return self
 
     @classmethod

@@ -117,6 +117,12 @@ def cmd_rows(args):
                 dg.wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.wire]
             x_own = dg.take_owned(x)
             ms = _t(lambda: dg.send_recv(x_own, "sum"), it=10, warm=3)
+            torch.cuda.synchronize()
+            t_cpu = time.perf_counter()
+            for _ in range(20):
+                dg.send_recv(x_own, "sum")
+            enq = (time.perf_counter() - t_cpu) / 20 * 1e3               # host time to ENQUEUE one step (no sync inside)
+            torch.cuda.synchronize()
             # phases on their own (each between its own pair of events)
             B = dg._b
             pk = _t(lambda: dg._start_exchange(x_own, "x", False), it=10, warm=2)
@@ -129,18 +135,42 @@ def cmd_rows(args):
             ideal = plan.local_edges / (E / t1)
             e_int, e_bnd = dg._index("xint").num_edges, dg._index("xbnd").num_edges
             pair_mb = max(xplan.recv_splits) * d * wb / 1e6
-            rows.append((r, plan.n_own, plan.local_edges, e_int, e_bnd, xplan.n_send, xplan.n_recv, ms, pk, it_, bd, ideal, pair_mb))
+            rows.append((r, plan.n_own, plan.local_edges, e_int, e_bnd, xplan.n_send, xplan.n_recv, ms, pk, it_, bd, ideal, pair_mb, enq,
+                         dg._fold("x", False)))
             worst["compute"] = max(worst["compute"], ms); worst["pair_mb"] = max(worst["pair_mb"], pair_mb)
             worst["ratio"] = max(worst["ratio"], ms / ideal)
             del dg, plan, xplan, x_own, out
-        for r, n_own, le, ei, eb, ns, nr, ms, pk, it_, bd, ideal, pmb in rows:
-            print("   rank %d: %7d rows %9d edges (interior %8d, boundary %9d) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms = pack %.3f + interior %.3f + boundary %.3f (+gaps) | ideal %.3f ms -> x%.2f"
-                  % (r, n_own, le, ei, eb, ns, nr, pmb, ms, pk, it_, bd, ideal, ms / ideal))
+        for r, n_own, le, ei, eb, ns, nr, ms, pk, it_, bd, ideal, pmb, enq, fold in rows:
+            print("   rank %d: %7d rows %9d edges (interior %8d, boundary %9d%s) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms (host enqueue %.3f) ; alone: pack %.3f, interior %.3f, boundary %.3f | ideal %.3f ms -> x%.2f"
+                  % (r, n_own, le, ei, eb, "; folded into one launch" if fold else "", ns, nr, pmb, ms, enq, pk, it_, bd, ideal, ms / ideal))
         t_link = worst["pair_mb"] / 1e3 / LINK * 1e3
         print("   slowest rank compute %.3f ms (worst compute/ideal x%.2f; ideal = E/P at the 1-GPU rate = %.3f ms) | exchange >= %.3f ms (largest pair block at %.0f GB/s per link)"
               % (worst["compute"], worst["ratio"], t1 / P, t_link, LINK))
         print("   predicted step: max(compute, exchange) = %.3f ms = %.2fx of one GPU; compute + exchange = %.3f ms = %.2fx"
               % (max(worst["compute"], t_link), t1 / max(worst["compute"], t_link), worst["compute"] + t_link, t1 / (worst["compute"] + t_link)), flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def cmd_csr(args):
+    """CSR build (row a1) against its SURVEY 8(d) byte model (28 B / edge: 16 read + 12 written, + 12 B / row)."""
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    print("sort digits: PGLAMD_SORT_MAXBITS=%s" % os.environ.get("PGLAMD_SORT_MAXBITS", "11 (default)"))
+    for name, scale, E in (("C2", 20, 20_000_000), ("C2'", 22, 100_000_000), ("sampled block", 17, 600_000), ("Cora-sized", 12, 13_264)):
+        N = 1 << scale
+        edges = rmat_edges(scale, E, seed=42, device=dev)
+        for tag, (u, v) in (("dst-keyed", (edges[:, 1], edges[:, 0])), ("src-keyed", (edges[:, 0], edges[:, 1]))):
+            ms = _t(lambda: pgl.ops.csr_build(u, v, N, want_i64=False, check_range=False), it=10, warm=3)
+            model = E * 28 + N * 12
+            print("%-14s %-9s |E|=%-10d N=2^%-2d csr_build %.3f ms = %6.2f G edges/s, %.0f GB/s of the 28 B/edge model = %.3f of 8 TB/s"
+                  % (name, tag, E, scale, ms, E / ms / 1e6, model / ms / 1e6, model / ms / 1e6 / 8000.0), flush=True)
+        c = pgl.ops.csr_build(edges[:, 1], edges[:, 0], N, want_i64=False, check_range=False)
+        u_sorted, v_sorted = c.row32.long(), c.col32.long()
+        ms = _t(lambda: pgl.ops.csr_from_sorted(u_sorted, v_sorted, N), it=10, warm=3)
+        print("%-14s %-9s |E|=%-10d N=2^%-2d csr_from_sorted %.3f ms (keys already grouped: no sort)" % (name, "sorted", E, scale, ms), flush=True)
+        del edges, c, u_sorted, v_sorted
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -176,6 +206,8 @@ def main():
         _run_script("bench_ops.py", args.rest)
     elif args.cmd == "layers":
         _run_script("prof_layers.py", args.rest)
+    elif args.cmd == "csr":
+        cmd_csr(args)
     else:
         raise SystemExit("subcommand %r is not wired up yet" % args.cmd)
 

@@ -9,7 +9,7 @@ import torch
 
 
 class TorchBackend(object):
-    def index(self, rows, cols, n_rows, edge_ids=None):
+    def index(self, rows, cols, n_rows, edge_ids=None, n_edge_rows=0):
         return (rows.long(), cols.long(), int(n_rows), None if edge_ids is None else edge_ids.long())
 
     def gather_rows(self, x, idx):

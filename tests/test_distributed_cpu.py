@@ -127,6 +127,14 @@ def test_two_rank_gloo_matches_single_graph(method, push):
         assert sum(g[3]["pushed_pairs"] for g in got) > 0              # the hub destination makes its pair push
 
 
+def test_two_rank_gloo_folded_interior(monkeypatch):
+    """A partition with (almost) no interior takes ONE launch over all rows after the wait instead of interior + boundary
+    (PGLAMD_FOLD_INTERIOR: forced here) -- forward for every reduce op and the gradients must not notice."""
+    monkeypatch.setenv("PGLAMD_FOLD_INTERIOR", "2.0")
+    test_two_rank_gloo_matches_single_graph("random", "auto")
+    test_two_rank_gloo_gradients_match_single_graph("auto")
+
+
 # ------------------------------------------------------------------------------------------------
 # 16-bit wire for fp32 features: same flow, the halo rows travel as fp16 / bf16
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,271 @@
+"""GPU tests (-m gpu) added in round 3: the hand-written CSR sort at every pass count, the sorted-input index, the two-table
+aggregation (pglamd_aggregate_ext) behind the single-write partitioned flow, the wire cast kernel, and per-element fp64 bounds
+for mean / max / min and the 16-bit storage types at BASELINE configs[1] size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pgl():
+    import pgl_amd
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    assert pgl_amd._ffi.lib().pglamd_device_arch().decode().startswith("gfx950")
+    return pgl_amd
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# a1: the hand-written radix sort behind pglamd_csr_build -- bit-exact vs the reference's compiled build_index
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,e,seed", [
+    (40, 30000, 1),                  # 6-bit keys: one pass, two tiles
+    (2000, 16384, 2),                # exactly one tile, 11 bits: one pass
+    (2049, 16385, 3),                # 12 bits: two passes of 6; one item in the second tile
+    (70000, 500000, 4),              # 17 bits: two passes
+    (1 << 20, 3000000, 5),           # 20 bits: two passes of 10 (the benchmark graph's key width)
+    ((1 << 22) + 5, 2500000, 6),     # 23 bits: three passes
+    (1 << 25, 1200000, 7),           # 25 bits: three passes of 9
+])
+def test_csr_sort_bit_exact_at_every_pass_count(pgl, ref_native, n, e, seed):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, n, e).astype(np.int64)
+    v = rng.integers(0, n, e).astype(np.int64)
+    u[rng.choice(e, e // 7, replace=False)] = n - 1           # a hub row at the top of the key range (every digit's last bin)
+    u[rng.choice(e, e // 9, replace=False)] = 0
+    ref = ref_native.build_index(u, v, n)
+    edges = dev(np.stack([v, u], 1))
+    c = pgl.ops.csr_build(edges[:, 1], edges[:, 0], n)         # strided int64 columns, as Graph passes them
+    for got, want, name in zip((c.degree, c.sorted_v, c.sorted_u, c.sorted_eid, c.indptr), ref,
+                               ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr")):
+        assert np.array_equal(host(got), want), name
+    assert np.array_equal(host(c.row32), ref[2]) and np.array_equal(host(c.col32), ref[1]) and np.array_equal(host(c.eid32), ref[3])
+    c2 = pgl.ops.csr_build(edges[:, 1], edges[:, 0], n, want_i64=False)
+    assert c2.sorted_v is None and np.array_equal(host(c2.eid32), ref[3]) and np.array_equal(host(c2.indptr), ref[4])
+
+
+def test_csr_sort_full_size_is_stable_and_complete(pgl):
+    """BASELINE configs[1] size (20 M edges, 2^20 rows): size-independent properties of a stable counting sort -- keys
+    non-decreasing, edge ids ascending inside a row, eid a permutation, (row, col) of position p = the edge eid[p]."""
+    from pgl_amd.utils.rmat import rmat_edges
+    N, E = 1 << 20, 20_000_000
+    edges = rmat_edges(20, E, seed=42, device=torch.device("cuda"))
+    c = pgl.ops.csr_build(edges[:, 1], edges[:, 0], N, want_i64=False)
+    row, col, eid = c.row32.long(), c.col32.long(), c.eid32.long()
+    assert bool((row[1:] >= row[:-1]).all())
+    same = row[1:] == row[:-1]
+    assert bool((eid[1:][same] > eid[:-1][same]).all())                      # stable: ascending original edge id inside a row
+    assert bool((torch.bincount(eid, minlength=E) == 1).all())                # a permutation
+    assert bool((edges[eid, 1] == row).all()) and bool((edges[eid, 0] == col).all())
+    assert bool((c.indptr[1:] - c.indptr[:-1] == torch.bincount(edges[:, 1], minlength=N)).all())
+
+
+def test_index_of_sorted_edges_needs_no_sort(pgl):
+    """EdgeIndex.from_sorted (sampled blocks are dst-sorted by construction, pgl/sampling/sage.py:144-147) == from_edges."""
+    rng = np.random.default_rng(11)
+    n_dst, n = 500, 4000
+    count = rng.integers(0, 12, n_dst)
+    dst = np.repeat(np.arange(n_dst), count).astype(np.int64)
+    src = rng.integers(0, n, len(dst)).astype(np.int64)
+    a = pgl.utils.edge_index.EdgeIndex.from_sorted(dev(dst), dev(src), n).csr
+    b = pgl.ops.csr_build(dev(dst), dev(src), n, want_i64=False)
+    for k in ("row32", "col32", "eid32", "indptr", "degree"):
+        assert np.array_equal(host(getattr(a, k)), host(getattr(b, k))), k
+    # the sampler uses it: its blocks aggregate like the index built the long way
+    edges = np.stack([rng.integers(0, 3000, 40000), rng.integers(0, 3000, 40000)], 1).astype(np.int64)
+    g = pgl.Graph(edges=edges, num_nodes=3000).tensor()
+    blocks, nodes = pgl.sampling.NeighborSampler(g, [6, 6], seed=5).sample_neighbors(dev(np.arange(100, dtype=np.int64)))
+    x = torch.randn(int(nodes.shape[0]), 16, device="cuda")
+    for blk, n_out in blocks:
+        e = blk.edges
+        want = pgl.Graph(edges=e, num_nodes=blk.num_nodes).send_recv(x[:blk.num_nodes], "sum")       # sorts
+        got = blk.send_recv(x[:blk.num_nodes], "sum")                                                  # does not
+        assert torch.equal(got, want)
+        xg = x[:blk.num_nodes].clone().requires_grad_(True)
+        blk.send_recv(xg, "mean").square().sum().backward()                                            # src index: built on demand
+        assert torch.isfinite(xg.grad).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# pglamd_aggregate_ext: two source tables, zero_indptr, the fix-up skip
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,d", [(torch.float32, 128), (torch.float32, 24), (torch.float32, 8), (torch.float16, 128),
+                                     (torch.float64, 16), (torch.int64, 4)])
+@pytest.mark.parametrize("op", ["sum", "max"])
+def test_two_table_aggregation_equals_the_concatenated_table(pgl, dtype, d, op):
+    rng = np.random.default_rng(3)
+    n_a, n_b, n_rows, e = 700, 900, 400, 30000
+    rows = rng.integers(0, n_rows, e); rows[:6000] = 17                       # a row longer than any chunk: partials + fix-up
+    cols = rng.integers(0, n_a + n_b, e)
+    if dtype.is_floating_point:
+        xa, xb = torch.randn(n_a, d, device="cuda").to(dtype), torch.randn(n_b, d, device="cuda").to(dtype)
+    else:
+        xa, xb = torch.randint(-50, 50, (n_a, d), device="cuda"), torch.randint(-50, 50, (n_b, d), device="cuda")
+    c = pgl.ops.csr_build(dev(rows.astype(np.int64)), dev(cols.astype(np.int64)), n_rows, want_i64=False)
+    want = pgl.ops.aggregate(torch.cat([xa, xb], 0), c, op, n_rows)
+    got = pgl.ops.aggregate(xa, c, op, n_rows, x2=xb)
+    assert torch.equal(got, want)                                             # same kernel, same order: bit-identical
+    # max_row hint: an index without long rows skips the fix-up launches and must still be right
+    rows2 = rng.integers(0, n_rows, 5000)
+    c2 = pgl.ops.csr_build(dev(rows2.astype(np.int64)), dev(cols[:5000].astype(np.int64)), n_rows, want_i64=False)
+    c2.max_row = int(c2.degree.max())
+    assert c2.max_row <= 64
+    assert torch.equal(pgl.ops.aggregate(xa, c2, op, n_rows, x2=xb), pgl.ops.aggregate(torch.cat([xa, xb], 0), c2, op, n_rows))
+
+
+def test_zero_indptr_leaves_other_rows_alone(pgl):
+    """The interior launch of a partition zero-fills only rows that are empty in the UNION index; rows that are empty in its
+    own index but belong to the boundary launch keep whatever they hold."""
+    n_rows, d = 300, 128
+    x = torch.randn(500, d, device="cuda")
+    rows_int = np.arange(0, 100).repeat(3).astype(np.int64)                   # interior rows 0..99
+    rows_all = np.concatenate([rows_int, np.arange(100, 200).repeat(2)])      # boundary rows 100..199; 200..299 empty
+    cols = np.random.default_rng(0).integers(0, 500, len(rows_all)).astype(np.int64)
+    c_int = pgl.ops.csr_build(dev(rows_int), dev(cols[:len(rows_int)]), n_rows, want_i64=False)
+    c_all = pgl.ops.csr_build(dev(rows_all), dev(cols), n_rows, want_i64=False)
+    out = torch.full((n_rows, d), 7.0, device="cuda")
+    pgl.ops.aggregate(x, c_int, "sum", n_rows, out=out, zero_indptr=c_all.indptr)
+    want = pgl.ops.aggregate(x, c_all, "sum", n_rows)
+    assert torch.equal(out[:100], want[:100])
+    assert bool((out[100:200] == 7.0).all())                                  # not this launch's rows
+    assert bool((out[200:] == 0).all())                                       # truly empty: cleared here
+    c_bnd = pgl.ops.csr_build(dev(rows_all[len(rows_int):]), dev(cols[len(rows_int):]), n_rows, want_i64=False)
+    pgl.ops.aggregate(x, c_bnd, "sum", n_rows, out=out, accumulate=2)
+    assert torch.equal(out, want)                                             # every row written exactly once, same values
+
+
+@pytest.mark.parametrize("wire", [torch.float16, torch.bfloat16])
+def test_wire_cast_gather(pgl, wire):
+    x = torch.randn(1000, 96, device="cuda")
+    idx = torch.randint(0, 1000, (377,), device="cuda", dtype=torch.int32)
+    packed = pgl.ops.gather_rows_cast(x, idx, wire)
+    assert packed.dtype == wire and torch.equal(packed, x[idx.long()].to(wire))
+    back = pgl.ops.gather_rows_cast(packed, None, torch.float32)
+    assert torch.equal(back, packed.float())
+    odd = torch.randn(50, 7, device="cuda")                                   # rows that are not 16-byte multiples
+    assert torch.equal(pgl.ops.gather_rows_cast(odd, None, wire), odd.to(wire))
+
+
+def test_single_write_partitioned_flow_on_one_gpu(pgl):
+    """DistGraph's interior / boundary launches (no process group: the exchanged rows are handed over by the test) reproduce
+    the single-graph result for every reduce op, with and without the folded single launch, and with the 16-bit wire."""
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    rng = np.random.default_rng(9)
+    n, e, d, P = 3000, 60000, 64, 4
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    edges[rng.choice(e, 5000, replace=False), 1] = 5
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    part = torch.from_numpy(rng.integers(0, P, n))
+    et = dev(edges)
+    dgs = [DistGraph(HaloPlan(et, n, part, r, P), device=torch.device("cuda")) for r in range(P)]
+    xs = [dg.take_owned(dev(x)) for dg in dgs]
+    packs = [dg.pack(xo) for dg, xo in zip(dgs, xs)]
+    for op in ("sum", "mean", "max", "min"):
+        want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
+        full = np.full_like(want, np.nan)
+        for r, dg in enumerate(dgs):
+            # what the all-to-all-v would deliver: peer q's block for me, in peer order
+            offs = [np.concatenate([[0], np.cumsum(dgq.plan.pull_splits)]) for dgq in dgs]
+            recv = torch.cat([packs[q][offs[q][r]:offs[q][r + 1]] for q in range(P)], 0)
+            full[host(dg.plan.own_global)] = host(dg.aggregate_with_halo(xs[r], recv, op))
+        if op in ("max", "min"):
+            assert np.array_equal(full, want), op
+        else:
+            np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max(), err_msg=op)
+
+
+# ------------------------------------------------------------------------------------------------
+# tighter parity bars: per-element fp64 bounds at BASELINE configs[1] size
+# ------------------------------------------------------------------------------------------------
+def _c2_graph():
+    from pgl_amd.utils.rmat import rmat_edges
+    N, E = 1 << 20, 20_000_000
+    edges = rmat_edges(20, E, seed=42, device=torch.device("cuda"))
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    x = torch.randn(N, 128, generator=gen, device="cuda", dtype=torch.float32)
+    return N, E, edges, x
+
+
+def _fp64_terms(edges, x64, N):
+    """sum_e x[src] and sum_e |x[src]| per destination in fp64 (index_add_ on the GPU: the independent formulation)."""
+    s = torch.zeros((N, x64.shape[1]), dtype=torch.float64, device=x64.device).index_add_(0, edges[:, 1], x64[edges[:, 0]])
+    a = torch.zeros((N, x64.shape[1]), dtype=torch.float64, device=x64.device).index_add_(0, edges[:, 1], x64[edges[:, 0]].abs())
+    return s, a
+
+
+def _assert_bound(got, want64, abs64, n_terms, eps, slack=4.0):
+    bound = slack * n_terms.clamp(min=1).double().unsqueeze(1) * eps * abs64 + torch.finfo(torch.float32).tiny
+    err = (got.double() - want64).abs()
+    bad = err > bound
+    assert not bool(bad.any()), "worst element: err %.3e vs bound %.3e" % (float((err - bound).max()), float(bound.flatten()[(err - bound).argmax()]))
+
+
+def test_c2_mean_max_min_per_element(pgl):
+    """mean within the fp32 reassociation bound of the fp64 mean, element by element; max / min EXACT (no arithmetic), against
+    an independent scatter_reduce formulation -- at |E| = 20 M, all 2^20 x 128 outputs."""
+    N, E, edges, x = _c2_graph()
+    g = pgl.Graph(edges=edges, num_nodes=N)
+    deg = torch.bincount(edges[:, 1], minlength=N)
+    s64, a64 = _fp64_terms(edges, x.double(), N)
+    mean = g.send_recv(x, "mean")
+    d = deg.clamp(min=1).double().unsqueeze(1)
+    _assert_bound(mean, s64 / d, a64 / d, deg + 1, float(np.finfo(np.float32).eps))
+    idx = edges[:, 1].unsqueeze(1).expand(-1, 128)
+    for op, red in (("max", "amax"), ("min", "amin")):
+        want = torch.zeros_like(x).scatter_reduce(0, idx, x[edges[:, 0]], red, include_self=False)
+        assert torch.equal(g.send_recv(x, op), want), op
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_c2_16bit_storage_per_element(pgl, dtype):
+    """fp16 / bf16 STORAGE with fp32 accumulation (BASELINE configs[4]'s layout) at configs[1] size: every output within the
+    fp32 reassociation bound of the fp64 sum of the SAME 16-bit inputs, plus one rounding of the result to the storage type."""
+    N, E, edges, x = _c2_graph()
+    xs = x.to(dtype)
+    g = pgl.Graph(edges=edges, num_nodes=N)
+    deg = torch.bincount(edges[:, 1], minlength=N)
+    s64, a64 = _fp64_terms(edges, xs.double(), N)
+    got = g.send_recv(xs, "sum")
+    assert got.dtype == dtype
+    eps_store = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8           # half an ulp of the stored result
+    bound = 4.0 * (deg + 1).double().unsqueeze(1) * float(np.finfo(np.float32).eps) * a64 + eps_store * s64.abs() + (6.0e-8 if dtype == torch.float16 else 1e-30)   # (+ fp16 subnormal spacing)
+    err = (got.double() - s64).abs()
+    finite = torch.isfinite(got.double())                                      # fp16 hub rows may overflow to inf: the fp64 sum says so too
+    assert bool((err[finite] <= bound[finite]).all()), float((err - bound)[finite].max())
+    assert bool((s64.abs()[~finite] > 6.0e4).all())
+
+
+def test_c3_send_ue_recv_mul_sum_per_element(pgl):
+    """send_ue_recv(mul, sum) with [E, H, 1] weights (the GAT path's aggregation, BASELINE configs[2] shapes) element by
+    element within the reassociation bound of fp64."""
+    from pgl_amd.utils.rmat import rmat_edges
+    N, E, H, D = 1 << 20, 20_000_000, 8, 16
+    edges = rmat_edges(20, E, seed=42, device=torch.device("cuda"))
+    gen = torch.Generator(device="cuda"); gen.manual_seed(11)
+    f = torch.randn(N, H, D, generator=gen, device="cuda")
+    w = torch.rand(E, H, 1, generator=gen, device="cuda")
+    g = pgl.Graph(edges=edges, num_nodes=N)
+    got = g.send_ue_recv(f, w, "mul", "sum").reshape(N, H * D)
+    src, dst = edges[:, 0], edges[:, 1]
+    s64 = torch.zeros((N, H * D), dtype=torch.float64, device="cuda")
+    a64 = torch.zeros((N, H * D), dtype=torch.float64, device="cuda")
+    step = 2_000_000                                                           # (the [E, H, D] message is never whole in memory)
+    for b in range(0, E, step):
+        m = (f[src[b:b + step]].double() * w[b:b + step].double()).reshape(-1, H * D)
+        s64.index_add_(0, dst[b:b + step], m)
+        a64.index_add_(0, dst[b:b + step], m.abs())
+    deg = torch.bincount(dst, minlength=N)
+    _assert_bound(got, s64, a64, deg + 2, float(np.finfo(np.float32).eps))
