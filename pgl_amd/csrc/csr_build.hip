@@ -5,8 +5,8 @@
 // Plan (all HBM-bound integer work, ~28 B/edge algorithmic):
 //   1. narrow the int64 keys (strided: a column of the [E,2] edge array) to int32, eid = iota;
 //   2. stable LSD radix sort over ceil(log2 N) key bits only -- HAND-WRITTEN for this job (round 3; rounds 1-2 called
-//      rocPRIM's radix_sort_pairs: three onesweep passes at 0.09 of the byte model): ceil(bits / 11) passes of <= 11 bits,
-//      i.e. TWO passes up to 4 M rows, each pass = block histograms -> scan -> stable scatter (see "the sort" below);
+//      rocPRIM's radix_sort_pairs: three onesweep passes at 0.09 of the byte model): ceil(bits / 10) passes of <= 10 bits,
+//      i.e. TWO passes up to 1 M rows, three up to 1 G, each pass = block histograms -> scan -> stable scatter (see "the sort" below);
 //      the first pass reads the caller's int64 (u, v) columns directly and the last one writes the int32 (row, col, eid)
 //      arrays the kernels read, so the narrow and unpack passes of the library version are gone;
 //      stability == ascending eid inside equal keys == the reference's order by construction;
@@ -104,23 +104,23 @@ __global__ __launch_bounds__(kBlock) void seg_ids_kernel(const int64_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // The sort.  One pass moves (key32, value64) pairs by one digit of BITS bits, stably:
-//   hist      every 1024-thread block counts the digits of its tile of 16 384 items (LDS atomics) -> hist[digit][block]
+//   hist      every 1024-thread block counts the digits of its tile of 8 192 items (LDS atomics) -> hist[digit][block]
 //   scan      exclusive scan of hist in (digit, block) order: one block per digit scans its row, one small kernel scans the
 //             row totals -> the global position of the first item of every (digit, block)
-//   scatter   the block reloads its tile; wave w owns items [w * 1024, (w + 1) * 1024) of it and walks them 64 at a time IN
+//   scatter   the block reloads its tile; wave w owns items [w * 512, (w + 1) * 512) of it and walks them 64 at a time IN
 //             ORDER.  Inside a 64-item step the lanes holding the same digit find each other with BITS ballots (peers = AND
 //             of ballot(bit) or its complement), rank = popcount of the peers below the lane, and the lowest peer bumps the
 //             wave's own 16-bit digit counter in LDS by the group size -- no atomics, and the order inside a wave is the
 //             item order.  A 16-step pass over the wave counters turns them into exclusive prefixes over the waves, so
 //             position = hist offset + prefix over earlier waves + count in earlier steps of this wave + rank: stable.
-//   Every lane writes its own pair; a (block, digit) run is 16 consecutive slots on average at 10 bits (64-byte key runs,
-//   128-byte value runs), and neighbouring blocks -- resident at the same time -- extend each other's runs in L2.
+//             The tile is then staged through LDS in block-sorted order and written out with consecutive lanes on
+//             consecutive slots of a digit's run; consecutive tiles run on the same XCD, so the seams of the runs meet in one L2.
 // Nothing here is graph specific except FIRST (keys / values come from the caller's strided int64 columns, ids are range
 // checked) and LAST (the outputs are the CSR arrays).
 // ------------------------------------------------------------------------------------------------
 constexpr int kSortThreads = 1024;
 constexpr int kSortWaves = kSortThreads / kWave;
-constexpr int kSortItems = 16;
+constexpr int kSortItems = 8;
 constexpr int kSortTile = kSortThreads * kSortItems;
 constexpr int kSortMaxBits = 11;
 
@@ -148,13 +148,19 @@ __device__ __forceinline__ int32_t sort_key(const SortArgs& a, int64_t idx, bool
     }
 }
 
+// logical tile of a block: consecutive tiles run on the SAME XCD (dispatch is round-robin over the 8 XCDs), so that the
+// partial cache lines two neighbouring tiles write at the seam of a digit's run meet in one L2
+__device__ __forceinline__ int64_t sort_tile(int nblk) { return xcd_swizzle(blockIdx.x, nblk); }
+
 template <int BITS, bool FIRST>
 __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(SortArgs a) {
     constexpr int BINS = 1 << BITS;
     __shared__ uint32_t h[BINS];
+    const int64_t tile = sort_tile(a.nblk);
+    if (tile < 0) return;
     for (int i = threadIdx.x; i < BINS; i += kSortThreads) h[i] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kSortTile;
+    const int64_t base = tile * kSortTile;
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < kSortItems; ++i) {
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(SortArgs a) {
     }
     if (FIRST && a.range_flag && __any(bad)) { if ((threadIdx.x & (kWave - 1)) == 0) atomicOr(a.range_flag, 1); }
     __syncthreads();
-    for (int i = threadIdx.x; i < BINS; i += kSortThreads) a.hist[(int64_t)i * a.nblk + blockIdx.x] = h[i];
+    for (int i = threadIdx.x; i < BINS; i += kSortThreads) a.hist[(int64_t)i * a.nblk + tile] = h[i];
 }
 
 // one block per digit: exclusive scan of its row of block counts, row total -> totals[digit]
@@ -205,22 +211,34 @@ __global__ __launch_bounds__(kBlock) void sort_scan_totals_kernel(const uint32_t
     for (int i = b; i < e; ++i) { dbase[i] = run; run += totals[i]; }
 }
 
+// The scatter stages the tile through LDS in block-sorted order, so that consecutive lanes write consecutive slots of a
+// digit's run (a first version let every lane store its own pair where it belongs: correct, and 35 % SLOWER than the library
+// sort it replaced -- 64 partial cache lines per store instruction).
 template <int BITS, bool FIRST, bool LAST>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) {
     constexpr int BINS = 1 << BITS;
+    constexpr int PER = BINS / kSortThreads > 0 ? BINS / kSortThreads : 1;     // digits per thread in the block-level scans
     __shared__ uint32_t gb[BINS];                         // global position of this block's first item of every digit
-    __shared__ uint16_t cnt[kSortWaves][BINS];            // per-wave digit counts, then exclusive prefixes over the waves
+    __shared__ uint32_t dstart[BINS];                     // position of every digit's first item in the block-sorted tile
+    __shared__ int32_t skey[kSortTile];
+    __shared__ uint64_t sval[kSortTile];                  // (its first bytes double as the per-wave digit counters, see cnt)
+    __shared__ uint32_t wave_tot[kSortWaves];
+    static_assert(sizeof(uint16_t) * kSortWaves * BINS <= sizeof(uint64_t) * kSortTile, "wave counters must fit the value stage");
+    uint16_t (*cnt)[BINS] = reinterpret_cast<uint16_t (*)[BINS]>(&sval[0]);   // [kSortWaves][BINS]: counts, then prefixes over waves
+    const int64_t tile = sort_tile(a.nblk);
+    if (tile < 0) return;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
-    for (int i = tid; i < BINS; i += kSortThreads) gb[i] = a.dbase[i] + a.hist[(int64_t)i * a.nblk + blockIdx.x];
+    for (int i = tid; i < BINS; i += kSortThreads) gb[i] = a.dbase[i] + a.hist[(int64_t)i * a.nblk + tile];
     {
         uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0]);
         for (int i = tid; i < kSortWaves * BINS / 2; i += kSortThreads) z[i] = 0;
     }
     __syncthreads();
-    const int64_t wbase = (int64_t)blockIdx.x * kSortTile + (int64_t)w * (kWave * kSortItems);
+    const int64_t tbase = tile * kSortTile;
+    const int64_t wbase = tbase + (int64_t)w * (kWave * kSortItems);
     int32_t key[kSortItems];
     uint64_t val[kSortItems];
-    uint16_t pos[kSortItems];
+    int pos[kSortItems];
     bool bad = false;
 #pragma unroll
     for (int s = 0; s < kSortItems; ++s) {
@@ -238,6 +256,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
         }
     }
     if (FIRST && a.range_flag && __any(bad)) { if (lane == 0) atomicOr(a.range_flag, 1); }
+    // rank inside the wave, in item order: the lanes of a 64-item step that hold the same digit find each other with BITS
+    // ballots; the lowest of them bumps the wave's counter of that digit by the group size
 #pragma unroll
     for (int s = 0; s < kSortItems; ++s) {
         const bool valid = wbase + s * kWave + lane < a.n;
@@ -254,49 +274,87 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
         int old = 0;
         if (valid && rank == 0) { old = cnt[w][d]; cnt[w][d] = (uint16_t)(old + __popcll(peers)); }
         old = __shfl(old, leader, kWave);
-        pos[s] = (uint16_t)(old + rank);
+        pos[s] = old + rank;
     }
     __syncthreads();
-    for (int d = tid; d < BINS; d += kSortThreads) {
-        uint32_t run = 0;
+    // counts -> exclusive prefixes over the waves (per digit); block totals -> exclusive scan over the digits
+    {
+        uint32_t tot[PER], sum = 0;
 #pragma unroll
-        for (int ww = 0; ww < kSortWaves; ++ww) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
+        for (int j = 0; j < PER; ++j) {
+            const int d = tid * PER + j;
+            uint32_t run = 0;
+            if (d < BINS) {
+#pragma unroll
+                for (int ww = 0; ww < kSortWaves; ++ww) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
+            }
+            tot[j] = run; sum += run;
+        }
+        uint32_t inc = sum;                               // inclusive scan of `sum` over the block: wave scan + wave totals
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) { const uint32_t t = __shfl_up(inc, off, kWave); if (lane >= off) inc += t; }
+        if (lane == kWave - 1) wave_tot[w] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int ww = 0; ww < w; ++ww) before += wave_tot[ww];
+        uint32_t run = before + inc - sum;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const int d = tid * PER + j; if (d < BINS) dstart[d] = run; run += tot[j]; }
     }
     __syncthreads();
+    // block-sorted position of every item (registers), then the stage may overwrite the counters
 #pragma unroll
     for (int s = 0; s < kSortItems; ++s) {
-        if (wbase + s * kWave + lane >= a.n) continue;
         const int d = (key[s] >> a.shift) & (BINS - 1);
-        const int64_t dest = (int64_t)gb[d] + cnt[w][d] + pos[s];
+        pos[s] += (int)dstart[d] + (int)cnt[w][d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s)
+        if (wbase + s * kWave + lane < a.n) { skey[pos[s]] = key[s]; sval[pos[s]] = val[s]; }
+    __syncthreads();
+    const int n_tile = (int)min((int64_t)kSortTile, a.n - tbase);
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s) {
+        const int i = s * kSortThreads + tid;
+        if (i >= n_tile) continue;
+        const int32_t k = skey[i];
+        const uint64_t vv = sval[i];
+        const int d = (k >> a.shift) & (BINS - 1);
+        const int64_t dest = (int64_t)gb[d] + (i - (int)dstart[d]);
         if constexpr (LAST) {
-            const int32_t nb = (int32_t)(uint32_t)(val[s] >> 32), e = (int32_t)(uint32_t)val[s];
-            if (a.row32) a.row32[dest] = key[s];
+            const int32_t nb = (int32_t)(uint32_t)(vv >> 32), e = (int32_t)(uint32_t)vv;
+            if (a.row32) a.row32[dest] = k;
             if (a.col32) a.col32[dest] = nb;
             if (a.eid32) a.eid32[dest] = e;
-            if (a.sorted_u) a.sorted_u[dest] = key[s];
+            if (a.sorted_u) a.sorted_u[dest] = k;
             if (a.sorted_v) a.sorted_v[dest] = nb;
             if (a.sorted_eid) a.sorted_eid[dest] = e;
         } else {
-            a.key_out[dest] = key[s];
-            a.val_out[dest] = val[s];
+            a.key_out[dest] = k;
+            a.val_out[dest] = vv;
         }
     }
 }
 
+// Widest digit a pass may take.  Measured (profiles/r03/csr_build.txt): 20-bit keys sort faster in 2 passes of 10 bits (0.64 ms at
+// 20 M edges) than in 3 of 7 (0.69); 22-bit keys faster in 3 passes of 8 / 7 / 7 (3.1 ms at 100 M edges) than in 2 of 11 (4.4):
+// at 11 bits a tile of 8 192 items leaves runs of four items per digit, too short to write whole cache lines.
 static int sort_max_bits() {
-    static int v = [] { const char* e = getenv("PGLAMD_SORT_MAXBITS"); int b = e ? atoi(e) : kSortMaxBits; return b < 6 ? 6 : b > kSortMaxBits ? kSortMaxBits : b; }();
+    static int v = [] { const char* e = getenv("PGLAMD_SORT_MAXBITS"); int b = e ? atoi(e) : 10; return b < 6 ? 6 : b > kSortMaxBits ? kSortMaxBits : b; }();
     return v;
 }
 
 template <int BITS, bool FIRST, bool LAST>
 static int32_t sort_pass_launch(const SortArgs& a, uint32_t* totals, hipStream_t st) {
-    hipLaunchKernelGGL((sort_hist_kernel<BITS, FIRST>), dim3((unsigned)a.nblk), dim3(kSortThreads), 0, st, a);
+    const unsigned grid = (unsigned)xcd_grid(a.nblk);
+    hipLaunchKernelGGL((sort_hist_kernel<BITS, FIRST>), dim3(grid), dim3(kSortThreads), 0, st, a);
     PGLAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(sort_scan_rows_kernel, dim3(1u << BITS), dim3(kBlock), 0, st, a.hist, totals, a.nblk);
     PGLAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(sort_scan_totals_kernel, dim3(1), dim3(kBlock), 0, st, totals, a.dbase, 1 << BITS);
     PGLAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL((sort_scatter_kernel<BITS, FIRST, LAST>), dim3((unsigned)a.nblk), dim3(kSortThreads), 0, st, a);
+    hipLaunchKernelGGL((sort_scatter_kernel<BITS, FIRST, LAST>), dim3(grid), dim3(kSortThreads), 0, st, a);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }

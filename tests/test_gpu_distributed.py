@@ -135,7 +135,7 @@ def _api_worker(rank, world, method):
     edges, rng = _rand_graph(n, e, 41, hub=5000)
     et = torch.as_tensor(edges, device=dev)
     g = pgl.Graph(edges=et, num_nodes=n)
-    dg = DistGraph.from_global(et, n, rank, world, method=method, device=dev)
+    dg = DistGraph.from_global(et, n, rank, world, method=method, device=dev, push="auto")     # (pull/push plan: the harder case)
     own = dg.plan.own_global
     mk = lambda *s: torch.as_tensor(rng.standard_normal(s).astype(np.float32), device=dev)
     x, w = mk(n, d), mk(n, d)
