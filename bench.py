@@ -45,7 +45,7 @@ def algorithmic_bytes(E, N, d, s):
 
 
 TRAFFIC_FILES = ("profiles/r03/traffic.json",)
-KERNEL_SOURCES = ("pgl_amd/csrc/aggregate_flat.hpp", "pgl_amd/csrc/aggregate.hpp", "pgl_amd/csrc/common.hpp")
+KERNEL_SOURCES = ("pgl_amd/csrc/aggregate_flat.hpp", "pgl_amd/csrc/aggregate.hpp", "pgl_amd/csrc/aggregate.hip", "pgl_amd/csrc/common.hpp")
 
 
 def kernel_source_hash():

@@ -240,6 +240,68 @@ def cmd_noreuse(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def cmd_traffic(args):
+    """Builds traffic.json -- the PMC record bench.py replays as roofline.traffic -- from one profiling session of the DEFAULT
+    bench command (scripts/gpu_r03_profile.sh): a --kernel-trace pass (per-grid average durations + the bench line of that very
+    run, which says which duration belongs to which leg) and separate --pmc FETCH_SIZE / WRITE_SIZE passes (per-grid averages).
+    Calibration as MI355X_MICROARCH.md prescribes ("calibrate on a known byte count in your own access pattern"): the
+    permutation leg reads and writes every byte exactly once, so fetch_factor = known read bytes / FETCH_SIZE there (the guide's
+    gfx950 "wide reads count half", ~2) and write_factor likewise; both are applied to the other legs.  The file is stamped with
+    the kernel symbol and the sha256 of the kernel sources: bench.py refuses to replay it for any other build."""
+    import collections
+    import csv
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    d = args.dir
+    line = [l for l in open(os.path.join(d, "trace_bench.json")).read().splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    legs = {"scale20_e20000000_d128_f32": rec["roofline"]["headline_workload"]["kernel_ms"],
+            "permutation_n8388608_d128_f32": rec["roofline"]["no_reuse"]["permutation"]["kernel_ms"],
+            "uniform_deg19_n16777216_d128_f32": rec["roofline"]["no_reuse"]["uniform_deg19"]["kernel_ms"],
+            "scale22_e100000000_d128_f32": rec["target_size"]["kernel_ms"]}
+    kname = rec["roofline"]["headline_workload"]["kernel"]
+    # per-grid average duration of the flat kernel in the trace pass
+    dur = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "agg_flat_kernel" in r["Kernel_Name"]:
+                dur[r.get("Grid_Size", r.get("Grid_Size_X"))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    grid_of = {}
+    for leg, ms in legs.items():
+        g = min(dur, key=lambda k: abs(sum(dur[k]) / len(dur[k]) - ms))
+        avg = sum(dur[g]) / len(dur[g])
+        assert abs(avg - ms) / ms < 0.1, (leg, ms, g, avg)
+        grid_of[leg] = (g, avg, len(dur[g]))
+    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "agg_flat_kernel" in r.get("Kernel_Name", ""):
+                pmc[r.get("Grid_Size")][r.get("Counter_Name")].append(float(r["Counter_Value"]))
+    avg = lambda g, c: sum(pmc[g][c]) / len(pmc[g][c])
+    n = 1 << 23
+    gp = grid_of["permutation_n8388608_d128_f32"][0]
+    known_r, known_w = n * (128 * 4 + 8), n * 128 * 4
+    ff = known_r / (avg(gp, "FETCH_SIZE") * 1024.0)
+    wf = known_w / (avg(gp, "WRITE_SIZE") * 1024.0)
+    out = {"_comment": "HBM-side traffic per launch of the dominant kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and "
+                       "--pmc WRITE_SIZE runs of the default bench command, scripts/gpu_r03_profile.sh), calibrated on the permutation "
+                       "leg (every byte read and written exactly once).  Counters include Infinity-Cache hits (MI355X_MICROARCH.md, HBM "
+                       "section), so traffic_bytes is an upper bound on HBM bytes.",
+           "stamp": {"kernel": kname, "source_sha256": bench.kernel_source_hash(), "sources": list(bench.KERNEL_SOURCES)},
+           "calibration": {"fetch_factor": ff, "write_factor": wf, "known_read_bytes": known_r, "known_write_bytes": known_w,
+                           "FETCH_SIZE_KB": avg(gp, "FETCH_SIZE"), "WRITE_SIZE_KB": avg(gp, "WRITE_SIZE"), "grid": gp},
+           "workloads": {}}
+    for leg, (g, ms_avg, calls) in grid_of.items():
+        fk, wk = avg(g, "FETCH_SIZE"), avg(g, "WRITE_SIZE")
+        out["workloads"][leg] = {"kernel": kname, "grid": g, "trace_avg_ms": ms_avg, "trace_calls": calls, "bench_kernel_ms": legs[leg],
+                                 "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "pmc_dispatches": len(pmc[g]["FETCH_SIZE"]),
+                                 "traffic_bytes": int(fk * 1024 * ff + wk * 1024 * wf)}
+    json.dump(out, open(args.out, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def cmd_csr(args):
     """CSR build (row a1) against its SURVEY 8(d) byte model (28 B / edge: 16 read + 12 written, + 12 B / row)."""
     import torch
@@ -284,6 +346,9 @@ def main():
     r.add_argument("--push", default="auto", choices=["auto", "never"])
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     sub.add_parser("noreuse")
+    tr = sub.add_parser("traffic")
+    tr.add_argument("--dir", required=True)
+    tr.add_argument("--out", required=True)
     for name in ("ops", "csr", "layers"):
         s_ = sub.add_parser(name)
         s_.add_argument("rest", nargs=argparse.REMAINDER)
@@ -300,6 +365,8 @@ def main():
         cmd_csr(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
+    elif args.cmd == "traffic":
+        cmd_traffic(args)
     else:
         raise SystemExit("subcommand %r is not wired up yet" % args.cmd)
 
