@@ -171,6 +171,25 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
                              const float* dst_scale, int32_t accumulate, void* out, void* workspace,
                              size_t workspace_bytes, void* stream);
 
+/* K1d  aggregation feeding a dense layer inside ONE kernel (row f1: "SpMM -> GEMM epilogue"; GCNConv's
+ * send_recv(sum) -> linear -> + bias -> activation, pgl/nn/conv.py:242-254, when input_size <= output_size):
+ *     agg[r, :] = dst_scale[r] * REDUCE_{p : row[p]==r} x[col[p], :]            (SUM or MEAN, F32, d_in = 64 or 128)
+ *     out[r, :] = act( agg[r, :] @ w + bias )                                    (w [d_in, d_out] row-major, d_out % 16 == 0)
+ * The flat aggregation kernel parks every finished row in a 16-row LDS tile and multiplies full tiles by w with
+ * v_mfma_f32_16x16x4_f32 (fp32 inputs, fp32 accumulation -- the reference's arithmetic up to re-association); only `out`
+ * is written.  The [n_rows, d_in] intermediate never travels through HBM, and the matrix cores run in the shadow of the row
+ * gathers.  agg_out (optional): the aggregated rows are ALSO stored (training: the weight gradient is agg^T @ d out).
+ * act: 0 none, 1 relu.  Rows without edges get act(bias).  Rows longer than a chunk go through the split-row fix-up, which
+ * applies the layer to them as a matrix-vector product.  Deterministic.  Workspace (8-byte aligned):
+ * pglamd_aggregate_dense_workspace_bytes. */
+size_t pglamd_aggregate_dense_workspace_bytes(int64_t num_edges, int64_t d_in, int64_t d_out);
+int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const int32_t* row, const int32_t* col,
+                               const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
+                               int64_t out_rows, int32_t reduce_op, const float* dst_scale,
+                               const float* w, const float* bias, int32_t act, int64_t d_out,
+                               float* agg_out, float* out, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* Measurement hook for the dominant kernel (bench.py roofline leg): between profile_begin and
  * profile_end every launch of the flat aggregation kernel is bracketed by HIP events on its own
  * launch stream; profile_end synchronises them and returns the summed kernel time (host out). */

@@ -423,6 +423,54 @@ def _tall_wgrad(g, x):
     return gw
 
 
+class _AggregateDense(torch.autograd.Function):
+    """out = act( (dst_scale * A x) @ W^T + b ) in one kernel (ops.aggregate_dense).  `weight` is nn.Linear's [d_out, d_in].
+    Backward (fp32, same kernels): dZ = d out masked by the activation; d b = column sums of dZ; d W = dZ^T agg (the kept
+    aggregate, split-reduction GEMM); d x = A^T (dst_scale * (dZ W)) = (A^T (dst_scale * dZ)) W by linearity -- the SAME fused
+    kernel on the transposed index with W as the layer, when its width allows, else aggregate-then-GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, csr, csr_t, act, dst_scale, reduce_op):
+        need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
+        out, agg = ops.aggregate_dense(x, csr, weight.t(), bias, act, reduce_op, dst_scale, keep_agg=need_w)
+        ctx.csr_t, ctx.act, ctx.reduce_op, ctx.csr = csr_t, act, reduce_op, csr
+        ctx.has_bias = bias is not None
+        ctx.n_x = int(x.shape[0])
+        ctx.save_for_backward(weight, out if act == "relu" else x.new_zeros(0), agg if agg is not None else x.new_zeros(0),
+                              dst_scale if dst_scale is not None else x.new_zeros(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        weight, out, agg, ds = ctx.saved_tensors
+        g = g.contiguous()
+        dz = g * (out > 0).to(g.dtype) if ctx.act == "relu" else g
+        gw = gb = gx = None
+        if ctx.needs_input_grad[1]:
+            gw = _tall_wgrad(dz, agg)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = dz.sum(0)
+        if ctx.needs_input_grad[0]:
+            scale = ds if ds.numel() else None
+            if ctx.reduce_op == "mean":
+                inv = 1.0 / (ctx.csr.indptr[1:] - ctx.csr.indptr[:-1]).clamp(min=1).to(torch.float32)
+                scale = inv if scale is None else scale * inv
+            dzs = dz if scale is None else dz * scale.reshape(-1, 1)
+            csr_t = ctx.csr_t()
+            if ops.aggregate_dense_supported(dzs, weight.shape[1]):
+                gx = ops.aggregate_dense(dzs, csr_t, weight, None, None, "sum", None, out_size=ctx.n_x)[0]
+            else:
+                gx = ops.aggregate(dzs, csr_t, "sum", ctx.n_x) @ weight
+        return gx, gw, gb, None, None, None, None, None
+
+
+def aggregate_dense(x, weight, bias, csr, csr_t, act=None, dst_scale=None, reduce_op="sum"):
+    """x [N, d_in] fp32 (already source-scaled), weight [d_out, d_in] (nn.Linear layout), bias [d_out] or None."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return _AggregateDense.apply(x, weight, bias, csr, csr_t, act, dst_scale, reduce_op)
+    return ops.aggregate_dense(x, csr, weight.t(), bias, act, reduce_op, dst_scale)[0]
+
+
 class _DualLinear(torch.autograd.Function):
     """z = x Wa^T + y Wb^T: the second GEMM accumulates into the first one's output (beta = 1), so GraphSage's
     `self_linear(x) + neigh_linear(agg)` (pgl/nn/conv.py:104-109) has no separate add pass; both biases go to the epilogue."""

@@ -212,6 +212,106 @@ extern "C" int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x
                            nullptr, dst_scale, accumulate, out, workspace, workspace_bytes, ex, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// pglamd_aggregate_dense: aggregation feeding a dense layer inside one kernel (the flat kernel with SINK = 1)
+// ------------------------------------------------------------------------------------------------
+namespace pglamd {
+__global__ __launch_bounds__(kBlock) void pack_weight_kernel(const float* __restrict__ w, int d_in, int d_out, float* __restrict__ wp) {
+    // wp[(ct * (d_in / 4) + kk) * 64 + lane] = w[(4 kk + lane / 16) * d_out + ct * 16 + lane % 16]: the B operand of
+    // v_mfma_f32_16x16x4_f32 for column tile ct and k-step kk, one coalesced 256-byte load per (ct, kk)
+    const int KK = d_in / 4;
+    const int64_t total = (int64_t)(d_out / 16) * KK * kWave;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int lane = (int)(i % kWave);
+        const int64_t t = i / kWave;
+        const int kk = (int)(t % KK), ct = (int)(t / KK);
+        wp[i] = w[(int64_t)(4 * kk + lane / 16) * d_out + ct * 16 + (lane & 15)];
+    }
+}
+
+template <int VEC>
+static int32_t launch_dense(AggParams p, hipStream_t st) {
+    const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
+    p.n_blocks = (int)nb;
+    p.n_grid_chunks = (int)xcd_grid(nb);
+    const int64_t zb = ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
+    const bool fixups = needs_fixups(p);
+    if (fixups) PGLAMD_HIP_CHECK(hipMemsetAsync(p.long_count, 0, 2 * sizeof(int), st));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool profiling = prof().on.load(std::memory_order_relaxed);
+    if (profiling) {
+        { std::lock_guard<std::mutex> lk(prof().mu); prof().last_kernel = std::string("agg_flat_kernel<float, ") + (VEC == 2 ? "2" : "1") + ", 1, 0, 0, dense sink>"; }
+        PGLAMD_HIP_CHECK(hipEventCreate(&e0));
+        PGLAMD_HIP_CHECK(hipEventCreate(&e1));
+        PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
+    }
+    hipLaunchKernelGGL((agg_flat_kernel<float, VEC, 1, 0, 0, false, true, 0, 1>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    PGLAMD_LAUNCH_CHECK();
+    if (profiling) {
+        PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
+        std::lock_guard<std::mutex> lk(prof().mu);
+        prof().ev.emplace_back(e0, e1);
+    }
+    if (fixups) {
+        hipLaunchKernelGGL((agg_fixup_kernel<float, VEC, 1, 0, false>), dim3((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
+        PGLAMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL((agg_fixup_kernel<float, VEC, 1, 0, true>), dim3((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks)), dim3(kFixWaves * kWave), 0, st, p);
+        PGLAMD_LAUNCH_CHECK();
+    }
+    return PGLAMD_OK;
+}
+}  // namespace pglamd
+
+extern "C" size_t pglamd_aggregate_dense_workspace_bytes(int64_t num_edges, int64_t d_in, int64_t d_out) {
+    return pglamd_aggregate_workspace_bytes(num_edges, d_in, PGLAMD_F32) + align_up((size_t)(d_in > 0 ? d_in : 1) * (size_t)(d_out > 0 ? d_out : 1) * 4, 256) + 256;
+}
+
+extern "C" int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const int32_t* row, const int32_t* col, const int64_t* indptr,
+                                          int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, int32_t reduce_op,
+                                          const float* dst_scale, const float* w, const float* bias, int32_t act, int64_t d_out,
+                                          float* agg_out, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!out || !w || !indptr || (num_edges > 0 && (!x || !row || !col))) return fail(PGLAMD_E_ARG, "aggregate_dense: NULL pointer");
+    if (num_edges < 0 || num_edges > kMaxEdges || n_csr_rows >= INT32_MAX || out_rows >= INT32_MAX)
+        return fail(PGLAMD_E_RANGE, "aggregate_dense: sizes beyond int32 engine range");
+    if ((d_in != 64 && d_in != 128) || d_out <= 0 || d_out % 16 != 0 || d_out > 1024)
+        return fail(PGLAMD_E_SHAPE, "aggregate_dense: d_in must be 64 or 128 and d_out a multiple of 16 up to 1024 (got %lld, %lld)", (long long)d_in, (long long)d_out);
+    if (reduce_op != PGLAMD_SUM && reduce_op != PGLAMD_MEAN) return fail(PGLAMD_E_ARG, "aggregate_dense: sum or mean");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(agg_out) | reinterpret_cast<uintptr_t>(workspace)) % 8 != 0)
+        return fail(PGLAMD_E_ARG, "aggregate_dense: x / agg_out / workspace must be 8-byte aligned");
+    if (!workspace || workspace_bytes < pglamd_aggregate_dense_workspace_bytes(num_edges, d_in, d_out))
+        return fail(PGLAMD_E_WORKSPACE, "aggregate_dense: workspace too small");
+    if (out_rows == 0) return PGLAMD_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // packed weight at the head of the workspace, the aggregation's own partial buffers behind it
+    float* wp = static_cast<float*>(workspace);
+    const size_t wp_bytes = align_up((size_t)d_in * (size_t)d_out * 4, 256);
+    {
+        const int64_t total = (d_out / 16) * (d_in / 4) * kWave;
+        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, kBlock), 1024)), dim3(kBlock), 0, st, w, (int)d_in, (int)d_out, wp);
+        PGLAMD_LAUNCH_CHECK();
+    }
+    char* ws = static_cast<char*>(workspace) + wp_bytes;
+    AggParams p{};
+    p.x = x; p.x2 = x; p.x_split = INT32_MAX; p.out = agg_out; p.row = row; p.col = col; p.indptr = indptr; p.zero_indptr = indptr;
+    p.dst_scale = dst_scale;
+    p.ldx = d_in; p.ldo = d_in; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)num_edges;
+    p.is_mean = reduce_op == PGLAMD_MEAN; p.gy = 1;
+    p.w = w; p.wp = wp; p.bias = bias; p.out2 = out; p.dout2 = (int)d_out; p.act = act;
+    p.j_base = 0; p.tile_cols = (int)d_in; p.zvec = 2; p.align = 1;
+    const int K = chunk_edges_for(num_edges);
+    p.chunk = K;
+    p.n_chunks = (int)ceil_div(num_edges > 0 ? num_edges : 1, (int64_t)K);
+    const size_t half = align_up((size_t)p.n_chunks * d_in * sizeof(float), 256);
+    const size_t lst = align_up((size_t)(p.n_chunks + 64) * sizeof(int), 256);
+    p.part_head = ws;
+    p.part_tail = ws + half;
+    p.long_count = reinterpret_cast<int*>(ws + 2 * half);
+    p.long_list = p.long_count + 64;
+    p.long_list2 = reinterpret_cast<int*>(ws + 2 * half + lst);
+    if (num_edges == 0) p.n_chunks = 0;                      // only the empty-row roles run
+    return d_in == 128 ? launch_dense<2>(p, st) : launch_dense<1>(p, st);
+}
+
 extern "C" int32_t pglamd_profile_begin(void) {
     std::lock_guard<std::mutex> lk(prof().mu);
     for (auto& pr : prof().ev) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

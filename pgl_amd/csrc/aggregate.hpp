@@ -35,6 +35,12 @@ struct AggParams {
     int align;                            // 1: never split rows of <= chunk edges (chunk_cut)
     int narrow_vec;                       // aggregate_narrow: rows may be moved with (<=16-byte) vector loads / stores
     int x_split;                          // INT32_MAX when there is no second table
+    // ---- SINK = 1 (aggregate_flat.hpp): the aggregated rows feed a dense layer without leaving the chip -------------------------
+    const float* w;                       // [d_in, dout2] row-major weight (split-row fix-up: one matrix-vector product per hub row)
+    const float* wp;                      // the same weight packed in MFMA B-operand order: wp[(ct * (d_in / 4) + kk) * 64 + lane]
+    const float* bias;                    // [dout2] or NULL
+    float* out2;                          // [out_rows, dout2]: act(dst_scale * aggregate(x) @ w + bias)
+    int dout2, act;                       // act: 0 none, 1 relu
     int max_row_edges;                    // host-side hint: longest row of the index (0 = unknown).  Rows of <= chunk edges are never
                                           // split (chunk_cut), so when it is <= chunk no partial exists and the fix-up launches are skipped
 };
@@ -95,6 +101,27 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
             for (int j = lane * 2; j < p.tile_cols; j += kWave * 2) *reinterpret_cast<VecT<T, 2>*>(dst + j) = VecT<T, 2>{};
         } else {
             for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = from_acc<T>(typename AccT<T>::type(0));
+        }
+    }
+}
+
+// Dense sink: an output row without any edge aggregates to 0, so its layer output is act(0 @ w + bias) = act(bias).
+__device__ __forceinline__ void dense_empty_rows_role(const AggParams& p, int64_t zb, int lane) {
+    const int64_t w = zb * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t r0 = w * kWave;
+    if (r0 >= p.out_rows) return;
+    const int64_t r = r0 + lane;
+    bool empty = false;
+    if (r < p.out_rows) empty = (r >= p.n_csr_rows) || (p.zero_indptr[r] == p.zero_indptr[r + 1]);
+    unsigned long long m = __ballot(empty);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        float* dst = p.out2 + (r0 + l) * (int64_t)p.dout2;
+        for (int j = lane; j < p.dout2; j += kWave) {
+            float v = p.bias ? p.bias[j] : 0.f;
+            if (p.act) v = v > 0.f ? v : 0.f;
+            dst[j] = v;
         }
     }
 }

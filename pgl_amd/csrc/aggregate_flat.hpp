@@ -21,16 +21,31 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 // 3 = as 1 for NT == 1 and y rows of <= 8 elements (attention weights [E,H,1]): the 8 x ypad operand values of a batch come
 //     from ONE wave-wide load (lane l: edge l / ypad, element l % ypad) and reach their lanes by ds_bpermute
 // UB > 0 selects the vector-index pipeline (NT == 1, no edge operand, no per-source scale): see the main loop
-template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true, int UB = 0>
+// SINK = 1 (fp32 sum / mean, one tile of 64 or 128 columns, no edge operand): a finished row is NOT the result -- it is one row
+//     of the left operand of a dense layer.  The wave parks finished rows in a 16-row LDS tile; a full tile is multiplied by the
+//     layer's weight with v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: the reference's precision), bias and activation are
+//     applied to the MFMA result and only THAT goes to memory: GCNConv's aggregate -> linear -> bias -> relu
+//     (pgl/nn/conv.py:242-254) without the [N, d] intermediate's round trip through HBM, and with the matrix cores working in
+//     the shadow of the row gathers (the kernel is HBM-bound; the MFMA pipe was idle).
+template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true, int UB = 0, int SINK = 0>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     constexpr int U = 8;
+    constexpr int kTileRows = 16;                      // rows per MFMA tile (v_mfma_f32_16x16x4_f32)
+    constexpr int kTileStride = kWave * VEC + 4;       // floats per parked row: +4 keeps the A-operand reads bank-conflict free
+    static_assert(SINK == 0 || (std::is_same_v<T, float> && NT == 1 && RCLS == 0 && YMODE == 0 && UB == 0 && (VEC == 1 || VEC == 2)),
+                  "the dense sink takes fp32 rows of 64 or 128 columns");
     using V = VecT<T, VEC>;
     using A = typename AccT<T>::type;
     using VA = VecT<A, VEC>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
     if ((int)blockIdx.x >= p.n_grid_chunks) {   // trailing blocks: zero-fill rows that receive no edge
-        zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
+        if constexpr (SINK == 1) {
+            if (p.out) zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
+            dense_empty_rows_role(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
+        } else {
+            zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
+        }
         return;
     }
     const int64_t lb = xcd_swizzle(blockIdx.x, p.n_blocks);
@@ -90,6 +105,56 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         asm volatile("" : "+s"(q));      // defeats hoisting of the field loads out of the store path
         return q;
     };
+    // ---- the dense sink (SINK == 1) ------------------------------------------------------------------------------------------
+    float (*sink_tile)[kTileRows][kTileStride] = nullptr;
+    int (*sink_rows)[kTileRows] = nullptr;
+    if constexpr (SINK == 1) {                          // (declared here so that the other instantiations allocate no LDS at all)
+        __shared__ float st[kWavesPerBlock][kTileRows][kTileStride];
+        __shared__ int sr[kWavesPerBlock][kTileRows];
+        sink_tile = st; sink_rows = sr;
+    }
+    int n_parked = 0;                                   // wave-uniform
+    auto flush_tile = [&]() {
+        if constexpr (SINK == 1) {
+            const cptr<AggParams> q = cold();
+            constexpr int KK = kWave * VEC / 4;         // k-steps of 4
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float a[KK];                                // A operand: lane l holds tile[l % 16][4 kk + l / 16]
+            const float* trow = &sink_tile[wib][lane & 15][lane >> 4];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) a[kk] = trow[4 * kk];
+            const float* __restrict__ wp = q->wp;
+            const float* __restrict__ bias = q->bias;
+            float* __restrict__ out2 = q->out2;
+            const int dout2 = q->dout2, relu = q->act;
+            const int64_t ldo2 = dout2;
+            const int n_ct = dout2 >> 4;
+            for (int ct = 0; ct < n_ct; ++ct) {
+                float b[KK];
+                const float* wt = wp + ((int64_t)ct * KK) * kWave + lane;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) b[kk] = wt[kk * kWave];
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                f4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], b[kk], acc4, 0, 0, 0);
+                const int colj = ct * 16 + (lane & 15);
+                const float bv = bias ? bias[colj] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {           // lane l holds C[4 (l / 16) + i][l % 16]
+                    const int rr = 4 * (lane >> 4) + i;
+                    if (rr < n_parked) {
+                        float v = acc4[i] + bv;
+                        if (relu) v = v > 0.f ? v : 0.f;
+                        out2[(int64_t)sink_rows[wib][rr] * ldo2 + colj] = v;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            n_parked = 0;
+        }
+    };
     auto store_partial = [&](bool head) {
         const cptr<AggParams> q = cold();
         A* dst = static_cast<A*>(head ? q->part_head : q->part_tail) + (int64_t)c * q->tile_cols;
@@ -143,8 +208,21 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                 V o;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
-                *reinterpret_cast<V*>(dst + j0[t]) = o;
+                if constexpr (SINK == 1) {
+                    // park the (scaled) row for the MFMA tile; the aggregated row itself is stored only if the caller keeps it
+                    // (training: the weight gradient needs it)
+                    float* tr = &sink_tile[wib][n_parked][0];
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) tr[j0[t] - q->j_base + k] = (float)ov[k];
+                    if (q->out) *reinterpret_cast<V*>(dst + j0[t]) = o;
+                } else {
+                    *reinterpret_cast<V*>(dst + j0[t]) = o;
+                }
             }
+        if constexpr (SINK == 1) {
+            if (lane == 0) sink_rows[wib][n_parked] = r;
+            if (++n_parked == kTileRows) flush_tile();
+        }
     };
     // closes row `cur` when the stream moved on to another row inside this chunk
     auto flush_mid = [&]() {
@@ -351,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     if (head_open) store_partial(true);                 // middle or closing piece of a long row
     else if (tail_open) store_partial(false);           // first piece of a LONG row that continues
     else store_final(cur);
+    if constexpr (SINK == 1) { if (n_parked > 0) flush_tile(); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -497,6 +576,32 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
         T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
         float ds = 1.f;
         if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
+        if constexpr (std::is_same_v<T, float> && NT == 1 && RCLS == 0) {
+            if (p.w) {
+                // dense sink (SINK == 1 of the flat kernel): a split (hub) row gets its layer output as one matrix-vector
+                // product -- there are a few thousand such rows at most, each worth >= a chunk of edges
+                __shared__ float fix_row[LONG ? 1 : kWavesPerBlock][kWave * VEC];
+                float* fr = fix_row[LONG ? 0 : wib];
+                const int d_in = p.tile_cols;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float v = (float)acc[0][k];
+                    if (p.is_mean) v = v / (float)(re - rs);
+                    if (p.dst_scale) v = v * ds;
+                    if (act[0]) { fr[j0[0] + k] = v; if (p.out) dst[j0[0] + k] = v; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int cj = lane; cj < p.dout2; cj += kWave) {
+                    float yv = p.bias ? p.bias[cj] : 0.f;
+                    for (int k = 0; k < d_in; ++k) yv += fr[k] * p.w[(int64_t)k * p.dout2 + cj];
+                    if (p.act) yv = yv > 0.f ? yv : 0.f;
+                    p.out2[(int64_t)r * p.dout2 + cj] = yv;
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
             if (act[t]) {

@@ -517,6 +517,17 @@ class Graph(object):
             raise ValueError("dst_scale must hold one value per destination node (%d), got %d" % (feature.shape[0], ds.numel()))
         return ag.aggregate(feature, self._csr_dst(), self._csr_src, "sum", None, None, "add", None, None, ss, ds)
 
+    def send_recv_dense(self, feature, weight, bias=None, act=None, src_scale=None, dst_scale=None, reduce_op="sum"):
+        """act( (dst_scale * REDUCE_{u->v} src_scale[u] * feature[u]) @ weight^T + bias ) with the aggregate never leaving the
+        chip (engine extension for GCNConv's aggregate -> linear -> bias -> activation, pgl/nn/conv.py:242-254).  fp32,
+        feature [N, 64 | 128], weight [d_out, d_in] (nn.Linear layout); differentiable in feature, weight and bias."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        if src_scale is not None:                                  # one pass over [N, d]: cheaper than a random 4-byte read per edge
+            feature = feature * src_scale.reshape(-1, 1).to(feature.dtype)
+        ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()
+        return ag.aggregate_dense(feature.contiguous(), weight, bias, self._csr_dst(), self._csr_src, act, ds, reduce_op)
+
     def propagate_step(self, feature, dst_scale, residual=None, residual_scale=0.0):
         """residual_scale * residual + dst_scale (.) (sum over in-edges of feature[src]) in one launch (engine extension
         for the k-hop propagation layers; fp32, dst_scale one value per node)."""

@@ -117,6 +117,7 @@ class GCNConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(output_size))
         self.norm = norm
         self.activation = _act(activation)
+        self.fused_dense = True       # False: aggregation and linear layer as separate kernels (round-2 path)
 
     def forward(self, graph, feature, norm=None):
         if self.norm and norm is None:
@@ -126,6 +127,15 @@ class GCNConv(nn.Module):
         fuse = norm is not None and feature.dtype == torch.float32 and norm.dtype == torch.float32 \
             and norm.numel() == feature.shape[0] and hasattr(graph, "send_recv_scaled") \
             and not (norm.requires_grad and torch.is_grad_enabled())       # the fused scales carry no gradient
+        dense = fuse and self.fused_dense and self.input_size <= self.output_size and hasattr(graph, "send_recv_dense") \
+            and feature.dim() == 2 and ops.aggregate_dense_supported(feature, self.output_size) \
+            and self.linear.weight.dtype == torch.float32 and self.activation in (None, F.relu)
+        if dense:
+            # aggregate -> W -> + bias -> relu in ONE kernel: finished rows go from the aggregation's registers through an LDS
+            # tile into the matrix cores; the [N, d] aggregate is never written (inference) or written once, never re-read
+            # (training: the weight gradient needs it)
+            return graph.send_recv_dense(feature, self.linear.weight, self.bias, "relu" if self.activation is F.relu else None,
+                                         norm, norm)
         if fuse:
             # (feature * norm) -> send_recv(sum) -> (* norm) as ONE pass over the edges.  Row scaling commutes with the
             # right-multiplication by W, so in the aggregate-first order the destination norm is applied inside the

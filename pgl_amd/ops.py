@@ -242,6 +242,39 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     return out
 
 
+def aggregate_dense_supported(x, d_out):
+    """Shapes pglamd_aggregate_dense covers: fp32 [N, 64 | 128] rows, d_out a multiple of 16 up to 1024."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and int(x.shape[1]) in (64, 128)
+            and int(d_out) % 16 == 0 and 0 < int(d_out) <= 1024)
+
+
+def aggregate_dense(x, csr, w, bias=None, act=None, reduce_op="sum", dst_scale=None, out_size=None, keep_agg=False):
+    """act( (dst_scale * REDUCE_{u->v} x[u]) @ w + bias ) in one kernel (pglamd_aggregate_dense; GCNConv's aggregate ->
+    linear -> bias -> activation, pgl/nn/conv.py:242-254).  w: [d_in, d_out] row-major.  -> (out, agg or None)."""
+    _need_cuda(x, w, bias, dst_scale)
+    x = x.contiguous(); w = w.contiguous()
+    d_in, d_out = int(x.shape[1]), int(w.shape[1])
+    if int(w.shape[0]) != d_in or w.dtype != torch.float32 or not aggregate_dense_supported(x, d_out):
+        raise ValueError("aggregate_dense: fp32 rows of 64 or 128 columns and a [d_in, d_out] fp32 weight with d_out %% 16 == 0 "
+                         "(got x %s %s, w %s)" % (tuple(x.shape), x.dtype, tuple(w.shape)))
+    if act not in (None, "relu"):
+        raise ValueError("aggregate_dense: activation None or 'relu'")
+    M = int(out_size) if (out_size is not None and int(out_size) > 0) else int(x.shape[0])
+    out = torch.empty((M, d_out), dtype=torch.float32, device=x.device)
+    agg = torch.empty((M, d_in), dtype=torch.float32, device=x.device) if keep_agg else None
+    if M == 0:
+        return out, agg
+    L = _ffi.lib()
+    ws = _ws(L.pglamd_aggregate_dense_workspace_bytes(csr.num_edges, d_in, d_out), x.device)
+    b = None if bias is None else bias.to(torch.float32).contiguous()
+    ds = None if dst_scale is None else dst_scale.to(torch.float32).contiguous()
+    with torch.cuda.device(x.device):
+        _ffi.check(L.pglamd_aggregate_dense(_ptr(x), d_in, _ptr(csr.row32), _ptr(csr.col32), _ptr(csr.indptr), csr.num_edges,
+                                            csr.num_nodes, M, REDUCE[reduce_op], _ptr(ds), _ptr(w), _ptr(b), 1 if act == "relu" else 0,
+                                            d_out, _ptr(agg), _ptr(out), _ptr(ws), ws.numel(), _stream(x)), "aggregate_dense")
+    return out, agg
+
+
 def profile_begin():
     """Start bracketing every flat-kernel launch with HIP events (bench.py roofline leg)."""
     _ffi.check(_ffi.lib().pglamd_profile_begin(), "profile_begin")

@@ -1,0 +1,40 @@
+#!/bin/bash
+# One GPU session = a list of steps, run on the GPU box through gpurun:
+#     gpurun --timeout 3000 -- 'bash scripts/gpu_session.sh TAG step [step ...]'
+# Every step writes gpurun_out/r03/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r03/.
+# Steps: diag tests tests:<pytest -k expr> bench rows_c2 rows_c2_p4 rows_c2_fp16 rows_c2p csr noreuse gcn train gat ops dtypes profile
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+TAG=$1; shift
+PARTS="scratch/parts"
+cd $R
+for STEP in "$@"; do
+  F=$O/${STEP//[:\/ ]/_}_$TAG.txt
+  echo "== $STEP"
+  case $STEP in
+    diag)       python scripts/prof.py diag > $F 2>&1 ;;
+    tests)      timeout 1500 python -m pytest tests -m gpu -q > $F 2>&1; echo "pytest rc=$?" >> $F; tail -6 $F ;;
+    tests:*)    timeout 1500 python -m pytest tests -m gpu -q -x -k "${STEP#tests:}" > $F 2>&1; echo "pytest rc=$?" >> $F; tail -25 $F ;;
+    bench)      timeout 600 python bench.py > $O/bench_n1_$TAG.json 2> $F; echo "bench rc=$?"; head -c 600 $O/bench_n1_$TAG.json; echo ;;
+    rows_c2)    timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 2,8 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -14 $F ;;
+    rows_c2_p4) timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 4 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -8 $F ;;
+    rows_c2_fp16) timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --wire fp16 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -4 $F ;;
+    rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
+    csr|noreuse|gcn|gat|ops|dtypes) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
+    train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
+    profile)
+      # rocprofv3 --kernel-trace --stats of the DEFAULT bench command, then separate --pmc FETCH_SIZE / WRITE_SIZE passes of the
+      # same command, then traffic.json (stamped with the kernel sources' hash) built from them
+      P=$O/pmc; rm -rf $P; mkdir -p $P
+      ( cd /tmp && export TMPDIR=/tmp
+        rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -o t -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $P/trace_bench.json 2> $P/trace.err
+        python $R/scripts/prof.py trace $(find $P/trace -name "*kernel_trace.csv" | head -1) agg_ > $P/kernel_trace_by_grid.txt
+        cp $(find $P/trace -name "*kernel_stats.csv" | head -1) $P/kernel_stats.csv
+        for C in FETCH_SIZE WRITE_SIZE; do
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $P/pmc_$C -o p -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $P/pmc_$C.json 2> $P/pmc_$C.err
+        done
+        python $R/scripts/prof.py traffic --dir $P --out $P/traffic.json > $P/traffic.log 2>&1 )
+      tail -30 $P/traffic.log; head -8 $P/kernel_trace_by_grid.txt
+      rm -rf $P/trace $P/pmc_FETCH_SIZE $P/pmc_WRITE_SIZE ;;
+    *) echo "unknown step $STEP" ;;
+  esac
+done

@@ -5,8 +5,15 @@
     python scripts/prof.py rows  [--scale 20 --edges 20000000 --parts 8 --partition kway|metis|random|FILE.npy]
                                                      per-rank COMPUTE of the row-partitioned layout on ONE GPU, phase by phase,
                                                      next to the bytes each rank receives and what they cost on xGMI
-    python scripts/prof.py ops                       one line per op of SURVEY 8(a) at C2 / C3 sizes (bench_ops)
+    python scripts/prof.py ops                       one line per op of SURVEY 8(a) at C2 / C3 sizes
     python scripts/prof.py csr                       CSR build (a1) at C2 / C2' / sampled-block sizes
+    python scripts/prof.py gcn                       GCNConv forward / training step through the fused aggregate -> dense kernel and without
+    python scripts/prof.py train [gcn sage gat ...]  ms per training step of one layer, fused paths on / off
+    python scripts/prof.py gat | dtypes              the GAT attention path at C3 / send_recv per storage type
+    python scripts/prof.py layers WHICH [train]      a few steps of one layer with nothing around them (the target of rocprofv3 --kernel-trace)
+    python scripts/prof.py traffic --dir D --out F   traffic.json from a profiling session (scripts/gpu_r03_profile.sh)
+    python scripts/prof.py trace CSV [filter]        per-(kernel, grid) summary of a rocprofv3 kernel trace
+    python scripts/prof.py variant NAME [-D macros]  build an experimental libpglamd_NAME.so next to the product library
     python scripts/prof.py noreuse                   the known-bytes roofline leg with clock / power telemetry of every GPU of the box
     python scripts/prof.py layers ...                per-kernel time of a layer's forward / training step
 
@@ -302,6 +309,44 @@ def cmd_traffic(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def cmd_gcn(args):
+    """GCNConv(128 -> 128, relu) at C2: forward and forward + backward, through the fused aggregate -> dense kernel and through
+    separate kernels (round-2 path), plus the bare pieces."""
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    N, E, d = 1 << 20, 20_000_000, 128
+    edges = rmat_edges(20, E, seed=42, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, d, generator=gen, device=dev)
+    g = pgl.Graph(edges=edges, num_nodes=N); g.adj_dst_index; g.adj_src_index
+    norm = pgl.nn.functional.degree_norm(g)
+    print("C2: RMAT scale 20, 20 M edges, d = 128 fp32")
+    print("  send_recv(sum)                      %.3f ms" % _t(lambda: g.send_recv(x, "sum")))
+    print("  send_recv_scaled(norm, norm)        %.3f ms" % _t(lambda: g.send_recv_scaled(x, norm, norm)))
+    for act in ("relu", None):
+        layer = pgl.nn.GCNConv(d, d, activation=act).to(dev)
+        for fused in (True, False):
+            layer.fused_dense = fused
+            with torch.no_grad():
+                f = _t(lambda: layer(g, x, norm), it=20, warm=5)
+            xi = x.clone().requires_grad_(True)
+
+            def step():
+                layer.zero_grad(set_to_none=True); xi.grad = None
+                layer(g, xi, norm).sum().backward()
+            fb = _t(step, it=10, warm=3)
+            print("  GCNConv(128->128, act=%-4s) %-22s forward %.3f ms   forward + backward (d x, d W, d b) %.3f ms"
+                  % (act, "fused aggregate->dense" if fused else "separate kernels", f, fb), flush=True)
+    w = torch.randn(d, d, generator=gen, device=dev) / d ** 0.5
+    csr = g._csr_dst()
+    print("  ops.aggregate_dense alone           %.3f ms (inference: no aggregate kept)   %.3f ms (aggregate kept)"
+          % (_t(lambda: pgl.ops.aggregate_dense(x, csr, w, None, "relu")), _t(lambda: pgl.ops.aggregate_dense(x, csr, w, None, "relu", keep_agg=True))))
+    print("  x @ w (hipBLASLt)                   %.3f ms" % _t(lambda: x @ w))
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def cmd_csr(args):
     """CSR build (row a1) against its SURVEY 8(d) byte model (28 B / edge: 16 read + 12 written, + 12 B / row)."""
     import torch
@@ -325,14 +370,187 @@ def cmd_csr(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-def _run_script(name, argv):
-    """Subcommands whose bodies still live in their own files."""
-    path = os.path.join(ROOT, "scripts", name)
-    sys.argv = [path] + list(argv)
-    import runpy
-    runpy.run_path(path, run_name="__main__")
+def _c2(with_src_index=True, scale=20, E=20_000_000):
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    g = pgl.Graph(edges=rmat_edges(scale, E, seed=42, device=dev), num_nodes=1 << scale)
+    g.adj_dst_index
+    if with_src_index:
+        g.adj_src_index
+    return pgl, dev, g
 
 
+def cmd_ops(args):
+    """One line per op of SURVEY 8(a) at C2 / C3 sizes: ms, algorithmic GB (section 8d byte model), GB/s, fraction of 8 TB/s."""
+    import torch
+    pgl, dev, g = _c2(scale=args.scale, E=args.edges)
+    N, E, H, D = g.num_nodes, g.num_edges, 8, 16
+    edges = g.edges
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, H * D, generator=gen, device=dev)
+
+    def report(name, ms, gbytes):
+        print("%-34s %8.3f ms  %7.2f GB alg  %8.1f GB/s  frac %.3f" % (name, ms, gbytes, gbytes / ms * 1e3, gbytes / ms * 1e3 / 8000), flush=True)
+    report("csr_build (K8), + int64 copies", _t(lambda: pgl.ops.csr_build(edges[:, 1], edges[:, 0], N), 5, 2), (E * (16 + 12 + 24) + N * 16) / 1e9)
+    report("csr_build (K8), engine index", _t(lambda: pgl.ops.csr_build(edges[:, 1], edges[:, 0], N, want_i64=False), 5, 2), (E * 28 + N * 16) / 1e9)
+    csr = g.adj_dst_index.csr
+    su64 = g.adj_dst_index._sorted_u
+    report("unique_segment", _t(lambda: pgl.ops.unique_segment(csr.degree, su64), 5, 2), (E * 16 + N * 24) / 1e9)
+    for op in ("sum", "mean", "max"):
+        report("send_recv %s d=128" % op, _t(lambda: g.send_recv(x, op)), (E * 516 + N * 520) / 1e9)
+    x64 = x[:, :64].contiguous(); x256 = torch.cat([x, x], 1)
+    report("send_recv sum d=64", _t(lambda: g.send_recv(x64, "sum")), (E * 260 + N * 264) / 1e9)
+    report("send_recv sum d=256", _t(lambda: g.send_recv(x256, "sum")), (E * 1028 + N * 1032) / 1e9)
+    a_s = torch.randn(N, H, generator=gen, device=dev); a_d = torch.randn(N, H, generator=gen, device=dev)
+    report("send_uv [N,8]+[N,8] (K3)", _t(lambda: g.send_uv(a_s, a_d, "add")), E * (32 + 32 + 32 + 8) / 1e9)
+    alpha = torch.nn.functional.leaky_relu(g.send_uv(a_s, a_d, "add"), 0.2)
+    report("edge_softmax [E,8] (K4)", _t(lambda: pgl.nn.functional.edge_softmax(g, alpha)), E * (32 + 32 + 4) / 1e9)
+    sm = pgl.nn.functional.edge_softmax(g, alpha).reshape(-1, H, 1)
+    xf = x.reshape(N, H, D)
+    report("send_ue_recv mul,sum (K2)", _t(lambda: g.send_ue_recv(xf, sm, "mul", "sum")), (E * (512 + 32 + 8) + N * 520) / 1e9)
+    uniq, seg = g.get_segment_ids(None, None, "dst")
+    nseg = int(uniq.shape[0])
+    msg = torch.randn(E, 32, generator=gen, device=dev)
+    report("segment_sum [E,32] (K5)", _t(lambda: pgl.ops.segment_reduce(msg, seg, "sum", nseg)), (E * (128 + 8) + nseg * 128) / 1e9)
+    report("gather_rows [E,128] (K6)", _t(lambda: pgl.ops.gather_rows(x, csr.col32)[:1], 3, 1), E * (512 + 512 + 4) / 1e9)
+    report("gat_aggregate fused (K3+K4+K2)", _t(lambda: pgl.ops.gat_aggregate(xf, a_s, a_d, csr, 0.2)), (E * 620 + N * 552) / 1e9)
+    seeds = torch.randperm(N, generator=gen, device=dev)[: min(N, 1_000_000)]
+    ms = _t(lambda: pgl.ops.sample_neighbors(csr, seeds, 25, seed=1), 5, 2)
+    nbr, cnt = pgl.ops.sample_neighbors(csr, seeds, 25, seed=1)
+    print("%-34s %8.3f ms  (%d seeds -> %d sampled edges, %.1f M edges/s)" % ("sample_neighbors k=25", ms, len(seeds), len(nbr), len(nbr) / ms / 1e3))
+    ms = _t(lambda: pgl.ops.reindex_graph(seeds, nbr, cnt), 5, 2)
+    print("%-34s %8.3f ms  (%.1f M ids/s)" % ("reindex_graph", ms, (len(seeds) + len(nbr)) / ms / 1e3))
+    try:                                                             # the CPU side of the same box
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import ref_native, ref_ops
+        gk = ref_native.load(build_if_missing=False)
+        e_cpu = edges.cpu().numpy()
+        if gk is not None:
+            t0 = time.perf_counter(); gk.build_index(e_cpu[:, 1].copy(), e_cpu[:, 0].copy(), N); dt = time.perf_counter() - t0
+            print("%-34s %8.1f ms  (reference graph_kernel.build_index, 1 core, %.1f M edges/s)" % ("CPU reference build_index", dt * 1e3, E / dt / 1e6))
+        x_cpu = x.cpu().numpy()
+        t0 = time.perf_counter(); ref_ops.c_send_u_recv(x_cpu, e_cpu[:, 0], e_cpu[:, 1], "sum"); dt = time.perf_counter() - t0
+        print("%-34s %8.1f ms  (C port of Paddle CPU send_u_recv, 1 core, %.1f M edges/s)" % ("CPU port send_u_recv d=128", dt * 1e3, E / dt / 1e6))
+    except Exception as ex:                                          # noqa: BLE001
+        print("cpu side skipped:", ex)
+
+
+def _layer(pgl, which):
+    return {"gcn": lambda: pgl.nn.GCNConv(128, 128), "gcn_relu": lambda: pgl.nn.GCNConv(128, 128, activation="relu"),
+            "sage": lambda: pgl.nn.GraphSageConv(128, 128, "mean"), "transformer": lambda: pgl.nn.TransformerConv(128, 16, 8, 0.0, 0.0),
+            "gat": lambda: pgl.nn.GATConv(128, 16, feat_drop=0.0, attn_drop=0.0, num_heads=8)}[which]().cuda()
+
+
+def cmd_layers(args):
+    """A few forward passes / training steps of ONE layer at C2 with nothing else around them -- the target of
+    `rocprofv3 --kernel-trace --stats -- python scripts/prof.py layers gat train` (per-kernel breakdown of a layer)."""
+    import torch
+    pgl, dev, g = _c2()
+    x = torch.randn(g.num_nodes, 128, device=dev)
+    layer = _layer(pgl, args.which)
+    if args.mode == "train":
+        x.requires_grad_(True)
+        for _ in range(8):
+            layer(g, x).sum().backward()
+    else:
+        layer.eval()
+        with torch.no_grad():
+            for _ in range(8):
+                layer(g, x)
+    torch.cuda.synchronize()
+
+
+def cmd_train(args):
+    """ms per TRAINING step (forward + backward incl. d/dx of one layer at C2), fused paths on and off."""
+    import torch
+    pgl, dev, g = _c2()
+    x0 = torch.randn(g.num_nodes, 128, device=dev)
+    for which in (args.which or ["gcn", "gcn_relu", "sage", "gat"]):
+        for fused in (True, False):
+            layer = _layer(pgl, which)
+            if hasattr(layer, "fused_dense"):
+                layer.fused_dense = fused
+            elif hasattr(layer, "fused"):
+                layer.fused = fused
+            elif not fused:
+                continue
+            x = x0.clone().requires_grad_(True)
+            ms = _t(lambda: layer(g, x).sum().backward(), 10, 3)
+            print("%-9s fused=%-5s %.3f ms / training step (fwd+bwd incl. d/dx)" % (which, fused, ms), flush=True)
+
+
+def cmd_gat(args):
+    """The GAT attention path at C3 (H = 8, D = 16): fused forward, fused forward + backward (with / without attention dropout),
+    and the reference-style four-op composition on the same engine."""
+    import torch
+    pgl, dev, g = _c2()
+    N, H, D = g.num_nodes, 8, 16
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    f = torch.randn(N, H, D, generator=gen, device=dev).requires_grad_(True)
+    a_s = torch.randn(N, H, generator=gen, device=dev).requires_grad_(True)
+    a_d = torch.randn(N, H, generator=gen, device=dev).requires_grad_(True)
+    w = torch.randn(N, H, D, generator=gen, device=dev)
+
+    def fused(p=0.0):
+        for t_ in (f, a_s, a_d):
+            t_.grad = None
+        (g.gat_aggregate(f, a_s, a_d, 0.2, p, 17) * w).sum().backward()
+
+    def unfused():
+        for t_ in (f, a_s, a_d):
+            t_.grad = None
+        al = torch.nn.functional.leaky_relu(g.send_uv(a_s, a_d, "add"), 0.2)
+        al = pgl.nn.functional.edge_softmax(g, al).reshape(-1, H, 1)
+        (g.send_ue_recv(f, al, "mul", "sum") * w).sum().backward()
+    with torch.no_grad():
+        print("fused forward only          %.3f ms" % _t(lambda: g.gat_aggregate(f, a_s, a_d, 0.2), 10, 2))
+    print("fused fwd+bwd               %.3f ms" % _t(lambda: fused(0.0), 10, 2))
+    print("fused fwd+bwd, dropout 0.6  %.3f ms" % _t(lambda: fused(0.6), 10, 2))
+    print("unfused fwd+bwd (reference-style composition on the same engine) %.3f ms" % _t(unfused, 3, 1))
+
+
+def cmd_dtypes(args):
+    """send_recv(sum) per storage type / width at C2 with the kernel each one launched."""
+    import torch
+    pgl, dev, g = _c2(with_src_index=False)
+    N, E = g.num_nodes, g.num_edges
+    for dt, d in ((torch.float32, 128), (torch.float16, 128), (torch.bfloat16, 128), (torch.float32, 64), (torch.float32, 32), (torch.float32, 256),
+                  (torch.float16, 256), (torch.float64, 32), (torch.float32, 8)):
+        x = torch.randn(N, d, device=dev).to(dt)
+        ms = _t(lambda: g.send_recv(x, "sum"), 20, 3)
+        es = x.element_size()
+        B = E * (d * es + 4) + N * (d * es + 8)
+        print("%-16s d=%-4d %.3f ms  %.2f Gedges/s  alg %.0f GB/s frac %.3f  %s" % (str(dt), d, ms, E / ms / 1e6, B / ms / 1e6, B / ms / 1e6 / 8000, pgl.ops.profile_last_kernel()))
+
+
+def cmd_variant(args):
+    """Builds an experimental variant of libpglamd.so next to the product one (extra -D macros, own object directory):
+    pgl_amd/csrc/variants/libpglamd_NAME.so; run anything against it with PGLAMD_LIB=<that path>."""
+    from pgl_amd import _build
+    vdir = os.path.join(_build.CSRC, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    print(_build.build(force=False, verbose=False, defines=args.defines, lib=os.path.join(vdir, "libpglamd_%s.so" % args.name),
+                       obj=os.path.join(_build.CSRC, "build", "variant_" + args.name)))
+
+
+def cmd_trace(args):
+    """Per-(kernel, grid size) summary of a rocprofv3 --kernel-trace CSV: calls, average / min / max duration."""
+    import collections
+    import csv
+    agg = collections.OrderedDict()
+    for r in csv.DictReader(open(args.csv)):
+        name = r["Kernel_Name"].replace("void ", "")
+        if args.filter and args.filter not in name:
+            continue
+        agg.setdefault((name[:110], r.get("Grid_Size", r.get("Grid_Size_X", "?"))), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("%-110s %12s %6s %10s %10s %10s" % ("kernel", "grid", "calls", "avg_us", "min_us", "max_us"))
+    for (name, grid), ds in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print("%-110s %12s %6d %10.1f %10.1f %10.1f" % (name, grid, len(ds), sum(ds) / len(ds), min(ds), max(ds)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -346,25 +564,32 @@ def main():
     r.add_argument("--push", default="auto", choices=["auto", "never"])
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     sub.add_parser("noreuse")
+    sub.add_parser("gcn")
     tr = sub.add_parser("traffic")
     tr.add_argument("--dir", required=True)
     tr.add_argument("--out", required=True)
-    for name in ("ops", "csr", "layers"):
-        s_ = sub.add_parser(name)
-        s_.add_argument("rest", nargs=argparse.REMAINDER)
+    sub.add_parser("csr")
+    o = sub.add_parser("ops"); o.add_argument("--scale", type=int, default=20); o.add_argument("--edges", type=int, default=20_000_000)
+    ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
+    ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
+    tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
+    sub.add_parser("gat"); sub.add_parser("dtypes")
+    va = sub.add_parser("variant"); va.add_argument("name"); va.add_argument("defines", nargs="*")
+    tc = sub.add_parser("trace"); tc.add_argument("csv"); tc.add_argument("filter", nargs="?", default="")
     args = ap.parse_args()
     if args.cmd == "diag":
         cmd_diag(args)
     elif args.cmd == "rows":
         cmd_rows(args)
-    elif args.cmd == "ops":
-        _run_script("bench_ops.py", args.rest)
-    elif args.cmd == "layers":
-        _run_script("prof_layers.py", args.rest)
+    elif args.cmd in ("ops", "layers", "train", "gat", "dtypes", "variant", "trace"):
+        {"ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
+         "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
+    elif args.cmd == "gcn":
+        cmd_gcn(args)
     elif args.cmd == "traffic":
         cmd_traffic(args)
     else:

@@ -269,3 +269,82 @@ def test_c3_send_ue_recv_mul_sum_per_element(pgl):
         a64.index_add_(0, dst[b:b + step], m.abs())
     deg = torch.bincount(dst, minlength=N)
     _assert_bound(got, s64, a64, deg + 2, float(np.finfo(np.float32).eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# f1: aggregation feeding the dense layer inside one kernel (pglamd_aggregate_dense)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d_in,d_out", [(128, 128), (128, 16), (64, 256), (64, 48)])
+@pytest.mark.parametrize("op,act", [("sum", "relu"), ("mean", None)])
+def test_aggregate_dense_equals_aggregate_then_linear(pgl, d_in, d_out, op, act):
+    rng = np.random.default_rng(d_in + d_out)
+    n, e = 3000, 50000
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n - 200, e)], 1).astype(np.int64)     # the last 200 rows stay empty
+    edges[rng.choice(e, 9000, replace=False), 1] = 77                                               # a hub row: split-row fix-up path
+    edges[rng.choice(e, 700, replace=False), 1] = 1500                                              # a row longer than one chunk
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, d_in)).astype(np.float32))
+    w = dev((rng.standard_normal((d_in, d_out)) / np.sqrt(d_in)).astype(np.float32))
+    b = dev(rng.standard_normal(d_out).astype(np.float32))
+    ds = dev(rng.random(n).astype(np.float32) + 0.5)
+    csr = g._csr_dst()
+    out, agg = pgl.ops.aggregate_dense(x, csr, w, b, act, op, ds, keep_agg=True)
+    want_agg = pgl.ops.aggregate(x, csr, op, n, dst_scale=ds)
+    want = want_agg.double() @ w.double() + b.double()
+    if act == "relu":
+        want = want.clamp(min=0)
+    assert torch.equal(agg, want_agg)                                        # the kept aggregate is the plain kernel's, bit for bit
+    scale = float(want.abs().max())
+    assert float((out.double() - want).abs().max()) <= 2e-6 * scale + 1e-6, float((out.double() - want).abs().max())
+    assert torch.equal(out[n - 200:], (b.clamp(min=0) if act == "relu" else b).expand(200, -1))      # empty rows: act(bias)
+    out2, none = pgl.ops.aggregate_dense(x, csr, w, None, act, op, ds)
+    want2 = want_agg.double() @ w.double()
+    if act == "relu":
+        want2 = want2.clamp(min=0)
+    assert none is None and float((out2.double() - want2).abs().max()) <= 2e-6 * scale + 1e-6
+
+
+def test_aggregate_dense_gradients_and_gcnconv(pgl):
+    """GCNConv through the fused kernel == GCNConv through separate kernels (round-2 path): outputs and all gradients; and the
+    reference-produced layer fixtures keep passing through it (tests/test_golden_layers.py runs GCNConv as built)."""
+    torch.manual_seed(0)
+    rng = np.random.default_rng(5)
+    n, e, d = 4000, 70000, 128
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    edges[rng.choice(e, 8000, replace=False), 1] = 9
+    edges[rng.choice(e, 6000, replace=False), 0] = 11                          # a hub SOURCE: split rows in the transposed (backward) walk
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    for act in ("relu", None):
+        layer = pgl.nn.GCNConv(d, d, activation=act).cuda()
+        with torch.no_grad():
+            layer.bias.copy_(torch.randn(d, device="cuda") * 0.1)
+        res = {}
+        for fused in (True, False):
+            layer.fused_dense = fused
+            layer.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = layer(g, xi)
+            (y * torch.linspace(0.5, 1.5, d, device="cuda")).sum().backward()
+            res[fused] = (y.detach(), xi.grad.clone(), layer.linear.weight.grad.clone(), layer.bias.grad.clone())
+        for a, b_, name in zip(res[True], res[False], ("out", "d x", "d W", "d b")):
+            tol = 2e-5 * float(b_.abs().max()) + 1e-6
+            assert float((a - b_).abs().max()) <= tol, (act, name, float((a - b_).abs().max()), tol)
+        with torch.no_grad():
+            layer.fused_dense = True
+            assert float((layer(g, x) - res[False][0]).abs().max()) <= 2e-5 * float(res[False][0].abs().max())
+
+
+def test_c2_aggregate_dense_per_element(pgl):
+    """BASELINE configs[1] size: the fused GCN layer output, every element within the fp32 re-association bound of the fp64 result
+    (sum over a row's edges AND over the 128 products of the dense layer)."""
+    N, E, edges, x = _c2_graph()
+    g = pgl.Graph(edges=edges, num_nodes=N)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    w = torch.randn(128, 128, generator=gen, device="cuda") / 128 ** 0.5
+    out, _ = pgl.ops.aggregate_dense(x, g._csr_dst(), w, None, None, "sum")
+    s64, a64 = _fp64_terms(edges, x.double(), N)
+    want = s64 @ w.double()
+    abs_terms = a64 @ w.double().abs()
+    deg = torch.bincount(edges[:, 1], minlength=N)
+    _assert_bound(out, want, abs_terms, deg + 130, float(np.finfo(np.float32).eps))
