@@ -4,25 +4,28 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is ONE pass of Graph.send_recv(x, "sum") (= pglamd_aggregate through the C ABI) over the
-whole synthetic graph with the feature matrix already resident in HBM.
-Workload (config.workload): BASELINE.json configs[1] -- RMAT (0.57,0.19,0.19,0.05) |V| = 2^20,
-|E| = 20 M, d = 128 fp32, graph seed 42, feature seed 7.
-N > 1: the SAME global graph and feature matrix (strong scaling).  The headline layout is north_star's (--parallel rows,
-the default): METIS row partition (pgl.partition.metis_partition's METIS through the C ABI), one RCCL halo all-to-all-v
-per step overlapped with the local-source edges, per rank pair the cheaper of pull and push (DistGraph).  The column layout
-is timed for a few steps and reported as a SECONDARY field (halo.alternatives_ms_per_step); --parallel auto also times the grid:
-  cols  the graph replicated on every GPU, the feature COLUMNS split: out[:, cols_r] = A x[:, cols_r] needs no data-path
-        collective at all (FeatureShardedGraph);
-  grid  2 row parts x N/2 column slices (GridShardedGraph).
-value = global |E| / max-rank time of the headline layout; halo bytes and the exchange-only time per rank ride along.
-N = 1 adds: roofline.no_reuse (permutation graph and uniform degree-19 graph: known bytes / event-timed kernel, a physical
-fraction <= 1 -> roofline.frac_no_reuse) and target_size (|E| = 100 M, north_star's size).
+A "step" is ONE pass of Graph.send_recv(x, "sum") (= pglamd_aggregate through the C ABI) over the whole synthetic graph with the
+feature matrix already resident in HBM.  Workload (config.workload): BASELINE.json configs[1] -- RMAT (0.57,0.19,0.19,0.05)
+|V| = 2^20, |E| = 20 M, d = 128 fp32, graph seed 42, feature seed 7.
 
-Output: one JSON line on rank 0 with the driver's contract fields plus
-  roofline     -- dominant kernel (agg_flat_kernel) algorithmic bytes / its HIP-event time vs 8 TB/s
-  cpu_baseline -- the oracle's C port of the Paddle CPU kernel (serial, raw COO order), timed on
-                  this box's host cores (rank 0, N = 1 only); the checker, never the product.
+N = 1, one JSON line with the driver's contract fields plus
+  roofline      PHYSICAL: achieved / frac come from the same kernel (agg_flat_kernel, d = 128 fp32 sum) on a graph whose gathered
+                bytes are KNOWN (uniform in-degree-19 graph over 8.6 GB of features: <= 3.5 % of the gathers can hit any cache),
+                timed with HIP events in this run; `traffic` = PMC bytes of that leg from profiles/r03/traffic.json, replayed only
+                when the file's stamp (kernel symbol + sha256 of the kernel sources) matches this tree, else null.  The headline
+                workload's own figures -- section 8(d) model bytes / kernel time, which is NOT a bandwidth on RMAT (hub rows live
+                in L2 / Infinity Cache) -- ride along under roofline.headline_workload, labelled; no ratio above 1 is printed.
+  timing        median / p95 over 100 event-timed runs of the step (SURVEY 8d protocol)
+  gcn_norm      send_recv(sum) with both degree norms, fused (one kernel) and unfused (three ops) -- SURVEY 8d "report both"
+  target_size   |E| = 100 M (north_star's size, SURVEY 8d C2'), same seeds, same op
+  cpu_baseline  the oracle's C port of the Paddle CPU kernel (serial raw-COO loop, 1 core; the checker, never the product), the
+                reference's own compiled build_index, an OpenMP CSR variant, scipy CSR @ dense and torch.index_add_ as sanity baselines
+
+N > 1 (strong scaling, the SAME global graph and features): north_star's layout -- row partition by the engine's own partitioner
+(pglamd_partition_edges: in-degree + 1 and rows balanced; --partition metis = the reference's METIS as an opt-in comparison), one
+RCCL halo all-to-all-v per step, interior rows aggregated while the rows travel, boundary rows afterwards from [owned | received]:
+every output row written once (DistGraph).  value = global |E| / max-rank time; halo bytes and the exchange-only time per rank ride
+along; target_size = the |E| = 100 M graph through the same flow.  --parallel cols / grid / auto time the alternative layouts.
 """
 import os
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (set before HIP initialises)

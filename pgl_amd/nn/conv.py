@@ -117,7 +117,10 @@ class GCNConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(output_size))
         self.norm = norm
         self.activation = _act(activation)
-        self.fused_dense = True       # False: aggregation and linear layer as separate kernels (round-2 path)
+        # True: aggregate -> W -> bias -> relu in ONE kernel (Graph.send_recv_dense / pglamd_aggregate_dense: finished rows go from
+        # the aggregation's registers through an LDS tile into the matrix cores).  Parity-green and measured SLOWER than the separate
+        # kernels in its first form (C2: 1.75 ms vs 1.14 + 0.36), so it is opt-in until it wins.
+        self.fused_dense = False
 
     def forward(self, graph, feature, norm=None):
         if self.norm and norm is None:

@@ -333,6 +333,7 @@ def test_aggregate_dense_gradients_and_gcnconv(pgl):
         with torch.no_grad():
             layer.fused_dense = True
             assert float((layer(g, x) - res[False][0]).abs().max()) <= 2e-5 * float(res[False][0].abs().max())
+            layer.fused_dense = False
 
 
 def test_c2_aggregate_dense_per_element(pgl):
