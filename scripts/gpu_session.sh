@@ -2,7 +2,7 @@
 # One GPU session = a list of steps, run on the GPU box through gpurun:
 #     gpurun --timeout 3000 -- 'bash scripts/gpu_session.sh TAG step [step ...]'
 # Every step writes gpurun_out/r03/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r03/.
-# Steps: diag tests tests:<pytest -k expr> bench rows_c2 rows_c2_p4 rows_c2_fp16 rows_c2p csr noreuse gcn train gat ops dtypes profile
+# Steps: diag tests tests:<pytest -k expr> bench rows_c2 rows_c2_p4 rows_c2_fp16 rows_c2p csr noreuse tlb gcn train gat ops dtypes profile
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 TAG=$1; shift
 PARTS="scratch/parts"
@@ -21,6 +21,23 @@ for STEP in "$@"; do
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     csr|noreuse|gcn|gat|ops|dtypes) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
+    tlb)
+      # address-translation counters of the known-bytes leg (the 29.5 / 34.1 ms bimodality across boxes): which TCP / UTCL
+      # counters this rocprofv3 offers, then one --pmc pass of the leg with the translation hit / miss pair
+      ( cd /tmp && export TMPDIR=/tmp
+        rocprofv3 -L 2>/dev/null | grep -i -E "utcl|tlb|translation" | head -40 > $F
+        rocprofv3 --kernel-trace --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum --output-format csv -d $O/tlb_pmc -o p -- python $R/scripts/prof.py noreuse >> $F 2>&1
+        python - <<PY >> $F
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob("$O/tlb_pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "agg_flat" in r.get("Kernel_Name", ""):
+            k = (r.get("Grid_Size"), r.get("Counter_Name")); agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+for k, (s, n) in sorted(agg.items()): print("agg_flat_kernel grid", k[0], k[1], "avg per dispatch %.0f" % (s / n), "n", n)
+PY
+        rm -rf $O/tlb_pmc )
+      grep -v amdgpu.ids $F | tail -30 ;;
     profile)
       # rocprofv3 --kernel-trace --stats of the DEFAULT bench command, then separate --pmc FETCH_SIZE / WRITE_SIZE passes of the
       # same command, then traffic.json (stamped with the kernel sources' hash) built from them
