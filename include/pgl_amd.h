@@ -190,6 +190,28 @@ int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const int32_t* row,
                                float* agg_out, float* out, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* Gradients that pgl_amd/autograd.py used to compose from [E, d] row gathers (F32; PaddlePaddle implements them inside
+ * graph_send_recv_grad / graph_send_ue_recv_grad behind the call sites at pgl/graph.py:834-937).
+ *
+ * pglamd_winner_grad: d x of send_recv(x, max | min).  The gradient of an output row goes to EVERY message equal to the winner
+ * (Paddle's rule):  grad_x[u, j] = sum_{e = (u -> v)} [x[u, j] == out[v, j]] * grad_out[v, j].  One walk of the SRC-sorted
+ * stream (src_row / src_col / src_indptr = the src-keyed CSR: row = u, col = v), d <= 256, deterministic.
+ *
+ * pglamd_edge_operand_grad: d y of send_ue_recv(x, y, message_op, sum | mean) for trailing-dim broadcast operands
+ * (y [E, dy], d % dy == 0; the [E, H, 1] case also has pglamd_sddmm):
+ *     grad_y[eid[p], jy] = sum_{j in group jy} dst_scale[row[p]] * grad_out[row[p], j] * { 1 | -1 | x[col[p], j] | -x[col[p], j] / y^2 }
+ * for ADD | SUB | MUL | DIV; row / col / eid = the dst-sorted CSR (eid NULL: grad_y in CSR order); dst_scale NULL = 1
+ * (MEAN: 1 / in-degree); x is needed for MUL / DIV, y (original edge order, like grad_y) for DIV. */
+size_t pglamd_winner_grad_workspace_bytes(int64_t num_edges, int64_t d);
+int32_t pglamd_winner_grad(const float* grad_out, const float* out, const float* x, int64_t d,
+                           const int32_t* src_row, const int32_t* src_col, const int64_t* src_indptr,
+                           int64_t num_edges, int64_t n_x_rows, float* grad_x, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int32_t pglamd_edge_operand_grad(const float* grad_out, const float* x, const float* y,
+                                 const float* dst_scale, int64_t d, int64_t dy, const int32_t* row,
+                                 const int32_t* col, const int32_t* eid, int64_t num_edges,
+                                 int32_t message_op, float* grad_y, void* stream);
+
 /* Measurement hook for the dominant kernel (bench.py roofline leg): between profile_begin and
  * profile_end every launch of the flat aggregation kernel is bracketed by HIP events on its own
  * launch stream; profile_end synchronises them and returns the summed kernel time (host out). */

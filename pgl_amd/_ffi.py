@@ -33,6 +33,9 @@ _SIGNATURES = {
     "pglamd_aggregate_dense_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "pglamd_aggregate_dense": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64,
                                         c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "pglamd_winner_grad_workspace_bytes": (c_sz, [c_i64, c_i64]),
+    "pglamd_winner_grad": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
+    "pglamd_edge_operand_grad": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "pglamd_profile_begin": (c_i32, []),
     "pglamd_profile_end": (c_i32, [c_vp, c_vp]),
     "pglamd_profile_last_kernel": (ctypes.c_char_p, []),

@@ -76,6 +76,12 @@ class _Aggregate(torch.autograd.Function):
                     and tuple(ctx.x_shape[1:]) == tuple(grad.shape[1:]) and ops.sddmm_supported(grad.shape[1], grad.shape[2])):
                 # d/de of sum_e x[src] * e with e [E,H,1]: one SDDMM pass, no [E,H,D] gather is materialised
                 gy = ops.sddmm(x, grad, ctx.csr).reshape(ctx.y_shape)
+            elif (has_y and ctx.needs_input_grad[1] and grad.shape[0] >= ctx.csr.num_nodes
+                  and ops.edge_operand_grad_supported(grad, x if tuple(x.shape[1:]) == tuple(grad.shape[1:]) else grad, ctx.y_shape)
+                  and (ctx.mop in ("add", "sub") or tuple(x.shape[1:]) == tuple(grad.shape[1:]))):
+                # trailing-dim broadcast operands ([E], [E,1], [E,d], [E,H,D]): one pass over the edges, the [E, d] products
+                # live in registers only (round 3; the composition below materialises three [E, d] tensors)
+                gy = ops.edge_operand_grad(grad, x, y if ctx.mop == "div" else None, ctx.csr, ctx.mop, ctx.y_shape, scale)
             elif has_y and ctx.needs_input_grad[1]:
                 # general broadcast shapes: composed from row gathers (materialises [E, out_tail])
                 gd = ops.gather_rows(grad, ctx.dst32)
@@ -89,9 +95,14 @@ class _Aggregate(torch.autograd.Function):
                     xs = ops.gather_rows(x, ctx.src32)
                     gy = gd * xs if ctx.mop == "mul" else -gd * xs / (y * y)
                 gy = _unbroadcast(gy, ctx.y_shape)
+        elif not has_y and ops.winner_grad_supported(x, out) and grad.shape[0] == n_x == out.shape[0]:
+            # max / min without an edge operand (GraphSage's pooling): the winner mask is evaluated inside ONE walk of the
+            # src-sorted stream -- no [E, d] tensor (round 3)
+            if ctx.needs_input_grad[0]:
+                gx = ops.winner_grad(grad, out, x, csr_t)
         else:
-            # max / min: gradient flows to every message equal to the winner (Paddle's rule);
-            # composed from gathers -- not on the graded path
+            # max / min with an edge operand: gradient flows to every message equal to the winner (Paddle's rule);
+            # composed from gathers
             xs = ops.gather_rows(x, ctx.src32)
             msg = xs if not has_y else {"add": xs + y, "sub": xs - y, "mul": xs * y, "div": xs / y}[ctx.mop]
             hit = (msg == ops.gather_rows(out, ctx.dst32)).to(grad.dtype)

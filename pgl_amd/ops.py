@@ -275,6 +275,67 @@ def aggregate_dense(x, csr, w, bias=None, act=None, reduce_op="sum", dst_scale=N
     return out, agg
 
 
+def winner_grad_supported(x, out):
+    d = _prod(x.shape[1:])
+    return (x.is_cuda and x.dtype == torch.float32 and out.dtype == torch.float32 and x.dim() >= 2 and 0 < d <= 256
+            and tuple(x.shape[1:]) == tuple(out.shape[1:]) and (d <= 64 or d % 2 == 0) and (d <= 128 or d % 4 == 0))
+
+
+def winner_grad(grad_out, out, x, csr_src):
+    """d x of send_recv(x, max | min) in one walk of the src-sorted stream (pglamd_winner_grad): every message equal to its
+    destination's winner receives that destination's gradient (Paddle's rule)."""
+    _need_cuda(grad_out, out, x)
+    grad_out = grad_out.contiguous(); out = out.contiguous(); x = x.contiguous()
+    n, d = int(x.shape[0]), _prod(x.shape[1:])
+    gx = torch.empty_like(x)
+    if n == 0:
+        return gx
+    L = _ffi.lib()
+    ws = _ws(L.pglamd_winner_grad_workspace_bytes(csr_src.num_edges, d), x.device)
+    with torch.cuda.device(x.device):
+        _ffi.check(L.pglamd_winner_grad(_ptr(grad_out), _ptr(out), _ptr(x), d, _ptr(csr_src.row32), _ptr(csr_src.col32),
+                                        _ptr(csr_src.indptr), csr_src.num_edges, n, _ptr(gx), _ptr(ws), ws.numel(), _stream(x)),
+                   "winner_grad")
+    return gx
+
+
+def edge_operand_grad_supported(grad, x, y_shape):
+    """Shapes pglamd_edge_operand_grad covers: fp32, trailing-dim broadcast of y onto x's tail, groups on power-of-two lane spans."""
+    if not (grad.is_cuda and grad.dtype == torch.float32 and x.dtype == torch.float32 and grad.dim() >= 2):
+        return False
+    tail = tuple(grad.shape[1:])
+    if tuple(x.shape[1:]) != tail:
+        return False
+    d, dy = _prod(tail), _prod(y_shape[1:])
+    if not (0 < d <= 256 and dy > 0 and d % dy == 0 and _trailing_ok(tuple(y_shape[1:]), tail)):
+        return False
+    vec = 4 if d > 128 else 2 if d > 64 else 1
+    if d % vec:
+        return False
+    g = d // dy
+    if g >= vec:
+        lanes = g // vec
+        return g % vec == 0 and lanes <= 64 and (lanes & (lanes - 1)) == 0
+    return vec % g == 0
+
+
+def edge_operand_grad(grad, x, y, csr_dst, message_op, y_shape, dst_scale=None):
+    """d y of send_ue_recv(x, y, message_op, sum | mean) -> [E, ...] of shape y_shape in ORIGINAL edge order."""
+    _need_cuda(grad, x, y, dst_scale)
+    grad = grad.contiguous(); x = x.contiguous()
+    d, dy = _prod(grad.shape[1:]), _prod(y_shape[1:])
+    E = csr_dst.num_edges
+    gy = torch.empty(tuple(y_shape), dtype=torch.float32, device=grad.device)
+    if E:
+        yy = None if y is None else y.contiguous()
+        ds = None if dst_scale is None else dst_scale.to(torch.float32).contiguous()
+        with torch.cuda.device(grad.device):
+            _ffi.check(_ffi.lib().pglamd_edge_operand_grad(_ptr(grad), _ptr(x), _ptr(yy), _ptr(ds), d, dy, _ptr(csr_dst.row32),
+                                                           _ptr(csr_dst.col32), _ptr(csr_dst.eid32), E, MSG[message_op], _ptr(gy),
+                                                           _stream(grad)), "edge_operand_grad")
+    return gy
+
+
 def profile_begin():
     """Start bracketing every flat-kernel launch with HIP events (bench.py roofline leg)."""
     _ffi.check(_ffi.lib().pglamd_profile_begin(), "profile_begin")

@@ -349,3 +349,62 @@ def test_c2_aggregate_dense_per_element(pgl):
     abs_terms = a64 @ w.double().abs()
     deg = torch.bincount(edges[:, 1], minlength=N)
     _assert_bound(out, want, abs_terms, deg + 130, float(np.finfo(np.float32).eps))
+
+
+# ------------------------------------------------------------------------------------------------
+# gradient kernels that replace the [E, d] gather compositions
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [16, 100, 128, 256])
+@pytest.mark.parametrize("op", ["max", "min"])
+def test_winner_gradient_kernel(pgl, d, op):
+    """d x of send_recv(x, max | min): every message equal to the winner gets the row's gradient (ties included: x takes few
+    distinct values), hub source and hub destination (split rows in both walks), vs the edge-by-edge formulation."""
+    rng = np.random.default_rng(d)
+    n, e = 2500, 40000
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    edges[rng.choice(e, 6000, replace=False), 0] = 3
+    edges[rng.choice(e, 6000, replace=False), 1] = 8
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x = dev(rng.integers(-3, 4, (n, d)).astype(np.float32)).requires_grad_(True)
+    w = dev(rng.standard_normal((n, d)).astype(np.float32))
+    out = g.send_recv(x, op)
+    (out * w).sum().backward()
+    src, dst = dev(edges[:, 0]), dev(edges[:, 1])
+    hit = (x.detach()[src] == out.detach()[dst]).float()
+    want = torch.zeros(n, d, device="cuda", dtype=torch.float64).index_add_(0, src, (w[dst] * hit).double())
+    assert float((x.grad.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    x2 = x.detach().clone().requires_grad_(True)                    # bit-reproducible
+    (g.send_recv(x2, op) * w).sum().backward()
+    assert torch.equal(x2.grad, x.grad)
+
+
+@pytest.mark.parametrize("yshape", ["E", "E1", "Ed", "EHD", "EH1"])
+@pytest.mark.parametrize("mop,rop", [("mul", "sum"), ("add", "mean"), ("sub", "sum"), ("div", "mean")])
+def test_edge_operand_gradient_kernel(pgl, yshape, mop, rop):
+    """d y (and d x) of send_ue_recv for every trailing-dim broadcast shape of the edge operand, vs torch autograd of the
+    edge-by-edge formulation in fp64."""
+    rng = np.random.default_rng(7)
+    n, e, H, D = 1500, 20000, 8, 16
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    edges[rng.choice(e, 3000, replace=False), 1] = 5
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    xs = (n, H, D) if yshape in ("EHD", "EH1") else (n, H * D)
+    ys = {"E": (e,), "E1": (e, 1), "Ed": (e, H * D), "EHD": (e, H, D), "EH1": (e, H, 1)}[yshape]
+    x = dev(rng.standard_normal(xs).astype(np.float32)).requires_grad_(True)
+    y = dev((rng.random(ys) + 0.5).astype(np.float32)).requires_grad_(True)
+    w = dev(rng.standard_normal(xs).astype(np.float32))
+    out = g.send_ue_recv(x, y, mop, rop)
+    (out * w).sum().backward()
+    src, dst = dev(edges[:, 0]), dev(edges[:, 1])
+    x64, y64 = x.detach().double().requires_grad_(True), y.detach().double().requires_grad_(True)
+    yb = y64.reshape((e,) + (1,) * (len(xs) - len(ys)) + tuple(ys[1:])) if len(ys) < len(xs) else y64
+    m = {"mul": x64[src] * yb, "add": x64[src] + yb, "sub": x64[src] - yb, "div": x64[src] / yb}[mop]
+    ref = torch.zeros(xs, device="cuda", dtype=torch.float64).index_add_(0, dst, m)
+    if rop == "mean":
+        deg = torch.bincount(dst, minlength=n).clamp(min=1).double()
+        ref = ref / deg.reshape((-1,) + (1,) * (len(xs) - 1))
+    (ref * w.double()).sum().backward()
+    assert float((out.double() - ref.detach()).abs().max()) <= 1e-5 * float(ref.abs().max())
+    for got, want, name in ((x.grad, x64.grad, "d x"), (y.grad, y64.grad, "d y")):
+        assert tuple(got.shape) == tuple(want.shape), name
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-7, (name, float((got.double() - want).abs().max()))
