@@ -10,6 +10,7 @@
     python scripts/prof.py gcn                       GCNConv forward / training step through the fused aggregate -> dense kernel and without
     python scripts/prof.py train [gcn sage gat ...]  ms per training step of one layer, fused paths on / off
     python scripts/prof.py gat | dtypes              the GAT attention path at C3 / send_recv per storage type
+    python scripts/prof.py gatsplit                  lower bound of the "SDDMM + weighted SpMM" split of the GAT backward vs the fused walk
     python scripts/prof.py layers WHICH [train]      a few steps of one layer with nothing around them (the target of rocprofv3 --kernel-trace)
     python scripts/prof.py traffic --dir D --out F   traffic.json from a profiling session (scripts/gpu_r03_profile.sh)
     python scripts/prof.py trace CSV [filter]        per-(kernel, grid) summary of a rocprofv3 kernel trace
@@ -344,6 +345,22 @@ def cmd_gcn(args):
     print("  ops.aggregate_dense alone           %.3f ms (inference: no aggregate kept)   %.3f ms (aggregate kept)"
           % (_t(lambda: pgl.ops.aggregate_dense(x, csr, w, None, "relu")), _t(lambda: pgl.ops.aggregate_dense(x, csr, w, None, "relu", keep_agg=True))))
     print("  x @ w (hipBLASLt)                   %.3f ms" % _t(lambda: x @ w))
+    b = torch.randn(d, generator=gen, device=dev)
+    try:
+        print("  relu(x @ w + b) one GEMM epilogue   %.3f ms (torch._addmm_activation)" % _t(lambda: torch._addmm_activation(b, x, w)))
+    except Exception as ex:                                          # noqa: BLE001
+        print("  torch._addmm_activation unavailable: %r" % ex)
+    # the symmetric norm as per-edge weights in CSR order (w_e = norm[src] norm[dst]): no prescale pass, no per-destination scale
+    class _NoEid(object):
+        pass
+    c2 = _NoEid()
+    for k in ("row32", "col32", "indptr", "num_edges", "num_nodes"):
+        setattr(c2, k, getattr(csr, k))
+    c2.eid32 = None
+    nv = norm.reshape(-1)
+    w_e = (nv[csr.col32.long()] * nv[csr.row32.long()]).reshape(-1, 1).contiguous()
+    print("  aggregate with CSR-order [E,1] weights %.3f ms (vs prescale + send_recv_scaled: %.3f ms)"
+          % (_t(lambda: pgl.ops.aggregate(x, c2, "sum", N, w_e, "mul")), _t(lambda: g.send_recv_scaled(x, norm, norm))))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -511,6 +528,41 @@ def cmd_gat(args):
     print("unfused fwd+bwd (reference-style composition on the same engine) %.3f ms" % _t(unfused, 3, 1))
 
 
+def cmd_gatsplit(args):
+    """would the GAT backward win if its src-sorted walk were split into (A) an SDDMM-shaped pass for the score
+    gradient and (B) a plain weighted SpMM for the feature gradient?  Both halves exist as kernels, so the split is bounded FROM
+    BELOW by timing them on the transposed graph with the edge tensors in CSR order (no permutation anywhere): pass A at least an
+    SDDMM (it also recomputes the softmax and gathers a 128-byte line of destination scalars per edge), pass B exactly the
+    CSR-order send_ue_recv(mul, sum).  Next to it: the fused backward as it is."""
+    import torch
+    pgl, dev, g = _c2()
+    N, E, H, D = g.num_nodes, g.num_edges, 8, 16
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    gT = pgl.Graph(edges=g.edges.flip(1).contiguous(), num_nodes=N)           # rows = the original sources
+    view = gT.edge_order("dst")
+    f = torch.randn(N, H, D, generator=gen, device=dev)
+    go = torch.randn(N, H, D, generator=gen, device=dev)
+    alpha = torch.rand(E, H, 1, generator=gen, device=dev)
+    with torch.no_grad():
+        t_a = _t(lambda: view.sddmm(go, f), 10, 3)                          # <g[v], f[u]>_h per edge, src-sorted order
+        t_b = _t(lambda: view.send_ue_recv(go, alpha, "mul", "sum"), 10, 3)  # d f[u] = sum alpha_e g[v], weights in CSR order
+    a_s = torch.randn(N, H, generator=gen, device=dev).requires_grad_(True)
+    a_d = torch.randn(N, H, generator=gen, device=dev).requires_grad_(True)
+    fr = f.clone().requires_grad_(True)
+    w = torch.randn(N, H, D, generator=gen, device=dev)
+
+    def fused():
+        for t_ in (fr, a_s, a_d):
+            t_.grad = None
+        (g.gat_aggregate(fr, a_s, a_d, 0.2, 0.0, 17) * w).sum().backward()
+    with torch.no_grad():
+        t_f = _t(lambda: g.gat_aggregate(fr, a_s, a_d, 0.2), 10, 3)
+    t_fb = _t(fused, 10, 3)
+    print("C3 (RMAT-20, 20 M edges, H = 8, D = 16)")
+    print("  fused GAT forward %.3f ms, forward + backward %.3f ms  =>  backward (walk + pack) ~ %.3f ms" % (t_f, t_fb, t_fb - t_f))
+    print("  split lower bound: pass A >= SDDMM in src order %.3f ms  +  pass B = CSR-order weighted SpMM %.3f ms  =  %.3f ms" % (t_a, t_b, t_a + t_b))
+
+
 def cmd_dtypes(args):
     """send_recv(sum) per storage type / width at C2 with the kernel each one launched."""
     import torch
@@ -573,7 +625,7 @@ def main():
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
-    sub.add_parser("gat"); sub.add_parser("dtypes")
+    sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
     va = sub.add_parser("variant"); va.add_argument("name"); va.add_argument("defines", nargs="*")
     tc = sub.add_parser("trace"); tc.add_argument("csv"); tc.add_argument("filter", nargs="?", default="")
     args = ap.parse_args()
@@ -581,8 +633,8 @@ def main():
         cmd_diag(args)
     elif args.cmd == "rows":
         cmd_rows(args)
-    elif args.cmd in ("ops", "layers", "train", "gat", "dtypes", "variant", "trace"):
-        {"ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
+    elif args.cmd in ("ops", "layers", "train", "gat", "dtypes", "variant", "trace", "gatsplit"):
+        {"gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
          "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
