@@ -187,7 +187,7 @@ def cmd_noreuse(args):
                 rec["vram_used"] = None
             for hw in glob.glob(os.path.join(devdir, "hwmon", "hwmon*")):
                 for f, key, div in (("power1_average", "power_w", 1e6), ("power1_input", "power_w", 1e6), ("temp1_input", "temp_c", 1e3),
-                                    ("power1_cap", "cap_w", 1e6)):
+                                    ("power1_cap", "cap_w", 1e6), ("freq1_input", "sclk_mhz", 1e6), ("freq2_input", "mclk_mhz", 1e6)):
                     try:
                         rec[key] = int(open(os.path.join(hw, f)).read()) / div
                     except Exception:                                # noqa: BLE001
@@ -240,10 +240,12 @@ def cmd_noreuse(args):
             continue                                                 # (connector nodes, not GPUs)
         vals = lambda k: [s_[card].get(k) for s_ in samples if s_[card].get(k) is not None]
         line = "  %-7s%s" % (card, " <- ours" if card == mine else "        ")
-        for k in ("sclk", "mclk", "fclk", "power_w", "temp_c", "cap_w"):
+        for k in ("sclk", "sclk_mhz", "mclk", "fclk", "power_w", "temp_c", "cap_w"):
             v = vals(k)
             if v:
                 line += "  %s %s..%s" % (k, ("%.0f" % min(v)), ("%.0f" % max(v)))
+                if k in ("sclk_mhz", "power_w"):
+                    line += " (mean %.0f)" % (sum(v) / len(v))
         print(line)
 
 

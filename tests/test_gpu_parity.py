@@ -485,7 +485,7 @@ def test_full_size_gat_path_properties(pgl, rmat20):
     sel = np.isin(e[:, 1], rows)
     sub = e[sel]
     want = R.np_send_ue_recv(host(x).reshape(-1, h, 16), host(alpha)[sel].reshape(-1, h, 1), sub[:, 0], sub[:, 1], "mul", "sum")
-    close(host(out)[rows], want[rows], scale=np.abs(want[rows]).max(), rtol=5e-5)
+    close(host(out)[rows], want[rows], scale=np.abs(want[rows]).max(), rtol=1e-5)     # north_star's stated bar (round 2 had 5e-5 here)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -408,3 +408,41 @@ def test_edge_operand_gradient_kernel(pgl, yshape, mop, rop):
     for got, want, name in ((x.grad, x64.grad, "d x"), (y.grad, y64.grad, "d y")):
         assert tuple(got.shape) == tuple(want.shape), name
         assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-7, (name, float((got.double() - want).abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# f3: the GPU sampler against the reference's compiled sample_subset, statistically
+# ------------------------------------------------------------------------------------------------
+def test_sample_neighbors_matches_the_reference_sampler_distribution(pgl, ref_native):
+    """graph_kernel.sample_subset (pgl/graph_kernel.pyx:266-298; what Graph.sample_predecessor calls) and pglamd_sample_neighbors
+    draw k of a hub's D in-neighbours without replacement.  The two are random, so they are compared as distributions: 400 draws
+    each, per-neighbour pick counts, two-sample chi-square (same totals) -- and each against the uniform expectation."""
+    from scipy.stats import chi2
+    rng = np.random.default_rng(21)
+    n, D, k, draws = 2000, 300, 16, 400
+    nbrs = rng.choice(n, D, replace=False).astype(np.int64)
+    edges = np.concatenate([np.stack([nbrs, np.full(D, 7)], 1), np.stack([rng.integers(0, n, 5000), rng.integers(8, n, 5000)], 1)]).astype(np.int64)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    csr = g.adj_dst_index.csr
+    hub = dev(np.array([7], dtype=np.int64))
+    ours = np.zeros(n, np.int64)
+    for s in range(draws):
+        got, cnt = pgl.ops.sample_neighbors(csr, hub, k, seed=1000 + s)
+        got = host(got)
+        assert int(cnt[0]) == k and len(set(got.tolist())) == k and set(got.tolist()) <= set(nbrs.tolist())   # without replacement, real neighbours
+        ours[got] += 1
+    np.random.seed(5)                                                # the reference draws from numpy's global generator
+    theirs = np.zeros(n, np.int64)
+    for _ in range(draws):
+        out = ref_native.sample_subset([nbrs.copy()], k, False)[0]
+        assert len(out) == k and len(set(out.tolist())) == k
+        theirs[np.asarray(out)] += 1
+    a, b = ours[nbrs].astype(np.float64), theirs[nbrs].astype(np.float64)
+    assert a.sum() == b.sum() == draws * k
+    stat2 = float(((a - b) ** 2 / np.maximum(a + b, 1)).sum())        # two-sample chi-square, D - 1 degrees of freedom
+    expect = draws * k / D
+    stat_ours = float(((a - expect) ** 2 / expect).sum())
+    stat_ref = float(((b - expect) ** 2 / expect).sum())
+    for name, st in (("ours vs reference", stat2), ("ours vs uniform", stat_ours), ("reference vs uniform", stat_ref)):
+        p = float(chi2.sf(st, D - 1))
+        assert p > 1e-4, (name, st, p)
