@@ -118,9 +118,15 @@ __global__ __launch_bounds__(kBlock) void seg_ids_kernel(const int64_t* __restri
 // Nothing here is graph specific except FIRST (keys / values come from the caller's strided int64 columns, ids are range
 // checked) and LAST (the outputs are the CSR arrays).
 // ------------------------------------------------------------------------------------------------
-constexpr int kSortThreads = 1024;
+#ifndef PGLAMD_SORT_THREADS          // (variant builds: scripts/prof.py variant NAME PGLAMD_SORT_THREADS=512 ...)
+#define PGLAMD_SORT_THREADS 1024
+#endif
+#ifndef PGLAMD_SORT_ITEMS
+#define PGLAMD_SORT_ITEMS 8
+#endif
+constexpr int kSortThreads = PGLAMD_SORT_THREADS;
 constexpr int kSortWaves = kSortThreads / kWave;
-constexpr int kSortItems = 8;
+constexpr int kSortItems = PGLAMD_SORT_ITEMS;
 constexpr int kSortTile = kSortThreads * kSortItems;
 constexpr int kSortMaxBits = 11;
 

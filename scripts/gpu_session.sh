@@ -21,6 +21,14 @@ for STEP in "$@"; do
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     csr|noreuse|gcn|gat|ops|dtypes|gatsplit) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
+    variants)
+      # every experimental build under pgl_amd/csrc/variants (scripts/prof.py variant ...): CSR parity + CSR timing through PGLAMD_LIB
+      for L in pgl_amd/csrc/variants/libpglamd_*.so; do
+        echo "== $L" >> $F
+        PGLAMD_LIB=$R/$L timeout 600 python -m pytest tests/test_gpu_round3.py -m gpu -q -x -k "csr_sort" 2>&1 | tail -2 >> $F
+        PGLAMD_LIB=$R/$L timeout 300 python scripts/prof.py csr 2>&1 | grep "csr_build" | grep "dst-keyed" >> $F
+      done
+      cat $F ;;
     tlb)
       # address-translation counters of the known-bytes leg (the 29.5 / 34.1 ms bimodality across boxes): which TCP / UTCL
       # counters this rocprofv3 offers, then one --pmc pass of the leg with the translation hit / miss pair

@@ -222,7 +222,17 @@ def cmd_noreuse(args):
     known = n * deg * (d * 4) * (1.0 - (256 + 32) * 2.0 ** 20 / (n * d * 4)) + n * deg * 8 + n * d * 4
     print("uniform in-degree-19 leg: %d launches, step ms min %.2f / median %.2f / max %.2f -> %.3f of 8 TB/s at the median"
           % (len(ts), ts[0], ts[len(ts) // 2], ts[-1], known / (ts[len(ts) // 2] * 1e-3) / 1e9 / 8000.0))
-    mine = max(before, key=lambda c: (samples[-1][c].get("vram_used") or 0) - (before[c].get("vram_used") or 0))
+    mine = None
+    try:                                                             # our card = the one at the PCI address HIP reports for device 0
+        pr = torch.cuda.get_device_properties(0)
+        addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        for devdir in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(devdir)) == addr:
+                mine = devdir.split("/")[4]
+    except Exception:                                                # noqa: BLE001
+        pass
+    if mine is None:                                                 # fall back: the card whose VRAM use jumped
+        mine = max(before, key=lambda c: (samples[-1][c].get("vram_used") or 0) - (before[c].get("vram_used") or 0))
     ident = {}
     for f in ("unique_id", "vbios_version", "device", "revision"):
         try:
