@@ -128,7 +128,7 @@ constexpr int kSortThreads = PGLAMD_SORT_THREADS;
 constexpr int kSortWaves = kSortThreads / kWave;
 constexpr int kSortItems = PGLAMD_SORT_ITEMS;
 constexpr int kSortTile = kSortThreads * kSortItems;
-constexpr int kSortMaxBits = 11;
+constexpr int kSortMaxBits = 10;
 
 struct SortArgs {
     const int64_t* u; int64_t us; const int64_t* v; int64_t vs;      // FIRST: strided int64 key / neighbour columns
@@ -372,8 +372,7 @@ static int32_t sort_pass(int bits, const SortArgs& a, uint32_t* totals, hipStrea
         case 7: return sort_pass_launch<7, FIRST, LAST>(a, totals, st);
         case 8: return sort_pass_launch<8, FIRST, LAST>(a, totals, st);
         case 9: return sort_pass_launch<9, FIRST, LAST>(a, totals, st);
-        case 10: return sort_pass_launch<10, FIRST, LAST>(a, totals, st);
-        default: return sort_pass_launch<11, FIRST, LAST>(a, totals, st);
+        default: return sort_pass_launch<10, FIRST, LAST>(a, totals, st);
     }
 }
 
