@@ -27,7 +27,7 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 //     applied to the MFMA result and only THAT goes to memory: GCNConv's aggregate -> linear -> bias -> relu
 //     (pgl/nn/conv.py:242-254) without the [N, d] intermediate's round trip through HBM, and with the matrix cores working in
 //     the shadow of the row gathers (the kernel is HBM-bound; the MFMA pipe was idle).
-template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true, int UB = 0, int SINK = 0>
+template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true, int UB = 0, int SINK = 0, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     constexpr int U = 8;
     constexpr int kTileRows = 16;                      // rows per MFMA tile (v_mfma_f32_16x16x4_f32)
@@ -60,11 +60,16 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     const cptr<int> eidp = as_const(p.eid);
     const T* __restrict__ x = static_cast<const T*>(p.x);
     const T* __restrict__ y = static_cast<const T*>(p.y);
-    // second source table (rows received from peers, pgl_amd.distributed): column ids >= x_split address it.  x2 arrives
-    // rebased by -x_split rows, so the address arithmetic is the same and the choice is one scalar select per edge.
+    // TWO: second source table (rows received from peers, pgl_amd.distributed): column ids >= x_split address it.  x2 arrives
+    // rebased by -x_split rows, so the address arithmetic is the same and the choice is one scalar select per edge -- compiled in
+    // only where asked for: the rows of <= 320 bytes are issue-bound, and three more scalar instructions per edge cost them 25 %
+    // (measured: d = 64 fp32 0.52 -> 0.69 ms with the select always on).
     const T* __restrict__ x2 = static_cast<const T*>(p.x2);
     const int xs = p.x_split;
-    auto src_row = [&](int cc) -> const T* { return (cc < xs ? x : x2) + (int64_t)cc * p.ldx; };
+    auto src_row = [&](int cc) -> const T* {
+        if constexpr (TWO) return (cc < xs ? x : x2) + (int64_t)cc * p.ldx;
+        else return x + (int64_t)cc * p.ldx;
+    };
     constexpr bool has_ss = SS;       // per-source scale compiled in only where asked for (keeps 16 SGPRs free otherwise)
     const bool is_max = p.is_max != 0;
 
@@ -725,28 +730,35 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     // 256-byte rows (d=64 fp32, d=128 fp16) are occupancy-bound: the two-deep pipeline (69 SGPRs, 8
     // workgroups/CU) measured 4 % faster there; everywhere else the three-deep one wins (up to 20 % on [E,8]).
     const size_t row_bytes = (size_t)p.tile_cols * sizeof(T);
+    const bool two = p.x_split != INT32_MAX;
+#define PGLAMD_LAUNCH_FLAT(...)                                                                                                          \
+    do {                                                                                                                                 \
+        if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p); \
+        else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);    \
+        PGLAMD_LAUNCH_CHECK();                                                                                                           \
+    } while (0)
     if constexpr (NT == 1 && YMODE == 0) {
         static const int vidx_max = [] { const char* e = getenv("PGLAMD_VIDX_BYTES"); return e ? atoi(e) : 320; }();
         if ((int)row_bytes <= vidx_max && !p.src_scale) {
-            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false, true, 16>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-            PGLAMD_LAUNCH_CHECK();
+            PGLAMD_LAUNCH_FLAT(false, true, 16);
             goto launched;
         }
         if (row_bytes >= 192 && row_bytes <= 320 && !p.src_scale) {
-            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-            PGLAMD_LAUNCH_CHECK();
+            PGLAMD_LAUNCH_FLAT(false, false, 0);
             goto launched;
         }
     }
     if constexpr (can_scale) {
-        if (p.src_scale)
+        if (p.src_scale) {           // (a second table excludes src_scale: aggregate_typed refuses the combination)
             hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
-        else
-            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+            PGLAMD_LAUNCH_CHECK();
+        } else {
+            PGLAMD_LAUNCH_FLAT(false, true, 0);
+        }
     } else {
-        hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+        PGLAMD_LAUNCH_FLAT(false, true, 0);
     }
-    PGLAMD_LAUNCH_CHECK();
+#undef PGLAMD_LAUNCH_FLAT
 launched:
     if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));

@@ -51,7 +51,7 @@ template <typename A> __device__ __forceinline__ A max_of(A a, A b) {
 // 16 rows per batch while they are cheap to hold (<= 8-byte lanes, >= 16-lane groups), 8 otherwise
 template <typename T, int VEC, int G> constexpr int group_batch() { return (G >= 16 && VEC * (int)sizeof(T) <= 8) ? 16 : 8; }
 
-template <typename T, int VEC, int G, int RCLS>
+template <typename T, int VEC, int G, int RCLS, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
     constexpr int S = kWave / G;
     constexpr int UB = group_batch<T, VEC, G>();  // edges per batch of a group
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kBlock) void agg_group_kernel(AggParams p) {
 #pragma unroll
             for (int i = 0; i < UB; ++i) {
                 const int cc = __shfl(cv[i / G], gbase + (i % G), kWave);
-                if (act && eb + i < e1) vx[i] = *reinterpret_cast<const V*>((cc < xs ? x : x2) + (int64_t)cc * p.ldx);
+                if (act && eb + i < e1) vx[i] = *reinterpret_cast<const V*>((TWO ? (cc < xs ? x : x2) : x) + (int64_t)cc * p.ldx);
             }
         }
     };
@@ -231,7 +231,8 @@ int32_t launch_group_one(AggParams p, hipStream_t st) {
         PGLAMD_HIP_CHECK(hipEventCreate(&ev1));
         PGLAMD_HIP_CHECK(hipEventRecord(ev0, st));
     }
-    hipLaunchKernelGGL((agg_group_kernel<T, VEC, G, RCLS>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    if (p.x_split != INT32_MAX) hipLaunchKernelGGL((agg_group_kernel<T, VEC, G, RCLS, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((agg_group_kernel<T, VEC, G, RCLS, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(ev1, st));

@@ -73,7 +73,7 @@ template <typename A> __device__ __forceinline__ void softmax_merge(A m1, A s1, 
 
 // RCLS: 0 sum / mean, 1 max / min, 2 softmax statistics (out[r] = 2*d values: the segment maxima, then the segment sums
 //       of exp(x - max), one 64-byte line for d = 8 fp32; partials use the same layout).   YMODE: 0 none, 1 y is [E] / [E,1] (one value per edge), 2 y is [E,d]
-template <typename T, int D, int RCLS, int YMODE>
+template <typename T, int D, int RCLS, int YMODE, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
     constexpr int NB = D * sizeof(typename AccT<T>::type) >= 64 ? 2 : 4;   // batches of 64 edges whose loads are issued together (fewer for 64-byte rows: registers)
     constexpr int VL = (D * sizeof(T) >= 16) ? (int)(16 / sizeof(T)) : D;   // elements per load instruction
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void agg_narrow_kernel(AggParams p) {
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            const T* xr = (cc[b] < xs ? x : x2) + (int64_t)cc[b] * p.ldx;
+            const T* xr = (TWO ? (cc[b] < xs ? x : x2) : x) + (int64_t)cc[b] * p.ldx;
             if (valid[b]) {
                 if (exact) {
 #pragma unroll
@@ -455,7 +455,8 @@ int32_t launch_one(AggParams p, int32_t dtype, hipStream_t st) {
         PGLAMD_HIP_CHECK(hipEventCreate(&ev1));
         PGLAMD_HIP_CHECK(hipEventRecord(ev0, st));
     }
-    hipLaunchKernelGGL((agg_narrow_kernel<T, D, RCLS, YMODE>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    if (p.x_split != INT32_MAX) hipLaunchKernelGGL((agg_narrow_kernel<T, D, RCLS, YMODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    else hipLaunchKernelGGL((agg_narrow_kernel<T, D, RCLS, YMODE, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(ev1, st));

@@ -104,7 +104,9 @@ __global__ __launch_bounds__(kBlock) void seg_ids_kernel(const int64_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // The sort.  One pass moves (key32, value64) pairs by one digit of BITS bits, stably:
-//   hist      every 1024-thread block counts the digits of its tile of 8 192 items (LDS atomics) -> hist[digit][block]
+//   hist      every 512-thread block counts the digits of its tile of 4 096 items (LDS atomics) -> hist[digit][block]
+//             (measured, profiles/r03/csr_build_variants.txt: 512 x 8 items -- two to three blocks per CU -- 0.63 / 2.5 ms at C2 / C2';
+//              1024 x 8: 0.64 / 3.1; 256 x 16: 0.76; tiles of 2 048 items: 0.95 - 1.0 ms, their runs per digit are too short)
 //   scan      exclusive scan of hist in (digit, block) order: one block per digit scans its row, one small kernel scans the
 //             row totals -> the global position of the first item of every (digit, block)
 //   scatter   the block reloads its tile; wave w owns items [w * 512, (w + 1) * 512) of it and walks them 64 at a time IN
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void seg_ids_kernel(const int64_t* __restri
 // checked) and LAST (the outputs are the CSR arrays).
 // ------------------------------------------------------------------------------------------------
 #ifndef PGLAMD_SORT_THREADS          // (variant builds: scripts/prof.py variant NAME PGLAMD_SORT_THREADS=512 ...)
-#define PGLAMD_SORT_THREADS 1024
+#define PGLAMD_SORT_THREADS 512
 #endif
 #ifndef PGLAMD_SORT_ITEMS
 #define PGLAMD_SORT_ITEMS 8
