@@ -625,7 +625,7 @@ def main():
     r.add_argument("--dim", type=int, default=128)
     r.add_argument("--parts", type=lambda s: [int(v) for v in s.split(",")], default=[2, 4, 8])
     r.add_argument("--partition", default="kway", help="kway | metis | random | path/with{P}.npy")
-    r.add_argument("--push", default="auto", choices=["auto", "never"])
+    r.add_argument("--push", default="never", choices=["never", "auto"], help="never = the product default (pull everywhere)")
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     sub.add_parser("noreuse")
     sub.add_parser("gcn")
