@@ -186,6 +186,15 @@ def cmd_noreuse(args):
             except Exception:                                        # noqa: BLE001
                 rec["vram_used"] = None
             for hw in glob.glob(os.path.join(devdir, "hwmon", "hwmon*")):
+                for tf in glob.glob(os.path.join(hw, "temp*_input")):   # edge / junction / mem (HBM) sensors, by their labels
+                    try:
+                        lab = open(tf.replace("_input", "_label")).read().strip()
+                    except Exception:                                    # noqa: BLE001
+                        lab = os.path.basename(tf)[:5]
+                    try:
+                        rec["t_" + lab] = int(open(tf).read()) / 1e3
+                    except Exception:                                    # noqa: BLE001
+                        pass
                 for f, key, div in (("power1_average", "power_w", 1e6), ("power1_input", "power_w", 1e6), ("temp1_input", "temp_c", 1e3),
                                     ("power1_cap", "cap_w", 1e6), ("freq1_input", "sclk_mhz", 1e6), ("freq2_input", "mclk_mhz", 1e6)):
                     try:
@@ -250,7 +259,8 @@ def cmd_noreuse(args):
             continue                                                 # (connector nodes, not GPUs)
         vals = lambda k: [s_[card].get(k) for s_ in samples if s_[card].get(k) is not None]
         line = "  %-7s%s" % (card, " <- ours" if card == mine else "        ")
-        for k in ("sclk", "sclk_mhz", "mclk", "fclk", "power_w", "temp_c", "cap_w"):
+        tkeys = sorted({k for s_ in samples for k in s_[card] if k.startswith("t_")})
+        for k in ["sclk", "sclk_mhz", "mclk", "fclk", "power_w", "cap_w"] + tkeys:
             v = vals(k)
             if v:
                 line += "  %s %s..%s" % (k, ("%.0f" % min(v)), ("%.0f" % max(v)))
