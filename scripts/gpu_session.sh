@@ -21,6 +21,14 @@ for STEP in "$@"; do
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     csr|noreuse|gcn|gat|ops|dtypes|gatsplit) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
+    trace:*)
+      # rocprofv3 --kernel-trace of `prof.py <subcommand ...>` -> per-(kernel, grid) durations
+      SUB="${STEP#trace:}"
+      ( cd /tmp && export TMPDIR=/tmp
+        rocprofv3 --kernel-trace --output-format csv -d $O/trace_tmp -o t -- python $R/scripts/prof.py $SUB > $F.run 2>&1
+        python $R/scripts/prof.py trace $(find $O/trace_tmp -name "*kernel_trace.csv" | head -1) > $F 2>&1
+        rm -rf $O/trace_tmp )
+      head -40 $F | cut -c1-200 ;;
     noreuse_vec4)  PGLAMD_VEC=4 timeout 600 python scripts/prof.py noreuse > $F 2>&1; grep "uniform\|our GPU\|<- ours" $F ;;
     variants)
       # every experimental build under pgl_amd/csrc/variants (scripts/prof.py variant ...): CSR parity + CSR timing through PGLAMD_LIB
