@@ -29,6 +29,25 @@ for STEP in "$@"; do
         python $R/scripts/prof.py trace $(find $O/trace_tmp -name "*kernel_trace.csv" | head -1) > $F 2>&1
         rm -rf $O/trace_tmp )
       head -40 $F | cut -c1-200 ;;
+    pmc_dtypes)
+      # fp16 vs bf16 storage (12 % apart at d = 128 since round 1): instruction and cycle counters of the two kernels
+      ( cd /tmp && export TMPDIR=/tmp
+        for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE"; do
+          N=$(echo $C | tr ' ' '_')
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_dt_$N -o p -- python $R/scripts/prof.py dtypes > /dev/null 2>&1
+        done
+        python - <<PY > $F
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob("$O/pmc_dt_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if "agg_flat_kernel" in n and ("__half" in n or "bfloat16" in n):
+            k = (n.split("(")[0][-75:], r.get("Grid_Size"), r.get("Counter_Name")); agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+for k, (s, c) in sorted(agg.items()): print("%-78s grid %-9s %-24s avg %.4g (n=%d)" % (k[0], k[1], k[2], s / c, c))
+PY
+        rm -rf $O/pmc_dt_* )
+      cat $F | cut -c1-200 ;;
     noreuse_vec4)  PGLAMD_VEC=4 timeout 600 python scripts/prof.py noreuse > $F 2>&1; grep "uniform\|our GPU\|<- ours" $F ;;
     variants)
       # every experimental build under pgl_amd/csrc/variants (scripts/prof.py variant ...): CSR parity + CSR timing through PGLAMD_LIB
