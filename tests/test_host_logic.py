@@ -297,3 +297,40 @@ print("fallback ok")
     env = dict(os.environ, PGLAMD_METIS_LIB=str(tmp_path / "no_such_libmetis.so"), PGLAMD_PARTITIONER="metis")   # the opt-in, helper absent
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
     assert r.returncode == 0 and "fallback ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_engine_partitioner_degenerate_inputs():
+    """The partitioner is on the default path of every multi-GPU run: empty graphs, more parts than nodes, isolated nodes, self
+    loops, stars, duplicate edges, zero and dominant vertex weights must give valid part ids (and the obvious answers where there
+    is one), and bad node ids must be refused."""
+    import pgl_amd
+    P = pgl_amd.ops.host_partition_edges
+
+    def run(e, n, k, **kw):
+        e = np.asarray(e, dtype=np.int64).reshape(-1, 2)
+        part, cut = P(e, n, k, **kw)
+        assert part.shape == (n,) and part.dtype == np.int64
+        if n:
+            assert part.min() >= 0 and part.max() < max(min(k, n), 1)
+        assert cut == (int((part[e[:, 0]] != part[e[:, 1]]).sum()) if len(e) else 0) or len(np.unique(e, axis=0)) != len(e)
+        return part
+    assert run([], 0, 4).size == 0
+    assert run([], 1, 4).tolist() == [0]
+    assert sorted(np.bincount(run([], 10, 3), minlength=3).tolist()) == [3, 3, 4]          # isolated nodes level the parts
+    assert sorted(run([[0, 1], [1, 2]], 3, 8).tolist()) == [0, 1, 2]                         # k > n: one node per part
+    assert (run([[0, 1], [1, 2]], 3, 1) == 0).all()
+    assert np.bincount(run([[i, i] for i in range(20)], 20, 4), minlength=4).tolist() == [5, 5, 5, 5]   # self loops are no edges
+    star = run([[0, i] for i in range(1, 2000)], 2000, 8)
+    assert np.bincount(star, minlength=8).max() <= 1.03 * 250 + 1
+    two = [[a, b] for a in range(50) for b in range(50) if a != b] + [[50 + a, 50 + b] for a in range(50) for b in range(50) if a != b] + [[0, 50]]
+    p = run(two, 100, 2)
+    assert len(set(p[:50].tolist())) == 1 and len(set(p[50:].tolist())) == 1 and p[0] != p[50]   # two cliques, one bridge
+    run([[0, 1]] * 1000 + [[1, 2]] * 10, 3, 2)
+    rng = np.random.default_rng(0)
+    e = rng.integers(0, 500, (5000, 2))
+    run(e, 500, 4, node_weights=np.zeros(500, np.int64))
+    run(e, 500, 4, node_weights=np.r_[10 ** 9, np.ones(499, np.int64)])
+    p = run(rng.integers(0, 5000, (60000, 2)), 5000, 7, node_weights=rng.integers(1, 50, 5000), node_weights2=np.ones(5000, np.int64), ub=1.03, ub2=1.1)
+    assert np.bincount(p, minlength=7).max() <= 1.1 * 5000 / 7 + 1
+    with pytest.raises((OverflowError, ValueError)):
+        P(np.array([[0, 5]]), 3, 2)
