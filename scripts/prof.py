@@ -96,12 +96,25 @@ def cmd_rows(args):
     dev = torch.device("cuda:0")
     scale, E, d = args.scale, args.edges, args.dim
     N = 1 << scale
-    edges = rmat_edges(scale, E, seed=42, device=dev)
     gen = torch.Generator(device=dev); gen.manual_seed(7)
+    if args.graph == "community":
+        # a graph a partitioner CAN cut (what BASELINE configs 3 / 4 look like): 256 communities, 90 % of the edges stay inside their
+        # source's community, node ids randomly permuted so that nothing is contiguous by accident
+        C = 256
+        src = torch.randint(0, N, (E,), generator=gen, device=dev)
+        inside = torch.rand(E, generator=gen, device=dev) < 0.9
+        dst = torch.where(inside, (src // (N // C)) * (N // C) + torch.randint(0, N // C, (E,), generator=gen, device=dev),
+                          torch.randint(0, N, (E,), generator=gen, device=dev))
+        perm = torch.randperm(N, generator=gen, device=dev)
+        edges = torch.stack([perm[src], perm[dst]], 1)
+        gname = "256 planted communities (90 %% intra-community edges, ids permuted), %d nodes" % N
+    else:
+        edges = rmat_edges(scale, E, seed=42, device=dev)
+        gname = "RMAT scale %d" % scale
     x = torch.randn(N, d, generator=gen, device=dev)
     g = pgl.Graph(edges=edges, num_nodes=N); g.adj_dst_index
     t1 = _t(lambda: g.send_recv(x, "sum"))
-    print("graph: RMAT scale %d, %d edges, d=%d fp32; 1 GPU: %.3f ms / step = %.2f G edges/s" % (scale, E, d, t1, E / t1 / 1e6), flush=True)
+    print("graph: %s, %d edges, d=%d fp32; 1 GPU: %.3f ms / step = %.2f G edges/s" % (gname, E, d, t1, E / t1 / 1e6), flush=True)
     LINK = 153.0
     for P in args.parts:
         t0 = time.time()
@@ -637,6 +650,7 @@ def main():
     r.add_argument("--partition", default="kway", help="kway | metis | random | path/with{P}.npy")
     r.add_argument("--push", default="never", choices=["never", "auto"], help="never = the product default (pull everywhere)")
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
+    r.add_argument("--graph", default="rmat", choices=["rmat", "community"])
     sub.add_parser("noreuse")
     sub.add_parser("gcn")
     tr = sub.add_parser("traffic")
