@@ -606,6 +606,7 @@ class DistGraph(object):
           <k>int      INTERIOR rows -- every source local -- with their edges            rows: n_own       cols: owned
           <k>bnd      BOUNDARY rows -- at least one received source -- with ALL their edges                cols: owned | received
           <k>all      every row with all its edges (taken instead of int + bnd when almost nothing is interior)
+          <k>recv / <k>send_t   the received rows' edges alone: added on top of the local-source edges (accumulate mode)
           <k>recv_t   transposed flow (gradients): what travels back, recv_buf_t[i] = sum of g over the rows that read
                       received row i                                                     rows: n_recv      cols: owned
           <k>int_t    owned rows no peer reads, with their transposed local edges        rows: n_own       cols: owned
@@ -638,6 +639,10 @@ class DistGraph(object):
                 rows, cols, nr = xp.send_rows, xp.send_cols, xp.n_send
             elif base == "recv_t":
                 rows, cols, nr = xp.recv_cols, xp.recv_rows, xp.n_recv
+            elif base == "recv":                                      # out[rows] += recv_buf[cols]   (accumulate mode)
+                rows, cols, nr = xp.recv_rows, xp.recv_cols, p.n_own
+            elif base == "send_t":                                    # g_own[rows] += returned_buf[cols]   (accumulate mode, backward)
+                rows, cols, nr = xp.send_cols, xp.send_rows, p.n_own
             elif base in ("int", "bnd", "all"):
                 boundary = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
                 boundary[xp.recv_rows] = True
@@ -764,14 +769,26 @@ class DistGraph(object):
         sfx = "_t" if transposed else ""
         started = self._start_exchange(x, kind, transposed)
         n_in = (xp.n_send if transposed else xp.n_recv) if started is not None else 0
-        if n_in and self._fold(kind, transposed):
+        mode = self._mode(kind, transposed, additive=reduce in ("sum", "mean"),
+                          row_bytes=max(1, x.element_size() * int(np.prod(tail)) if tail else x.element_size())) if n_in else "split"
+        if mode == "fold":
             # (almost) no interior -- a power-law graph cut 8 ways: one launch over every row after the wait instead of an
-            # interior launch with nothing to overlap (a launch costs ~10 us of GPU time whatever it carries)
+            # interior launch with nothing to overlap (a launch costs ~20 us of GPU time whatever it carries)
             work, in_buf, unpack = started
             work.wait()
             if unpack is not None:
                 unpack()
             out = B.aggregate(x, self._index(kind + "all" + sfx), reduce, p.n_own, dst_scale=scale_k, x2=in_buf)
+        elif mode == "accumulate":
+            # most edges are local, most rows have a few remote sources: ALL local-source edges run under the exchange, the
+            # received rows' edges are added on top afterwards (their rows are read-modify-written)
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k)
+            work, in_buf, unpack = started
+            work.wait()
+            if unpack is not None:
+                unpack()
+            B.aggregate(in_buf, self._index(kind + ("send_t" if transposed else "recv")), reduce, p.n_own, dst_scale=scale_k, out=out,
+                        accumulate=1)
         else:
             out = B.aggregate(x, self._index(kind + "int" + sfx), reduce, p.n_own, dst_scale=scale_k,
                               zero_indptr=self._zero_indptr(transposed) if n_in else None)    # overlaps the exchange
@@ -787,11 +804,21 @@ class DistGraph(object):
             out = out * post
         return out
 
-    def _fold(self, kind, transposed):
-        """True when the interior of this flow holds so few edges (< PGLAMD_FOLD_INTERIOR, default 3 %, of the local ones) that
-        overlapping them with the exchange buys less than their launch costs.  Decided once per (plan, direction) from the
-        plan's own counts -- no index is built for the decision."""
-        key = ("fold", kind, transposed)
+    # edges / s of the aggregation kernel on a rank-sized problem, fixed cost of one aggregation launch (counter reset, kernel ramp
+    # and tail, two fix-up launches), xGMI link rate and latency of one all-to-all-v: the cost model `_mode` chooses with (measured
+    # on MI355X, profiles/r03/rows_*.txt; only the ORDER of the three estimates matters)
+    _RATE, _LAUNCH, _LINK, _LAT, _RMW = 15.0e9, 20.0e-6, 150.0e9, 30.0e-6, 5.0e12
+
+    def _mode(self, kind, transposed, additive=True, row_bytes=512):
+        """How this flow spends the time the exchange takes -- decided once per (plan, direction) from the plan's own counts:
+          "split"       interior rows during the exchange, boundary rows afterwards from [owned | received]: every row written once.
+                        Best when most ROWS have no remote source.
+          "fold"        one launch over all rows after the wait: nothing to overlap (a power-law graph cut 8 ways: 0.1 % interior).
+          "accumulate"  local-source EDGES of all rows during the exchange, the received rows' edges added afterwards (the rows they
+                        touch are read-modify-written; sum / mean only).  Best when most EDGES are local but most rows have a few
+                        remote sources (a graph with communities and 10 % random cross edges: 91 % local edges, 17 % interior).
+        estimate = max(before-the-wait work, exchange) + after-the-wait work, with the constants above; PGLAMD_FLOW forces one."""
+        key = ("mode", kind, transposed, additive)
         hit = self._idx.get(key)
         if hit is None:
             p = self.plan
@@ -800,11 +827,27 @@ class DistGraph(object):
             if transposed:
                 mark[xp.send_cols] = True
                 e_int = int((~mark[p.loc_cols]).sum())
+                e_rem, n_in, splits = int(xp.send_rows.shape[0]), xp.n_send, xp.send_splits
             else:
                 mark[xp.recv_rows] = True
                 e_int = int((~mark[p.loc_rows]).sum())
-            hit = e_int < float(os.environ.get("PGLAMD_FOLD_INTERIOR", "0.03")) * max(p.local_edges, 1)
+                e_rem, n_in, splits = int(xp.recv_rows.shape[0]), xp.n_recv, xp.recv_splits
+            e_loc = int(p.loc_rows.shape[0])
+            n_bnd = int(mark.sum())
+            R, L = self._RATE, self._LAUNCH
+            xch = max(splits) * row_bytes / self._LINK + self._LAT if n_in else 0.0
+            est = {"fold": xch + (e_loc + e_rem) / R + L,
+                   "split": max(e_int / R + L, xch) + (e_loc - e_int + e_rem) / R + L}
+            if additive:
+                est["accumulate"] = max(e_loc / R + L, xch) + e_rem / R + L + 2.0 * n_bnd * row_bytes / self._RMW
+            hit = min(est, key=est.get)
+            forced = os.environ.get("PGLAMD_FLOW", "")
+            if forced in est:
+                hit = forced
+            elif os.environ.get("PGLAMD_FOLD_INTERIOR"):              # (round-3 knob kept for the tests: fold below this interior share)
+                hit = "fold" if e_int < float(os.environ["PGLAMD_FOLD_INTERIOR"]) * max(p.local_edges, 1) else "split"
             self._idx[key] = hit
+            self._idx[("mode_estimates", kind, transposed, additive)] = est
         return hit
 
     def _sum_like(self, x_own, reduce_func, extra_dst_scale=None):

@@ -12,6 +12,7 @@ for STEP in "$@"; do
   echo "== $STEP"
   case $STEP in
     diag)       python scripts/prof.py diag > $F 2>&1 ;;
+    smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $F 2>&1; echo "smoke rc=$?" >> $F; tail -3 $F ;;
     tests)      timeout 1500 python -m pytest tests -m gpu -q > $F 2>&1; echo "pytest rc=$?" >> $F; tail -6 $F ;;
     tests:*)    timeout 1500 python -m pytest tests -m gpu -q -x -k "${STEP#tests:}" > $F 2>&1; echo "pytest rc=$?" >> $F; tail -25 $F ;;
     bench)      timeout 600 python bench.py > $O/bench_n1_$TAG.json 2> $F; echo "bench rc=$?"; head -c 600 $O/bench_n1_$TAG.json; echo ;;

@@ -145,141 +145,43 @@ def cmd_rows(args):
                 dg.send_recv(x_own, "sum")
             enq = (time.perf_counter() - t_cpu) / 20 * 1e3               # host time to ENQUEUE one step (no sync inside)
             torch.cuda.synchronize()
-            # phases on their own (each between its own pair of events)
+            # phases on their own (each between its own pair of events), for the flow mode the plan's cost model chose
             B = dg._b
+            mode = dg._mode("x", False, True, d * 4)
             pk = _t(lambda: dg._start_exchange(x_own, "x", False), it=10, warm=2)
-            zi = dg._zero_indptr(False)
-            it_ = _t(lambda: B.aggregate(x_own, dg._index("xint"), "sum", plan.n_own, zero_indptr=zi), it=10, warm=2)
             out = torch.empty_like(x_own)
             in_buf = dg._buffer("inx0" if not args.wire else "inwx0", (xplan.n_recv, d), torch.float32, dev)
-            bd = _t(lambda: B.aggregate(x_own, dg._index("xbnd"), "sum", plan.n_own, out=out, accumulate=2, x2=in_buf), it=10, warm=2) if xplan.n_recv else 0.0
+            if mode == "split":
+                zi = dg._zero_indptr(False)
+                pre = _t(lambda: B.aggregate(x_own, dg._index("xint"), "sum", plan.n_own, zero_indptr=zi), it=10, warm=2)
+                post = _t(lambda: B.aggregate(x_own, dg._index("xbnd"), "sum", plan.n_own, out=out, accumulate=2, x2=in_buf), it=10, warm=2) if xplan.n_recv else 0.0
+                e_pre, e_post = dg._index("xint").num_edges, dg._index("xbnd").num_edges
+            elif mode == "fold":
+                pre = 0.0
+                post = _t(lambda: B.aggregate(x_own, dg._index("xall"), "sum", plan.n_own, x2=in_buf), it=10, warm=2)
+                e_pre, e_post = 0, dg._index("xall").num_edges
+            else:
+                pre = _t(lambda: B.aggregate(x_own, dg._index("loc"), "sum", plan.n_own), it=10, warm=2)
+                post = _t(lambda: B.aggregate(in_buf, dg._index("xrecv"), "sum", plan.n_own, out=out, accumulate=1), it=10, warm=2)
+                e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
             wb = 2 if args.wire else 4
             ideal = plan.local_edges / (E / t1)
-            e_int, e_bnd = dg._index("xint").num_edges, dg._index("xbnd").num_edges
             pair_mb = max(xplan.recv_splits) * d * wb / 1e6
-            rows.append((r, plan.n_own, plan.local_edges, e_int, e_bnd, xplan.n_send, xplan.n_recv, ms, pk, it_, bd, ideal, pair_mb, enq,
-                         dg._fold("x", False)))
+            xch = pair_mb / 1e3 / LINK * 1e3
+            pred = pk + max(pre, xch) + post
+            rows.append((r, plan.n_own, plan.local_edges, e_pre, e_post, xplan.n_send, xplan.n_recv, ms, pk, pre, post, ideal, pair_mb, enq, mode, pred))
             worst["compute"] = max(worst["compute"], ms); worst["pair_mb"] = max(worst["pair_mb"], pair_mb)
-            worst["ratio"] = max(worst["ratio"], ms / ideal)
+            worst["ratio"] = max(worst["ratio"], ms / ideal); worst["pred"] = max(worst.get("pred", 0.0), pred)
             del dg, plan, xplan, x_own, out
-        for r, n_own, le, ei, eb, ns, nr, ms, pk, it_, bd, ideal, pmb, enq, fold in rows:
-            print("   rank %d: %7d rows %9d edges (interior %8d, boundary %9d%s) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms (host enqueue %.3f) ; alone: pack %.3f, interior %.3f, boundary %.3f | ideal %.3f ms -> x%.2f"
-                  % (r, n_own, le, ei, eb, "; folded into one launch" if fold else "", ns, nr, pmb, ms, enq, pk, it_, bd, ideal, ms / ideal))
+        for r, n_own, le, e_pre, e_post, ns, nr, ms, pk, pre, post, ideal, pmb, enq, mode, pred in rows:
+            print("   rank %d: %7d rows %9d edges, flow %-10s (%8d edges before the wait, %9d after) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms (host enqueue %.3f); alone: pack %.3f, before %.3f, after %.3f | ideal %.3f ms -> x%.2f | with the exchange: %.3f ms"
+                  % (r, n_own, le, mode, e_pre, e_post, ns, nr, pmb, ms, enq, pk, pre, post, ideal, ms / ideal, pred))
         t_link = worst["pair_mb"] / 1e3 / LINK * 1e3
         print("   slowest rank compute %.3f ms (worst compute/ideal x%.2f; ideal = E/P at the 1-GPU rate = %.3f ms) | exchange >= %.3f ms (largest pair block at %.0f GB/s per link)"
               % (worst["compute"], worst["ratio"], t1 / P, t_link, LINK))
-        print("   predicted step: max(compute, exchange) = %.3f ms = %.2fx of one GPU; compute + exchange = %.3f ms = %.2fx"
-              % (max(worst["compute"], t_link), t1 / max(worst["compute"], t_link), worst["compute"] + t_link, t1 / (worst["compute"] + t_link)), flush=True)
-
-
-# ------------------------------------------------------------------------------------------------------------------
-def cmd_noreuse(args):
-    """The known-bytes roofline leg (uniform in-degree-19 graph over 2^24 rows, d = 128 fp32: the kernel and graph of
-    bench.py's roofline.frac) run for a few seconds while a sampler thread reads every GPU's clocks / power from sysfs:
-    which card is ours (VRAM jumps), what its sclk / mclk / fclk and power do UNDER this load, and the per-launch time
-    distribution -- the data behind the 29.5 ms / 34.1 ms bimodality across boxes."""
-    import threading
-    import torch
-    import pgl_amd as pgl
-    dev = torch.device("cuda:0")
-
-    def snapshot():
-        out = {}
-        for devdir in sorted(glob.glob("/sys/class/drm/card*/device")):
-            card = devdir.split("/")[4]
-            rec = {}
-            for f in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
-                try:
-                    cur = [l for l in open(os.path.join(devdir, f)).read().split("\n") if l.strip().endswith("*")]
-                    rec[f[7:]] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit())) if cur else None
-                except Exception:                                    # noqa: BLE001
-                    rec[f[7:]] = None
-            try:
-                rec["vram_used"] = int(open(os.path.join(devdir, "mem_info_vram_used")).read())
-            except Exception:                                        # noqa: BLE001
-                rec["vram_used"] = None
-            for hw in glob.glob(os.path.join(devdir, "hwmon", "hwmon*")):
-                for tf in glob.glob(os.path.join(hw, "temp*_input")):   # edge / junction / mem (HBM) sensors, by their labels
-                    try:
-                        lab = open(tf.replace("_input", "_label")).read().strip()
-                    except Exception:                                    # noqa: BLE001
-                        lab = os.path.basename(tf)[:5]
-                    try:
-                        rec["t_" + lab] = int(open(tf).read()) / 1e3
-                    except Exception:                                    # noqa: BLE001
-                        pass
-                for f, key, div in (("power1_average", "power_w", 1e6), ("power1_input", "power_w", 1e6), ("temp1_input", "temp_c", 1e3),
-                                    ("power1_cap", "cap_w", 1e6), ("freq1_input", "sclk_mhz", 1e6), ("freq2_input", "mclk_mhz", 1e6)):
-                    try:
-                        rec[key] = int(open(os.path.join(hw, f)).read()) / div
-                    except Exception:                                # noqa: BLE001
-                        pass
-            out[card] = rec
-        return out
-
-    before = snapshot()
-    gen = torch.Generator(device=dev); gen.manual_seed(1)
-    n, deg, d = 1 << 24, 19, 128
-    src = torch.randint(0, n, (n * deg,), generator=gen, device=dev)
-    dst = torch.arange(n, device=dev).repeat_interleave(deg)
-    g = pgl.Graph(edges=torch.stack([src, dst], 1), num_nodes=n); g.adj_dst_index
-    del src, dst
-    x = torch.randn(n, d, generator=gen, device=dev)
-    for _ in range(3):
-        g.send_recv(x, "sum")
-    torch.cuda.synchronize()
-    samples, stop = [], threading.Event()
-
-    def sampler():
-        while not stop.is_set():
-            samples.append(snapshot())
-            time.sleep(0.1)
-    th = threading.Thread(target=sampler); th.start()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
-    for a, b in ev:
-        a.record(); g.send_recv(x, "sum"); b.record()
-    torch.cuda.synchronize()
-    stop.set(); th.join()
-    ts = sorted(a.elapsed_time(b) for a, b in ev)
-    known = n * deg * (d * 4) * (1.0 - (256 + 32) * 2.0 ** 20 / (n * d * 4)) + n * deg * 8 + n * d * 4
-    print("uniform in-degree-19 leg: %d launches, step ms min %.2f / median %.2f / max %.2f -> %.3f of 8 TB/s at the median"
-          % (len(ts), ts[0], ts[len(ts) // 2], ts[-1], known / (ts[len(ts) // 2] * 1e-3) / 1e9 / 8000.0))
-    mine = None
-    try:                                                             # our card = the one at the PCI address HIP reports for device 0
-        pr = torch.cuda.get_device_properties(0)
-        addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-        for devdir in glob.glob("/sys/class/drm/card*/device"):
-            if os.path.basename(os.path.realpath(devdir)) == addr:
-                mine = devdir.split("/")[4]
-    except Exception:                                                # noqa: BLE001
-        pass
-    if mine is None:                                                 # fall back: the card whose VRAM use jumped
-        mine = max(before, key=lambda c: (samples[-1][c].get("vram_used") or 0) - (before[c].get("vram_used") or 0))
-    ident = {}
-    for f in ("unique_id", "vbios_version", "device", "revision"):
-        try:
-            ident[f] = open("/sys/class/drm/%s/device/%s" % (mine, f)).read().strip()
-        except Exception:                                            # noqa: BLE001
-            pass
-    try:
-        ident["pci"] = os.path.basename(os.path.realpath("/sys/class/drm/%s/device" % mine))
-    except Exception:                                                # noqa: BLE001
-        pass
-    print("our GPU is %s %s (VRAM %+.1f GB during the run); %d telemetry samples"
-          % (mine, ident, ((samples[-1][mine]["vram_used"] or 0) - (before[mine]["vram_used"] or 0)) / 1e9, len(samples)))
-    for card in sorted(before):
-        if before[card].get("sclk") is None and before[card].get("vram_used") is None:
-            continue                                                 # (connector nodes, not GPUs)
-        vals = lambda k: [s_[card].get(k) for s_ in samples if s_[card].get(k) is not None]
-        line = "  %-7s%s" % (card, " <- ours" if card == mine else "        ")
-        tkeys = sorted({k for s_ in samples for k in s_[card] if k.startswith("t_")})
-        for k in ["sclk", "sclk_mhz", "mclk", "fclk", "power_w", "cap_w"] + tkeys:
-            v = vals(k)
-            if v:
-                line += "  %s %s..%s" % (k, ("%.0f" % min(v)), ("%.0f" % max(v)))
-                if k in ("sclk_mhz", "power_w"):
-                    line += " (mean %.0f)" % (sum(v) / len(v))
-        print(line)
+        print("   predicted step: pack + max(work before the wait, exchange) + work after the wait, slowest rank = %.3f ms = %.2fx of one GPU"
+              "   [bounds: max(compute, exchange) = %.2fx, compute + exchange = %.2fx]"
+              % (worst["pred"], t1 / worst["pred"], t1 / max(worst["compute"], t_link), t1 / (worst["compute"] + t_link)), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------------------------

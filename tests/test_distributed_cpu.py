@@ -127,12 +127,37 @@ def test_two_rank_gloo_matches_single_graph(method, push):
         assert sum(g[3]["pushed_pairs"] for g in got) > 0              # the hub destination makes its pair push
 
 
-def test_two_rank_gloo_folded_interior(monkeypatch):
-    """A partition with (almost) no interior takes ONE launch over all rows after the wait instead of interior + boundary
-    (PGLAMD_FOLD_INTERIOR: forced here) -- forward for every reduce op and the gradients must not notice."""
-    monkeypatch.setenv("PGLAMD_FOLD_INTERIOR", "2.0")
+@pytest.mark.parametrize("flow", ["fold", "accumulate", "split"])
+def test_two_rank_gloo_every_flow_mode(monkeypatch, flow):
+    """DistGraph picks how to spend the exchange time from a cost model (split: interior rows under the exchange, boundary rows after;
+    fold: one launch after the wait; accumulate: all local-source edges under the exchange, received edges added after).  Forced one
+    by one here (PGLAMD_FLOW): forward for every reduce op and the gradients must not notice which one ran."""
+    monkeypatch.setenv("PGLAMD_FLOW", flow)
     test_two_rank_gloo_matches_single_graph("random", "auto")
     test_two_rank_gloo_gradients_match_single_graph("auto")
+    test_two_rank_gloo_matches_single_graph("kway", "never")
+
+
+def test_flow_mode_follows_the_graph():
+    """The cost model's choice on three kinds of partition: no locality at all -> fold; communities with a few random cross edges per
+    row -> accumulate (most EDGES local, most rows touched by a remote source); clean communities -> split (most ROWS interior)."""
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    rng = np.random.default_rng(0)
+    n, P, deg = 16000, 8, 20
+    part = torch.from_numpy(np.repeat(np.arange(P), n // P))
+    own = np.repeat(np.arange(P), n // P)
+
+    def graph(cross):
+        src = rng.integers(0, n, n * deg)
+        same = rng.random(n * deg) >= cross
+        dst = np.where(same, own[src] * (n // P) + rng.integers(0, n // P, n * deg), rng.integers(0, n, n * deg))
+        return torch.from_numpy(np.stack([src, dst], 1).astype(np.int64))
+    modes = []
+    for cross in (1.0, 0.08, 0.0005):
+        dg = DistGraph(HaloPlan(graph(cross), n, part, 0, P), backend=TorchBackend())
+        dg._LAUNCH = dg._LAT = 0.0            # (a 40 k-edge share is all latency: judge the model on its size-independent terms)
+        modes.append(dg._mode("x", False, True, 512))
+    assert modes == ["fold", "accumulate", "split"], modes
 
 
 # ------------------------------------------------------------------------------------------------

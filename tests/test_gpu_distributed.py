@@ -227,8 +227,11 @@ def _api_worker(rank, world, method):
     return st
 
 
-@pytest.mark.parametrize("world,method", [(2, "metis"), (3, "random")])
-def test_distgraph_every_method_forward_backward_vs_single_gpu(world, method):
+@pytest.mark.parametrize("world,method,flow", [(2, "kway", ""), (3, "random", ""), (2, "metis", "split"), (3, "random", "fold"), (2, "kway", "accumulate")])
+def test_distgraph_every_method_forward_backward_vs_single_gpu(world, method, flow, monkeypatch):
+    """... on the HIP kernels, with the flow mode the cost model picks ("") and with each of the three forced (PGLAMD_FLOW)."""
+    if flow:
+        monkeypatch.setenv("PGLAMD_FLOW", flow)
     stats = _spawn(_api_worker, world, method)
     assert sum(s["local_edges"] for s in stats) == 40000
     assert all(s["recv_rows"] <= s["pull_only_recv_rows"] for s in stats)
