@@ -162,12 +162,17 @@ int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t
  *   max_row_edges   longest row of the index, or 0 when unknown.  No row of <= chunk edges is ever split between waves, so a
  *                   launcher that sees max_row_edges <= its chunk skips the counter reset and both fix-up launches
  *                   (pack indices of a halo plan: every row has one edge).
+ *   ldx, ldout      row strides in elements of x (and x2) and of out; 0 = dense (dx / dout).  A launch may read and write a
+ *                   COLUMN BLOCK of wider matrices: pass the address of the block's first column, its width as dx / dout and
+ *                   the full row length as the stride.  The column-pipelined halo exchange aggregates columns [0, d/2) of the
+ *                   received rows while columns [d/2, d) are still on the wire.  (With accumulate 0 a strided output needs
+ *                   num_edges > 0: the stand-alone zero-fill of an edgeless index is dense.)
  * ---------------------------------------------------------------------------------------------- */
 int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx,
-                             const void* y, int64_t dy, const int32_t* eid, const int32_t* row,
+                             int64_t ldx, const void* y, int64_t dy, const int32_t* eid, const int32_t* row,
                              const int32_t* col, const int64_t* indptr, const int64_t* zero_indptr,
                              int64_t max_row_edges, int64_t num_edges, int64_t n_csr_rows,
-                             int64_t out_rows, int64_t dout, int32_t message_op, int32_t reduce_op,
+                             int64_t out_rows, int64_t dout, int64_t ldout, int32_t message_op, int32_t reduce_op,
                              const float* dst_scale, int32_t accumulate, void* out, void* workspace,
                              size_t workspace_bytes, void* stream);
 
@@ -379,8 +384,9 @@ int32_t pglamd_scatter_rows(const void* x, int64_t d, int32_t elem_bytes, const 
 
 /* K6w  row gather with a dtype change -- the wire pack / unpack of the halo exchange (16-bit wire for fp32 features):
  *   out[i, :] = cast(x[index[i], :]),  index int32 [n_index] or NULL (identity: a row-wise conversion of n_index rows).
- *   (x_dtype, out_dtype): F32 -> F16 | BF16 | F32, F16 | BF16 -> F32.  Stands where the reference would paddle.gather + cast. */
-int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64_t d, const int32_t* index,
+ *   (x_dtype, out_dtype): F32 -> F16 | BF16 | F32, F16 | BF16 -> F32.  Stands where the reference would paddle.gather + cast.
+ *   ldx: row stride of x in elements (0 = d): packs a column block of a wider matrix; out is dense [n_index, d]. */
+int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64_t d, int64_t ldx, const int32_t* index,
                                 int64_t n_index, void* out, int32_t out_dtype, void* stream);
 
 /* K9  degree_norm.  Replaces cast/clip/pow in GF.degree_norm (pgl/nn/functional/graph_op.py:46-55):

@@ -28,8 +28,8 @@ _SIGNATURES = {
     "pglamd_aggregate_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "pglamd_aggregate": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
                                   c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
-    "pglamd_aggregate_ext": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
-                                      c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
+    "pglamd_aggregate_ext": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
+                                      c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_aggregate_dense_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "pglamd_aggregate_dense": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64,
                                         c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -59,7 +59,7 @@ _SIGNATURES = {
     "pglamd_sddmm": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
     "pglamd_seg_ptr_from_ids": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_vp]),
     "pglamd_gather_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp]),
-    "pglamd_gather_rows_cast": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp]),
+    "pglamd_gather_rows_cast": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i32, c_vp]),
     "pglamd_scatter_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "pglamd_degree_norm": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp]),
     "pglamd_sample_neighbors_count": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),

@@ -200,14 +200,15 @@ extern "C" int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_ro
                            src_scale, dst_scale, accumulate, out, workspace, workspace_bytes, AggExtra{}, stream);
 }
 
-extern "C" int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx, const void* y,
-                                        int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
+extern "C" int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx, int64_t ldx,
+                                        const void* y, int64_t dy, const int32_t* eid, const int32_t* row, const int32_t* col,
                                         const int64_t* indptr, const int64_t* zero_indptr, int64_t max_row_edges,
-                                        int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, int64_t dout,
+                                        int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, int64_t dout, int64_t ldout,
                                         int32_t message_op, int32_t reduce_op, const float* dst_scale, int32_t accumulate,
                                         void* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (ldx < 0 || ldout < 0) return fail(PGLAMD_E_ARG, "aggregate_ext: negative row stride");
     AggExtra ex;
-    ex.x2 = x2; ex.x_split = x_split; ex.zero_indptr = zero_indptr; ex.max_row_edges = max_row_edges;
+    ex.x2 = x2; ex.x_split = x_split; ex.zero_indptr = zero_indptr; ex.max_row_edges = max_row_edges; ex.ldx = ldx; ex.ldo = ldout;
     return aggregate_entry(x, dtype, dx, y, dy, eid, row, col, indptr, num_edges, n_csr_rows, out_rows, dout, message_op, reduce_op,
                            nullptr, dst_scale, accumulate, out, workspace, workspace_bytes, ex, stream);
 }

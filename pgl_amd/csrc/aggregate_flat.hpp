@@ -95,6 +95,12 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                 acc[t][k] = RCLS == 0 ? A(0) : Limits<A>::lo();
     };
     reset();
+#ifdef PGLAMD_FLAT_EXTRA_LDS            // occupancy experiment (scripts/prof.py variant): the same kernel with fewer resident workgroups
+    {
+        __shared__ float occupancy_pad[PGLAMD_FLAT_EXTRA_LDS / 4];
+        if (p.E == -12345) { occupancy_pad[threadIdx.x] = (float)lane; __syncthreads(); acc[0][0] += (A)occupancy_pad[threadIdx.x ^ 1]; }
+    }
+#endif
     // min / max: one v_max per element over order-reversed values for min (aggregate_group.hpp: order_flip), turned back at every store
     const bool neg = RCLS == 1 && !is_max;
 
@@ -850,9 +856,12 @@ template <typename T> int max_tiles(int vec) { return (sizeof(T) == 2 && vec == 
 
 // What pglamd_aggregate_ext adds to pglamd_aggregate (include/pgl_amd.h): a second source table for column ids >= x_split
 // (x2 = NULL: none), the indptr that decides which rows the zero-fill clears (NULL: the launch's own), and the longest row of
-// the index as a hint (0 = unknown) that lets the launcher skip the split-row fix-up when no row can be split.
+// the index as a hint (0 = unknown) that lets the launcher skip the split-row fix-up when no row can be split, and row strides
+// (elements; 0 = dense) of x / x2 and out: a launch may read and write a COLUMN BLOCK of wider matrices (the column-pipelined
+// halo exchange aggregates columns [0, d/2) while columns [d/2, d) are still on the wire).
 struct AggExtra {
     const void* x2 = nullptr; int64_t x_split = 0; const int64_t* zero_indptr = nullptr; int64_t max_row_edges = 0;
+    int64_t ldx = 0, ldo = 0;
 };
 
 // argument list of aggregate_typed<T> for the explicit instantiations (aggregate*.hip)
@@ -870,19 +879,26 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     if (accumulate && rop == PGLAMD_MEAN)
         return fail(PGLAMD_E_ARG, "aggregate: accumulate with MEAN is undefined (use SUM with dst_scale = 1/degree)");
     const int64_t* zip = ex.zero_indptr ? ex.zero_indptr : indptr;
-    if (E == 0) return accumulate ? PGLAMD_OK : zero_empty_rows(zip, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
+    const int64_t ldx = ex.ldx ? ex.ldx : dx, ldo = ex.ldo ? ex.ldo : dout;
+    if (ldx < dx || ldo < dout) return fail(PGLAMD_E_SHAPE, "aggregate_ext: row stride shorter than the row (ldx %lld < %lld or ldout %lld < %lld)",
+                                            (long long)ldx, (long long)dx, (long long)ldo, (long long)dout);
+    if (E == 0) {
+        if (accumulate) return PGLAMD_OK;
+        if (ldo != dout) return fail(PGLAMD_E_ARG, "aggregate_ext: an index without edges cannot zero-fill a strided output");
+        return zero_empty_rows(zip, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
+    }
 
     AggParams p{};
     p.x = x; p.y = y; p.out = out; p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
     p.zero_indptr = zip;
     // the second table is rebased by -x_split rows here, so that the kernels address both tables with the same column id
-    p.x2 = ex.x2 ? static_cast<const char*>(ex.x2) - ex.x_split * dx * (int64_t)sizeof(T) : x;
+    p.x2 = ex.x2 ? static_cast<const char*>(ex.x2) - ex.x_split * ldx * (int64_t)sizeof(T) : x;
     p.x_split = ex.x2 ? (int)ex.x_split : INT32_MAX;
     p.max_row_edges = (int)std::min<int64_t>(ex.max_row_edges, INT32_MAX);
     if (ex.x2 && (src_scale || dout != dx))
         return fail(PGLAMD_E_ARG, "aggregate_ext: a second source table excludes src_scale and source-side broadcasting");
     p.src_scale = src_scale; p.dst_scale = dst_scale;
-    p.ldx = dx; p.ldy = dy; p.ldo = dout; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)E;
+    p.ldx = ldx; p.ldy = dy; p.ldo = ldo; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)E;
     p.mop = mop; p.is_mean = rop == PGLAMD_MEAN; p.is_max = rop == PGLAMD_MAX; p.accumulate = accumulate;
     const int rcls = (rop == PGLAMD_SUM || rop == PGLAMD_MEAN) ? 0 : 1;
     const int gx = (int)(dout / dx);
@@ -897,7 +913,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
                                  (y && gy == 1 ? reinterpret_cast<uintptr_t>(y) : 0) |
                                  reinterpret_cast<uintptr_t>(ws);
-    while (vmax > 1 && (dout % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0)) vmax >>= 1;
+    while (vmax > 1 && (dout % vmax != 0 || ldx % vmax != 0 || ldo % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0)) vmax >>= 1;
     int ymode = 0;
     if (y) {
         if (gy == 1) ymode = 2;
@@ -959,7 +975,8 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
             q.chunk = nk; q.n_chunks = (int)ceil_div(E, nk);
             q.j_base = 0; q.tile_cols = (int)dout;
             const size_t lv = std::min<size_t>(16, (size_t)dout * sizeof(T));
-            q.narrow_vec = (lv & (lv - 1)) == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
+            q.narrow_vec = (lv & (lv - 1)) == 0 && ((size_t)ldx * sizeof(T)) % lv == 0 && ((size_t)ldo * sizeof(T)) % lv == 0 &&
+                           (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
                                                     (y && dy == dout ? reinterpret_cast<uintptr_t>(y) : 0)) % lv == 0;
             bool handled = false;
             rc = launch_narrow(q, dtype_code<T>(), rcls, y ? dy : 0, st, &handled);

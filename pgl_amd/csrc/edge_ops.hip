@@ -317,7 +317,7 @@ template <> __device__ __forceinline__ __half wire_from_f32<__half>(float v) { r
 template <> __device__ __forceinline__ __hip_bfloat16 wire_from_f32<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 
 template <typename TI, typename TO, int VEC>
-__global__ __launch_bounds__(kBlock) void gather_cast_kernel(const TI* __restrict__ x, int64_t d, const int32_t* __restrict__ index,
+__global__ __launch_bounds__(kBlock) void gather_cast_kernel(const TI* __restrict__ x, int64_t d, int64_t ldx, const int32_t* __restrict__ index,
                                                              int64_t n_index, TO* __restrict__ out) {
     struct alignas(sizeof(TI) * VEC) VI { TI v[VEC]; };
     struct alignas(sizeof(TO) * VEC) VO { TO v[VEC]; };
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void gather_cast_kernel(const TI* __restric
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t r = i / per, j = (i - r * per) * VEC;
         const int64_t s = index ? (int64_t)index[r] : r;
-        const VI a = *reinterpret_cast<const VI*>(x + s * d + j);
+        const VI a = *reinterpret_cast<const VI*>(x + s * ldx + j);
         VO o;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o.v[k] = wire_from_f32<TO>(wire_to_f32<TI>(a.v[k]));
@@ -334,27 +334,29 @@ __global__ __launch_bounds__(kBlock) void gather_cast_kernel(const TI* __restric
 }
 
 template <typename TI, typename TO>
-int32_t gather_cast(const void* x, int64_t d, const int32_t* index, int64_t n, void* out, hipStream_t st) {
+int32_t gather_cast(const void* x, int64_t d, int64_t ldx, const int32_t* index, int64_t n, void* out, hipStream_t st) {
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out);
-    if (d % 4 == 0 && al % 16 == 0)
-        hipLaunchKernelGGL((gather_cast_kernel<TI, TO, 4>), dim3(grid_for(n * (d / 4))), dim3(kBlock), 0, st, static_cast<const TI*>(x), d, index, n, static_cast<TO*>(out));
+    if (d % 4 == 0 && ldx % 4 == 0 && al % 16 == 0)
+        hipLaunchKernelGGL((gather_cast_kernel<TI, TO, 4>), dim3(grid_for(n * (d / 4))), dim3(kBlock), 0, st, static_cast<const TI*>(x), d, ldx, index, n, static_cast<TO*>(out));
     else
-        hipLaunchKernelGGL((gather_cast_kernel<TI, TO, 1>), dim3(grid_for(n * d)), dim3(kBlock), 0, st, static_cast<const TI*>(x), d, index, n, static_cast<TO*>(out));
+        hipLaunchKernelGGL((gather_cast_kernel<TI, TO, 1>), dim3(grid_for(n * d)), dim3(kBlock), 0, st, static_cast<const TI*>(x), d, ldx, index, n, static_cast<TO*>(out));
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }
 }  // namespace
 
-extern "C" int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64_t d, const int32_t* index, int64_t n_index,
+extern "C" int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64_t d, int64_t ldx, const int32_t* index, int64_t n_index,
                                            void* out, int32_t out_dtype, void* stream) {
     if (n_index < 0 || d < 0 || (n_index > 0 && d > 0 && (!x || !out))) return fail(PGLAMD_E_ARG, "gather_rows_cast: bad argument");
+    if (ldx == 0) ldx = d;
+    if (ldx < d) return fail(PGLAMD_E_SHAPE, "gather_rows_cast: row stride %lld shorter than the row %lld", (long long)ldx, (long long)d);
     if (n_index == 0 || d == 0) return PGLAMD_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_F16) return gather_cast<float, __half>(x, d, index, n_index, out, st);
-    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_BF16) return gather_cast<float, __hip_bfloat16>(x, d, index, n_index, out, st);
-    if (x_dtype == PGLAMD_F16 && out_dtype == PGLAMD_F32) return gather_cast<__half, float>(x, d, index, n_index, out, st);
-    if (x_dtype == PGLAMD_BF16 && out_dtype == PGLAMD_F32) return gather_cast<__hip_bfloat16, float>(x, d, index, n_index, out, st);
-    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_F32) return gather_cast<float, float>(x, d, index, n_index, out, st);
+    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_F16) return gather_cast<float, __half>(x, d, ldx, index, n_index, out, st);
+    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_BF16) return gather_cast<float, __hip_bfloat16>(x, d, ldx, index, n_index, out, st);
+    if (x_dtype == PGLAMD_F16 && out_dtype == PGLAMD_F32) return gather_cast<__half, float>(x, d, ldx, index, n_index, out, st);
+    if (x_dtype == PGLAMD_BF16 && out_dtype == PGLAMD_F32) return gather_cast<__hip_bfloat16, float>(x, d, ldx, index, n_index, out, st);
+    if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_F32) return gather_cast<float, float>(x, d, ldx, index, n_index, out, st);
     return fail(PGLAMD_E_DTYPE, "gather_rows_cast: F32 <-> F16 / BF16 only (got %d -> %d)", x_dtype, out_dtype);
 }
 

@@ -584,7 +584,8 @@ class DistGraph(object):
         return {"partition": self.method, "local_rows": p.n_own, "local_edges": p.local_edges, "halo_rows": p.n_halo,
                 "send_rows": int(x.n_send), "recv_rows": int(x.n_recv), "pull_only_recv_rows": p.n_halo,
                 "pushed_pairs": int(x.pushed_pairs), "edges_local_src": int(p.loc_rows.shape[0]),
-                "edges_halo_src": int(p.hal_rows.shape[0])}
+                "edges_halo_src": int(p.hal_rows.shape[0]),
+                "flow": (self._idx.get(("ran", "x", False)) or self._mode("x", False)) if p.world > 1 else "single rank"}
 
     def indegree(self, nodes=None):
         """pgl/graph.py:1524-1527 (global in-degree of the owned nodes; `nodes` = local row ids)."""
@@ -706,11 +707,17 @@ class DistGraph(object):
         return w if (w is not None and dtype == torch.float32 and w in (torch.float16, torch.bfloat16)) else dtype
 
     # ---- the exchange: pack -> all-to-all-v (asynchronous) ------------------------------------------------------------
-    def _start_exchange(self, x, kind, transposed):
+    def _start_exchange(self, x, kind, transposed, cols=None):
         """-> (work, in_buf, unpack) or None when this plan moves nothing.  Pack = ONE launch: a row gather straight into
         the wire buffer (in the wire dtype) when every send row is a single owned row, otherwise the aggregation kernel over
-        the send index (pushed partial rows; the transposed flow's pre-summed gradients) followed by the wire cast."""
+        the send index (pushed partial rows; the transposed flow's pre-summed gradients) followed by the wire cast.
+        cols = (c0, c1): only that column block of the [n_own, d] rows travels (the pipelined flow: one exchange per block; the
+        kernels read the block in place through the row stride)."""
         p, B = self.plan, self._b
+        blk = ""
+        if cols is not None:
+            blk = "c%d" % cols[0]
+            x = x[:, cols[0]:cols[1]]
         xp = self.xplan if kind == "x" else p
         if transposed:
             first, n_out, n_in, out_splits, in_splits = kind + "recv_t", xp.n_recv, xp.n_send, xp.recv_splits, xp.send_splits
@@ -720,11 +727,11 @@ class DistGraph(object):
             return None
         tail = tuple(x.shape[1:])
         wire = self._wire(x.dtype)
-        tag = "%s%d" % (kind, transposed)
+        tag = "%s%d%s" % (kind, transposed, blk)
         out_buf = self._buffer("out" + tag, (n_out,) + tail, wire, x.device)
         if n_out:
             plain = (not transposed) and int(xp.pushed_pairs) == 0
-            if plain and wire != x.dtype:
+            if plain and (wire != x.dtype or cols is not None):
                 B.gather_rows_cast(x, self._send_cols32(kind), wire, out_buf)
             elif plain:
                 out_buf = B.gather_rows(x, self._send_cols32(kind))
@@ -767,10 +774,36 @@ class DistGraph(object):
         elif scale is not None and x.dtype != torch.float32:          # kernel scales are fp32-only
             post, scale_k = scale.to(x.dtype).reshape((-1,) + (1,) * len(tail)), None
         sfx = "_t" if transposed else ""
+        additive = reduce in ("sum", "mean")
+        row_bytes = max(1, x.element_size() * int(np.prod(tail)) if tail else x.element_size())
+        if p.world > 1 and self._pipelined(kind, transposed, additive, x, row_bytes):
+            # COLUMN-PIPELINED (all ranks agreed on it): the rows travel in two column blocks, one all-to-all-v each.  While block
+            # 0 is on the wire block 1 is packed and the local-source edges run; the received rows' edges of block 0 are added
+            # while block 1 is still travelling.  Same arithmetic as "accumulate" (every output element: local edges first, then
+            # the received ones in index order), so the two agree bit for bit.
+            d = int(x.shape[1])
+            h = (d // 2 + 15) // 16 * 16
+            blocks = [(0, h), (h, d)]
+            started = [self._start_exchange(x, kind, transposed, cols=c) for c in blocks]
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k)
+            recv = kind + ("send_t" if transposed else "recv")
+            for st, (c0, c1) in zip(started, blocks):
+                if st is None:
+                    continue
+                work, in_buf, unpack = st
+                work.wait()
+                if (xp.n_send if transposed else xp.n_recv):
+                    if unpack is not None:
+                        unpack()
+                    B.aggregate(in_buf, self._index(recv), reduce, p.n_own, dst_scale=scale_k, out=out[:, c0:c1], accumulate=1)
+            self._idx[("ran", kind, transposed)] = "pipeline"
+            if post is not None:
+                out = out * post
+            return out
         started = self._start_exchange(x, kind, transposed)
         n_in = (xp.n_send if transposed else xp.n_recv) if started is not None else 0
-        mode = self._mode(kind, transposed, additive=reduce in ("sum", "mean"),
-                          row_bytes=max(1, x.element_size() * int(np.prod(tail)) if tail else x.element_size())) if n_in else "split"
+        mode = self._mode(kind, transposed, additive=additive, row_bytes=row_bytes) if n_in else "split"
+        self._idx[("ran", kind, transposed)] = mode
         if mode == "fold":
             # (almost) no interior -- a power-law graph cut 8 ways: one launch over every row after the wait instead of an
             # interior launch with nothing to overlap (a launch costs ~20 us of GPU time whatever it carries)
@@ -805,9 +838,10 @@ class DistGraph(object):
         return out
 
     # edges / s of the aggregation kernel on a rank-sized problem, fixed cost of one aggregation launch (counter reset, kernel ramp
-    # and tail, two fix-up launches), xGMI link rate and latency of one all-to-all-v: the cost model `_mode` chooses with (measured
-    # on MI355X, profiles/r03/rows_*.txt; only the ORDER of the three estimates matters)
-    _RATE, _LAUNCH, _LINK, _LAT, _RMW = 15.0e9, 20.0e-6, 150.0e9, 30.0e-6, 5.0e12
+    # and tail, two fix-up launches), xGMI link rate and latency of one all-to-all-v, rate of a pass that reads and rewrites rows:
+    # the cost model `_mode` / `_pipelined` choose with (measured on MI355X, profiles/r03/rows_*.txt; only the ORDER of the
+    # estimates matters).  _HALF: what a half-width row costs more per byte than a full one.
+    _RATE, _LAUNCH, _LINK, _LAT, _RMW, _HALF = 15.0e9, 20.0e-6, 150.0e9, 30.0e-6, 5.0e12, 1.1
 
     def _mode(self, kind, transposed, additive=True, row_bytes=512):
         """How this flow spends the time the exchange takes -- decided once per (plan, direction) from the plan's own counts:
@@ -817,7 +851,9 @@ class DistGraph(object):
           "accumulate"  local-source EDGES of all rows during the exchange, the received rows' edges added afterwards (the rows they
                         touch are read-modify-written; sum / mean only).  Best when most EDGES are local but most rows have a few
                         remote sources (a graph with communities and 10 % random cross edges: 91 % local edges, 17 % interior).
-        estimate = max(before-the-wait work, exchange) + after-the-wait work, with the constants above; PGLAMD_FLOW forces one."""
+        estimate = pack + max(before-the-wait work, exchange) + after-the-wait work, with the constants above; PGLAMD_FLOW forces
+        one.  ("pipeline" -- accumulate with the rows travelling in two column blocks -- changes the number of collectives, so it
+        is not a per-rank choice: see _pipelined.)"""
         key = ("mode", kind, transposed, additive)
         hit = self._idx.get(key)
         if hit is None:
@@ -827,27 +863,64 @@ class DistGraph(object):
             if transposed:
                 mark[xp.send_cols] = True
                 e_int = int((~mark[p.loc_cols]).sum())
-                e_rem, n_in, splits = int(xp.send_rows.shape[0]), xp.n_send, xp.send_splits
+                e_rem, n_in, n_out, splits = int(xp.send_rows.shape[0]), xp.n_send, xp.n_recv, xp.send_splits
             else:
                 mark[xp.recv_rows] = True
                 e_int = int((~mark[p.loc_rows]).sum())
-                e_rem, n_in, splits = int(xp.recv_rows.shape[0]), xp.n_recv, xp.recv_splits
+                e_rem, n_in, n_out, splits = int(xp.recv_rows.shape[0]), xp.n_recv, xp.n_send, xp.recv_splits
             e_loc = int(p.loc_rows.shape[0])
             n_bnd = int(mark.sum())
-            R, L = self._RATE, self._LAUNCH
+            R, L, H = self._RATE, self._LAUNCH, self._HALF
             xch = max(splits) * row_bytes / self._LINK + self._LAT if n_in else 0.0
-            est = {"fold": xch + (e_loc + e_rem) / R + L,
-                   "split": max(e_int / R + L, xch) + (e_loc - e_int + e_rem) / R + L}
+            pack = 2.0 * n_out * row_bytes / self._RMW + L if n_out else 0.0
+            rmw = 2.0 * n_bnd * row_bytes / self._RMW
+            est = {"fold": pack + xch + (e_loc + e_rem) / R + L,
+                   "split": pack + max(e_int / R + L, xch) + (e_loc - e_int + e_rem) / R + L}
             if additive:
-                est["accumulate"] = max(e_loc / R + L, xch) + e_rem / R + L + 2.0 * n_bnd * row_bytes / self._RMW
+                est["accumulate"] = pack + max(e_loc / R + L, xch) + e_rem / R + L + rmw
             hit = min(est, key=est.get)
+            if additive:
+                # two column blocks: block 0 arrives at t_a; the compute stream has packed both blocks and run the local edges by
+                # t_c; block 1 follows block 0 on the same links
+                half_x = 0.5 * (xch - self._LAT) + self._LAT if n_in else 0.0
+                t_a = 0.5 * pack + half_x
+                t_c = pack + (L if n_out else 0.0) + e_loc / R + L
+                rem = H * 0.5 * e_rem / R + L
+                end_a = max(t_a, t_c) + rem
+                est["pipeline"] = max(end_a, t_a + half_x) + rem + rmw
             forced = os.environ.get("PGLAMD_FLOW", "")
-            if forced in est:
+            if forced in est and forced != "pipeline":
                 hit = forced
             elif os.environ.get("PGLAMD_FOLD_INTERIOR"):              # (round-3 knob kept for the tests: fold below this interior share)
                 hit = "fold" if e_int < float(os.environ["PGLAMD_FOLD_INTERIOR"]) * max(p.local_edges, 1) else "split"
             self._idx[key] = hit
             self._idx[("mode_estimates", kind, transposed, additive)] = est
+        return hit
+
+    def _pipelined(self, kind, transposed, additive, x, row_bytes):
+        """True when this aggregation travels in two column blocks (two all-to-all-v per step instead of one).  Every rank must
+        take the same answer, so it is agreed ONCE per (plan, direction, row width): each rank puts up its own estimate of the best
+        single-exchange flow and of the pipelined one, the maxima over ranks are compared (the slowest rank sets the step).
+        Eligible: sum / mean of fp32 [n_own, d] rows, d a multiple of 32 (both blocks keep 64-byte alignment).
+        PGLAMD_FLOW=pipeline forces it where eligible, any other PGLAMD_FLOW value rules it out."""
+        if not (additive and x.dim() == 2 and x.dtype == torch.float32 and int(x.shape[1]) % 32 == 0):
+            return False
+        forced = os.environ.get("PGLAMD_FLOW", "")
+        if forced or os.environ.get("PGLAMD_FOLD_INTERIOR"):
+            return forced == "pipeline"
+        key = ("pipelined", kind, transposed, row_bytes)
+        hit = self._idx.get(key)
+        if hit is None:
+            self._mode(kind, transposed, additive, row_bytes)
+            est = self._idx[("mode_estimates", kind, transposed, additive)]
+            mine = [min(v for k, v in est.items() if k != "pipeline"), est["pipeline"]]
+            if _group_ready(self.group):
+                on_gpu = dist.get_backend(self.group) == "nccl"
+                t = torch.tensor(mine, dtype=torch.float64, device=x.device if on_gpu else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                mine = t.tolist()
+            hit = bool(mine[1] < mine[0])
+            self._idx[key] = hit
         return hit
 
     def _sum_like(self, x_own, reduce_func, extra_dst_scale=None):

@@ -176,6 +176,12 @@ _GAT_POS_STATS = os.environ.get("PGLAMD_GAT_POS_STATS", "1") != "0"
 _PRESCALE_ROW_BYTES = int(os.environ.get("PGLAMD_PRESCALE_ROW_BYTES", "704"))
 
 
+def _row_strided(t):
+    """True for a 2-D column block of a wider row-major matrix (t = m[:, a:b]): rows are contiguous, the row stride is not
+    the row length.  pglamd_aggregate_ext / pglamd_gather_rows_cast take such views as they are (ldx / ldout)."""
+    return t.dim() == 2 and t.shape[1] > 0 and t.stride(1) == 1 and t.stride(0) > t.shape[1] and not t.is_contiguous()
+
+
 def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None,
               out=None, accumulate=False, x2=None, zero_indptr=None):
     """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
@@ -184,12 +190,21 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     2 overwrite only the rows that receive edges (include/pgl_amd.h).
     x2 / zero_indptr (pglamd_aggregate_ext, row-partitioned graphs): column ids >= x.shape[0] read row (id - x.shape[0]) of
     x2 (the rows received from peers); rows are zero-filled where zero_indptr -- not the index's own indptr -- says they
-    have no edge.  An index carrying `max_row` (longest row) lets the library skip the split-row fix-up launches."""
+    have no edge.  An index carrying `max_row` (longest row) lets the library skip the split-row fix-up launches.
+    x and out may be COLUMN BLOCKS of wider matrices (m[:, a:b]; no edge operand, no src_scale, no x2): the kernels walk them
+    with the parent's row stride, nothing is copied."""
     _need_cuda(x, y, src_scale, dst_scale, x2, zero_indptr)
     L = _ffi.lib()
-    x = x.contiguous()
+    ldx = ldo = 0
+    if y is None and src_scale is None and x2 is None:
+        if _row_strided(x):
+            ldx = int(x.stride(0))
+        if out is not None and _row_strided(out):
+            ldo = int(out.stride(0))
+    if not ldx:
+        x = x.contiguous()
     max_row = int(getattr(csr, "max_row", 0) or 0)
-    ext = x2 is not None or zero_indptr is not None or max_row > 0
+    ext = x2 is not None or zero_indptr is not None or max_row > 0 or ldx > 0 or ldo > 0
     if x2 is not None:
         x2 = x2.contiguous()
         if x2.dtype != x.dtype or tuple(x2.shape[1:]) != tuple(x.shape[1:]) or src_scale is not None:
@@ -219,17 +234,20 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
             raise ValueError("accumulate=True needs an existing `out`")
         out = torch.empty((M,) + tuple(tail), dtype=x.dtype, device=x.device)
     else:
-        if tuple(out.shape) != (M,) + tuple(tail) or out.dtype != x.dtype or not out.is_contiguous():
+        if tuple(out.shape) != (M,) + tuple(tail) or out.dtype != x.dtype or not (out.is_contiguous() or ldo):
             raise ValueError("out must be a contiguous %s tensor of dtype %s" % ((M,) + tuple(tail), x.dtype))
     if M == 0 or dout == 0:
+        return out
+    if ldo and not accumulate and csr.num_edges == 0:
+        out.zero_()
         return out
     code = _code(x.dtype)
     ws = _ws(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
     if ext and src_scale is None:
         with torch.cuda.device(x.device):
-            _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, _ptr(y), dy,
+            _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(y), dy,
                                               _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
-                                              _ptr(csr.indptr), _ptr(zero_indptr), max_row, csr.num_edges, csr.num_nodes, M, dout,
+                                              _ptr(csr.indptr), _ptr(zero_indptr), max_row, csr.num_edges, csr.num_nodes, M, dout, ldo,
                                               MSG[message_op], REDUCE[reduce_op], _ptr(dst_scale), int(accumulate), _ptr(out),
                                               _ptr(ws), ws.numel(), _stream(x)), "aggregate_ext")
         return out
@@ -626,9 +644,11 @@ def gather_rows(x, index):
 
 def gather_rows_cast(x, index, out_dtype, out=None):
     """out[i] = cast(x[index[i]]) (index None: a row-wise conversion) -- pglamd_gather_rows_cast, the wire pack / unpack of the
-    halo exchange.  fp32 <-> fp16 / bf16."""
+    halo exchange.  fp32 <-> fp16 / bf16 (and fp32 -> fp32: a plain pack).  x may be a column block m[:, a:b] of a wider matrix."""
     _need_cuda(x, index)
-    x = x.contiguous()
+    ldx = int(x.stride(0)) if _row_strided(x) else 0
+    if not ldx:
+        x = x.contiguous()
     n = int(x.shape[0]) if index is None else int(index.shape[0])
     if index is not None:
         index = index.contiguous()
@@ -641,7 +661,7 @@ def gather_rows_cast(x, index, out_dtype, out=None):
         raise ValueError("gather_rows_cast: out must be a contiguous %s tensor of dtype %s" % ((n,) + tuple(x.shape[1:]), out_dtype))
     if n and d:
         with torch.cuda.device(x.device):
-            _ffi.check(_ffi.lib().pglamd_gather_rows_cast(_ptr(x), _code(x.dtype), d, _ptr(index), n, _ptr(out), _code(out_dtype),
+            _ffi.check(_ffi.lib().pglamd_gather_rows_cast(_ptr(x), _code(x.dtype), d, ldx, _ptr(index), n, _ptr(out), _code(out_dtype),
                                                           _stream(x)), "gather_rows_cast")
     return out
 

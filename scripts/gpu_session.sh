@@ -20,6 +20,8 @@ for STEP in "$@"; do
     rows_c2_p4) timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 4 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -8 $F ;;
     rows_c2_fp16) timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --wire fp16 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -4 $F ;;
     rows_community) timeout 900 python scripts/prof.py rows --graph community --scale 20 --edges 20000000 --parts 8 --partition kway > $F 2>&1; tail -14 $F ;;
+    rows_c2p_pipe) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow pipeline --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
+    rows_c2_pipe)  timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow pipeline --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     csr|noreuse|gcn|gat|ops|dtypes|gatsplit) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
@@ -57,6 +59,15 @@ PY
         echo "== $L" >> $F
         PGLAMD_LIB=$R/$L timeout 600 python -m pytest tests/test_gpu_round3.py -m gpu -q -x -k "csr_sort" 2>&1 | tail -2 >> $F
         PGLAMD_LIB=$R/$L timeout 300 python scripts/prof.py csr 2>&1 | grep "csr_build" | grep "dst-keyed" >> $F
+      done
+      cat $F ;;
+    variants:*)
+      # `prof.py <subcommand>` against every experimental build (PGLAMD_LIB) and against the product library
+      SUB="${STEP#variants:}"
+      echo "== product" > $F; timeout 300 python scripts/prof.py $SUB 2>&1 | grep -v amdgpu.ids | head -${VLINES:-4} >> $F
+      for L in pgl_amd/csrc/variants/libpglamd_*.so; do
+        echo "== $L" >> $F
+        PGLAMD_LIB=$R/$L timeout 300 python scripts/prof.py $SUB 2>&1 | grep -v amdgpu.ids | head -${VLINES:-4} >> $F
       done
       cat $F ;;
     tlb)

@@ -96,6 +96,8 @@ def cmd_rows(args):
     dev = torch.device("cuda:0")
     scale, E, d = args.scale, args.edges, args.dim
     N = 1 << scale
+    if args.flow:
+        os.environ["PGLAMD_FLOW"] = args.flow
     gen = torch.Generator(device=dev); gen.manual_seed(7)
     if args.graph == "community":
         # a graph a partitioner CAN cut (what BASELINE configs 3 / 4 look like): 256 communities, 90 % of the edges stay inside their
@@ -147,28 +149,45 @@ def cmd_rows(args):
             torch.cuda.synchronize()
             # phases on their own (each between its own pair of events), for the flow mode the plan's cost model chose
             B = dg._b
-            mode = dg._mode("x", False, True, d * 4)
-            pk = _t(lambda: dg._start_exchange(x_own, "x", False), it=10, warm=2)
-            out = torch.empty_like(x_own)
-            in_buf = dg._buffer("inx0" if not args.wire else "inwx0", (xplan.n_recv, d), torch.float32, dev)
-            if mode == "split":
-                zi = dg._zero_indptr(False)
-                pre = _t(lambda: B.aggregate(x_own, dg._index("xint"), "sum", plan.n_own, zero_indptr=zi), it=10, warm=2)
-                post = _t(lambda: B.aggregate(x_own, dg._index("xbnd"), "sum", plan.n_own, out=out, accumulate=2, x2=in_buf), it=10, warm=2) if xplan.n_recv else 0.0
-                e_pre, e_post = dg._index("xint").num_edges, dg._index("xbnd").num_edges
-            elif mode == "fold":
-                pre = 0.0
-                post = _t(lambda: B.aggregate(x_own, dg._index("xall"), "sum", plan.n_own, x2=in_buf), it=10, warm=2)
-                e_pre, e_post = 0, dg._index("xall").num_edges
-            else:
-                pre = _t(lambda: B.aggregate(x_own, dg._index("loc"), "sum", plan.n_own), it=10, warm=2)
-                post = _t(lambda: B.aggregate(in_buf, dg._index("xrecv"), "sum", plan.n_own, out=out, accumulate=1), it=10, warm=2)
-                e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
             wb = 2 if args.wire else 4
-            ideal = plan.local_edges / (E / t1)
             pair_mb = max(xplan.recv_splits) * d * wb / 1e6
             xch = pair_mb / 1e3 / LINK * 1e3
-            pred = pk + max(pre, xch) + post
+            out = torch.empty_like(x_own)
+            if dg._pipelined("x", False, True, x_own, d * 4):
+                # two column blocks: block 0 arrives at t_a, block 1 follows it on the same links (and cannot start before it is
+                # packed); the compute stream packs both blocks, runs the local edges, then adds block 0's and block 1's edges
+                mode, h = "pipeline", (d // 2 + 15) // 16 * 16
+                pk0 = _t(lambda: dg._start_exchange(x_own, "x", False, cols=(0, h)), it=10, warm=2)
+                pk1 = _t(lambda: dg._start_exchange(x_own, "x", False, cols=(h, d)), it=10, warm=2)
+                pre = _t(lambda: B.aggregate(x_own, dg._index("loc"), "sum", plan.n_own), it=10, warm=2)
+                nm = "inwx0c%d" if args.wire else "inx0c%d"
+                in0, in1 = dg._buf[nm % 0], dg._buf[nm % h]
+                po0 = _t(lambda: B.aggregate(in0, dg._index("xrecv"), "sum", plan.n_own, out=out[:, :h], accumulate=1), it=10, warm=2)
+                po1 = _t(lambda: B.aggregate(in1, dg._index("xrecv"), "sum", plan.n_own, out=out[:, h:], accumulate=1), it=10, warm=2)
+                pk, post = pk0 + pk1, po0 + po1
+                e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
+                t_a = pk0 + xch * h / d
+                end_a = max(t_a, pk + pre) + po0
+                pred = max(end_a, max(t_a, pk) + xch * (d - h) / d) + po1
+            else:
+                mode = dg._mode("x", False, True, d * 4)
+                pk = _t(lambda: dg._start_exchange(x_own, "x", False), it=10, warm=2)
+                in_buf = dg._buffer("inx0" if not args.wire else "inwx0", (xplan.n_recv, d), torch.float32, dev)
+                if mode == "split":
+                    zi = dg._zero_indptr(False)
+                    pre = _t(lambda: B.aggregate(x_own, dg._index("xint"), "sum", plan.n_own, zero_indptr=zi), it=10, warm=2)
+                    post = _t(lambda: B.aggregate(x_own, dg._index("xbnd"), "sum", plan.n_own, out=out, accumulate=2, x2=in_buf), it=10, warm=2) if xplan.n_recv else 0.0
+                    e_pre, e_post = dg._index("xint").num_edges, dg._index("xbnd").num_edges
+                elif mode == "fold":
+                    pre = 0.0
+                    post = _t(lambda: B.aggregate(x_own, dg._index("xall"), "sum", plan.n_own, x2=in_buf), it=10, warm=2)
+                    e_pre, e_post = 0, dg._index("xall").num_edges
+                else:
+                    pre = _t(lambda: B.aggregate(x_own, dg._index("loc"), "sum", plan.n_own), it=10, warm=2)
+                    post = _t(lambda: B.aggregate(in_buf, dg._index("xrecv"), "sum", plan.n_own, out=out, accumulate=1), it=10, warm=2)
+                    e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
+                pred = pk + max(pre, xch) + post
+            ideal = plan.local_edges / (E / t1)
             rows.append((r, plan.n_own, plan.local_edges, e_pre, e_post, xplan.n_send, xplan.n_recv, ms, pk, pre, post, ideal, pair_mb, enq, mode, pred))
             worst["compute"] = max(worst["compute"], ms); worst["pair_mb"] = max(worst["pair_mb"], pair_mb)
             worst["ratio"] = max(worst["ratio"], ms / ideal); worst["pred"] = max(worst.get("pred", 0.0), pred)
@@ -179,7 +198,7 @@ def cmd_rows(args):
         t_link = worst["pair_mb"] / 1e3 / LINK * 1e3
         print("   slowest rank compute %.3f ms (worst compute/ideal x%.2f; ideal = E/P at the 1-GPU rate = %.3f ms) | exchange >= %.3f ms (largest pair block at %.0f GB/s per link)"
               % (worst["compute"], worst["ratio"], t1 / P, t_link, LINK))
-        print("   predicted step: pack + max(work before the wait, exchange) + work after the wait, slowest rank = %.3f ms = %.2fx of one GPU"
+        print("   predicted step (pack + max(work before the wait, exchange) + work after the wait; pipeline: block 1 travels under block 0's edges), slowest rank = %.3f ms = %.2fx of one GPU"
               "   [bounds: max(compute, exchange) = %.2fx, compute + exchange = %.2fx]"
               % (worst["pred"], t1 / worst["pred"], t1 / max(worst["compute"], t_link), t1 / (worst["compute"] + t_link)), flush=True)
 
@@ -287,6 +306,47 @@ def cmd_gcn(args):
         print("  relu(x @ w + b) one GEMM epilogue   %.3f ms (torch._addmm_activation)" % _t(lambda: torch._addmm_activation(b, x, w)))
     except Exception as ex:                                          # noqa: BLE001
         print("  torch._addmm_activation unavailable: %r" % ex)
+    # aggregate -> dense WITHOUT a fused kernel: the rows in K blocks of equal edge count, block k's GEMM (hipBLASLt, bias + relu in its
+    # epilogue) on a second stream while block k+1 aggregates -- the matrix cores work in the shadow of the gathers if the two kernels
+    # really share the CUs
+    class _Sub(object):
+        pass
+    for K in (2, 4, 8, 16):
+        cut = [0]
+        for k in range(1, K):
+            cut.append(int(torch.searchsorted(csr.indptr, torch.tensor(E * k // K, device=dev)).item()))
+        cut.append(N)
+        subs = []
+        for r0, r1 in zip(cut[:-1], cut[1:]):
+            e0, e1 = int(csr.indptr[r0]), int(csr.indptr[r1])
+            c = _Sub()
+            c.row32 = (csr.row32[e0:e1] - r0).contiguous(); c.col32 = csr.col32[e0:e1]; c.eid32 = None
+            c.indptr = (csr.indptr[r0:r1 + 1] - e0).contiguous(); c.num_edges, c.num_nodes, c.max_row = e1 - e0, r1 - r0, 0
+            subs.append((r0, r1, c))
+        agg = torch.empty(N, d, device=dev); out = torch.empty(N, d, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        evs = [torch.cuda.Event() for _ in subs]
+
+        def blocked(two_streams):
+            main = torch.cuda.current_stream(dev)
+            if two_streams:
+                side.wait_stream(main)
+            for (r0, r1, c), ev in zip(subs, evs):
+                pgl.ops.aggregate(x, c, "sum", r1 - r0, out=agg[r0:r1])
+                if two_streams:
+                    ev.record(main)
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        torch._addmm_activation(b, agg[r0:r1], w, out=out[r0:r1])
+                else:
+                    torch._addmm_activation(b, agg[r0:r1], w, out=out[r0:r1])
+            if two_streams:
+                main.wait_stream(side)
+        ref = torch.relu(g.send_recv(x, "sum") @ w + b)
+        blocked(True); torch.cuda.synchronize()
+        err = float((out - ref).abs().max() / ref.abs().max())
+        print("  aggregate || GEMM in %2d row blocks: two streams %.3f ms, one stream %.3f ms (unblocked: aggregate + GEMM = %.3f ms; max rel diff %.1e)"
+              % (K, _t(lambda: blocked(True)), _t(lambda: blocked(False)), _t(lambda: torch._addmm_activation(b, g.send_recv(x, "sum"), w)), err), flush=True)
     # the symmetric norm as per-edge weights in CSR order (w_e = norm[src] norm[dst]): no prescale pass, no per-destination scale
     class _NoEid(object):
         pass
@@ -553,6 +613,7 @@ def main():
     r.add_argument("--push", default="never", choices=["never", "auto"], help="never = the product default (pull everywhere)")
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     r.add_argument("--graph", default="rmat", choices=["rmat", "community"])
+    r.add_argument("--flow", default="", choices=["", "split", "fold", "accumulate", "pipeline"], help="force one flow (PGLAMD_FLOW) instead of the cost model's")
     sub.add_parser("noreuse")
     sub.add_parser("gcn")
     tr = sub.add_parser("traffic")

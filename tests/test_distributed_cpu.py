@@ -161,6 +161,51 @@ def test_flow_mode_follows_the_graph():
 
 
 # ------------------------------------------------------------------------------------------------
+# column-pipelined flow: the rows travel in two column blocks (two all-to-all-v per step), agreed on by all ranks
+# ------------------------------------------------------------------------------------------------
+def _pipe_worker(rank, world, push, wire, forced):
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph(d=128)
+    dg = DistGraph.from_global(torch.from_numpy(edges), x.shape[0], rank, world, method="random", backend=TorchBackend(), push=push)
+    dg.wire_dtype = wire
+    if not forced:
+        dg._LINK, dg._LAT, dg._LAUNCH = 1.0e3, 0.0, 0.0   # a slow link without fixed costs: every estimate favours hiding it, the
+        #                                                    agreement (one all-reduce of the ranks' estimates) must say pipeline
+    x_own = dg.take_owned(torch.from_numpy(x))
+    xg = x_own.clone().requires_grad_(True)
+    out = dg.send_recv(xg, "mean")
+    (out * out).sum().backward()
+    res = {"sum": dg.send_recv(x_own, "sum").numpy(), "mean": out.detach().numpy(), "grad": xg.grad.numpy(),
+           "flow": dg.stats()["flow"], "flow_t": dg._idx.get(("ran", "x", True))}
+    return (rank, dg.plan.own_global.numpy(), res)
+
+
+@pytest.mark.parametrize("world,push,wire,forced", [(2, "never", None, True), (3, "auto", None, True), (2, "never", torch.float16, True),
+                                                    (3, "never", None, False)])
+def test_gloo_column_pipelined_flow(monkeypatch, world, push, wire, forced):
+    """PGLAMD_FLOW=pipeline (or the ranks' own agreement, last case): forward, mean scaling and the gradients equal the single graph's,
+    and every rank ran the same flow (a rank on its own would deadlock the second all-to-all-v)."""
+    if forced:
+        monkeypatch.setenv("PGLAMD_FLOW", "pipeline")
+    got = _spawn(_pipe_worker, world, push, wire, forced)
+    edges, x = _graph(d=128)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    src, dst = torch.from_numpy(edges[:, 0]), torch.from_numpy(edges[:, 1])
+    s = torch.zeros_like(xt).index_add(0, dst, xt[src])
+    m = s / torch.bincount(dst, minlength=x.shape[0]).clamp(min=1).reshape(-1, 1)
+    (m * m).sum().backward()
+    want = {"sum": s.detach().numpy(), "mean": m.detach().numpy(), "grad": xt.grad.numpy()}
+    tol = 1e-5 if wire is None else 4e-3
+    for key, w in want.items():
+        full = np.full_like(w, np.nan)
+        for _, own, res in got:
+            full[own] = res[key]
+        assert np.isfinite(full).all(), key
+        assert np.abs(full - w).max() <= tol * np.abs(w).max(), key
+    assert [g[2]["flow"] for g in got] == ["pipeline"] * world and [g[2]["flow_t"] for g in got] == ["pipeline"] * world
+
+
+# ------------------------------------------------------------------------------------------------
 # 16-bit wire for fp32 features: same flow, the halo rows travel as fp16 / bf16
 # ------------------------------------------------------------------------------------------------
 def _wire_worker(rank, world, wire):

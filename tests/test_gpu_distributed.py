@@ -227,9 +227,10 @@ def _api_worker(rank, world, method):
     return st
 
 
-@pytest.mark.parametrize("world,method,flow", [(2, "kway", ""), (3, "random", ""), (2, "metis", "split"), (3, "random", "fold"), (2, "kway", "accumulate")])
+@pytest.mark.parametrize("world,method,flow", [(2, "kway", ""), (3, "random", ""), (2, "metis", "split"), (3, "random", "fold"), (2, "kway", "accumulate"),
+                                              (2, "kway", "pipeline"), (3, "random", "pipeline")])
 def test_distgraph_every_method_forward_backward_vs_single_gpu(world, method, flow, monkeypatch):
-    """... on the HIP kernels, with the flow mode the cost model picks ("") and with each of the three forced (PGLAMD_FLOW)."""
+    """... on the HIP kernels, with the flow mode the cost model picks ("") and with each one forced (PGLAMD_FLOW; "pipeline" takes effect for sum / mean of fp32 rows)."""
     if flow:
         monkeypatch.setenv("PGLAMD_FLOW", flow)
     stats = _spawn(_api_worker, world, method)

@@ -159,6 +159,44 @@ def test_wire_cast_gather(pgl, wire):
     assert torch.equal(pgl.ops.gather_rows_cast(odd, None, wire), odd.to(wire))
 
 
+@pytest.mark.parametrize("dtype,d,op", [(torch.float32, 128, "sum"), (torch.float32, 64, "sum"), (torch.float32, 32, "max"),
+                                         (torch.float16, 128, "sum"), (torch.float64, 32, "min"), (torch.int32, 16, "sum")])
+def test_column_block_aggregation_reads_and_writes_in_place(pgl, dtype, d, op):
+    """pglamd_aggregate_ext's ldx / ldout: a launch over the column block m[:, a:b] of wider row-major matrices equals the launch over
+    a dense copy of the block, bit for bit, for every kernel family (flat, grouped, lane-per-edge), with split rows (fix-up
+    path), in overwrite and accumulate mode -- and the columns outside the block are not touched."""
+    rng = np.random.default_rng(11)
+    n_src, n_rows, e, D = 900, 500, 40000, 2 * d + 16
+    rows = rng.integers(0, n_rows, e); rows[:7000] = 23                       # a row longer than any chunk
+    cols = rng.integers(0, n_src, e)
+    if dtype.is_floating_point:
+        m, o = torch.randn(n_src, D, device="cuda").to(dtype), torch.randn(n_rows, D, device="cuda").to(dtype)
+    else:
+        m, o = torch.randint(-50, 50, (n_src, D), device="cuda", dtype=dtype), torch.randint(-50, 50, (n_rows, D), device="cuda", dtype=dtype)
+    c = pgl.ops.csr_build(dev(rows.astype(np.int64)), dev(cols.astype(np.int64)), n_rows, want_i64=False)
+    for a in (0, 16, d + 16):
+        xv = m[:, a:a + d]
+        want = pgl.ops.aggregate(xv.contiguous(), c, op, n_rows)
+        assert torch.equal(pgl.ops.aggregate(xv, c, op, n_rows), want)       # strided source, dense result
+        for acc in (0, 1, 2):
+            got_m, ref = o.clone(), o.clone()
+            ov = got_m[:, a:a + d]
+            block = ref[:, a:a + d].contiguous()
+            pgl.ops.aggregate(xv.contiguous(), c, op, n_rows, out=block, accumulate=acc)
+            ref[:, a:a + d] = block
+            pgl.ops.aggregate(xv, c, op, n_rows, out=ov, accumulate=acc)     # strided source AND strided result
+            assert torch.equal(got_m, ref), (a, acc)
+
+
+def test_column_block_wire_pack(pgl):
+    m = torch.randn(1000, 160, device="cuda")
+    idx = torch.randint(0, 1000, (377,), device="cuda", dtype=torch.int32)
+    for a, b in ((0, 64), (64, 160), (4, 11)):
+        for wire in (torch.float32, torch.float16, torch.bfloat16):
+            got = pgl.ops.gather_rows_cast(m[:, a:b], idx, wire)
+            assert got.is_contiguous() and torch.equal(got, m[idx.long(), a:b].to(wire))
+
+
 def test_single_write_partitioned_flow_on_one_gpu(pgl):
     """DistGraph's interior / boundary launches (no process group: the exchanged rows are handed over by the test) reproduce
     the single-graph result for every reduce op, with and without the folded single launch, and with the 16-bit wire."""
