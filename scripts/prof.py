@@ -162,8 +162,14 @@ def cmd_rows(args):
                 pre = _t(lambda: B.aggregate(x_own, dg._index("loc"), "sum", plan.n_own), it=10, warm=2)
                 nm = "inwx0c%d" if args.wire else "inx0c%d"
                 in0, in1 = dg._buf[nm % 0], dg._buf[nm % h]
-                po0 = _t(lambda: B.aggregate(in0, dg._index("xrecv"), "sum", plan.n_own, out=out[:, :h], accumulate=1), it=10, warm=2)
-                po1 = _t(lambda: B.aggregate(in1, dg._index("xrecv"), "sum", plan.n_own, out=out[:, h:], accumulate=1), it=10, warm=2)
+                if args.wire:                                     # 16-bit wire: the unpack (cast back to fp32) belongs to the work after the wait
+                    w0, w1 = dg._buf["inx0c%d" % 0], dg._buf["inx0c%d" % h]
+                    un0 = lambda: B.gather_rows_cast(w0, None, torch.float32, in0)
+                    un1 = lambda: B.gather_rows_cast(w1, None, torch.float32, in1)
+                else:
+                    un0 = un1 = lambda: None
+                po0 = _t(lambda: (un0(), B.aggregate(in0, dg._index("xrecv"), "sum", plan.n_own, out=out[:, :h], accumulate=1)), it=10, warm=2)
+                po1 = _t(lambda: (un1(), B.aggregate(in1, dg._index("xrecv"), "sum", plan.n_own, out=out[:, h:], accumulate=1)), it=10, warm=2)
                 pk, post = pk0 + pk1, po0 + po1
                 e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
                 t_a = pk0 + xch * h / d
@@ -184,7 +190,8 @@ def cmd_rows(args):
                     e_pre, e_post = 0, dg._index("xall").num_edges
                 else:
                     pre = _t(lambda: B.aggregate(x_own, dg._index("loc"), "sum", plan.n_own), it=10, warm=2)
-                    post = _t(lambda: B.aggregate(in_buf, dg._index("xrecv"), "sum", plan.n_own, out=out, accumulate=1), it=10, warm=2)
+                    un = (lambda: B.gather_rows_cast(dg._buf["inx0"], None, torch.float32, in_buf)) if args.wire else (lambda: None)
+                    post = _t(lambda: (un(), B.aggregate(in_buf, dg._index("xrecv"), "sum", plan.n_own, out=out, accumulate=1)), it=10, warm=2)
                     e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
                 pred = pk + max(pre, xch) + post
             ideal = plan.local_edges / (E / t1)
