@@ -435,25 +435,29 @@ def _tall_wgrad(g, x):
 
 
 class _AggregateDense(torch.autograd.Function):
-    """out = act( (dst_scale * A x) @ W^T + b ) in one kernel (ops.aggregate_dense).  `weight` is nn.Linear's [d_out, d_in].
-    Backward (fp32, same kernels): dZ = d out masked by the activation; d b = column sums of dZ; d W = dZ^T agg (the kept
-    aggregate, split-reduction GEMM); d x = A^T (dst_scale * (dZ W)) = (A^T (dst_scale * dZ)) W by linearity -- the SAME fused
-    kernel on the transposed index with W as the layer, when its width allows, else aggregate-then-GEMM."""
+    """out = act( (dst_scale * A (src_scale * x)) @ W^T + b ) in one kernel (ops.aggregate_dense).  `weight` is nn.Linear's
+    [d_out, d_in]; the scales carry no gradient.  Backward (fp32, same kernels): dZ = d out masked by the activation; d b = column
+    sums of dZ; d W = dZ^T agg (the kept aggregate, split-reduction GEMM); d x = src_scale * A^T (dst_scale * (dZ W))
+    = src_scale * ((A^T (dst_scale * dZ)) W) -- row scaling commutes with the right-multiplication -- i.e. the SAME fused kernel on the
+    transposed index with W as the layer and src_scale as ITS per-row scale (no element pass of its own), when the width allows,
+    else aggregate-then-GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, csr, csr_t, act, dst_scale, reduce_op):
+    def forward(ctx, x, weight, bias, csr, csr_t, act, src_scale, dst_scale, reduce_op):
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
-        out, agg = ops.aggregate_dense(x, csr, weight.t(), bias, act, reduce_op, dst_scale, keep_agg=need_w)
+        xs = x if src_scale is None else x * src_scale.reshape(-1, 1)
+        out, agg = ops.aggregate_dense(xs, csr, weight.t(), bias, act, reduce_op, dst_scale, keep_agg=need_w)
         ctx.csr_t, ctx.act, ctx.reduce_op, ctx.csr = csr_t, act, reduce_op, csr
         ctx.has_bias = bias is not None
         ctx.n_x = int(x.shape[0])
-        ctx.save_for_backward(weight, out if act == "relu" else x.new_zeros(0), agg if agg is not None else x.new_zeros(0),
-                              dst_scale if dst_scale is not None else x.new_zeros(0))
+        none = x.new_zeros(0)
+        ctx.save_for_backward(weight, out if act == "relu" else none, agg if agg is not None else none,
+                              dst_scale if dst_scale is not None else none, src_scale if src_scale is not None else none)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        weight, out, agg, ds = ctx.saved_tensors
+        weight, out, agg, ds, ss = ctx.saved_tensors
         g = g.contiguous()
         dz = g * (out > 0).to(g.dtype) if ctx.act == "relu" else g
         gw = gb = gx = None
@@ -468,18 +472,20 @@ class _AggregateDense(torch.autograd.Function):
                 scale = inv if scale is None else scale * inv
             dzs = dz if scale is None else dz * scale.reshape(-1, 1)
             csr_t = ctx.csr_t()
+            back = ss if ss.numel() else None
             if ops.aggregate_dense_supported(dzs, weight.shape[1]):
-                gx = ops.aggregate_dense(dzs, csr_t, weight, None, None, "sum", None, out_size=ctx.n_x)[0]
+                gx = ops.aggregate_dense(dzs, csr_t, weight, None, None, "sum", back, out_size=ctx.n_x)[0]
             else:
-                gx = ops.aggregate(dzs, csr_t, "sum", ctx.n_x) @ weight
-        return gx, gw, gb, None, None, None, None, None
+                gx = ops.aggregate(dzs, csr_t, "sum", ctx.n_x, dst_scale=back) @ weight
+        return gx, gw, gb, None, None, None, None, None, None
 
 
-def aggregate_dense(x, weight, bias, csr, csr_t, act=None, dst_scale=None, reduce_op="sum"):
-    """x [N, d_in] fp32 (already source-scaled), weight [d_out, d_in] (nn.Linear layout), bias [d_out] or None."""
+def aggregate_dense(x, weight, bias, csr, csr_t, act=None, dst_scale=None, reduce_op="sum", src_scale=None):
+    """x [N, d_in] fp32, weight [d_out, d_in] (nn.Linear layout), bias [d_out] or None; src_scale / dst_scale one value per node."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
-        return _AggregateDense.apply(x, weight, bias, csr, csr_t, act, dst_scale, reduce_op)
-    return ops.aggregate_dense(x, csr, weight.t(), bias, act, reduce_op, dst_scale)[0]
+        return _AggregateDense.apply(x, weight, bias, csr, csr_t, act, src_scale, dst_scale, reduce_op)
+    xs = x if src_scale is None else x * src_scale.reshape(-1, 1)
+    return ops.aggregate_dense(xs, csr, weight.t(), bias, act, reduce_op, dst_scale)[0]
 
 
 class _DualLinear(torch.autograd.Function):

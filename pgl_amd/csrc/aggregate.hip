@@ -26,6 +26,7 @@
 //   * Logical blocks are remapped so consecutive chunks (consecutive destination rows) run on
 //     the same XCD: partition-ordered graphs then reuse source rows in that XCD's private L2.
 #include "aggregate_flat.hpp"
+#include "aggregate_dense2.hpp"
 
 namespace pglamd {
 
@@ -258,6 +259,7 @@ static int32_t launch_dense(AggParams p, hipStream_t st) {
         PGLAMD_LAUNCH_CHECK();
         hipLaunchKernelGGL((agg_fixup_kernel<float, VEC, 1, 0, true>), dim3((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks)), dim3(kFixWaves * kWave), 0, st, p);
         PGLAMD_LAUNCH_CHECK();
+        return launch_dense_hub<VEC>(p, st);
     }
     return PGLAMD_OK;
 }
@@ -286,10 +288,18 @@ extern "C" int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const in
     // packed weight at the head of the workspace, the aggregation's own partial buffers behind it
     float* wp = static_cast<float*>(workspace);
     const size_t wp_bytes = align_up((size_t)d_in * (size_t)d_out * 4, 256);
+    // two forms (aggregate_dense2.hpp says why): the specialised workgroup (W resident in LDS, a matrix wave) where W fits,
+    // the per-wave tiles of the flat kernel (SINK = 1) otherwise.  PGLAMD_DENSE_FORM=1 | 2 forces one (A/B runs).
+    static const int form_env = [] { const char* e = getenv("PGLAMD_DENSE_FORM"); return e ? atoi(e) : 0; }();
+    const bool form2 = form_env != 1 && dense2_covers(d_in, d_out) && reinterpret_cast<uintptr_t>(w) % 16 == 0;
+    if (form_env == 2 && !form2) return fail(PGLAMD_E_SHAPE, "aggregate_dense: form 2 needs d_in * d_out * 4 + ring <= 80 KB");
     {
-        const int64_t total = (d_out / 16) * (d_in / 4) * kWave;
-        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, kBlock), 1024)), dim3(kBlock), 0, st, w, (int)d_in, (int)d_out, wp);
-        PGLAMD_LAUNCH_CHECK();
+        const int64_t total = form2 ? d_in * d_out : (d_out / 16) * (d_in / 4) * kWave;
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(total, kBlock), 1024);
+        if (!form2) {                                         // (form 2 packs W while it stages it into LDS)
+            hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(kBlock), 0, st, w, (int)d_in, (int)d_out, wp);
+            PGLAMD_LAUNCH_CHECK();
+        }
     }
     char* ws = static_cast<char*>(workspace) + wp_bytes;
     AggParams p{};
@@ -310,6 +320,7 @@ extern "C" int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const in
     p.long_list = p.long_count + 64;
     p.long_list2 = reinterpret_cast<int*>(ws + 2 * half + lst);
     if (num_edges == 0) p.n_chunks = 0;                      // only the empty-row roles run
+    if (form2) return d_in == 128 ? launch_dense2<2>(p, st) : launch_dense2<1>(p, st);
     return d_in == 128 ? launch_dense<2>(p, st) : launch_dense<1>(p, st);
 }
 

@@ -589,25 +589,17 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
         if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
         if constexpr (std::is_same_v<T, float> && NT == 1 && RCLS == 0) {
             if (p.w) {
-                // dense sink (SINK == 1 of the flat kernel): a split (hub) row gets its layer output as one matrix-vector
-                // product -- there are a few thousand such rows at most, each worth >= a chunk of edges
-                __shared__ float fix_row[LONG ? 1 : kWavesPerBlock][kWave * VEC];
-                float* fr = fix_row[LONG ? 0 : wib];
-                const int d_in = p.tile_cols;
+                // dense sink (aggregate -> dense layer in one launch): the finished, scaled hub row goes back into the row's own
+                // tail-partial slot (nobody reads T[a] after this task); dense_hub_kernel multiplies all such rows by the layer's
+                // weight 16 at a time on the matrix cores afterwards.  (As a matrix-vector product per row right here it cost
+                // 0.19 ms at C2 -- one dependent L2 load per k-step -- as much as the whole matrix work of the launch.)
+                float* slot = static_cast<float*>(p.part_tail) + (int64_t)a * p.tile_cols;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float v = (float)acc[0][k];
                     if (p.is_mean) v = v / (float)(re - rs);
                     if (p.dst_scale) v = v * ds;
-                    if (act[0]) { fr[j0[0] + k] = v; if (p.out) dst[j0[0] + k] = v; }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (int cj = lane; cj < p.dout2; cj += kWave) {
-                    float yv = p.bias ? p.bias[cj] : 0.f;
-                    for (int k = 0; k < d_in; ++k) yv += fr[k] * p.w[(int64_t)k * p.dout2 + cj];
-                    if (p.act) yv = yv > 0.f ? yv : 0.f;
-                    p.out2[(int64_t)r * p.dout2 + cj] = yv;
+                    if (act[0]) { slot[j0[0] + k] = v; if (p.out) dst[j0[0] + k] = v; }
                 }
                 __builtin_amdgcn_wave_barrier();
                 continue;

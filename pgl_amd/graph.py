@@ -523,10 +523,9 @@ class Graph(object):
         feature [N, 64 | 128], weight [d_out, d_in] (nn.Linear layout); differentiable in feature, weight and bias."""
         if not self._is_tensor:
             raise ValueError("You must call Graph.tensor()")
-        if src_scale is not None:                                  # one pass over [N, d]: cheaper than a random 4-byte read per edge
-            feature = feature * src_scale.reshape(-1, 1).to(feature.dtype)
-        ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()
-        return ag.aggregate_dense(feature.contiguous(), weight, bias, self._csr_dst(), self._csr_src, act, ds, reduce_op)
+        ss = None if src_scale is None else src_scale.reshape(-1).to(feature.dtype).contiguous()   # (applied as one pass over [N, d]:
+        ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()                     #  cheaper than a 4-byte read per edge)
+        return ag.aggregate_dense(feature.contiguous(), weight, bias, self._csr_dst(), self._csr_src, act, ds, reduce_op, ss)
 
     def propagate_step(self, feature, dst_scale, residual=None, residual_scale=0.0):
         """residual_scale * residual + dst_scale (.) (sum over in-edges of feature[src]) in one launch (engine extension

@@ -144,10 +144,11 @@ class GCNConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(output_size))
         self.norm = norm
         self.activation = _act(activation)
-        # True: aggregate -> W -> bias -> relu in ONE kernel (Graph.send_recv_dense / pglamd_aggregate_dense: finished rows go from
-        # the aggregation's registers through an LDS tile into the matrix cores).  Parity-green and measured SLOWER than the separate
-        # kernels in its first form (C2: 1.75 ms vs 1.14 + 0.36), so it is opt-in until it wins.
-        self.fused_dense = False
+        # True: aggregate -> W -> bias -> relu in ONE launch (Graph.send_recv_dense / pglamd_aggregate_dense: producer waves hand
+        # finished rows through an LDS ring to matrix waves that hold W in LDS).  Measured at C2,
+        # 128 -> 128: forward 1.49 vs 1.64 ms, forward + backward 3.67 vs 3.97 ms.  False: aggregate, then the GEMM with bias and
+        # activation in its epilogue (what every other shape takes anyway).
+        self.fused_dense = True
 
     def forward(self, graph, feature, norm=None):
         if self.norm and norm is None:

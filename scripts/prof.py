@@ -307,6 +307,17 @@ def cmd_gcn(args):
     csr = g._csr_dst()
     print("  ops.aggregate_dense alone           %.3f ms (inference: no aggregate kept)   %.3f ms (aggregate kept)"
           % (_t(lambda: pgl.ops.aggregate_dense(x, csr, w, None, "relu")), _t(lambda: pgl.ops.aggregate_dense(x, csr, w, None, "relu", keep_agg=True))))
+    def kernel_only(fn, n=20):
+        fn(); torch.cuda.synchronize()
+        pgl.ops.profile_begin()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        ms, launches = pgl.ops.profile_end()
+        return ms / max(launches, 1), pgl.ops.profile_last_kernel()
+    k1, n1 = kernel_only(lambda: g.send_recv(x, "sum"))
+    k2, n2 = kernel_only(lambda: pgl.ops.aggregate_dense(x, csr, w, None, "relu"))
+    print("  main kernel alone (HIP events inside the library): %s %.3f ms | %s %.3f ms" % (n1, k1, n2, k2))
     print("  x @ w (hipBLASLt)                   %.3f ms" % _t(lambda: x @ w))
     b = torch.randn(d, generator=gen, device=dev)
     try:

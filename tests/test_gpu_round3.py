@@ -342,6 +342,59 @@ def test_aggregate_dense_equals_aggregate_then_linear(pgl, d_in, d_out, op, act)
     assert none is None and float((out2.double() - want2).abs().max()) <= 2e-6 * scale + 1e-6
 
 
+@pytest.mark.parametrize("shape", ["one edge per row", "tiny", "no edges", "stars"])
+def test_aggregate_dense_ring_protocol_shapes(pgl, shape):
+    """The specialised-workgroup form (aggregate_dense2.hpp): graphs that stress its hand-over of rows -- 64 rows per 64 edges (the
+    matrix waves are the bottleneck and the ring runs full), fewer chunks than resident workgroups, no edge at all (every row is
+    act(bias)), and a few rows that own all the edges (everything goes through the split-row fix-up)."""
+    rng = np.random.default_rng(1)
+    d_in, d_out = 128, 128
+    if shape == "one edge per row":
+        n = 300_000
+        edges = np.stack([rng.integers(0, n, n), rng.permutation(n)], 1).astype(np.int64)
+    elif shape == "tiny":
+        n = 50
+        edges = np.stack([rng.integers(0, n, 120), rng.integers(0, n, 120)], 1).astype(np.int64)
+    elif shape == "no edges":
+        n = 1000
+        edges = np.zeros((0, 2), np.int64)
+    else:
+        n = 5000
+        edges = np.stack([rng.integers(0, n, 200_000), rng.integers(0, 3, 200_000)], 1).astype(np.int64)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, d_in)).astype(np.float32))
+    w = dev((rng.standard_normal((d_in, d_out)) / np.sqrt(d_in)).astype(np.float32))
+    b = dev(rng.standard_normal(d_out).astype(np.float32))
+    csr = g._csr_dst()
+    for _ in range(3):                                                        # (repeated: a protocol race would not repeat its result)
+        out, agg = pgl.ops.aggregate_dense(x, csr, w, b, "relu", "sum", None, keep_agg=True)
+        want_agg = pgl.ops.aggregate(x, csr, "sum", n)
+        want = (want_agg.double() @ w.double() + b.double()).clamp(min=0)
+        assert torch.equal(agg, want_agg)
+        assert float((out.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
+
+
+def test_aggregate_dense_first_form_still_agrees(pgl):
+    """PGLAMD_DENSE_FORM=1 (per-wave tiles of the flat kernel; what shapes whose weight does not fit in LDS take) in a process of
+    its own -- the form is chosen once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, pgl_amd as pgl\n"
+        "rng = np.random.default_rng(0); n, e = 3000, 50000\n"
+        "edges = np.stack([rng.integers(0, n, e), rng.integers(0, n - 100, e)], 1).astype(np.int64); edges[:9000, 1] = 7\n"
+        "g = pgl.Graph(edges=edges, num_nodes=n).tensor()\n"
+        "x = torch.randn(n, 128, device='cuda'); w = torch.randn(128, 128, device='cuda') / 11.3; b = torch.randn(128, device='cuda')\n"
+        "out, agg = pgl.ops.aggregate_dense(x, g._csr_dst(), w, b, 'relu', 'sum', None, keep_agg=True)\n"
+        "want = (pgl.ops.aggregate(x, g._csr_dst(), 'sum', n).double() @ w.double() + b.double()).clamp(min=0)\n"
+        "assert float((out.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6\n"
+        "print('form1 ok')\n")
+    env = dict(os.environ, PGLAMD_DENSE_FORM="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "form1 ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_aggregate_dense_gradients_and_gcnconv(pgl):
     """GCNConv through the fused kernel == GCNConv through separate kernels (round-2 path): outputs and all gradients; and the
     reference-produced layer fixtures keep passing through it (tests/test_golden_layers.py runs GCNConv as built)."""
