@@ -180,12 +180,17 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
  * send_recv(sum) -> linear -> + bias -> activation, pgl/nn/conv.py:242-254, when input_size <= output_size):
  *     agg[r, :] = dst_scale[r] * REDUCE_{p : row[p]==r} x[col[p], :]            (SUM or MEAN, F32, d_in = 64 or 128)
  *     out[r, :] = act( agg[r, :] @ w + bias )                                    (w [d_in, d_out] row-major, d_out % 16 == 0)
- * The flat aggregation kernel parks every finished row in a 16-row LDS tile and multiplies full tiles by w with
- * v_mfma_f32_16x16x4_f32 (fp32 inputs, fp32 accumulation -- the reference's arithmetic up to re-association); only `out`
- * is written.  The [n_rows, d_in] intermediate never travels through HBM, and the matrix cores run in the shadow of the row
- * gathers.  agg_out (optional): the aggregated rows are ALSO stored (training: the weight gradient is agg^T @ d out).
- * act: 0 none, 1 relu.  Rows without edges get act(bias).  Rows longer than a chunk go through the split-row fix-up, which
- * applies the layer to them as a matrix-vector product.  Deterministic.  Workspace (8-byte aligned):
+ * Two forms behind this entry (pgl_amd/csrc/aggregate_dense2.hpp says why):
+ *   - where w fits in LDS (d_in * d_out * 4 + ring <= 80 KB): persistent workgroups of 8 producer waves + 4 matrix waves; the
+ *     producers walk the edges and hand finished rows through a ring in LDS to the matrix waves, which hold w in LDS for the
+ *     life of the workgroup and multiply 16 rows at a time with v_mfma_f32_16x16x4_f32;
+ *   - otherwise: every wave of the flat aggregation kernel parks its finished rows in a 16-row LDS tile of its own and
+ *     multiplies it by w (B operand from memory).
+ * fp32 inputs, fp32 accumulation -- the reference's arithmetic up to re-association; only `out` is written: the [n_rows, d_in]
+ * intermediate never travels through HBM, and the matrix cores run in the shadow of the row gathers.
+ * agg_out (optional): the aggregated rows are ALSO stored (training: the weight gradient is agg^T @ d out).
+ * act: 0 none, 1 relu.  Rows without edges get act(bias).  Rows longer than a chunk go through the split-row fix-up and get the
+ * layer from a small MFMA kernel afterwards.  Deterministic.  w 16-byte aligned for the first form.  Workspace (8-byte aligned):
  * pglamd_aggregate_dense_workspace_bytes. */
 size_t pglamd_aggregate_dense_workspace_bytes(int64_t num_edges, int64_t d_in, int64_t d_out);
 int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const int32_t* row, const int32_t* col,
