@@ -459,12 +459,18 @@ class _AggregateDense(torch.autograd.Function):
     def backward(ctx, g):
         weight, out, agg, ds, ss = ctx.saved_tensors
         g = g.contiguous()
-        dz = g * (out > 0).to(g.dtype) if ctx.act == "relu" else g
         gw = gb = gx = None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.act == "relu" and ops.row_epilogue_supported(g, int(g.shape[1])):
+            # relu mask and the bias gradient's column sums in ONE pass over [N, d] (compare + multiply + sum as three torch
+            # kernels: 0.45 ms at C2)
+            dz, gb = ops.row_epilogue_backward(g, out, None, "relu", False, want_bias=want_b)
+        else:
+            dz = g * (out > 0).to(g.dtype) if ctx.act == "relu" else g
+            if want_b:
+                gb = dz.sum(0)
         if ctx.needs_input_grad[1]:
             gw = _tall_wgrad(dz, agg)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = dz.sum(0)
         if ctx.needs_input_grad[0]:
             scale = ds if ds.numel() else None
             if ctx.reduce_op == "mean":
