@@ -43,24 +43,34 @@ inline bool dense2_covers(int64_t d_in, int64_t d_out) {
     return (d_in == 64 || d_in == 128) && d_out % 16 == 0 && d_out > 0 && dense2_lds_bytes((int)d_in, (int)d_out) <= 80 * 1024;
 }
 
-// wp2[((ct * KK/4 + k4) * 64 + lane) * 4 + j] = w[(4 (4 k4 + j) + lane / 16) * d_out + ct * 16 + lane % 16]
-__global__ __launch_bounds__(kBlock) void pack_weight2_kernel(const float* __restrict__ w, int d_in, int d_out, float* __restrict__ wp) {
-    const int K4 = d_in / 16;
-    const int64_t total = (int64_t)(d_out / 16) * K4 * kWave * 4;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int j = (int)(i & 3);
-        const int lane = (int)((i >> 2) % kWave);
-        const int64_t t = (i >> 2) / kWave;
-        const int k4 = (int)(t % K4), ct = (int)(t / K4);
-        wp[i] = w[(int64_t)(4 * (4 * k4 + j) + lane / 16) * d_out + ct * 16 + (lane & 15)];
-    }
-}
-
 // rows without any edge: aggregate 0, layer output act(bias)
 __global__ __launch_bounds__(kBlock) void dense_empty_rows_kernel(AggParams p) {
     const int lane = threadIdx.x & (kWave - 1);
     if (p.out) zero_empty_rows_role<float>(p, (int64_t)blockIdx.x, lane);
     dense_empty_rows_role(p, (int64_t)blockIdx.x, lane);
+}
+
+// One step of the empty-row work inside the fused kernel: rows [64 step, 64 step + 64); those without any edge get act(bias)
+// (and a zero aggregate where the caller keeps it).
+template <int VEC>
+__device__ __forceinline__ void d2_empty_rows_step(const AggParams& p, int step, int lane) {
+    using V = VecT<float, VEC>;
+    const int64_t r0 = (int64_t)step * kWave, r = r0 + lane;
+    bool empty = false;
+    if (r < p.out_rows) empty = r >= p.n_csr_rows || p.zero_indptr[r] == p.zero_indptr[r + 1];
+    unsigned long long m = __ballot(empty);
+    float* keep = static_cast<float*>(p.out);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        float* dst = p.out2 + (r0 + l) * (int64_t)p.dout2;
+        for (int j = lane; j < p.dout2; j += kWave) {
+            float v = p.bias ? p.bias[j] : 0.f;
+            if (p.act) v = v > 0.f ? v : 0.f;
+            dst[j] = v;
+        }
+        if (keep) *reinterpret_cast<V*>(keep + (r0 + l) * p.ldo + lane * VEC) = V{};
+    }
 }
 
 template <int VEC>
@@ -89,7 +99,11 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
     const int per_xcd = (p.n_chunks + kXcds - 1) / kXcds;
     const int x_base = xcd * per_xcd;
     const int x_lim = x_base + per_xcd < p.n_chunks ? x_base + per_xcd : p.n_chunks;
-    if (x_base >= x_lim) return;
+    if (x_base >= x_lim) {                              // (fewer chunks than XCDs: this workgroup only has its share of the empty rows)
+        if (wave == kD2Cons - 1)
+            for (int st = (int)blockIdx.x; st < (int)((p.out_rows + kWave - 1) / kWave); st += (int)gridDim.x) d2_empty_rows_step<VEC>(p, st, lane);
+        return;
+    }
     {
         // W -> LDS in MFMA B-operand order, straight from the layer's row-major [d_in, d_out] weight (coalesced 16-byte reads,
         // scattered LDS writes):   wl[((ct * KK/4 + k4) * 64 + l) * 4 + j] = w[(4 (4 k4 + j) + l / 16) * d_out + ct * 16 + l % 16]
@@ -123,25 +137,7 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
         const int n_steps = (int)((p.out_rows + kWave - 1) / kWave);
         const int z_stride = (int)gridDim.x;
         int zstep = wave == kD2Cons - 1 ? (int)blockIdx.x : n_steps;   // ONE matrix wave per workgroup owns them
-        float* __restrict__ keep = static_cast<float*>(p.out);
-        auto empty_step = [&]() {
-            const int64_t r0 = (int64_t)zstep * kWave, r = r0 + lane;
-            zstep += z_stride;
-            bool empty = false;
-            if (r < p.out_rows) empty = r >= p.n_csr_rows || p.zero_indptr[r] == p.zero_indptr[r + 1];
-            unsigned long long m = __ballot(empty);
-            while (m) {
-                const int l = __builtin_ctzll(m);
-                m &= m - 1;
-                float* dst = out2 + (r0 + l) * (int64_t)dout;
-                for (int j = lane; j < dout; j += kWave) {
-                    float v = bias ? bias[j] : 0.f;
-                    if (relu) v = v > 0.f ? v : 0.f;
-                    dst[j] = v;
-                }
-                if (keep) *reinterpret_cast<V*>(keep + (r0 + l) * p.ldo + lane * VEC) = V{};
-            }
-        };
+        auto empty_step = [&]() { d2_empty_rows_step<VEC>(p, zstep, lane); zstep += z_stride; };
         // the same wave keeps the workgroup's queue of chunk batches two ahead of the producers' claims
         int* xcd_ctr = p.long_count + 8 + xcd;                 // zeroed by the launcher
         int published = 0;

@@ -342,10 +342,10 @@ def test_aggregate_dense_equals_aggregate_then_linear(pgl, d_in, d_out, op, act)
     assert none is None and float((out2.double() - want2).abs().max()) <= 2e-6 * scale + 1e-6
 
 
-@pytest.mark.parametrize("shape", ["one edge per row", "tiny", "no edges", "stars"])
+@pytest.mark.parametrize("shape", ["one edge per row", "tiny", "few chunks", "no edges", "stars"])
 def test_aggregate_dense_ring_protocol_shapes(pgl, shape):
     """The specialised-workgroup form (aggregate_dense2.hpp): graphs that stress its hand-over of rows -- 64 rows per 64 edges (the
-    matrix waves are the bottleneck and the ring runs full), fewer chunks than resident workgroups, no edge at all (every row is
+    matrix waves are the bottleneck and the ring runs full), fewer chunks than resident workgroups (and than XCDs), no edge at all (every row is
     act(bias)), and a few rows that own all the edges (everything goes through the split-row fix-up)."""
     rng = np.random.default_rng(1)
     d_in, d_out = 128, 128
@@ -355,6 +355,9 @@ def test_aggregate_dense_ring_protocol_shapes(pgl, shape):
     elif shape == "tiny":
         n = 50
         edges = np.stack([rng.integers(0, n, 120), rng.integers(0, n, 120)], 1).astype(np.int64)
+    elif shape == "few chunks":                       # fewer chunks than XCDs: most workgroups only have empty rows to write
+        n = 20000
+        edges = np.stack([rng.integers(0, n, 900), rng.integers(0, n, 900)], 1).astype(np.int64)
     elif shape == "no edges":
         n = 1000
         edges = np.zeros((0, 2), np.int64)
