@@ -389,7 +389,8 @@ int32_t pglamd_scatter_rows(const void* x, int64_t d, int32_t elem_bytes, const 
 
 /* K6w  row gather with a dtype change -- the wire pack / unpack of the halo exchange (16-bit wire for fp32 features):
  *   out[i, :] = cast(x[index[i], :]),  index int32 [n_index] or NULL (identity: a row-wise conversion of n_index rows).
- *   (x_dtype, out_dtype): F32 -> F16 | BF16 | F32, F16 | BF16 -> F32.  Stands where the reference would paddle.gather + cast.
+ *   (x_dtype, out_dtype): F32 -> F16 | BF16 | F32, F16 | BF16 -> F32, F16 -> F16, BF16 -> BF16 (a plain pack of a column block).
+ *   Stands where the reference would paddle.gather + cast.
  *   ldx: row stride of x in elements (0 = d): packs a column block of a wider matrix; out is dense [n_index, d]. */
 int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64_t d, int64_t ldx, const int32_t* index,
                                 int64_t n_index, void* out, int32_t out_dtype, void* stream);

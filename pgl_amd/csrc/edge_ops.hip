@@ -357,7 +357,9 @@ extern "C" int32_t pglamd_gather_rows_cast(const void* x, int32_t x_dtype, int64
     if (x_dtype == PGLAMD_F16 && out_dtype == PGLAMD_F32) return gather_cast<__half, float>(x, d, ldx, index, n_index, out, st);
     if (x_dtype == PGLAMD_BF16 && out_dtype == PGLAMD_F32) return gather_cast<__hip_bfloat16, float>(x, d, ldx, index, n_index, out, st);
     if (x_dtype == PGLAMD_F32 && out_dtype == PGLAMD_F32) return gather_cast<float, float>(x, d, ldx, index, n_index, out, st);
-    return fail(PGLAMD_E_DTYPE, "gather_rows_cast: F32 <-> F16 / BF16 only (got %d -> %d)", x_dtype, out_dtype);
+    if (x_dtype == PGLAMD_F16 && out_dtype == PGLAMD_F16) return gather_cast<__half, __half>(x, d, ldx, index, n_index, out, st);
+    if (x_dtype == PGLAMD_BF16 && out_dtype == PGLAMD_BF16) return gather_cast<__hip_bfloat16, __hip_bfloat16>(x, d, ldx, index, n_index, out, st);
+    return fail(PGLAMD_E_DTYPE, "gather_rows_cast: F32 <-> F16 / BF16, or the same 16- / 32-bit float type (got %d -> %d)", x_dtype, out_dtype);
 }
 
 extern "C" int32_t pglamd_scatter_rows(const void* x, int64_t d, int32_t elem_bytes, const void* index, int32_t index_i64,

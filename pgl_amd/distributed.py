@@ -901,9 +901,9 @@ class DistGraph(object):
         """True when this aggregation travels in two column blocks (two all-to-all-v per step instead of one).  Every rank must
         take the same answer, so it is agreed ONCE per (plan, direction, row width): each rank puts up its own estimate of the best
         single-exchange flow and of the pipelined one, the maxima over ranks are compared (the slowest rank sets the step).
-        Eligible: sum / mean of fp32 [n_own, d] rows, d a multiple of 32 (both blocks keep 64-byte alignment).
+        Eligible: sum / mean of fp32 / fp16 / bf16 [n_own, d] rows, d a multiple of 32 (both blocks stay at least 32-byte aligned).
         PGLAMD_FLOW=pipeline forces it where eligible, any other PGLAMD_FLOW value rules it out."""
-        if not (additive and x.dim() == 2 and x.dtype == torch.float32 and int(x.shape[1]) % 32 == 0):
+        if not (additive and x.dim() == 2 and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and int(x.shape[1]) % 32 == 0):
             return False
         forced = os.environ.get("PGLAMD_FLOW", "")
         if forced or os.environ.get("PGLAMD_FOLD_INTERIOR"):

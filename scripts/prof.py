@@ -329,7 +329,7 @@ def cmd_gcn(args):
     # really share the CUs
     class _Sub(object):
         pass
-    for K in (2, 4, 8, 16):
+    for K in (2, 8):
         cut = [0]
         for k in range(1, K):
             cut.append(int(torch.searchsorted(csr.indptr, torch.tensor(E * k // K, device=dev)).item()))

@@ -195,6 +195,10 @@ def test_column_block_wire_pack(pgl):
         for wire in (torch.float32, torch.float16, torch.bfloat16):
             got = pgl.ops.gather_rows_cast(m[:, a:b], idx, wire)
             assert got.is_contiguous() and torch.equal(got, m[idx.long(), a:b].to(wire))
+    for dt in (torch.float16, torch.bfloat16):                                 # 16-bit feature storage: a plain pack of the block
+        mh = m.to(dt)
+        for a, b in ((0, 64), (64, 160), (8, 24)):
+            assert torch.equal(pgl.ops.gather_rows_cast(mh[:, a:b], idx, dt), mh[idx.long(), a:b])
 
 
 def test_single_write_partitioned_flow_on_one_gpu(pgl):
