@@ -59,18 +59,18 @@ PY
       ( cd /tmp && export TMPDIR=/tmp
         for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
           N=$(echo $C | tr ' ' '_')
-          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc_gat_$N -o p -- python $R/scripts/prof.py gat > /dev/null 2>&1
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/gatpmc_$N -o p -- python $R/scripts/prof.py gat > /dev/null 2>&1
         done
         python - <<PY > $F
 import csv, glob, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 dur = collections.defaultdict(lambda: [0.0, 0])
-for f in glob.glob("$O/pmc_gat_*/**/*counter_collection.csv", recursive=True):
+for f in glob.glob("$O/gatpmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "")
         if "gat_" in n:
             k = (n.split("(")[0][-60:], r.get("Grid_Size"), r.get("Counter_Name")); agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
-for f in glob.glob("$O/pmc_gat_FETCH_SIZE/**/*kernel_trace.csv", recursive=True):
+for f in glob.glob("$O/gatpmc_FETCH_SIZE/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "")
         if "gat_" in n:
@@ -79,7 +79,7 @@ print("C3: RMAT-20, 20 M edges, 8 heads x 16; counters per launch (FETCH_SIZE / 
 for k, (s, c) in sorted(agg.items()): print("%-62s grid %-9s %-24s avg %.4g (n=%d)" % (k[0], k[1], k[2], s / c, c))
 for k, (s, c) in sorted(dur.items()): print("%-62s grid %-9s duration under the counter pass avg %.1f us (n=%d)" % (k[0], k[1], s / c, c))
 PY
-        rm -rf $O/pmc_gat_* )
+        rm -rf $O/gatpmc_* )
       cat $F | cut -c1-200 ;;
     noreuse_vec4)  PGLAMD_VEC=4 timeout 600 python scripts/prof.py noreuse > $F 2>&1; grep "uniform\|our GPU\|<- ours" $F ;;
     variants)
