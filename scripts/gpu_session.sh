@@ -54,6 +54,15 @@ for k, (s, c) in sorted(agg.items()): print("%-78s grid %-9s %-24s avg %.4g (n=%
 PY
         rm -rf $O/pmc_dt_* )
       cat $F | cut -c1-200 ;;
+    sampled)
+      # mini-batch GraphSAGE on device-sampled blocks (examples/train_graphsage_sampled.py --sampler gpu): kernel trace of two epochs --
+      # which kernels a step is made of, and that no library sort is among them (blocks come out of the sampler grouped by destination)
+      ( cd /tmp && export TMPDIR=/tmp
+        rocprofv3 --kernel-trace --stats --output-format csv -d $O/sampled_tmp -o t -- python $R/examples/train_graphsage_sampled.py --sampler gpu --epochs 2 > $F.run 2>&1
+        S=$(find $O/sampled_tmp -name "*kernel_stats.csv" | head -1)
+        { tail -4 $F.run; echo; echo "kernels by total time (rocprofv3 --kernel-trace --stats):"; head -25 $S | cut -c1-220; echo; echo "library sort kernels in the trace: $(grep -c -i "rocprim.*radix\|onesweep\|merge_sort" $S)"; } > $F
+        rm -rf $O/sampled_tmp )
+      cat $F | cut -c1-200 ;;
     pmc_gat)
       # the fused GAT kernels at C3 (forward, backward walk, pack): bytes fetched / written and 128-byte lines per launch
       ( cd /tmp && export TMPDIR=/tmp
