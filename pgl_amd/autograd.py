@@ -420,6 +420,20 @@ def row_epilogue(z, bias=None, act=None, normalize=False):
     return ops.row_epilogue(z, bias, act, normalize)[0]
 
 
+def column_sum(g):
+    """g.sum(0) for [N, C] with N in the millions (bias gradients): two stages, [S, N / S, C] -> [S, C] -> [C].  The stock one-stage
+    reduction picks 64 workgroups for a narrow odd C and takes 6.9 ms at N = 2^20, C = 41 (1.5 % of what the pass should cost);
+    in two stages every stage has thousands of independent outputs."""
+    n = g.shape[0]
+    if g.dim() != 2 or n < 65536:
+        return g.sum(0)
+    g = g.contiguous()
+    split = 1024
+    m = n // split * split
+    out = g[:m].view(split, m // split, -1).sum(1).sum(0)
+    return out if m == n else out + g[m:].sum(0)
+
+
 def _tall_wgrad(g, x):
     """g^T x for [N, out] / [N, in] with N in the millions: the reduction over N split into 256 batched slabs (bmm -> sum); the
     stock GEMM runs the whole reduction serially per output tile (1.9 ms vs 0.33 ms at N = 2^20, 128 x 128)."""
@@ -468,7 +482,7 @@ class _AggregateDense(torch.autograd.Function):
         else:
             dz = g * (out > 0).to(g.dtype) if ctx.act == "relu" else g
             if want_b:
-                gb = dz.sum(0)
+                gb = column_sum(dz)
         if ctx.needs_input_grad[1]:
             gw = _tall_wgrad(dz, agg)
         if ctx.needs_input_grad[0]:

@@ -50,7 +50,7 @@ class _TallLinearFn(torch.autograd.Function):
             if m < n:
                 gw = gw + g[m:].t() @ x[m:]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(0)
+            gb = ag.column_sum(g)
         return gx, gw, gb
 
 
@@ -71,7 +71,7 @@ class _LinearReLUFn(torch.autograd.Function):
         dz = g * (y > 0).to(g.dtype)
         gx = dz @ weight if ctx.needs_input_grad[0] else None
         gw = ag._tall_wgrad(dz, x) if ctx.needs_input_grad[1] else None
-        gb = dz.sum(0) if ctx.needs_input_grad[2] else None
+        gb = ag.column_sum(dz) if ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
 

@@ -513,6 +513,74 @@ def cmd_train(args):
             print("%-9s fused=%-5s %.3f ms / training step (fwd+bwd incl. d/dx)" % (which, fused, ms), flush=True)
 
 
+def cmd_model(args):
+    """One full training step (forward, cross-entropy at every node, backward, Adam) of the reference examples' models at C2 size:
+    examples/gcn/train.py's GCN (2 x GCNConv(relu) + Linear), examples/gat/train.py's GAT (2 x GATConv, 8 heads), and the
+    GraphSage of examples/graphsage (2 x GraphSageConv(mean) + Linear), hidden 128, 41 classes.  Run under
+    `gpu_session.sh trace:"model gcn"` for the per-kernel picture of a whole step."""
+    import torch
+    import torch.nn.functional as F
+    sys.path.insert(0, os.path.join(ROOT, "pgl_amd", "compat"))          # `import paddle` as the reference's examples do
+    import paddle.nn as pnn
+    import paddle.nn.functional as PF
+    pgl, dev, g = _c2()
+    N, d, hid, ncls = g.num_nodes, 128, 128, 41
+    head = {"Linear": pnn.Linear, "loss": PF.cross_entropy}
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, d, generator=gen, device=dev)
+    y = torch.randint(0, ncls, (N,), generator=gen, device=dev)
+
+    class GCN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convs = torch.nn.ModuleList([pgl.nn.GCNConv(d, hid, activation="relu"), pgl.nn.GCNConv(hid, hid, activation="relu")])
+            self.out = head["Linear"](hid, ncls)
+
+        def forward(self, g, h):
+            norm = pgl.nn.functional.degree_norm(g)
+            for c in self.convs:
+                h = c(g, h, norm)
+            return self.out(h)
+
+    class SAGE(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convs = torch.nn.ModuleList([pgl.nn.GraphSageConv(d, hid, "mean"), pgl.nn.GraphSageConv(hid, hid, "mean")])
+            self.out = head["Linear"](hid, ncls)
+
+        def forward(self, g, h):
+            for c in self.convs:
+                h = c(g, h, act="relu")
+            return self.out(h)
+
+    class GAT(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = pgl.nn.GATConv(d, 16, feat_drop=0.0, attn_drop=0.0, num_heads=8, activation="elu")
+            self.c2 = pgl.nn.GATConv(128, ncls, feat_drop=0.0, attn_drop=0.0, num_heads=1, concat=False)
+
+        def forward(self, g, h):
+            return self.c2(g, self.c1(g, h))
+    for which in (args.which or ["gcn", "sage", "gat"]):
+        for name, lin, lossf in (("engine's Linear + gathered cross-entropy (pgl_amd/compat/paddle)", pnn.Linear, PF.cross_entropy),
+                                 ("torch.nn.Linear + torch cross_entropy", torch.nn.Linear, F.cross_entropy)):
+            if which == "gat" and lin is torch.nn.Linear:
+                continue                                              # (no classifier head in that model)
+            head["Linear"], head["loss"] = lin, lossf
+            model = {"gcn": GCN, "sage": SAGE, "gat": GAT}[which]().to(dev)
+            opt = torch.optim.Adam(model.parameters(), lr=0.01)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss = head["loss"](model(g, x), y)
+                loss.backward()
+                opt.step()
+            with torch.no_grad():
+                inf = _t(lambda: model(g, x), 5, 2)
+            print("%-5s 2 layers, hidden 128, 41 classes at C2, head = %s: inference %.3f ms, training step (loss + backward + Adam) %.3f ms"
+                  % (which, name, inf, _t(step, 5, 2)), flush=True)
+
+
 def cmd_gat(args):
     """The GAT attention path at C3 (H = 8, D = 16): fused forward, fused forward + backward (with / without attention dropout),
     and the reference-style four-op composition on the same engine."""
@@ -642,6 +710,7 @@ def main():
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
+    mo = sub.add_parser("model"); mo.add_argument("which", nargs="*")
     sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
     va = sub.add_parser("variant"); va.add_argument("name"); va.add_argument("defines", nargs="*")
     tc = sub.add_parser("trace"); tc.add_argument("csv"); tc.add_argument("filter", nargs="?", default="")
@@ -650,8 +719,8 @@ def main():
         cmd_diag(args)
     elif args.cmd == "rows":
         cmd_rows(args)
-    elif args.cmd in ("ops", "layers", "train", "gat", "dtypes", "variant", "trace", "gatsplit"):
-        {"gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
+    elif args.cmd in ("ops", "layers", "train", "model", "gat", "dtypes", "variant", "trace", "gatsplit"):
+        {"model": cmd_model, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
          "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
