@@ -434,6 +434,31 @@ def test_aggregate_dense_gradients_and_gcnconv(pgl):
             layer.fused_dense = False
 
 
+@pytest.mark.parametrize("heads,dim,concat", [(1, 41, False), (8, 7, False), (3, 5, True)])
+def test_gatconv_odd_head_dimensions_take_the_fused_kernel(pgl, heads, dim, concat):
+    """A head dimension the fused GAT kernel does not take as it is (the classifier layer of examples/gat/train.py: D = num_class) is
+    zero-padded into it; outputs and every gradient equal the reference's four-op composition on the same engine."""
+    torch.manual_seed(2)
+    rng = np.random.default_rng(4)
+    n, e, d = 3000, 40000, 64
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    edges[rng.choice(e, 6000, replace=False), 1] = 13
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    layer = pgl.nn.GATConv(d, dim, feat_drop=0.0, attn_drop=0.0, num_heads=heads, concat=concat).cuda()
+    res = {}
+    for fused in (True, False):
+        layer.fused = fused
+        layer.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = layer(g, xi)
+        (y * torch.linspace(0.5, 1.5, y.shape[1], device="cuda")).sum().backward()
+        res[fused] = [y.detach(), xi.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    assert res[True][0].shape == (n, heads * dim if concat else dim)
+    for a, b_ in zip(res[True], res[False]):
+        assert float((a - b_).abs().max()) <= 5e-5 * float(b_.abs().max()) + 1e-6
+
+
 def test_c2_aggregate_dense_per_element(pgl):
     """BASELINE configs[1] size: the fused GCN layer output, every element within the fp32 re-association bound of the fp64 result
     (sum over a row's edges AND over the 128 products of the dense layer)."""
