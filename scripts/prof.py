@@ -581,6 +581,55 @@ def cmd_model(args):
                   % (which, name, inf, _t(step, 5, 2)), flush=True)
 
 
+def cmd_distmodel(args):
+    """One rank's share of a row-partitioned 2-layer GCN training step (the example model of `model`, on DistGraph): rank 0 of an
+    8-way partition of the C2 graph (or --scale / --edges), no process group -- every kernel of the rank runs on its real sizes,
+    only the all-to-all-v itself is absent.  Run under `gpu_session.sh trace:"distmodel"` for the per-kernel picture."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "pgl_amd", "compat"))
+    import paddle.nn as pnn
+    import paddle.nn.functional as PF
+    import pgl_amd as pgl
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    scale, E, P, d, hid, ncls = args.scale, args.edges, 8, 128, 128, 41
+    N = 1 << scale
+    edges = rmat_edges(scale, E, seed=42, device=dev)
+    path = os.path.join(ROOT, "scratch", "parts", "rmat%d_e%d_p%d_kway.npy" % (scale, E, P))
+    part = torch.from_numpy(np.load(path).astype(np.int64)) if os.path.exists(path) else DistGraph.partition(edges, N, P, "kway", rank=0)
+    dg = DistGraph(HaloPlan(edges, N, part, args.rank, P), device=dev)
+    del edges
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(dg.plan.n_own, d, generator=gen, device=dev)
+    y = torch.randint(0, ncls, (dg.plan.n_own,), generator=gen, device=dev)
+
+    class GCN(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convs = torch.nn.ModuleList([pgl.nn.GCNConv(d, hid, activation="relu"), pgl.nn.GCNConv(hid, hid, activation="relu")])
+            self.out = pnn.Linear(hid, ncls)
+
+        def forward(self, g, h):
+            norm = pgl.nn.functional.degree_norm(g)
+            for c in self.convs:
+                h = c(g, h, norm)
+            return self.out(h)
+    model = GCN().to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        PF.cross_entropy(model(dg, x), y).backward()
+        opt.step()
+    with torch.no_grad():
+        inf = _t(lambda: model(dg, x), 5, 2)
+    st = dg.stats()
+    print("rank %d of %d, RMAT scale %d, %d edges: %d rows, %d local edges, flow %s: 2-layer GCN inference %.3f ms, training step %.3f ms; send_recv(sum) alone %.3f ms"
+          % (args.rank, P, scale, E, st["local_rows"], st["local_edges"], dg.stats()["flow"], inf, _t(step, 5, 2), _t(lambda: dg.send_recv(x, "sum"), 5, 2)))
+
+
 def cmd_gat(args):
     """The GAT attention path at C3 (H = 8, D = 16): fused forward, fused forward + backward (with / without attention dropout),
     and the reference-style four-op composition on the same engine."""
@@ -711,6 +760,8 @@ def main():
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
     mo = sub.add_parser("model"); mo.add_argument("which", nargs="*")
+    dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
+    dm.add_argument("--rank", type=int, default=0)
     sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
     va = sub.add_parser("variant"); va.add_argument("name"); va.add_argument("defines", nargs="*")
     tc = sub.add_parser("trace"); tc.add_argument("csv"); tc.add_argument("filter", nargs="?", default="")
@@ -719,8 +770,8 @@ def main():
         cmd_diag(args)
     elif args.cmd == "rows":
         cmd_rows(args)
-    elif args.cmd in ("ops", "layers", "train", "model", "gat", "dtypes", "variant", "trace", "gatsplit"):
-        {"model": cmd_model, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
+    elif args.cmd in ("ops", "layers", "train", "model", "distmodel", "gat", "dtypes", "variant", "trace", "gatsplit"):
+        {"model": cmd_model, "distmodel": cmd_distmodel, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
          "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
