@@ -40,7 +40,7 @@ class Net(torch.nn.Module):
             self.convs = torch.nn.ModuleList([pgl.nn.GATConv(din, hidden // 8, 0.0, 0.0, 8, activation="elu"),
                                               pgl.nn.GATConv(hidden, hidden // 8, 0.0, 0.0, 8, activation="elu")])
         self.kind = kind
-        self.out = torch.nn.Linear(hidden, classes)
+        self.out = pgl.nn.Linear(hidden, classes)            # (split-reduction weight / bias gradients: the rank's rows are many)
 
     def forward(self, g, x):
         for conv in self.convs:
@@ -95,7 +95,7 @@ def main():
     for epoch in range(args.epochs):
         torch.cuda.synchronize(); t0 = time.time()
         logits = model(dg, x)
-        loss = F.cross_entropy(logits[train], y[train], reduction="sum") / n_train          # global mean over all ranks' train nodes
+        loss = pgl.nn.functional.cross_entropy(logits[train], y[train], reduction="sum") / n_train          # global mean over all ranks' train nodes
         opt.zero_grad(set_to_none=True)
         loss.backward()
         if world > 1:                                                                      # data-parallel parameters: sum of the ranks' gradients

@@ -100,6 +100,18 @@ def _linear(n_in, n_out, bias=True):
     return lin
 
 
+class Linear(_Linear):
+    """A dense layer for heads on top of the graph layers (engine extension; the reference's examples say paddle.nn.Linear, which
+    pgl_amd/compat/paddle maps to the same class): torch.nn.Linear's parameters and values, Paddle's initialisation (Xavier-uniform
+    weight, zero bias), and weight / bias gradients computed in split reductions when the input has millions of rows."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super(Linear, self).__init__(int(in_features), int(out_features), bias=bias)
+        nn.init.xavier_uniform_(self.weight)
+        if bias:
+            nn.init.zeros_(self.bias)
+
+
 class GraphSageConv(nn.Module):
     """pgl/nn/conv.py:46-115."""
 

@@ -334,3 +334,40 @@ def test_engine_partitioner_degenerate_inputs():
     assert np.bincount(p, minlength=7).max() <= 1.1 * 5000 / 7 + 1
     with pytest.raises((OverflowError, ValueError)):
         P(np.array([[0, 5]]), 3, 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# classifier-head pieces (pgl_amd.nn.Linear / nn.functional.cross_entropy, behind compat paddle.nn.Linear / cross_entropy)
+# ------------------------------------------------------------------------------------------------
+def test_engine_cross_entropy_and_linear_equal_torch():
+    """Same values and gradients as torch.nn.functional.cross_entropy / torch.nn.Linear: what changes is how the gradients of
+    inputs with millions of rows are reduced (split reductions instead of one 64-workgroup pass)."""
+    import torch
+    import torch.nn.functional as F
+    import pgl_amd as pgl
+    from pgl_amd import autograd as ag
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3000, 41, generator=g, requires_grad=True)
+    y = torch.randint(0, 41, (3000,), generator=g)
+    y[::7] = -100
+    for red in ("mean", "sum", "none"):
+        a = pgl.nn.functional.cross_entropy(x, y, reduction=red)
+        b = F.cross_entropy(x, y, reduction=red, ignore_index=-100)
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), red
+        ga, = torch.autograd.grad(a.sum(), x)
+        gb, = torch.autograd.grad(b.sum(), x)
+        assert torch.allclose(ga, gb, rtol=1e-5, atol=1e-7), red
+    big = torch.randn(70001, 24, generator=g)
+    assert torch.allclose(ag.column_sum(big), big.sum(0), rtol=1e-4, atol=1e-3)
+    torch.manual_seed(1)
+    lin = pgl.nn.Linear(24, 5)
+    ref = torch.nn.Linear(24, 5)
+    ref.load_state_dict(lin.state_dict())
+    xin = big.clone().requires_grad_(True)
+    xref = big.clone().requires_grad_(True)
+    cot = torch.randn(70001, 5, generator=g)
+    (lin(xin) * cot).sum().backward()
+    (ref(xref) * cot).sum().backward()
+    assert torch.allclose(xin.grad, xref.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-2)
+    assert torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-2)
