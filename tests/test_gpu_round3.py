@@ -381,6 +381,30 @@ def test_aggregate_dense_ring_protocol_shapes(pgl, shape):
         assert float((out.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
 
 
+def test_aggregate_dense_soak(pgl):
+    """Sixty random graphs (a few hundred to a few hundred thousand edges, power-law-ish destinations, random widths) through the
+    specialised-workgroup kernel: the hand-over of rows between producer and matrix waves is timing dependent, so it is exercised on
+    many shapes, twice each, against aggregate-then-matmul."""
+    rng = np.random.default_rng(2024)
+    for it in range(60):
+        n = int(rng.integers(50, 60000))
+        e = int(rng.integers(100, 300000))
+        d_in = int(rng.choice([64, 128]))
+        d_out = int(rng.choice([16, 48, 64, 128]))
+        dst = (rng.random(e) ** int(rng.integers(1, 5)) * n).astype(np.int64)          # exponent 1: uniform; 4: a few heavy rows
+        edges = np.stack([rng.integers(0, n, e), np.minimum(dst, n - 1)], 1).astype(np.int64)
+        g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+        x = dev(rng.standard_normal((n, d_in)).astype(np.float32))
+        w = dev((rng.standard_normal((d_in, d_out)) / np.sqrt(d_in)).astype(np.float32))
+        b = dev(rng.standard_normal(d_out).astype(np.float32))
+        csr = g._csr_dst()
+        want = (pgl.ops.aggregate(x, csr, "sum", n).double() @ w.double() + b.double()).clamp(min=0)
+        tol = 2e-6 * float(want.abs().max()) + 1e-6
+        for _ in range(2):
+            out, _agg = pgl.ops.aggregate_dense(x, csr, w, b, "relu", "sum")
+            assert float((out.double() - want).abs().max()) <= tol, (it, n, e, d_in, d_out)
+
+
 def test_aggregate_dense_first_form_still_agrees(pgl):
     """PGLAMD_DENSE_FORM=1 (per-wave tiles of the flat kernel; what shapes whose weight does not fit in LDS take) in a process of
     its own -- the form is chosen once per process."""
