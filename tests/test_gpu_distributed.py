@@ -259,3 +259,46 @@ def test_distributed_full_batch_training_example_matches_one_gpu(model):
                   "--master-port", str(_free_port())], dict(os.environ, PGLAMD_DRYRUN="1"))
     assert one[-1] < one[0]
     np.testing.assert_allclose(two, one, rtol=2e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# the row-partitioned flow on a power-law graph that is not a toy: RMAT scale 18 (262 144 nodes, 4 M edges), d = 128, the engine's own
+# partitioner, every flow the cost model can choose -- owned rows and gradients equal the single-GPU result
+# ------------------------------------------------------------------------------------------------
+def _rmat_flow_worker(rank, world, flow, dtype_name):
+    import pgl_amd as pgl
+    from pgl_amd.distributed import DistGraph
+    from pgl_amd.utils.rmat import rmat_edges
+    if flow:
+        os.environ["PGLAMD_FLOW"] = flow
+    dev = torch.device("cuda:0")
+    scale, e, d = 18, 4_000_000, 128
+    n = 1 << scale
+    edges = rmat_edges(scale, e, seed=42, device=dev)
+    g = pgl.Graph(edges=edges, num_nodes=n)
+    dg = DistGraph.from_global(edges, n, rank, world, method="kway", device=dev)
+    own = dg.plan.own_global
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    dt = {"fp32": torch.float32, "fp16": torch.float16}[dtype_name]
+    x = torch.randn(n, d, generator=gen, device=dev).to(dt)
+    tol = 2e-5 if dt == torch.float32 else 4e-3
+    for op in ("sum", "mean"):
+        with torch.no_grad():
+            _close(dg.send_recv(dg.take_owned(x), op).float(), g.send_recv(x, op)[own].float(), tol, "%s %s forward" % (flow, op))
+    if dt == torch.float32:
+        cot = torch.randn(n, d, generator=gen, device=dev)
+        xf = x.clone().requires_grad_(True)
+        (g.send_recv(xf, "mean") * cot).sum().backward()
+        xo = dg.take_owned(x).requires_grad_(True)
+        (dg.send_recv(xo, "mean") * cot[own]).sum().backward()
+        _close(xo.grad, xf.grad[own], 1e-4, "%s gradient" % flow)
+    return dg.stats()["flow"]
+
+
+@pytest.mark.parametrize("world,flow,dtype_name", [(2, "", "fp32"), (3, "pipeline", "fp32"), (2, "accumulate", "fp32"), (2, "pipeline", "fp16")])
+def test_partitioned_flows_on_rmat18_vs_single_gpu(world, flow, dtype_name):
+    flows = _spawn(_rmat_flow_worker, world, flow, dtype_name)
+    # one exchange per step or two: that the ranks must agree on (how a rank spends a single exchange is its own business)
+    assert len({f == "pipeline" for f in flows}) == 1, flows
+    if flow:
+        assert set(flows) == {flow}, flows
