@@ -761,9 +761,11 @@ class DistGraph(object):
     # ---- the overlapped two-phase flow (forward and, with the indices transposed, backward) --------------------------------
     def _flow(self, x, scale, transposed, reduce="sum", kind="x"):
         """out[v] = scale[v] * REDUCE over ALL in-edges of owned row v (transposed: the gradient of that).  SURVEY 8e steps
-        1-4: pack -> all-to-all-v on the side stream -> INTERIOR rows (every source local) while the rows travel -> wait ->
-        BOUNDARY rows from the two tables [owned | received].  Every output row is written exactly once: by the interior
-        launch (which also zero-fills rows without any edge) or by the boundary launch -- nothing is read-modify-written."""
+        1-4: pack -> all-to-all-v on the side stream -> work that needs no received row while the rows travel -> wait -> the rest.
+        WHAT runs under the exchange is chosen per plan (`_mode`, `_pipelined`): "split" -- INTERIOR rows (every source local)
+        before the wait, BOUNDARY rows from the two tables [owned | received] after it, every output row written exactly once;
+        "fold" -- one launch over all rows after the wait; "accumulate" -- all local-source edges before, the received rows' edges
+        added after; "pipeline" -- accumulate with the rows travelling in two column blocks, block 1 under block 0's edges."""
         p, B = self.plan, self._b
         xp = self.xplan if kind == "x" else p
         tail = tuple(x.shape[1:])
