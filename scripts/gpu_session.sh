@@ -54,6 +54,28 @@ for k, (s, c) in sorted(agg.items()): print("%-78s grid %-9s %-24s avg %.4g (n=%
 PY
         rm -rf $O/pmc_dt_* )
       cat $F | cut -c1-200 ;;
+    pmc_dense)
+      # the fused aggregate -> dense kernel against the aggregation + GEMM it replaces: bytes fetched / written, MFMA and LDS counters
+      ( cd /tmp && export TMPDIR=/tmp
+        rocprofv3 -L 2>/dev/null | grep -o -i -E "\b(SQ_[A-Z0-9_]*MFMA[A-Z0-9_]*|SQ_[A-Z0-9_]*LDS[A-Z0-9_]*)\b" | sort -u | tr '\n' ' ' > $F.counters
+        for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_LDS"; do
+          N=$(echo $C | tr ' ' '_')
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/densepmc_$N -o p -- python $R/scripts/prof.py dense > $F.$N.log 2>&1 || echo "pass $C failed" >> $F.fail
+        done
+        python - <<PY > $F
+import csv, glob, collections
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob("$O/densepmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if "agg_dense2" in n or ("agg_flat_kernel<float, 2, 1, 0, 0" in n and r.get("Grid_Size") == "6049792") or n.startswith("Cijk") or "dense_hub" in n:
+            k = (n.split("(")[0][-52:], r.get("Grid_Size"), r.get("Counter_Name")); agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
+print("C2, d_in = d_out = 128 fp32; counters per launch (FETCH_SIZE / WRITE_SIZE in KB as reported; wide reads count half on gfx950)")
+for k, (s, c) in sorted(agg.items()): print("%-54s grid %-9s %-30s avg %.4g (n=%d)" % (k[0], k[1], k[2], s / c, c))
+print("MFMA / LDS counters this rocprofv3 lists: " + open("$F.counters").read())
+PY
+        cat $F.fail >> $F 2>/dev/null; rm -rf $O/densepmc_* $F.counters $F.*.log $F.fail )
+      cat $F | cut -c1-220 ;;
     sampled)
       # mini-batch GraphSAGE on device-sampled blocks (examples/train_graphsage_sampled.py --sampler gpu): kernel trace of two epochs --
       # which kernels a step is made of, and that no library sort is among them (blocks come out of the sampler grouped by destination)

@@ -513,6 +513,25 @@ def cmd_train(args):
             print("%-9s fused=%-5s %.3f ms / training step (fwd+bwd incl. d/dx)" % (which, fused, ms), flush=True)
 
 
+def cmd_dense(args):
+    """A few launches of the fused aggregate -> dense kernel, of the plain aggregation and of the GEMM it replaces, at C2: the target of
+    the counter passes of `gpu_session.sh pmc_dense` (bytes fetched / written, MFMA and LDS activity per kernel)."""
+    import torch
+    pgl, dev, g = _c2()
+    N, d = g.num_nodes, 128
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, d, generator=gen, device=dev)
+    w = torch.randn(d, d, generator=gen, device=dev) / d ** 0.5
+    b = torch.randn(d, generator=gen, device=dev)
+    csr = g._csr_dst()
+    for _ in range(5):
+        pgl.ops.aggregate_dense(x, csr, w, b, "relu")
+        agg = g.send_recv(x, "sum")
+        torch._addmm_activation(b, agg, w)
+    torch.cuda.synchronize()
+    print("5 x (aggregate_dense | send_recv(sum) + relu(agg @ w + b)) at C2")
+
+
 def cmd_model(args):
     """One full training step (forward, cross-entropy at every node, backward, Adam) of the reference examples' models at C2 size:
     examples/gcn/train.py's GCN (2 x GCNConv(relu) + Linear), examples/gat/train.py's GAT (2 x GATConv, 8 heads), and the
@@ -760,6 +779,7 @@ def main():
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
     mo = sub.add_parser("model"); mo.add_argument("which", nargs="*")
+    sub.add_parser("dense")
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
     dm.add_argument("--rank", type=int, default=0)
     sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
@@ -770,8 +790,8 @@ def main():
         cmd_diag(args)
     elif args.cmd == "rows":
         cmd_rows(args)
-    elif args.cmd in ("ops", "layers", "train", "model", "distmodel", "gat", "dtypes", "variant", "trace", "gatsplit"):
-        {"model": cmd_model, "distmodel": cmd_distmodel, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
+    elif args.cmd in ("ops", "layers", "train", "model", "dense", "distmodel", "gat", "dtypes", "variant", "trace", "gatsplit"):
+        {"model": cmd_model, "dense": cmd_dense, "distmodel": cmd_distmodel, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
          "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
