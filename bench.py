@@ -209,14 +209,14 @@ def target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note, steps=10):
     fn(); fn(); fn()
     t = timed(fn, steps) / steps * 1e3
     t_x = timed(lambda: dg.exchange_only(x_own), 5) / 5 * 1e3
-    st = dg.stats()
+    st = dg.stats()                                              # (after the timed steps: "flow" is the one that ran)
     allp = torch.zeros((world, 3), dtype=torch.float64, device=dev)
     allp[rank, 0], allp[rank, 1], allp[rank, 2] = float(st["recv_rows"]) * d * 4, float(st["local_edges"]), float(st["local_rows"])
     dist.all_reduce(allp)
     rec = {"workload": "RMAT scale %d |V|=%d |E|=%d d=%d fp32 (north_star target size, SURVEY 8d C2'), row partition (%s) x%d"
                        % (scale, N, E, d, st["partition"], world),
            "value": E / (t * 1e-3), "unit": "edges/s", "ms_per_step": t, "steps": steps, "exchange_only_ms": t_x,
-           "partition_and_plan_s": t_plan, "pushed_pairs": st["pushed_pairs"], "recv_bytes_per_rank": allp[:, 0].tolist(),
+           "partition_and_plan_s": t_plan, "pushed_pairs": st["pushed_pairs"], "flow": st["flow"], "recv_bytes_per_rank": allp[:, 0].tolist(),
            "edges_per_rank": allp[:, 1].tolist(), "rows_per_rank": allp[:, 2].tolist()}
     del dg, x_own
     torch.cuda.empty_cache()
@@ -442,7 +442,8 @@ def main():
             allp = torch.zeros((world, 2), dtype=torch.float64, device=dev)
             allp[rank, 0], allp[rank, 1] = float(halo["recv_rows"]) * d * 4, float(halo["send_rows"]) * d * 4
             dist.all_reduce(allp)                                    # (a sum of one-hot rows = an all-gather every backend has)
-            halo.update(exchange_only_ms=t_x, recv_bytes_per_rank=allp[:, 0].tolist(), send_bytes_per_rank=allp[:, 1].tolist())
+            halo.update(exchange_only_ms=t_x, recv_bytes_per_rank=allp[:, 0].tolist(), send_bytes_per_rank=allp[:, 1].tolist(),
+                        flow=dg.stats()["flow"])                     # the flow that RAN (the trials above were steps): DESIGN section 5
         for k in list(built):
             if k != mode:
                 del built[k]

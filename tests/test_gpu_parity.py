@@ -1380,6 +1380,7 @@ def test_bench_multi_rank_code_path_dry_run():
     assert rec["target_size"]["value"] > 0 and len(rec["target_size"]["recv_bytes_per_rank"]) == 2
     assert set(rec["halo"]["alternatives_ms_per_step"]) >= {"rows", "cols"}
     assert rec["halo"]["exchange_only_ms"] > 0 and len(rec["halo"]["recv_bytes_per_rank"]) == 2
+    assert rec["halo"]["flow"] in ("split", "fold", "accumulate", "pipeline") and rec["target_size"]["flow"] in ("split", "fold", "accumulate", "pipeline")
 
 
 @pytest.mark.parametrize("H,D", [(4, 8), (8, 16), (1, 64), (3, 4)])
