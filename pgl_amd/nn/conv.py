@@ -167,10 +167,11 @@ class GCNConv(nn.Module):
             norm = GF.degree_norm(graph)
         if self.input_size > self.output_size:
             feature = self.linear(feature)
-        fuse = norm is not None and feature.dtype == torch.float32 and norm.dtype == torch.float32 \
+        fuse = norm is not None and feature.dtype in (torch.float32, torch.float16, torch.bfloat16) and norm.dtype == torch.float32 \
             and norm.numel() == feature.shape[0] and hasattr(graph, "send_recv_scaled") \
             and not (norm.requires_grad and torch.is_grad_enabled())       # the fused scales carry no gradient
-        dense = fuse and self.fused_dense and self.input_size <= self.output_size and hasattr(graph, "send_recv_dense") \
+        dense = fuse and feature.dtype == torch.float32 and self.fused_dense and self.input_size <= self.output_size \
+            and hasattr(graph, "send_recv_dense") \
             and feature.dim() == 2 and ops.aggregate_dense_supported(feature, self.output_size) \
             and self.linear.weight.dtype == torch.float32 and self.activation in (None, F.relu)
         if dense:
@@ -186,7 +187,7 @@ class GCNConv(nn.Module):
             output = graph.send_recv_scaled(feature, norm, norm)
             if self.input_size <= self.output_size:
                 tall = output.shape[0] >= 65536 and torch.is_grad_enabled()
-                if self.activation is F.relu and self.linear.weight.dtype == torch.float32 and hasattr(torch, "_addmm_activation"):
+                if self.activation is F.relu and self.linear.weight.dtype == output.dtype and hasattr(torch, "_addmm_activation"):
                     # bias + relu in the GEMM's own epilogue: no pass over [N, d] after the GEMM at all (round 3; round 2 ran
                     # them as one row kernel after it: 0.21 ms at C2)
                     return _linear_relu(output, self.linear.weight, self.bias)
@@ -201,6 +202,9 @@ class GCNConv(nn.Module):
                     output = self.activation(output)
                 return output
         else:
+            if norm is not None and norm.dtype != feature.dtype and feature.dtype in (torch.float16, torch.bfloat16):
+                norm = norm.to(feature.dtype)                  # 16-bit feature storage (BASELINE config 4) stays 16-bit: fp32 accumulation
+                #                                                happens inside the aggregation kernel, not by promoting [N, d] tensors
             if norm is not None:
                 feature = feature * norm
             output = graph.send_recv(feature, "sum")
@@ -243,12 +247,18 @@ class GATConv(nn.Module):
             feature = self.feat_dropout(feature)
         feature = self.linear(feature)
         feature = feature.reshape(-1, self.num_heads, self.hidden_size)
+        store_dtype = feature.dtype
+        w_src, w_dst = self.weight_src, self.weight_dst
+        if store_dtype in (torch.float16, torch.bfloat16):
+            # 16-bit layers: the dense projection ran in the storage dtype; scores, softmax and the weighted aggregation (the fused
+            # kernel and the score kernels are fp32) run on an fp32 copy of the projected features, the result goes back to 16 bits
+            feature, w_src, w_dst = feature.float(), w_src.float(), w_dst.float()
         if feature.shape[0] >= 4096:
             # sum_d feat[n,h,d] * w[h,d] for both weight vectors as ONE [N, H*D] x [H*D, 2H] GEMM with block-diagonal
             # weights (one read of the features instead of four element passes over [N, H, D])
             eye = torch.eye(self.num_heads, dtype=feature.dtype, device=feature.device).unsqueeze(1)
-            proj = torch.cat([(self.weight_src.unsqueeze(2) * eye).reshape(-1, self.num_heads),
-                              (self.weight_dst.unsqueeze(2) * eye).reshape(-1, self.num_heads)], dim=1)
+            proj = torch.cat([(w_src.unsqueeze(2) * eye).reshape(-1, self.num_heads),
+                              (w_dst.unsqueeze(2) * eye).reshape(-1, self.num_heads)], dim=1)
             feat2d = feature.reshape(-1, self.num_heads * self.hidden_size)
             # (its weight gradient is again a [H*D, N] x [N, 2H] reduction over N: split-reduction variant)
             att = _TallLinearFn.apply(feat2d, proj.t().contiguous(), None) if (torch.is_grad_enabled() and feat2d.shape[0] >= 65536) \
@@ -256,8 +266,8 @@ class GATConv(nn.Module):
             attn_src = att[:, :self.num_heads].contiguous()
             attn_dst = att[:, self.num_heads:].contiguous()
         else:
-            attn_src = torch.sum(feature * self.weight_src, dim=-1)
-            attn_dst = torch.sum(feature * self.weight_dst, dim=-1)
+            attn_src = torch.sum(feature * w_src, dim=-1)
+            attn_dst = torch.sum(feature * w_dst, dim=-1)
         D = self.hidden_size
         vec = 4 if D % 4 == 0 else 2 if D % 2 == 0 else 1
         fusable = (feature.dtype == torch.float32 and hasattr(graph, "gat_aggregate") and self.fused
@@ -287,7 +297,7 @@ class GATConv(nn.Module):
                 output = torch.mean(output, dim=1)
             if self.activation is not None:
                 output = self.activation(output)
-            return output
+            return output if output.dtype == store_dtype else output.to(store_dtype)
         alpha = graph.send_uv(attn_src, attn_dst, "add")
         alpha = self.leaky_relu(alpha)
         alpha = GF.edge_softmax(graph, alpha)
@@ -301,4 +311,4 @@ class GATConv(nn.Module):
             output = torch.mean(output, dim=1)
         if self.activation is not None:
             output = self.activation(output)
-        return output
+        return output if output.dtype == store_dtype else output.to(store_dtype)
