@@ -302,3 +302,39 @@ def test_partitioned_flows_on_rmat18_vs_single_gpu(world, flow, dtype_name):
     assert len({f == "pipeline" for f in flows}) == 1, flows
     if flow:
         assert set(flows) == {flow}, flows
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 4's shape of use: a 2-layer GCN on fp16 features over a row partition
+# ------------------------------------------------------------------------------------------------
+def _gcn_fp16_worker(rank, world):
+    import pgl_amd as pgl
+    from pgl_amd.distributed import DistGraph
+    dev = torch.device("cuda:0")
+    n, e, d = 6000, 90000, 128
+    edges, rng = _rand_graph(n, e, 77, hub=6000)
+    et = torch.as_tensor(edges, device=dev)
+    g = pgl.Graph(edges=et, num_nodes=n)
+    dg = DistGraph.from_global(et, n, rank, world, method="kway", device=dev)
+    own = dg.plan.own_global
+    x = torch.as_tensor(rng.standard_normal((n, d)).astype(np.float32), device=dev)
+    torch.manual_seed(3)
+    l1, l2 = pgl.nn.GCNConv(d, d, activation="relu").to(dev), pgl.nn.GCNConv(d, 32).to(dev)
+    with torch.no_grad():
+        ref = l2(g, l1(g, x))                                          # fp32, whole graph
+    for dt, tol in ((torch.float16, 6e-3), (torch.bfloat16, 4e-2)):
+        h1, h2 = pgl.nn.GCNConv(d, d, activation="relu").to(dev), pgl.nn.GCNConv(d, 32).to(dev)
+        h1.load_state_dict(l1.state_dict()); h2.load_state_dict(l2.state_dict())
+        h1, h2 = h1.to(dt), h2.to(dt)
+        xo = dg.take_owned(x.to(dt)).requires_grad_(True)
+        out = h2(dg, h1(dg, xo))
+        assert out.dtype == dt
+        _close(out.float(), ref[own], tol, "2-layer GCN on %s features over %d ranks" % (dt, world))
+        out.float().sum().backward()                                   # the transposed flows run in the storage dtype too
+        assert xo.grad is not None and xo.grad.dtype == dt and bool(torch.isfinite(xo.grad.float()).all())
+    return True
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_layer_gcn_on_16bit_features_over_a_row_partition(world):
+    _spawn(_gcn_fp16_worker, world)
