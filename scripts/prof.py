@@ -532,6 +532,65 @@ def cmd_dense(args):
     print("5 x (aggregate_dense | send_recv(sum) + relu(agg @ w + b)) at C2")
 
 
+def cmd_sizes(args):
+    """Size probes for the BASELINE configurations that are parity cases, not bench lines: a products-like whole graph (config 3's
+    graph: 124 M edges, d = 100, mean aggregation) and a papers100M-like share of one rank of eight (config 4: 16.8 M nodes, 200 M
+    edges, fp16 features) -- index build, aggregation rate, one layer, memory."""
+    import time
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    t = _t
+    def c4():
+        dev = torch.device("cuda:0")
+        scale, E, d = 21, 123_718_280, 100
+        N = 1 << scale
+        edges = rmat_edges(scale, E, seed=42, device=dev)
+        g = pgl.Graph(edges=edges, num_nodes=N); g.adj_dst_index; g.adj_src_index
+        del edges
+        gen = torch.Generator(device=dev); gen.manual_seed(7)
+        x = torch.randn(N, d, generator=gen, device=dev)
+        t = _t
+        for op in ("sum", "mean", "max"):
+            ms = t(lambda: g.send_recv(x, op), 5, 2)
+            print("C4-like: RMAT scale %d, %d edges, d = %d fp32: send_recv(%s) %.3f ms = %.2f G edges/s" % (scale, E, d, op, ms, E / ms / 1e6), flush=True)
+        xh = x.half()
+        print("fp16 storage send_recv(mean) %.3f ms" % t(lambda: g.send_recv(xh, "mean"), 5, 2), flush=True)
+        layer = pgl.nn.GraphSageConv(d, 128, "mean").to(dev)
+        with torch.no_grad():
+            print("GraphSageConv(100 -> 128, mean) forward %.3f ms" % t(lambda: layer(g, x, act="relu"), 5, 2), flush=True)
+        xi = x.clone().requires_grad_(True)
+        def step():
+            layer.zero_grad(set_to_none=True); xi.grad = None
+            layer(g, xi, act="relu").sum().backward()
+        print("GraphSageConv(100 -> 128, mean) forward + backward %.3f ms" % t(step, 3, 1), flush=True)
+    def c5():
+        dev = torch.device("cuda:0")
+        scale, E, d = 24, 200_000_000, 128
+        N = 1 << scale
+        t0 = time.time()
+        edges = rmat_edges(scale, E, seed=42, device=dev)
+        torch.cuda.synchronize(); t1 = time.time()
+        g = pgl.Graph(edges=edges, num_nodes=N); g.adj_dst_index
+        torch.cuda.synchronize(); t2 = time.time()
+        del edges
+        print("C5-like per-rank share: RMAT scale %d (%d nodes), %d edges: generate %.2f s, dst index %.3f s, memory in use %.1f GB"
+              % (scale, N, E, t1 - t0, t2 - t1, torch.cuda.memory_allocated() / 1e9), flush=True)
+        gen = torch.Generator(device=dev); gen.manual_seed(7)
+        x = torch.randn(N, d, generator=gen, device=dev, dtype=torch.float16)
+        t = _t
+        for op in ("sum", "mean"):
+            ms = t(lambda: g.send_recv(x, op), 3, 1)
+            print("  fp16 [N, 128] send_recv(%s) %.3f ms = %.2f G edges/s" % (op, ms, E / ms / 1e6), flush=True)
+        torch.manual_seed(0)
+        layer = pgl.nn.GCNConv(d, d, activation="relu").to(dev).half()
+        with torch.no_grad():
+            print("  GCNConv(128 -> 128, relu) fp16 forward %.3f ms; peak memory %.1f GB" % (t(lambda: layer(g, x), 3, 1), torch.cuda.max_memory_allocated() / 1e9), flush=True)
+    c4()
+    torch.cuda.empty_cache()
+    c5()
+
+
 def cmd_model(args):
     """One full training step (forward, cross-entropy at every node, backward, Adam) of the reference examples' models at C2 size:
     examples/gcn/train.py's GCN (2 x GCNConv(relu) + Linear), examples/gat/train.py's GAT (2 x GATConv, 8 heads), and the
@@ -780,6 +839,7 @@ def main():
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
     mo = sub.add_parser("model"); mo.add_argument("which", nargs="*")
     sub.add_parser("dense")
+    sub.add_parser("sizes")
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
     dm.add_argument("--rank", type=int, default=0)
     sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
@@ -790,8 +850,8 @@ def main():
         cmd_diag(args)
     elif args.cmd == "rows":
         cmd_rows(args)
-    elif args.cmd in ("ops", "layers", "train", "model", "dense", "distmodel", "gat", "dtypes", "variant", "trace", "gatsplit"):
-        {"model": cmd_model, "dense": cmd_dense, "distmodel": cmd_distmodel, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
+    elif args.cmd in ("ops", "layers", "train", "model", "dense", "sizes", "distmodel", "gat", "dtypes", "variant", "trace", "gatsplit"):
+        {"model": cmd_model, "dense": cmd_dense, "sizes": cmd_sizes, "distmodel": cmd_distmodel, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
          "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
