@@ -280,15 +280,25 @@ class GATConv(nn.Module):
             Dp = 1
             while Dp < D:
                 Dp *= 2
-            if self.num_heads * Dp <= 256:
-                feature = F.pad(feature, (0, Dp - D))
+            if Dp <= 256:
+                if Dp != D:
+                    feature = F.pad(feature, (0, Dp - D))
                 fusable = True
         if fusable:
             # the four graph ops below as ONE pass over the edges (forward) and two (backward);
             # attention dropout is drawn inside the kernel from (seed, edge id, head)
             p = self.attn_drop if (self.training and self.attn_drop > 1e-15) else 0.0
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
-            output = graph.gat_aggregate(feature, attn_src, attn_dst, 0.2, p, seed)
+            Dk = int(feature.shape[-1])
+            per = max(1, (64 * (4 if Dk % 4 == 0 else 2 if Dk % 2 == 0 else 1)) // Dk)      # heads one launch takes (H * D <= 256)
+            if self.num_heads <= per:
+                output = graph.gat_aggregate(feature, attn_src, attn_dst, 0.2, p, seed)
+            else:
+                # more heads x head_dim than one 64-lane tile holds (8 x 64): heads are independent, so they go through the fused
+                # kernel in groups -- a few [N, h, D] slices copied, against [E, H, D] message tensors in the four-op composition
+                output = torch.cat([graph.gat_aggregate(feature[:, h0:h0 + per].contiguous(), attn_src[:, h0:h0 + per].contiguous(),
+                                                        attn_dst[:, h0:h0 + per].contiguous(), 0.2, p, seed + h0)
+                                    for h0 in range(0, self.num_heads, per)], dim=1)
             if output.shape[-1] != D:
                 output = output[..., :D]
             if self.concat:

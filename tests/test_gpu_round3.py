@@ -458,10 +458,11 @@ def test_aggregate_dense_gradients_and_gcnconv(pgl):
             layer.fused_dense = False
 
 
-@pytest.mark.parametrize("heads,dim,concat", [(1, 41, False), (8, 7, False), (3, 5, True)])
+@pytest.mark.parametrize("heads,dim,concat", [(1, 41, False), (8, 7, False), (3, 5, True), (8, 64, True), (6, 48, False)])
 def test_gatconv_odd_head_dimensions_take_the_fused_kernel(pgl, heads, dim, concat):
     """A head dimension the fused GAT kernel does not take as it is (the classifier layer of examples/gat/train.py: D = num_class) is
-    zero-padded into it; outputs and every gradient equal the reference's four-op composition on the same engine."""
+    zero-padded into it, more heads x head_dim than one launch holds (8 x 64) go through it in groups of heads; outputs and every
+    gradient equal the reference's four-op composition on the same engine."""
     torch.manual_seed(2)
     rng = np.random.default_rng(4)
     n, e, d = 3000, 40000, 64
