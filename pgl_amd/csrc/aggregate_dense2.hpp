@@ -34,7 +34,9 @@ constexpr int kD2Threads = (kD2Prod + kD2Cons) * kWave;
 #define PGLAMD_D2_RING 28
 #endif
 constexpr int kD2Ring = PGLAMD_D2_RING;                          // row slots (>= 16: a tile must fit; 28 keeps the workgroup under 80 KB)
-constexpr int kD2SpinLimit = 1 << 22;                // bound of every LDS wait (~0.3 s): a protocol bug fails a test instead of hanging the GPU
+constexpr int kD2SpinLimit = 1 << 22;                // bound of every LDS wait (~0.3 s of spinning; real waits are microseconds).  A wait that runs into
+                                                     // it is a protocol bug: the wave TRAPS -- the launch fails loudly (hipErrorLaunchFailure at the next
+                                                     // synchronisation) instead of hanging the GPU or returning rows that were never multiplied.
 
 inline size_t dense2_lds_bytes(int d_in, int d_out) {
     return ((size_t)d_in * d_out + (size_t)kD2Ring * (d_in + 4)) * sizeof(float) + (2 * kD2Ring + 12) * sizeof(int);
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
                 }
                 refill();
                 __builtin_amdgcn_s_sleep(PGLAMD_D2_SLEEP);
-                if (++spins > kD2SpinLimit) { n = 0; break; }      // (never in a correct run: a bounded wait cannot hang the GPU)
+                if (++spins > kD2SpinLimit) __builtin_trap();
             }
             if (n <= 0) break;
             // A operand: lane l holds row (l % 16) of the tile, columns 4 kk + l / 16
@@ -194,8 +196,10 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
             // the slots are free again once their contents sit in registers; tiles are released in order (the producers compare
             // their slot number with ONE counter), which only serialises these few LDS reads, not the multiplications
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            for (spins = 0; __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 16 * t && spins < kD2SpinLimit; ++spins)
+            for (spins = 0; __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 16 * t; ++spins) {
+                if (spins > kD2SpinLimit) __builtin_trap();
                 __builtin_amdgcn_s_sleep(1);
+            }
             if (lane == 0) __hip_atomic_store(&ctl[1], 16 * t + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifdef PGLAMD_D2_SKIP_MFMA                       // experiment: the producers alone (tiles are released, nothing is multiplied)
             continue;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
         if (lane == 0) slot = __hip_atomic_fetch_add(&ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         slot = wave_uniform(slot);
         for (int spins = 0; slot - __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= kD2Ring; ++spins) {
-            if (spins > kD2SpinLimit) return;                    // (never in a correct run)
+            if (spins > kD2SpinLimit) __builtin_trap();
             __builtin_amdgcn_s_sleep(1);
         }
         const int pos = slot % kD2Ring;
@@ -336,8 +340,10 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
         int claim_v = 0;
         if (lane == 0) claim_v = __hip_atomic_fetch_add(&ctl[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const int k = wave_uniform(claim_v), bno = k / kD2Prod;
-        for (int spins = 0; __hip_atomic_load(&ctl[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= bno && spins < kD2SpinLimit; ++spins)
+        for (int spins = 0; __hip_atomic_load(&ctl[5], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= bno; ++spins) {
+            if (spins > kD2SpinLimit) __builtin_trap();
             __builtin_amdgcn_s_sleep(1);
+        }
         c = wave_uniform(__hip_atomic_load(&ctl[8 + (bno & 3)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) + k % kD2Prod;
         if (c >= x_lim) break;
         const int e0 = chunk_cut(rowp, ipc, c * p.chunk, p.chunk, p.E);
