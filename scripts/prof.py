@@ -211,6 +211,116 @@ def cmd_rows(args):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def cmd_noreuse(args):
+    """The known-bytes roofline leg (uniform in-degree-19 graph over 2^24 rows, d = 128 fp32: the kernel and graph of
+    bench.py's roofline.frac) run for a few seconds while a sampler thread reads every GPU's clocks / power from sysfs:
+    which card is ours (VRAM jumps), what its sclk / mclk / fclk and power do UNDER this load, and the per-launch time
+    distribution -- the data behind the 29.5 ms / 34.1 ms bimodality across boxes."""
+    import threading
+    import torch
+    import pgl_amd as pgl
+    dev = torch.device("cuda:0")
+
+    def snapshot():
+        out = {}
+        for devdir in sorted(glob.glob("/sys/class/drm/card*/device")):
+            card = devdir.split("/")[4]
+            rec = {}
+            for f in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+                try:
+                    cur = [l for l in open(os.path.join(devdir, f)).read().split("\n") if l.strip().endswith("*")]
+                    rec[f[7:]] = int("".join(ch for ch in cur[0].split(":")[1] if ch.isdigit())) if cur else None
+                except Exception:                                    # noqa: BLE001
+                    rec[f[7:]] = None
+            try:
+                rec["vram_used"] = int(open(os.path.join(devdir, "mem_info_vram_used")).read())
+            except Exception:                                        # noqa: BLE001
+                rec["vram_used"] = None
+            for hw in glob.glob(os.path.join(devdir, "hwmon", "hwmon*")):
+                for tf in glob.glob(os.path.join(hw, "temp*_input")):   # edge / junction / mem (HBM) sensors, by their labels
+                    try:
+                        lab = open(tf.replace("_input", "_label")).read().strip()
+                    except Exception:                                    # noqa: BLE001
+                        lab = os.path.basename(tf)[:5]
+                    try:
+                        rec["t_" + lab] = int(open(tf).read()) / 1e3
+                    except Exception:                                    # noqa: BLE001
+                        pass
+                for f, key, div in (("power1_average", "power_w", 1e6), ("power1_input", "power_w", 1e6), ("temp1_input", "temp_c", 1e3),
+                                    ("power1_cap", "cap_w", 1e6), ("freq1_input", "sclk_mhz", 1e6), ("freq2_input", "mclk_mhz", 1e6)):
+                    try:
+                        rec[key] = int(open(os.path.join(hw, f)).read()) / div
+                    except Exception:                                # noqa: BLE001
+                        pass
+            out[card] = rec
+        return out
+
+    before = snapshot()
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    n, deg, d = 1 << 24, 19, 128
+    src = torch.randint(0, n, (n * deg,), generator=gen, device=dev)
+    dst = torch.arange(n, device=dev).repeat_interleave(deg)
+    g = pgl.Graph(edges=torch.stack([src, dst], 1), num_nodes=n); g.adj_dst_index
+    del src, dst
+    x = torch.randn(n, d, generator=gen, device=dev)
+    for _ in range(3):
+        g.send_recv(x, "sum")
+    torch.cuda.synchronize()
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            samples.append(snapshot())
+            time.sleep(0.1)
+    th = threading.Thread(target=sampler); th.start()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+    for a, b in ev:
+        a.record(); g.send_recv(x, "sum"); b.record()
+    torch.cuda.synchronize()
+    stop.set(); th.join()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    known = n * deg * (d * 4) * (1.0 - (256 + 32) * 2.0 ** 20 / (n * d * 4)) + n * deg * 8 + n * d * 4
+    print("uniform in-degree-19 leg: %d launches, step ms min %.2f / median %.2f / max %.2f -> %.3f of 8 TB/s at the median"
+          % (len(ts), ts[0], ts[len(ts) // 2], ts[-1], known / (ts[len(ts) // 2] * 1e-3) / 1e9 / 8000.0))
+    mine = None
+    try:                                                             # our card = the one at the PCI address HIP reports for device 0
+        pr = torch.cuda.get_device_properties(0)
+        addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        for devdir in glob.glob("/sys/class/drm/card*/device"):
+            if os.path.basename(os.path.realpath(devdir)) == addr:
+                mine = devdir.split("/")[4]
+    except Exception:                                                # noqa: BLE001
+        pass
+    if mine is None:                                                 # fall back: the card whose VRAM use jumped
+        mine = max(before, key=lambda c: (samples[-1][c].get("vram_used") or 0) - (before[c].get("vram_used") or 0))
+    ident = {}
+    for f in ("unique_id", "vbios_version", "device", "revision"):
+        try:
+            ident[f] = open("/sys/class/drm/%s/device/%s" % (mine, f)).read().strip()
+        except Exception:                                            # noqa: BLE001
+            pass
+    try:
+        ident["pci"] = os.path.basename(os.path.realpath("/sys/class/drm/%s/device" % mine))
+    except Exception:                                                # noqa: BLE001
+        pass
+    print("our GPU is %s %s (VRAM %+.1f GB during the run); %d telemetry samples"
+          % (mine, ident, ((samples[-1][mine]["vram_used"] or 0) - (before[mine]["vram_used"] or 0)) / 1e9, len(samples)))
+    for card in sorted(before):
+        if before[card].get("sclk") is None and before[card].get("vram_used") is None:
+            continue                                                 # (connector nodes, not GPUs)
+        vals = lambda k: [s_[card].get(k) for s_ in samples if s_[card].get(k) is not None]
+        line = "  %-7s%s" % (card, " <- ours" if card == mine else "        ")
+        tkeys = sorted({k for s_ in samples for k in s_[card] if k.startswith("t_")})
+        for k in ["sclk", "sclk_mhz", "mclk", "fclk", "power_w", "cap_w"] + tkeys:
+            v = vals(k)
+            if v:
+                line += "  %s %s..%s" % (k, ("%.0f" % min(v)), ("%.0f" % max(v)))
+                if k in ("sclk_mhz", "power_w"):
+                    line += " (mean %.0f)" % (sum(v) / len(v))
+        print(line)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def cmd_traffic(args):
     """Builds traffic.json -- the PMC record bench.py replays as roofline.traffic -- from one profiling session of the DEFAULT
     bench command (scripts/gpu_r03_profile.sh): a --kernel-trace pass (per-grid average durations + the bench line of that very
