@@ -9,16 +9,19 @@
     python scripts/prof.py csr                       CSR build (a1) at C2 / C2' / sampled-block sizes
     python scripts/prof.py gcn                       GCNConv forward / training step through the fused aggregate -> dense kernel and without
     python scripts/prof.py train [gcn sage gat ...]  ms per training step of one layer, fused paths on / off
+    python scripts/prof.py model [gcn sage gat]      the reference examples' MODELS at C2: inference and one whole training step
+    python scripts/prof.py distmodel [--scale ..]    one rank's share of a row-partitioned 2-layer GCN training step (no process group)
+    python scripts/prof.py dense                     a few launches of the fused aggregate -> dense kernel and of what it replaces (counter passes)
+    python scripts/prof.py sizes                     probes at the sizes of BASELINE configs 3 and 4 (products-like, papers100M-like share)
     python scripts/prof.py gat | dtypes              the GAT attention path at C3 / send_recv per storage type
     python scripts/prof.py gatsplit                  lower bound of the "SDDMM + weighted SpMM" split of the GAT backward vs the fused walk
     python scripts/prof.py layers WHICH [train]      a few steps of one layer with nothing around them (the target of rocprofv3 --kernel-trace)
-    python scripts/prof.py traffic --dir D --out F   traffic.json from a profiling session (scripts/gpu_r03_profile.sh)
+    python scripts/prof.py traffic --dir D --out F   traffic.json from a profiling session (scripts/gpu_session.sh TAG profile)
     python scripts/prof.py trace CSV [filter]        per-(kernel, grid) summary of a rocprofv3 kernel trace
     python scripts/prof.py variant NAME [-D macros]  build an experimental libpglamd_NAME.so next to the product library
     python scripts/prof.py noreuse                   the known-bytes roofline leg with clock / power telemetry of every GPU of the box
-    python scripts/prof.py layers ...                per-kernel time of a layer's forward / training step
 
-Each subcommand prints plain text; the GPU session scripts (scripts/gpu_*.sh) redirect it into gpurun_out/, and what is quoted in
+Each subcommand prints plain text; scripts/gpu_session.sh redirects it into gpurun_out/, and what is quoted in
 DESIGN.md is copied to profiles/rNN/.
 """
 import argparse
