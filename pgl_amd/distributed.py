@@ -902,7 +902,8 @@ class DistGraph(object):
     def _pipelined(self, kind, transposed, additive, x, row_bytes):
         """True when this aggregation travels in two column blocks (two all-to-all-v per step instead of one).  Every rank must
         take the same answer, so it is agreed ONCE per (plan, direction, row width): each rank puts up its own estimate of the best
-        single-exchange flow and of the pipelined one, the maxima over ranks are compared (the slowest rank sets the step).
+        single-exchange flow and of the pipelined one, the maxima over ranks are compared (the slowest rank sets the step); the
+        pipelined flow is taken when it is at least 10 % ahead.
         Eligible: sum / mean of fp32 / fp16 / bf16 [n_own, d] rows, d a multiple of 32 (both blocks stay at least 32-byte aligned).
         PGLAMD_FLOW=pipeline forces it where eligible, any other PGLAMD_FLOW value rules it out."""
         if not (additive and x.dim() == 2 and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and int(x.shape[1]) % 32 == 0):
@@ -921,7 +922,7 @@ class DistGraph(object):
                 t = torch.tensor(mine, dtype=torch.float64, device=x.device if on_gpu else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
                 mine = t.tolist()
-            hit = bool(mine[1] < mine[0])
+            hit = bool(mine[1] < 0.9 * mine[0])            # (a second collective per step has to buy at least 10 %)
             self._idx[key] = hit
         return hit
 
