@@ -843,7 +843,7 @@ class DistGraph(object):
     # and tail, two fix-up launches), xGMI link rate and latency of one all-to-all-v, rate of a pass that reads and rewrites rows:
     # the cost model `_mode` / `_pipelined` choose with (measured on MI355X, profiles/r03/rows_*.txt; only the ORDER of the
     # estimates matters).  _HALF: what a half-width row costs more per byte than a full one.
-    _RATE, _LAUNCH, _LINK, _LAT, _RMW, _HALF = 15.0e9, 20.0e-6, 150.0e9, 30.0e-6, 5.0e12, 1.1
+    _RATE, _LAUNCH, _LINK, _LAT, _RMW, _HALF = 15.0e9, 30.0e-6, 150.0e9, 30.0e-6, 5.0e12, 1.1
 
     def _mode(self, kind, transposed, additive=True, row_bytes=512):
         """How this flow spends the time the exchange takes -- decided once per (plan, direction) from the plan's own counts:
