@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -264,7 +265,7 @@ void contract(const Graph& g, const std::vector<int32_t>& cmap, int32_t nc, int 
                     const int32_t cu = cmap[g.adj[p]];
                     if (cu == (int32_t)cv) continue;
                     if (slot[cu] < 0) { slot[cu] = (int32_t)(A.size() - start); A.push_back(cu); W.push_back(g.ew[p]); }
-                    else W[start + slot[cu]] += g.ew[p];
+                    else { int32_t& w = W[start + slot[cu]]; w = (int32_t)std::min<int64_t>((int64_t)w + g.ew[p], INT32_MAX); }   // saturating: > 2^31 merged weight between two coarse vertices (graphs beyond ~1e9 edges) must not wrap negative
                 }
             }
             deg[cv] = (int64_t)A.size() - start;

@@ -731,10 +731,10 @@ class DistGraph(object):
         out_buf = self._buffer("out" + tag, (n_out,) + tail, wire, x.device)
         if n_out:
             plain = (not transposed) and int(xp.pushed_pairs) == 0
-            if plain and (wire != x.dtype or cols is not None):
-                B.gather_rows_cast(x, self._send_cols32(kind), wire, out_buf)
+            if plain and x.dtype in (torch.float32, torch.float16, torch.bfloat16):
+                B.gather_rows_cast(x, self._send_cols32(kind), wire, out_buf)    # (same-dtype "casts" too: the persistent wire buffer is written in place)
             elif plain:
-                out_buf = B.gather_rows(x, self._send_cols32(kind))
+                out_buf = B.gather_rows(x, self._send_cols32(kind))              # fp64 / integer rows: the generic row move
             else:
                 acc = out_buf if wire == x.dtype else self._buffer("acc" + tag, (n_out,) + tail, x.dtype, x.device)
                 B.aggregate(x, self._index(first), "sum", n_out, out=acc)
@@ -856,24 +856,27 @@ class DistGraph(object):
         estimate = pack + max(before-the-wait work, exchange) + after-the-wait work, with the constants above; PGLAMD_FLOW forces
         one.  ("pipeline" -- accumulate with the rows travelling in two column blocks -- changes the number of collectives, so it
         is not a per-rank choice: see _pipelined.)"""
-        key = ("mode", kind, transposed, additive)
+        key = ("mode", kind, transposed, additive, row_bytes)
         hit = self._idx.get(key)
         if hit is None:
             p = self.plan
             xp = self.xplan if kind == "x" else p
-            mark = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
-            if transposed:
-                mark[xp.send_cols] = True
-                e_int = int((~mark[p.loc_cols]).sum())
-                e_rem, n_in, n_out, splits = int(xp.send_rows.shape[0]), xp.n_send, xp.n_recv, xp.send_splits
-            else:
-                mark[xp.recv_rows] = True
-                e_int = int((~mark[p.loc_rows]).sum())
-                e_rem, n_in, n_out, splits = int(xp.recv_rows.shape[0]), xp.n_recv, xp.n_send, xp.recv_splits
-            e_loc = int(p.loc_rows.shape[0])
-            n_bnd = int(mark.sum())
+            ckey = ("mode_counts", kind, transposed)                  # the plan's counts: once per (plan, direction) ...
+            counts = self._idx.get(ckey)
+            if counts is None:
+                mark = torch.zeros(p.n_own, dtype=torch.bool, device=p.loc_rows.device)
+                if transposed:
+                    mark[xp.send_cols] = True
+                    e_int = int((~mark[p.loc_cols]).sum())
+                    e_rem, n_in, n_out, splits = int(xp.send_rows.shape[0]), xp.n_send, xp.n_recv, xp.send_splits
+                else:
+                    mark[xp.recv_rows] = True
+                    e_int = int((~mark[p.loc_rows]).sum())
+                    e_rem, n_in, n_out, splits = int(xp.recv_rows.shape[0]), xp.n_recv, xp.n_send, xp.recv_splits
+                counts = self._idx[ckey] = (e_int, e_rem, n_in, n_out, max(splits) if len(splits) else 0, int(p.loc_rows.shape[0]), int(mark.sum()))
+            e_int, e_rem, n_in, n_out, max_split, e_loc, n_bnd = counts   # ... the estimates per row width (ADVICE r3)
             R, L, H = self._RATE, self._LAUNCH, self._HALF
-            xch = max(splits) * row_bytes / self._LINK + self._LAT if n_in else 0.0
+            xch = max_split * row_bytes / self._LINK + self._LAT if n_in else 0.0
             pack = 2.0 * n_out * row_bytes / self._RMW + L if n_out else 0.0
             rmw = 2.0 * n_bnd * row_bytes / self._RMW
             est = {"fold": pack + xch + (e_loc + e_rem) / R + L,
@@ -896,7 +899,7 @@ class DistGraph(object):
             elif os.environ.get("PGLAMD_FOLD_INTERIOR"):              # (round-3 knob kept for the tests: fold below this interior share)
                 hit = "fold" if e_int < float(os.environ["PGLAMD_FOLD_INTERIOR"]) * max(p.local_edges, 1) else "split"
             self._idx[key] = hit
-            self._idx[("mode_estimates", kind, transposed, additive)] = est
+            self._idx[("mode_estimates", kind, transposed, additive, row_bytes)] = est
         return hit
 
     def _pipelined(self, kind, transposed, additive, x, row_bytes):
@@ -915,7 +918,7 @@ class DistGraph(object):
         hit = self._idx.get(key)
         if hit is None:
             self._mode(kind, transposed, additive, row_bytes)
-            est = self._idx[("mode_estimates", kind, transposed, additive)]
+            est = self._idx[("mode_estimates", kind, transposed, additive, row_bytes)]
             mine = [min(v for k, v in est.items() if k != "pipeline"), est["pipeline"]]
             if _group_ready(self.group):
                 on_gpu = dist.get_backend(self.group) == "nccl"

@@ -24,7 +24,13 @@ def map_edges(eids, edges, reindex):
 
 
 def metis_partition(num_nodes, adj_indptr, sorted_v, nparts, node_weights=None, edge_weights=None, recursive=False):
-    """pgl/graph_kernel.pyx:434-472 (K-way; the reference's wrapper never takes the recursive branch: pgl/partition.py:80-89)."""
+    """pgl/graph_kernel.pyx:434-472 (K-way; the reference's wrapper never takes the recursive branch: pgl/partition.py:80-89).
+    Like pgl_amd.partition.metis_partition: the engine's own k-way partitioner answers unless PGLAMD_PARTITIONER=metis opted
+    into the reference's vendored METIS AND its helper library is built."""
     if recursive:
         raise NotImplementedError("recursive METIS is not exposed (pgl/partition.py:80: 'recursive metis always core dump')")
-    return ops.host_partition_metis(num_nodes, adj_indptr, sorted_v, nparts, node_weights, edge_weights)[0]
+    from .partition import metis_kway_csr
+    part = metis_kway_csr(num_nodes, adj_indptr, sorted_v, nparts, node_weights, edge_weights)
+    if part is None:
+        part, _ = ops.host_partition_kway(num_nodes, adj_indptr, sorted_v, nparts, node_weights, edge_weights, 0)
+    return part

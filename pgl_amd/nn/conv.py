@@ -187,7 +187,8 @@ class GCNConv(nn.Module):
             output = graph.send_recv_scaled(feature, norm, norm)
             if self.input_size <= self.output_size:
                 tall = output.shape[0] >= 65536 and torch.is_grad_enabled()
-                if self.activation is F.relu and self.linear.weight.dtype == output.dtype and hasattr(torch, "_addmm_activation"):
+                if self.activation is F.relu and self.linear.weight.dtype == output.dtype and hasattr(torch, "_addmm_activation") \
+                        and output.dim() == 2 and self.bias.dtype == output.dtype:
                     # bias + relu in the GEMM's own epilogue: no pass over [N, d] after the GEMM at all (round 3; round 2 ran
                     # them as one row kernel after it: 0.21 ms at C2)
                     return _linear_relu(output, self.linear.weight, self.bias)

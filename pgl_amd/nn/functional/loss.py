@@ -12,7 +12,7 @@ def cross_entropy(input, label, ignore_index=-100, reduction="mean"):   # noqa: 
     label = label.long()
     logp = F.log_softmax(input, dim=-1)
     keep = label != ignore_index
-    picked = -logp.gather(-1, label.clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    picked = -logp.gather(-1, torch.where(keep, label, label.new_zeros(())).unsqueeze(-1)).squeeze(-1)   # only ignored rows are redirected: any other out-of-range label still fails in the gather
     picked = torch.where(keep, picked, picked.new_zeros(()))
     if reduction == "none":
         return picked

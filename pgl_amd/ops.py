@@ -40,6 +40,24 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+_WS_HOT = {}
+_WS_HOT_MAX = 1 << 30
+
+
+def _ws_hot(nbytes, device):
+    """Scratch of the per-step ops (aggregate, segment ops, the GAT kernels): one grow-only buffer per (device, stream)
+    instead of an allocator round trip per call.  A kernel's scratch is consumed inside the call that filled it, so calls
+    queued on ONE stream can share it; another stream gets its own.  Requests above 1 GiB are not held."""
+    nbytes = max(int(nbytes), 256)
+    if nbytes > _WS_HOT_MAX:
+        return _ws(nbytes, device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS_HOT.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _WS_HOT[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return buf
+
+
 def _code(dtype):
     if dtype not in _DTYPE:
         raise TypeError("pgl_amd: unsupported dtype %s" % dtype)
@@ -242,7 +260,7 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
         out.zero_()
         return out
     code = _code(x.dtype)
-    ws = _ws(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
+    ws = _ws_hot(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
     if ext and src_scale is None:
         with torch.cuda.device(x.device):
             _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(y), dy,
@@ -283,7 +301,7 @@ def aggregate_dense(x, csr, w, bias=None, act=None, reduce_op="sum", dst_scale=N
     if M == 0:
         return out, agg
     L = _ffi.lib()
-    ws = _ws(L.pglamd_aggregate_dense_workspace_bytes(csr.num_edges, d_in, d_out), x.device)
+    ws = _ws_hot(L.pglamd_aggregate_dense_workspace_bytes(csr.num_edges, d_in, d_out), x.device)
     b = None if bias is None else bias.to(torch.float32).contiguous()
     ds = None if dst_scale is None else dst_scale.to(torch.float32).contiguous()
     with torch.cuda.device(x.device):
@@ -309,7 +327,7 @@ def winner_grad(grad_out, out, x, csr_src):
     if n == 0:
         return gx
     L = _ffi.lib()
-    ws = _ws(L.pglamd_winner_grad_workspace_bytes(csr_src.num_edges, d), x.device)
+    ws = _ws_hot(L.pglamd_winner_grad_workspace_bytes(csr_src.num_edges, d), x.device)
     with torch.cuda.device(x.device):
         _ffi.check(L.pglamd_winner_grad(_ptr(grad_out), _ptr(out), _ptr(x), d, _ptr(csr_src.row32), _ptr(csr_src.col32),
                                         _ptr(csr_src.indptr), csr_src.num_edges, n, _ptr(gx), _ptr(ws), ws.numel(), _stream(x)),
@@ -428,7 +446,7 @@ def segment_reduce(data, segment_ids, pool_type="sum", num_segments=None):
         return out
     L = _ffi.lib()
     code = _code(data.dtype)
-    ws = _ws(L.pglamd_segment_reduce_workspace_bytes(n, d, R, code), data.device)
+    ws = _ws_hot(L.pglamd_segment_reduce_workspace_bytes(n, d, R, code), data.device)
     with torch.cuda.device(data.device):
         _ffi.check(L.pglamd_segment_reduce(_ptr(data), code, _ptr(segment_ids), int(segment_ids.dtype == torch.int64),
                                            n, d, R, REDUCE[pool_type], _ptr(out), _ptr(ws), ws.numel(),
@@ -469,7 +487,7 @@ def segment_softmax(data, view):
         return out
     L = _ffi.lib()
     code = _code(data.dtype)
-    ws = _ws(L.pglamd_segment_softmax_workspace_bytes(n, d, n_seg, code), data.device)
+    ws = _ws_hot(L.pglamd_segment_softmax_workspace_bytes(n, d, n_seg, code), data.device)
     with torch.cuda.device(data.device):
         _ffi.check(L.pglamd_segment_softmax(_ptr(data), code, n, d, _ptr(view.row32), _ptr(view.perm32),
                                             _ptr(view.elem_seg32), _ptr(view.seg_ptr), n_seg, _ptr(out), _ptr(ws),
@@ -502,7 +520,7 @@ def gat_aggregate(feature, attn_src, attn_dst, csr, negative_slope=0.2, out_size
     if M == 0:                                             # an empty share of a partitioned graph: nothing to launch
         return (out, mx, sm, out_pos, s_pos) if return_stats else out
     L = _ffi.lib()
-    ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), feature.device)
+    ws = _ws_hot(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), feature.device)
     with torch.cuda.device(feature.device):
         _ffi.check(L.pglamd_gat_aggregate(_ptr(feature), _ptr(attn_src), _ptr(attn_dst), H, D, float(negative_slope),
                                           float(drop_p), int(seed) & 0xFFFFFFFF, _ptr(csr.row32), _ptr(csr.col32),
@@ -531,7 +549,7 @@ def gat_backward(grad_out, feature, out, attn_src, attn_dst, row_max, row_sum, c
     if n == 0:
         return gf, g_src, (g_dst if g_dst is not None else torch.empty((0, H), dtype=torch.float32, device=feature.device))
     L = _ffi.lib()
-    ws = _ws(L.pglamd_gat_backward_workspace_bytes(csr_dst.num_edges, n, H, D), feature.device)
+    ws = _ws_hot(L.pglamd_gat_backward_workspace_bytes(csr_dst.num_edges, n, H, D), feature.device)
     with torch.cuda.device(feature.device):
         _ffi.check(L.pglamd_gat_backward(_ptr(grad_out), _ptr(feature), _ptr(attn_src), _ptr(attn_dst), _ptr(row_max),
                                          _ptr(row_sum), _ptr(out), H, D, float(negative_slope), float(drop_p),
@@ -608,7 +626,7 @@ def add_score_backward(x_by_col, y_by_row, w, grad_score, csr, n_rows, negative_
         wpart = torch.empty((max(int(L.pglamd_add_score_chunks(csr.num_edges)), 1), H * D), dtype=torch.float32, device=out.device)
         if csr.num_edges == 0:
             wpart.zero_()
-    ws = _ws(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), out.device)
+    ws = _ws_hot(L.pglamd_gat_aggregate_workspace_bytes(csr.num_edges, H, D), out.device)
     with torch.cuda.device(out.device):
         _ffi.check(L.pglamd_add_score_backward(_ptr(x_by_col), _ptr(y_by_row), _ptr(w), _ptr(grad_score), H, D, float(negative_slope),
                                                _ptr(csr.row32), _ptr(csr.col32), _ptr(csr.eid32), _ptr(csr.indptr), csr.num_edges,

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU session = a list of steps, run on the GPU box through gpurun:
 #     gpurun --timeout 3000 -- 'bash scripts/gpu_session.sh TAG step [step ...]'
-# Every step writes gpurun_out/r03/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r03/.
+# Every step writes gpurun_out/r04/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r04/.
 # Steps: diag tests tests:<pytest -k expr> bench rows_c2 rows_c2_p4 rows_c2_fp16 rows_c2p csr noreuse tlb gcn train gat ops dtypes profile
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r04}; mkdir -p $O
 TAG=$1; shift
 PARTS="scratch/parts"
 cd $R
@@ -25,6 +25,40 @@ for STEP in "$@"; do
     rows_c2_pipe)  timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow pipeline --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     csr|noreuse|gcn|gat|ops|dtypes|gatsplit|model) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
+    edgeops)    timeout 600 python scripts/prof.py edgeops > $F 2>&1; grep -v amdgpu.ids $F ;;
+    pmc_edgeops)
+      # rows a7 / a8 / a10 in original edge order: fetched / written bytes, L2 hit rate and memory-side request mix per KERNEL
+      # (`prof.py edgeops --only pmc` runs the three ops three times each; one rocprofv3 --pmc pass per counter group)
+      ( cd /tmp && export TMPDIR=/tmp
+        for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
+          N=$(echo $C | tr ' ' '_' | cut -c1-40)
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/eopmc_$N -o p -- python $R/scripts/prof.py edgeops --only pmc > $F.$N.log 2>&1 || echo "pass $C failed" >> $F.fail
+        done
+        python - <<PY > $F
+import csv, glob, collections
+print("C3 size (RMAT-20, 20 M edges); counters per launch = mean over the LAST 3 launches of each kernel")
+print("FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them (gfx950: wide streaming reads are tallied at half, MI355X_MICROARCH.md)")
+agg = collections.OrderedDict(); dur = collections.OrderedDict()
+skip = ("at::", "rmat", "elementwise", "rocprim", "csr_", "sort_", "hist", "scan", "narrow_i64", "seg_ptr", "unique")
+for f in sorted(glob.glob("$O/eopmc_*/**/*counter_collection.csv", recursive=True)):
+    rows = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if any(k in n for k in skip): continue
+        rows.setdefault((n.replace("void ", "").split("(")[0][-70:], r.get("Grid_Size"), r.get("Counter_Name")), []).append(float(r["Counter_Value"]))
+    for k, v in rows.items(): agg[k] = (sum(v[-3:]) / len(v[-3:]), len(v))
+for f in sorted(glob.glob("$O/eopmc_FETCH_SIZE/**/*kernel_trace.csv", recursive=True)):
+    rows = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if any(k in n for k in skip): continue
+        rows.setdefault((n.replace("void ", "").split("(")[0][-70:], r.get("Grid_Size", r.get("Grid_Size_X"))), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k, v in rows.items(): dur[k] = sum(v[-3:]) / len(v[-3:])
+for (k, g, c), (v, n) in agg.items(): print("%-72s grid %-9s %-24s %.6g  (launches %d)" % (k, g, c, v, n))
+for (k, g), v in dur.items(): print("%-72s grid %-9s duration under the counter pass %.1f us" % (k, g, v))
+PY
+        cat $F.fail >> $F 2>/dev/null; rm -rf $O/eopmc_* $F.*.log $F.fail )
+      cat $F | cut -c1-200 ;;
     gcn_form1)  PGLAMD_DENSE_FORM=1 timeout 600 python scripts/prof.py gcn 2>&1 | grep -v amdgpu.ids | head -9 > $F; cat $F ;;
     train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
     trace:*)

@@ -582,6 +582,41 @@ def cmd_ops(args):
         print("cpu side skipped:", ex)
 
 
+def cmd_edgeops(args):
+    """The original-edge-order ops at C3 size (rows a7 / a8 / a10 / a4): send_uv [N,8]+[N,8], edge_softmax [E,8], segment_sum [E,32],
+    gather_rows [E,128].  With --only NAME it runs just that op a few times: the target of the rocprofv3 --pmc passes
+    (gpu_session.sh pmc_edgeops), otherwise one timing line per op with its byte model."""
+    import torch
+    pgl, dev, g = _c2(with_src_index=False, scale=args.scale, E=args.edges)
+    N, E, H = g.num_nodes, g.num_edges, 8
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    a_s = torch.randn(N, H, generator=gen, device=dev); a_d = torch.randn(N, H, generator=gen, device=dev)
+    alpha = torch.nn.functional.leaky_relu(g.send_uv(a_s, a_d, "add"), 0.2)
+    uniq, seg = g.get_segment_ids(None, None, "dst")
+    nseg = int(uniq.shape[0])
+    msg = torch.randn(E, 32, generator=gen, device=dev)
+    x = torch.randn(N, 128, generator=gen, device=dev)
+    csr = g.adj_dst_index.csr
+    view = g.edge_order("dst") if hasattr(g, "edge_order") else None
+    ops = {
+        "send_uv": (lambda: g.send_uv(a_s, a_d, "add"), E * (32 + 32 + 32 + 8), E * (32 + 8) + 2 * N * 32),
+        "edge_softmax": (lambda: pgl.nn.functional.edge_softmax(g, alpha), E * (32 + 32 + 4), E * (64 + 12) + N * 8),
+        "segment_sum": (lambda: pgl.ops.segment_reduce(msg, seg, "sum", nseg), E * (128 + 8) + nseg * 128, E * (128 + 8) + nseg * 128),
+        "gather_rows": (lambda: pgl.ops.gather_rows(x, csr.col32)[:1], E * (512 + 512 + 4), E * (512 + 4) + N * 512),
+    }
+    if args.only:
+        for name in (["send_uv", "edge_softmax", "segment_sum"] if args.only == "pmc" else [args.only]):
+            for _ in range(3):
+                ops[name][0]()
+            torch.cuda.synchronize()
+        return
+    print("C3 size: RMAT scale %d, |E| = %d; model = SURVEY 8(d)-style bytes with every gather charged; compulsory = each table read once" % (args.scale, E))
+    for name, (fn, model, comp) in ops.items():
+        ms = _t(fn, it=10 if name != "gather_rows" else 3, warm=2)
+        print("%-14s %8.3f ms   model %6.2f GB = %.3f of 8 TB/s   compulsory %6.2f GB = %.3f of 8 TB/s"
+              % (name, ms, model / 1e9, model / ms / 1e6 / 8000.0, comp / 1e9, comp / ms / 1e6 / 8000.0), flush=True)
+
+
 def _layer(pgl, which):
     return {"gcn": lambda: pgl.nn.GCNConv(128, 128), "gcn_relu": lambda: pgl.nn.GCNConv(128, 128, activation="relu"),
             "sage": lambda: pgl.nn.GraphSageConv(128, 128, "mean"), "transformer": lambda: pgl.nn.TransformerConv(128, 16, 8, 0.0, 0.0),
@@ -956,6 +991,8 @@ def main():
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
     dm.add_argument("--rank", type=int, default=0)
     sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
+    eo = sub.add_parser("edgeops"); eo.add_argument("--scale", type=int, default=20); eo.add_argument("--edges", type=int, default=20_000_000)
+    eo.add_argument("--only", default="", choices=["", "pmc", "send_uv", "edge_softmax", "segment_sum", "gather_rows"])
     va = sub.add_parser("variant"); va.add_argument("name"); va.add_argument("defines", nargs="*")
     tc = sub.add_parser("trace"); tc.add_argument("csv"); tc.add_argument("filter", nargs="?", default="")
     args = ap.parse_args()
@@ -963,6 +1000,8 @@ def main():
         cmd_diag(args)
     elif args.cmd == "rows":
         cmd_rows(args)
+    elif args.cmd == "edgeops":
+        cmd_edgeops(args)
     elif args.cmd in ("ops", "layers", "train", "model", "dense", "sizes", "distmodel", "gat", "dtypes", "variant", "trace", "gatsplit"):
         {"model": cmd_model, "dense": cmd_dense, "sizes": cmd_sizes, "distmodel": cmd_distmodel, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
          "trace": cmd_trace}[args.cmd](args)
