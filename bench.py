@@ -25,7 +25,12 @@ N > 1 (strong scaling, the SAME global graph and features): north_star's layout 
 (pglamd_partition_edges: in-degree + 1 and rows balanced; --partition metis = the reference's METIS as an opt-in comparison), one
 RCCL halo all-to-all-v per step, interior rows aggregated while the rows travel, boundary rows afterwards from [owned | received]:
 every output row written once (DistGraph).  value = global |E| / max-rank time; halo bytes and the exchange-only time per rank ride
-along; target_size = the |E| = 100 M graph through the same flow.  --parallel cols / grid / auto time the alternative layouts.
+along; target_size = the |E| = 100 M graph through the same flow.  The run is self-diagnosing (PhaseWatchdog): per-phase wall times
+on stderr, candidates tried from the most conservative flow / transport up (halo.candidates: fold over torch.distributed, the cost
+model's flow over torch.distributed, the same over the library's own RCCL communicator -- --transport), the timed region on the
+fastest; a phase that exceeds its limit ends the run with the best COMPLETED measurement instead of hanging, and a failure of
+the target-size leg cannot lose the headline.  --alternatives also times the feature-column layout; --parallel cols / grid make
+another layout the headline.
 """
 import os
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (set before HIP initialises)
@@ -223,6 +228,70 @@ def target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note, steps=10):
     return rec
 
 
+class PhaseWatchdog(object):
+    """N > 1 runs are self-diagnosing: every phase (partition + plan, each candidate's trial, the timed region, the target-size
+    leg) runs under a deadline.  A phase that is still running at its deadline -- a collective that never completes, a rank
+    that died inside one -- ends the run instead of hanging it: rank 0 prints the JSON line of the best measurement COMPLETED so
+    far (labelled with the phase that hung), every rank leaves with os._exit.  Each rank runs its own watchdog on the same
+    schedule, so the ranks stuck behind the one that hung leave as well.  Phase wall times go to stderr on rank 0."""
+
+    def __init__(self, rank, emit, grace=3.0):
+        import threading
+        self.rank, self.emit, self.grace = rank, emit, grace
+        self.best = None                    # callable -> the record to print if a later phase hangs (rank 0 only)
+        self.hang_next = False
+        self.deadline, self.name, self.t0 = None, None, time.perf_counter()
+        self.t_phase = 0.0
+        self.lock = threading.Lock()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def note(self, msg):
+        if self.rank == 0:
+            print("[bench %7.1fs] %s" % (time.perf_counter() - self.t0, msg), file=sys.stderr, flush=True)
+
+    def begin(self, name, seconds):
+        with self.lock:
+            self.name, self.deadline, self.t_phase = name, time.perf_counter() + seconds, time.perf_counter()
+        self.note("phase %r (limit %.0f s)" % (name, seconds))
+        if self.hang_next:                                           # test seam (PGLAMD_BENCH_HANG_AFTER=<phase>): the phase after it never finishes
+            while True:
+                time.sleep(1.0)
+
+    def end(self):
+        with self.lock:
+            name, dt = self.name, time.perf_counter() - self.t_phase
+            self.name, self.deadline = None, None
+        if name == os.environ.get("PGLAMD_BENCH_HANG_AFTER"):
+            self.hang_next = True
+        self.note("phase %r done in %.2f s" % (name, dt))
+        return dt
+
+    def _run(self):
+        while True:
+            time.sleep(0.25)
+            with self.lock:
+                late = self.deadline is not None and time.perf_counter() > self.deadline
+                name = self.name
+            if not late:
+                continue
+            print("[bench] rank %d: phase %r exceeded its limit -- ending the run" % (self.rank, name), file=sys.stderr, flush=True)
+            rc = 3
+            if self.rank == 0 and self.best is not None:
+                try:
+                    rec = self.best()
+                    rec["aborted"] = {"phase": name, "what": "this phase did not finish within its limit; the line reports the best "
+                                                             "measurement completed before it"}
+                    self.emit(rec)
+                    rc = 0
+                except Exception as ex:                              # noqa: BLE001
+                    print("[bench] could not emit the fallback record: %r" % ex, file=sys.stderr, flush=True)
+            elif self.rank != 0:
+                time.sleep(self.grace)                               # rank 0 prints first
+                rc = 0
+            os._exit(rc)
+
+
 def cpu_baseline(edges_cpu, x_cpu, budget_s=12.0):
     """Oracle C port of the Paddle CPU kernel (kind "port": serial loop over the edges in raw COO
     order, 1 core) timed on this box: whole passes over the SAME graph and features until about
@@ -305,7 +374,15 @@ def main():
                     help="'never' (default) = halo source rows are pulled, every edge is aggregated by its destination's owner (what the "
                          "partitioner balanced); 'auto' = per rank pair the cheaper of pulling source rows and pushing pre-aggregated "
                          "destination rows (fewer bytes, but it moves edge work between ranks)")
-    ap.add_argument("--no-alternatives", action="store_true", help="N > 1: time only the headline layout")
+    ap.add_argument("--no-alternatives", action="store_true", help="(kept for compatibility: alternatives are off unless --alternatives)")
+    ap.add_argument("--alternatives", action="store_true", help="N > 1: also time the other layouts (feature columns) as secondary fields")
+    ap.add_argument("--transport", default="auto", choices=["auto", "torch", "abi"],
+                    help="N > 1 halo transport: 'torch' = torch.distributed all_to_all_single (RCCL), 'abi' = the library's own RCCL "
+                         "communicator on its side stream (pglamd_halo_exchange_*, SURVEY 8b), 'auto' = time both, report both, run the "
+                         "timed region on the faster")
+    ap.add_argument("--phase-limit", type=float, default=float(os.environ.get("PGLAMD_BENCH_PHASE_LIMIT", "150")),
+                    help="N > 1: seconds a phase (one candidate's trial, the timed region) may take before the run ends with the best "
+                         "completed measurement; set-up phases (partition + plan, the target-size leg) get 4x")
     ap.add_argument("--target-scale", type=int, default=22, help="target_size leg: RMAT scale (north_star: 22)")
     ap.add_argument("--target-edges", type=int, default=100_000_000, help="target_size leg: edges (north_star: 100 M)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -350,6 +427,7 @@ def main():
         halo = None
     else:
         import torch.distributed as dist
+        import pgl_amd.distributed as pd
         from pgl_amd.distributed import DistGraph, FeatureShardedGraph, GridShardedGraph
         sync = lambda: torch.cuda.synchronize()
         barrier = lambda: dist.barrier()
@@ -364,91 +442,124 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
-        t_setup = time.perf_counter()
-
-        def note(msg):
-            if rank == 0:                                            # progress to stderr: where the setup time of an N > 1 run goes
-                print("[bench %6.1fs] %s" % (time.perf_counter() - t_setup, msg), file=sys.stderr, flush=True)
-
-        def build(name):
-            """-> (step, stats, (d_loc, n_loc, e_loc), extra)"""
-            note("building layout %r" % name)
-            if name == "rows":
-                dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push)
-                x_own = dg.take_owned(x)
-                st = dg.stats()
-                return (lambda: dg.send_recv(x_own, "sum")), st, (d, st["local_rows"], st["local_edges"]), (dg, x_own)
-            if name == "cols":
-                g = pgl.Graph(edges=edges, num_nodes=N)
-                g.adj_dst_index
-                fs = FeatureShardedGraph(g, rank, world)
-                x_cols = fs.take_cols(x)
-                return (lambda: fs.send_recv(x_cols, "sum")), fs.stats(), (int(x_cols.shape[1]), N, E), None
-            pr = 2 if world % 2 == 0 else 1                          # grid: 2 row parts x world/2 column slices
-            gg = GridShardedGraph(edges, N, rank, world, grid=(pr, world // pr), method=args.partition, device=dev, push=args.push)
-            blk = gg.take(x)
-            st = gg.stats()
-            return (lambda: gg.send_recv(blk, "sum")), st, (int(blk.shape[1]), st["local_rows"], st["local_edges"]), None
-
-        # The headline layout is north_star's: METIS row partition + halo all-to-all-v (--parallel rows).  The other layouts
-        # are timed for a few steps and reported as SECONDARY fields (halo.alternatives_ms_per_step); "auto" promotes the
-        # fastest one to the headline and says so in config.parallelism.
-        # (the grid costs a second METIS run -- about a minute at this scale -- so it is a candidate of --parallel auto / grid only)
-        order = {"rows": ["rows", "cols"], "cols": ["cols"], "grid": ["grid"], "auto": ["rows", "cols", "grid"]}[args.parallel]
-        if args.no_alternatives:
-            order = order[:1]
-        built, trial = {}, {}
-
         def agreed(ok):
             """True only if the step succeeded on EVERY rank (a rank that failed must not leave the others waiting in a collective)."""
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(int(flag.item()))
 
-        for name in order:
-            err = None
-            try:
-                built[name] = build(name)
-            except Exception as ex:                                  # noqa: BLE001
-                err = ex
-            if not agreed(err is None):                              # phase 1: every rank built the layout
-                built.pop(name, None)
-                print("[bench] layout %r not built (rank %d: %r)" % (name, rank, err), file=sys.stderr, flush=True)
-                if name == order[0] and args.parallel != "auto":
-                    raise err if err is not None else RuntimeError("layout %r failed on another rank" % name)
-                continue
-            t_trial = 0.0
-            try:
-                fn = built[name][0]
-                fn(); fn()
-                t_trial = timed(fn, max(args.warmup, 3)) / max(args.warmup, 3) * 1e3
-            except Exception as ex:                                  # noqa: BLE001 -- (a failure inside a collective ends the job anyway)
-                err = ex
-            if not agreed(err is None):                              # phase 2: it ran on every rank
-                built.pop(name, None)
-                print("[bench] layout %r failed (rank %d: %r)" % (name, rank, err), file=sys.stderr, flush=True)
-                if name == order[0] and args.parallel != "auto":
-                    raise err if err is not None else RuntimeError("layout %r failed on another rank" % name)
-                continue
-            trial[name] = t_trial
-            note("layout %r: %.3f ms/step over %d trial steps" % (name, t_trial, max(args.warmup, 3)))
-        mode = min(trial, key=trial.get) if args.parallel == "auto" else order[0]
-        step, halo, (d_loc, n_loc, e_loc), extra = built[mode]
-        halo = dict(halo, mode=mode, alternatives_ms_per_step=trial)
+        def base_record(ms_step, how):
+            """The contract fields of an N > 1 line for a measured ms/step."""
+            return {"metric": "aggregated edges/sec (GCN send+recv_sum, d=%d)" % d, "value": E / (ms_step * 1e-3), "unit": "edges/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+                    "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "timed": how}
+
+        wd = PhaseWatchdog(rank, lambda rec: print(json.dumps(rec), flush=True))
+        note = wd.note
+        lim = args.phase_limit
+        n_trial = max(args.warmup, 3)
+        trial, cands, built = {}, [], {}
+        mode = "rows" if args.parallel in ("rows", "auto") else args.parallel
+        extra = None
+
         if mode == "rows":
-            # exchange alone (pack kernel + all-to-all-v + wait, no aggregation) and its bytes, per rank and worst rank
-            dg, x_own = extra
-            t_x = timed(lambda: dg.exchange_only(x_own), max(args.warmup, 3)) / max(args.warmup, 3) * 1e3
+            # ---- north_star's layout: row partition + one halo all-to-all-v per step ------------------------------------------------
+            wd.begin("partition + halo plan", 4 * lim)
+            dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push)
+            x_own = dg.take_owned(x)
+            st0 = dg.stats()
+            wd.end()
+            step = lambda: dg.send_recv(x_own, "sum")
+            # Candidates, most conservative first: one exchange and ONE aggregation launch after the wait ("fold") over
+            # torch.distributed's all_to_all_single; then the flow the cost model picks (interior rows or local edges during the
+            # exchange, possibly two column blocks in flight); then the same over the library's own RCCL communicator and side
+            # stream (pglamd_halo_exchange_*).  Every trial runs under the phase limit; a candidate that raises is dropped on all
+            # ranks; one that hangs ends the run with the best candidate measured before it.
+            want = [("fold", "torch"), ("", "torch")] if args.transport in ("auto", "torch") else []
+            if args.transport in ("auto", "abi"):
+                want.append(("", "abi"))
+            best = None
+            for flow, transport in want:
+                label = "%s/%s" % (flow or "cost-model", transport)
+                wd.begin("trial %s" % label, lim)
+                err, ms = None, None
+                try:
+                    pd.set_flow(flow, transport, graphs=[dg])
+                    step(); step()
+                except Exception as ex:                              # noqa: BLE001
+                    err = ex
+                if not agreed(err is None):
+                    cands.append({"flow": flow or "cost-model", "transport": transport, "status": "failed", "error": repr(err)[:300]})
+                    print("[bench] candidate %s failed (rank %d: %r)" % (label, rank, err), file=sys.stderr, flush=True)
+                    wd.end()
+                    continue
+                ms = timed(step, n_trial) / n_trial * 1e3
+                ran = dg.stats()["flow"]
+                cands.append({"flow": flow or "cost-model", "ran_flow": ran, "transport": transport, "status": "ok", "trial_ms_per_step": ms,
+                              "trial_steps": n_trial})
+                wd.end()
+                note("candidate %-22s -> %.3f ms/step (flow that ran: %s)" % (label, ms, ran))
+                if best is None or ms < best[0]:
+                    best = (ms, flow, transport, ran)
+                    wd.best = (lambda ms=ms, label=label, ran=ran: dict(
+                        base_record(ms, "trial of %d steps of candidate %s (a later phase did not finish)" % (n_trial, label)),
+                        config={"workload": "RMAT scale %d |V|=%d |E|=%d d=%d fp32" % (args.scale, N, E, d), "parallelism":
+                                "row partition (%s) x%d + halo all-to-all-v, flow %s" % (st0["partition"], world, ran)},
+                        roofline={"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+                        halo=dict(st0, mode="rows", candidates=cands)))
+            if best is None:
+                raise RuntimeError("bench.py: no halo-exchange candidate ran on every rank: %r" % cands)
+            pd.set_flow(best[1], best[2], graphs=[dg])
+            step(); step()
+            trial["rows"] = best[0]
+            halo = dict(st0, mode="rows", candidates=cands, chosen={"flow": best[1] or "cost-model", "transport": best[2]})
+            d_loc, n_loc, e_loc = d, st0["local_rows"], st0["local_edges"]
+            extra = (dg, x_own)
+            # exchange alone (pack kernel + all-to-all-v + wait, no aggregation) and its bytes, per rank
+            wd.begin("exchange only", lim)
+            t_x = timed(lambda: dg.exchange_only(x_own), n_trial) / n_trial * 1e3
             allp = torch.zeros((world, 2), dtype=torch.float64, device=dev)
             allp[rank, 0], allp[rank, 1] = float(halo["recv_rows"]) * d * 4, float(halo["send_rows"]) * d * 4
             dist.all_reduce(allp)                                    # (a sum of one-hot rows = an all-gather every backend has)
             halo.update(exchange_only_ms=t_x, recv_bytes_per_rank=allp[:, 0].tolist(), send_bytes_per_rank=allp[:, 1].tolist(),
-                        flow=dg.stats()["flow"])                     # the flow that RAN (the trials above were steps): DESIGN section 5
-        for k in list(built):
-            if k != mode:
-                del built[k]
+                        flow=dg.stats()["flow"])                     # the flow that RAN: DESIGN section 5
+            wd.end()
+            if args.alternatives:                                    # the feature-column layout as a secondary field (not by default:
+                wd.begin("alternative layout: feature columns", 2 * lim)   # the first hardware run spends its minutes on rows + target size)
+                try:
+                    g2 = pgl.Graph(edges=edges, num_nodes=N); g2.adj_dst_index
+                    fs = FeatureShardedGraph(g2, rank, world)
+                    x_cols = fs.take_cols(x)
+                    fn = lambda: fs.send_recv(x_cols, "sum")
+                    fn(); fn()
+                    trial["cols"] = timed(fn, n_trial) / n_trial * 1e3
+                    del g2, fs, x_cols
+                except Exception as ex:                              # noqa: BLE001
+                    print("[bench] alternative layout failed (rank %d: %r)" % (rank, ex), file=sys.stderr, flush=True)
+                wd.end()
+            halo["alternatives_ms_per_step"] = trial
+        else:
+            # ---- the other layouts as the headline, on request (--parallel cols | grid) ---------------------------------------------
+            wd.begin("layout %r" % mode, 4 * lim)
+            if mode == "cols":
+                g2 = pgl.Graph(edges=edges, num_nodes=N); g2.adj_dst_index
+                fs = FeatureShardedGraph(g2, rank, world)
+                x_cols = fs.take_cols(x)
+                step, halo, (d_loc, n_loc, e_loc) = (lambda: fs.send_recv(x_cols, "sum")), fs.stats(), (int(x_cols.shape[1]), N, E)
+            else:
+                pr = 2 if world % 2 == 0 else 1                      # grid: 2 row parts x world/2 column slices
+                gg = GridShardedGraph(edges, N, rank, world, grid=(pr, world // pr), method=args.partition, device=dev, push=args.push)
+                blk = gg.take(x)
+                st = gg.stats()
+                step, halo, (d_loc, n_loc, e_loc) = (lambda: gg.send_recv(blk, "sum")), st, (int(blk.shape[1]), st["local_rows"], st["local_edges"])
+            step(); step()
+            trial[mode] = timed(step, n_trial) / n_trial * 1e3
+            halo = dict(halo, mode=mode, alternatives_ms_per_step=trial)
+            wd.end()
         del x
 
+    if world > 1:
+        wd.begin("timed region: %d warm-up + %d steps" % (args.warmup, args.steps), 2 * lim)
     for _ in range(args.warmup):
         step()
     sync(); barrier(); sync()
@@ -468,10 +579,30 @@ def main():
         dt = float(t.item())
 
     # N > 1: north_star's target size (|E| = 100 M, SURVEY 8d C2') through the same partitioned flow -- every rank regenerates the
-    # graph from the seed, rank 0 partitions it with the engine's partitioner (seconds), all ranks time the same steps
+    # graph from the seed, rank 0 partitions it with the engine's partitioner (seconds), all ranks time the same steps.  The
+    # headline above is complete at this point: if this leg raises or hangs, the line is printed without it.
     target_rec = None
+    if world > 1:
+        wd.end()
+        ms_done, flow_done = dt / args.steps * 1e3, (halo.get("flow") if isinstance(halo, dict) else None)
+        wd.best = lambda: dict(base_record(ms_done, "%d steps after %d warm-up steps, barrier + synchronize on both sides, max over ranks"
+                                           % (args.steps, args.warmup)),
+                               config={"workload": "RMAT scale %d |V|=%d |E|=%d d=%d fp32" % (args.scale, N, E, d),
+                                       "parallelism": "layout %s x%d, flow %s" % (mode, world, flow_done)},
+                               roofline={"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},
+                               halo=halo)
     if world > 1 and mode == "rows" and not args.no_extra_legs:
-        target_rec = target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note)
+        wd.begin("target size leg (|E| = %d)" % args.target_edges, 6 * lim)
+        err = None
+        try:
+            target_rec = target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note)
+        except Exception as ex:                                      # noqa: BLE001
+            err = ex
+            target_rec = {"error": repr(ex)[:400]}
+            print("[bench] target-size leg failed on rank %d: %r" % (rank, ex), file=sys.stderr, flush=True)
+        wd.end()
+    if world > 1:
+        wd.begin("report", lim)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -511,6 +642,8 @@ def main():
                            "kernel": kname, "headline_workload": head}
         if halo is not None:
             rec["halo"] = halo
+        if world > 1:
+            rec["timed"] = "%d steps after %d warm-up steps, barrier + synchronize on both sides, max over ranks" % (args.steps, args.warmup)
         if world > 1 and target_rec is not None:
             rec["target_size"] = target_rec
         if world == 1:
@@ -540,6 +673,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+        wd.end()
         dist.destroy_process_group()
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PGLAMD_ABI_VERSION 1
+#define PGLAMD_ABI_VERSION 2
 
 /* status codes */
 #define PGLAMD_OK 0
@@ -188,6 +188,9 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
  *     multiplies it by w (B operand from memory).
  * fp32 inputs, fp32 accumulation -- the reference's arithmetic up to re-association; only `out` is written: the [n_rows, d_in]
  * intermediate never travels through HBM, and the matrix cores run in the shadow of the row gathers.
+ * edge_scale (optional, ABI 2): one fp32 value per edge POSITION of the sorted stream, multiplied into the gathered row
+ *     (agg[r] = dst_scale[r] * SUM_p edge_scale[p] * x[col[p]]): GCN's source-side degree norm (pgl/nn/conv.py:242) laid out
+ *     along the stream once per graph -- 4 sequential bytes per edge instead of a pass over [N, d_in] per layer.
  * agg_out (optional): the aggregated rows are ALSO stored (training: the weight gradient is agg^T @ d out).
  * act: 0 none, 1 relu.  Rows without edges get act(bias).  Rows longer than a chunk go through the split-row fix-up and get the
  * layer from a small MFMA kernel afterwards.  Deterministic.  w 16-byte aligned for the first form.  Workspace (8-byte aligned):
@@ -195,8 +198,8 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
 size_t pglamd_aggregate_dense_workspace_bytes(int64_t num_edges, int64_t d_in, int64_t d_out);
 int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const int32_t* row, const int32_t* col,
                                const int64_t* indptr, int64_t num_edges, int64_t n_csr_rows,
-                               int64_t out_rows, int32_t reduce_op, const float* dst_scale,
-                               const float* w, const float* bias, int32_t act, int64_t d_out,
+                               int64_t out_rows, int32_t reduce_op, const float* edge_scale,
+                               const float* dst_scale, const float* w, const float* bias, int32_t act, int64_t d_out,
                                float* agg_out, float* out, void* workspace, size_t workspace_bytes,
                                void* stream);
 
@@ -438,6 +441,17 @@ int32_t pglamd_row_epilogue(const float* z, const float* bias, int64_t n_rows, i
 int32_t pglamd_row_epilogue_backward(const float* dy, const float* y, const float* inv_norm,
                                      int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
                                      float* dz, float* col_partials, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Feature slabs with a known address-translation layout (engine extension; in the reference Paddle's allocator owns device
+ * memory behind Graph.tensor(), pgl/graph.py:1090-1123).  Random 512-byte row gathers over several GB miss the per-CU
+ * translation cache on more than half of the rows, so the page-table fragment size of the slab matters:
+ *   mode 0  hipMalloc (comparison partner)
+ *   mode 1  ONE physical allocation (hipMemCreate) mapped into a 1 GiB-aligned virtual range in one piece
+ * out_bytes (optional) = the mapped size (>= bytes).  pglamd_slab_free synchronises the device, then unmaps / frees.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t pglamd_slab_alloc(size_t bytes, int32_t mode, void** out_ptr, size_t* out_bytes);
+int32_t pglamd_slab_free(void* ptr);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange step of the row-partitioned path.  Replaces the collective of the reference's

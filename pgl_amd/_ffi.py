@@ -31,7 +31,7 @@ _SIGNATURES = {
     "pglamd_aggregate_ext": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
                                       c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_aggregate_dense_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
-    "pglamd_aggregate_dense": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_i64,
+    "pglamd_aggregate_dense": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
                                         c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_winner_grad_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "pglamd_winner_grad": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_sz, c_vp]),
@@ -76,6 +76,8 @@ _SIGNATURES = {
     "pglamd_row_epilogue_partials": (c_i64, [c_i64]),
     "pglamd_row_epilogue": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.c_float, c_vp, c_vp, c_vp]),
     "pglamd_row_epilogue_backward": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "pglamd_slab_alloc": (c_i32, [c_sz, c_i32, c_vp, c_vp]),
+    "pglamd_slab_free": (c_i32, [c_vp]),
     "pglamd_comm_unique_id": (c_i32, [c_vp]),
     "pglamd_comm_init": (c_i32, [c_i32, c_i32, c_vp, c_vp]),
     "pglamd_comm_destroy": (c_i32, [c_vp]),
@@ -87,7 +89,7 @@ _SIGNATURES = {
     "pglamd_partition_metis": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _ERRORS = {-1: ValueError, -2: TypeError, -3: OverflowError, -4: RuntimeError, -5: RuntimeError, -6: ValueError, -7: RuntimeError, -8: RuntimeError}
 
 

@@ -459,8 +459,7 @@ class _AggregateDense(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, csr, csr_t, act, src_scale, dst_scale, reduce_op):
         need_w = weight.requires_grad or (bias is not None and bias.requires_grad)
-        xs = x if src_scale is None else x * src_scale.reshape(-1, 1)
-        out, agg = ops.aggregate_dense(xs, csr, weight.t(), bias, act, reduce_op, dst_scale, keep_agg=need_w)
+        out, agg = ops.aggregate_dense(x, csr, weight.t(), bias, act, reduce_op, dst_scale, keep_agg=need_w, src_scale=src_scale)
         ctx.csr_t, ctx.act, ctx.reduce_op, ctx.csr = csr_t, act, reduce_op, csr
         ctx.has_bias = bias is not None
         ctx.n_x = int(x.shape[0])
@@ -490,13 +489,14 @@ class _AggregateDense(torch.autograd.Function):
             if ctx.reduce_op == "mean":
                 inv = 1.0 / (ctx.csr.indptr[1:] - ctx.csr.indptr[:-1]).clamp(min=1).to(torch.float32)
                 scale = inv if scale is None else scale * inv
-            dzs = dz if scale is None else dz * scale.reshape(-1, 1)
             csr_t = ctx.csr_t()
             back = ss if ss.numel() else None
-            if ops.aggregate_dense_supported(dzs, weight.shape[1]):
-                gx = ops.aggregate_dense(dzs, csr_t, weight, None, None, "sum", back, out_size=ctx.n_x)[0]
+            # (the destination scale of the forward is the per-SOURCE scale of the transposed walk: it rides along the transposed
+            #  stream as one value per edge position -- no element pass over d Z)
+            if ops.aggregate_dense_supported(dz, weight.shape[1]):
+                gx = ops.aggregate_dense(dz, csr_t, weight, None, None, "sum", back, out_size=ctx.n_x, src_scale=scale)[0]
             else:
-                gx = ops.aggregate(dzs, csr_t, "sum", ctx.n_x, dst_scale=back) @ weight
+                gx = ops.aggregate(dz, csr_t, "sum", ctx.n_x, src_scale=scale, dst_scale=back) @ weight
         return gx, gw, gb, None, None, None, None, None, None
 
 
@@ -504,8 +504,7 @@ def aggregate_dense(x, weight, bias, csr, csr_t, act=None, dst_scale=None, reduc
     """x [N, d_in] fp32, weight [d_out, d_in] (nn.Linear layout), bias [d_out] or None; src_scale / dst_scale one value per node."""
     if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
         return _AggregateDense.apply(x, weight, bias, csr, csr_t, act, src_scale, dst_scale, reduce_op)
-    xs = x if src_scale is None else x * src_scale.reshape(-1, 1)
-    return ops.aggregate_dense(xs, csr, weight.t(), bias, act, reduce_op, dst_scale)[0]
+    return ops.aggregate_dense(x, csr, weight.t(), bias, act, reduce_op, dst_scale, src_scale=src_scale)[0]
 
 
 class _DualLinear(torch.autograd.Function):

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void pack_weight_kernel(const float* __rest
     }
 }
 
-template <int VEC>
+template <int VEC, int SS = 0>
 static int32_t launch_dense(AggParams p, hipStream_t st) {
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     p.n_blocks = (int)nb;
@@ -247,7 +247,7 @@ static int32_t launch_dense(AggParams p, hipStream_t st) {
         PGLAMD_HIP_CHECK(hipEventCreate(&e1));
         PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL((agg_flat_kernel<float, VEC, 1, 0, 0, false, true, 0, 1>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+    hipLaunchKernelGGL((agg_flat_kernel<float, VEC, 1, 0, 0, SS, true, 0, 1>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));
@@ -271,8 +271,8 @@ extern "C" size_t pglamd_aggregate_dense_workspace_bytes(int64_t num_edges, int6
 
 extern "C" int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const int32_t* row, const int32_t* col, const int64_t* indptr,
                                           int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, int32_t reduce_op,
-                                          const float* dst_scale, const float* w, const float* bias, int32_t act, int64_t d_out,
-                                          float* agg_out, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                                          const float* edge_scale, const float* dst_scale, const float* w, const float* bias, int32_t act,
+                                          int64_t d_out, float* agg_out, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!out || !w || !indptr || (num_edges > 0 && (!x || !row || !col))) return fail(PGLAMD_E_ARG, "aggregate_dense: NULL pointer");
     if (num_edges < 0 || num_edges > kMaxEdges || n_csr_rows >= INT32_MAX || out_rows >= INT32_MAX)
         return fail(PGLAMD_E_RANGE, "aggregate_dense: sizes beyond int32 engine range");
@@ -305,6 +305,7 @@ extern "C" int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const in
     AggParams p{};
     p.x = x; p.x2 = x; p.x_split = INT32_MAX; p.out = agg_out; p.row = row; p.col = col; p.indptr = indptr; p.zero_indptr = indptr;
     p.dst_scale = dst_scale;
+    p.src_scale = edge_scale; p.ss_by_pos = edge_scale ? 1 : 0;      // one scale per edge POSITION of the sorted stream
     p.ldx = d_in; p.ldo = d_in; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)num_edges;
     p.is_mean = reduce_op == PGLAMD_MEAN; p.gy = 1;
     p.w = w; p.wp = wp; p.bias = bias; p.out2 = out; p.dout2 = (int)d_out; p.act = act;
@@ -320,6 +321,10 @@ extern "C" int32_t pglamd_aggregate_dense(const float* x, int64_t d_in, const in
     p.long_list = p.long_count + 64;
     p.long_list2 = reinterpret_cast<int*>(ws + 2 * half + lst);
     if (num_edges == 0) p.n_chunks = 0;                      // only the empty-row roles run
+    if (edge_scale) {
+        if (form2) return d_in == 128 ? launch_dense2<2, true>(p, st) : launch_dense2<1, true>(p, st);
+        return d_in == 128 ? launch_dense<2, 2>(p, st) : launch_dense<1, 2>(p, st);
+    }
     if (form2) return d_in == 128 ? launch_dense2<2>(p, st) : launch_dense2<1>(p, st);
     return d_in == 128 ? launch_dense<2>(p, st) : launch_dense<1>(p, st);
 }

@@ -19,6 +19,7 @@ struct AggParams {
     const int* row; const int* col; const int* eid;
     const int64_t* indptr;
     const float* src_scale; const float* dst_scale;
+    int ss_by_pos;                        // 1: src_scale holds one value per EDGE POSITION of the sorted stream (src_scale[p], read in order) instead of one per source node
     void* part_head; void* part_tail;     // [n_chunks, tile_cols] of ACC each
     int* long_count; int* long_list;      // [2] counters + work list of split-row fix-up tasks (workspace)
     int* long_list2;                      // second-level list: rows with more than kFixShort partials

@@ -75,7 +75,9 @@ __device__ __forceinline__ void d2_empty_rows_step(const AggParams& p, int step,
     }
 }
 
-template <int VEC>
+// ES: every edge carries a scale, laid out along the sorted stream (p.src_scale[position]; AggParams::ss_by_pos) -- GCN's source-side
+// degree norm without a pass over [N, d_in] before the launch: 4 sequential bytes per edge, one vector load per batch of 8 edges.
+template <int VEC, bool ES = false>
 __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) {
     constexpr int U = 8;
     constexpr int DIN = kWave * VEC;
@@ -326,14 +328,20 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
 #pragma unroll
         for (int i = 0; i < U; ++i) { rr[i] = rowp[e + i]; cc[i] = colp[e + i]; }
     };
-    auto load_rows = [&](const int (&cc)[U], V (&vx)[U]) {
+    const float* __restrict__ es_v = p.src_scale;
+    auto load_rows = [&](int eb, const int (&cc)[U], V (&vx)[U], float& sv) {
+        if constexpr (ES) sv = es_v[eb + (lane & (U - 1))];              // lane i < 8: the scale of edge i of the batch
 #pragma unroll
         for (int i = 0; i < U; ++i) vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc[i] * p.ldx + j0);
     };
-    auto consume_one = [&](int r, const V& vx) {
+    auto consume_one = [&](int r, const V& vx, float s) {
         if (r != cur) { close_row(); cur = r; reset(); }
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) acc[k] += vx.v[k];
+        for (int k = 0; k < VEC; ++k) { if constexpr (ES) acc[k] += vx.v[k] * s; else acc[k] += vx.v[k]; }
+    };
+    auto lane_scale = [&](float sv, int i) -> float {
+        if constexpr (ES) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), i));
+        else return 1.f;
     };
 
     for (;;) {
@@ -358,17 +366,20 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
         const int n_full = (e1 - e0) / U;
         int cA[U], rA[U], cB[U], rB[U];
         V xA[U];
-        if (n_full > 0) { load_idx(e, cA, rA); load_rows(cA, xA); }
+        float svA = 1.f;
+        if (n_full > 0) { load_idx(e, cA, rA); load_rows(e, cA, xA, svA); }
         if (n_full > 1) load_idx(e + U, cB, rB);
         for (int g = 0; g < n_full; ++g) {
             int cC[U], rC[U];
             V xB[U];
+            float svB = 1.f;
             const bool more = g + 1 < n_full, more2 = g + 2 < n_full;
-            if (more) load_rows(cB, xB);
+            if (more) load_rows(e + U, cB, xB, svB);
             if (more2) load_idx(e + 2 * U, cC, rC);
 #pragma unroll
-            for (int i = 0; i < U; ++i) consume_one(rA[i], xA[i]);
+            for (int i = 0; i < U; ++i) consume_one(rA[i], xA[i], lane_scale(svA, i));
             if (more) {
+                svA = svB;
 #pragma unroll
                 for (int i = 0; i < U; ++i) { rA[i] = rB[i]; xA[i] = xB[i]; }
             }
@@ -381,7 +392,9 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
         for (; e < e1; ++e) {
             const int r = rowp[e];
             const V vx = *reinterpret_cast<const V*>(x + (int64_t)colp[e] * p.ldx + j0);
-            consume_one(r, vx);
+            float s = 1.f;
+            if constexpr (ES) { int ei = e; asm volatile("" : "+v"(ei)); s = es_v[ei]; }     // (wave-uniform index through the vector path)
+            consume_one(r, vx, s);
         }
         const bool tail_open = e1 < p.E && rowp[e1] == cur;
         if (head_open) store_partial(true);
@@ -446,13 +459,13 @@ static int32_t launch_dense_hub(const AggParams& p, hipStream_t st) {
     return PGLAMD_OK;
 }
 
-template <int VEC>
+template <int VEC, bool ES = false>
 static int32_t launch_dense2(AggParams p, hipStream_t st) {
     const int d_in = kWave * VEC;
     const size_t lds = dense2_lds_bytes(d_in, p.dout2);
     static bool attr_set = false;                           // (per instantiation; idempotent, so a race only repeats it)
     if (!attr_set) {
-        PGLAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_dense2_kernel<VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        PGLAMD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_dense2_kernel<VEC, ES>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
     static const int n_cu = [] {
@@ -463,7 +476,7 @@ static int32_t launch_dense2(AggParams p, hipStream_t st) {
     static const bool dbg = [&] {
         if (!getenv("PGLAMD_D2_DEBUG")) return false;
         int nblk = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, agg_dense2_kernel<VEC>, kD2Threads, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nblk, agg_dense2_kernel<VEC, ES>, kD2Threads, lds);
         fprintf(stderr, "[pglamd] agg_dense2_kernel<%d>: %zu bytes of LDS, %d threads -> %d resident workgroups per CU (%s), %d CUs\n", VEC, lds, kD2Threads, nblk, hipGetErrorString(e), n_cu);
         return true;
     }();
@@ -488,7 +501,7 @@ static int32_t launch_dense2(AggParams p, hipStream_t st) {
         PGLAMD_HIP_CHECK(hipEventCreate(&e1));
         PGLAMD_HIP_CHECK(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL((agg_dense2_kernel<VEC>), dim3((unsigned)p.n_grid_chunks), dim3(kD2Threads), lds, st, p);
+    hipLaunchKernelGGL((agg_dense2_kernel<VEC, ES>), dim3((unsigned)p.n_grid_chunks), dim3(kD2Threads), lds, st, p);
     PGLAMD_LAUNCH_CHECK();
     if (profiling) {
         PGLAMD_HIP_CHECK(hipEventRecord(e1, st));

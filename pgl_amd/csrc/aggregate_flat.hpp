@@ -27,7 +27,9 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 //     applied to the MFMA result and only THAT goes to memory: GCNConv's aggregate -> linear -> bias -> relu
 //     (pgl/nn/conv.py:242-254) without the [N, d] intermediate's round trip through HBM, and with the matrix cores working in
 //     the shadow of the row gathers (the kernel is HBM-bound; the MFMA pipe was idle).
-template <typename T, int VEC, int NT, int RCLS, int YMODE, bool SS = false, bool PIPE3 = true, int UB = 0, int SINK = 0, bool TWO = false>
+// SS: 0 no per-source scale, 1 src_scale[col] (one random 4-byte read per edge), 2 src_scale[p] by edge POSITION (the scale of every
+//     edge's source laid out along the sorted stream once per graph: 4 sequential bytes per edge)
+template <typename T, int VEC, int NT, int RCLS, int YMODE, int SS = 0, bool PIPE3 = true, int UB = 0, int SINK = 0, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     constexpr int U = 8;
     constexpr int kTileRows = 16;                      // rows per MFMA tile (v_mfma_f32_16x16x4_f32)
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         if constexpr (TWO) return (cc < xs ? x : x2) + (int64_t)cc * p.ldx;
         else return x + (int64_t)cc * p.ldx;
     };
-    constexpr bool has_ss = SS;       // per-source scale compiled in only where asked for (keeps 16 SGPRs free otherwise)
+    constexpr bool has_ss = SS != 0;  // per-source scale compiled in only where asked for (keeps 16 SGPRs free otherwise)
     const bool is_max = p.is_max != 0;
 
     // lane -> column mapping
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     // Vector loads retire in issue order (vmcnt), so the id load of batch g+2 is issued BEFORE the rows of batch g+1:
     // waiting for it one iteration later then never waits for younger row gathers.
     auto load_cl = [&](int e, int& cl) {
-        if constexpr (has_ss) cl = col_v ? col_v[e + (lane & (U - 1))] : e + (lane & (U - 1));
+        if constexpr (SS == 2) cl = e + (lane & (U - 1));                 // by position: no dependence on the column ids at all
+        else if constexpr (has_ss) cl = col_v ? col_v[e + (lane & (U - 1))] : e + (lane & (U - 1));
     };
     // YMODE 3: lane l carries element (l % ypad) of the operand row of edge (l / ypad) of the batch
     const int* __restrict__ eid_v = p.eid;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         // in flight per wave) at ~50 SGPRs.  Measured at C2: d=64 fp32 0.71 -> 0.63 ms, d=32 0.74 -> 0.62, fp16 d=128 0.86 -> 0.70;
         // UB = 32 was slower again (0.72 at d=32), and 512-byte rows gain nothing (they are byte-bound), so it stops at 320 B.  Same three stages: ids of batch g+2 are issued BEFORE the rows of g+1
         // (vector loads retire in issue order, so waiting for them one iteration later never waits for younger gathers).
-        static_assert(NT == 1 && YMODE == 0 && !SS, "vector-index pipeline: single tile, no operands");
+        static_assert(NT == 1 && YMODE == 0 && SS == 0, "vector-index pipeline: single tile, no operands");
         const int* __restrict__ row_v = p.row;
         const int* __restrict__ colv = p.col;
         const int li = lane & (UB - 1);
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     for (; e < e1; ++e) {   // remainder (< U edges): one at a time
         int r = rowp[e];
         int cc = colp ? colp[e] : e;
-        float s = has_ss ? scale_of(cc) : 1.f;
+        float s = has_ss ? scale_of(SS == 2 ? e : cc) : 1.f;
         V vx[NT], vy[NT];
         const T* xr = src_row(cc);
 #pragma unroll
@@ -748,7 +751,14 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     }
     if constexpr (can_scale) {
         if (p.src_scale) {           // (a second table excludes src_scale: aggregate_typed refuses the combination)
-            hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+            bool by_pos = false;
+            if constexpr (std::is_same_v<T, float> && YMODE == 0) {
+                if (p.ss_by_pos) {
+                    by_pos = true;
+                    hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, 2>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+                }
+            }
+            if (!by_pos) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, 1>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
             PGLAMD_LAUNCH_CHECK();
         } else {
             PGLAMD_LAUNCH_FLAT(false, true, 0);
@@ -881,6 +891,18 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     }
 
     AggParams p{};
+    // A one-value edge operand given IN THE ORDER OF THE SORTED STREAM (eid NULL) and multiplied into fp32 rows that are summed
+    // is a per-edge scale read sequentially: it rides in the flat kernel's scale slot (SS = 2: one coalesced 4-byte load per
+    // edge) instead of the general edge-operand path.  This is how GCN's source-side degree norm is applied (pgl/nn/conv.py:242):
+    // norm[col[p]] laid out once per graph, rather than a pass over [N, d] per layer or a random 4-byte read per edge.
+    if constexpr (std::is_same_v<T, float>) {
+        if (y && dy == 1 && !eid && mop == PGLAMD_MUL && (rop == PGLAMD_SUM || rop == PGLAMD_MEAN) && !src_scale && !ex.x2 && dout == dx &&
+            (size_t)dout * sizeof(T) > 128) {
+            src_scale = static_cast<const float*>(y);
+            p.ss_by_pos = 1;
+            y = nullptr; dy = 0;
+        }
+    }
     p.x = x; p.y = y; p.out = out; p.row = row; p.col = col; p.eid = eid; p.indptr = indptr;
     p.zero_indptr = zip;
     // the second table is rebased by -x_split rows here, so that the kernels address both tables with the same column id

@@ -22,21 +22,72 @@ template <typename T> __device__ __forceinline__ T mop_apply(T a, T b, int mop) 
 // One thread per output element group; for the GAT shape (dx=dy=dout=8 fp32) each thread moves a
 // float4, two threads per edge, so a wave writes 1 KiB contiguous.
 // ------------------------------------------------------------------------------------------------
+#ifndef PGLAMD_EDGE_UNROLL           // (variant builds: scripts/prof.py variant NAME PGLAMD_EDGE_UNROLL=4 PGLAMD_EDGE_NT=1)
+#define PGLAMD_EDGE_UNROLL 4
+#endif
+#ifndef PGLAMD_EDGE_NT
+#define PGLAMD_EDGE_NT 1
+#endif
+constexpr int kEdgeUnroll = PGLAMD_EDGE_UNROLL;
+
+// streamed-once operands (edge ids in, [E, ...] results out) bypass the cache hierarchy's retention, so that the 160 MB of
+// ids and 640 MB of results of a C3-sized call do not evict the two 32 MB node tables the gathers live on
+template <typename V> __device__ __forceinline__ V stream_load(const V* p) {
+#if PGLAMD_EDGE_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+template <typename V> __device__ __forceinline__ void stream_store(V* p, const V& v) {
+#if PGLAMD_EDGE_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+// element group i -> (edge, first element of the group): per = groups per edge, a power of two when log2per >= 0
+__device__ __forceinline__ void split_group(int64_t i, int64_t per, int log2per, int64_t& e, int64_t& g) {
+    if (log2per >= 0) { e = i >> log2per; g = i & (per - 1); }
+    else { e = i / per; g = i - e * per; }
+}
+static int log2_or_neg(int64_t v) { int l = 0; while ((int64_t(1) << l) < v) ++l; return (int64_t(1) << l) == v ? l : -1; }
+
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void send_uv_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t d,
                                                              const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-                                                             int64_t E, int mop, T* __restrict__ out) {
-    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+                                                             int64_t E, int mop, int log2per, T* __restrict__ out) {
+    typedef T V __attribute__((ext_vector_type(VEC)));
     const int64_t per = d / VEC;
     const int64_t total = E * per;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t e = i / per, j = (i - e * per) * VEC;
-        const V a = *reinterpret_cast<const V*>(x + (int64_t)src[e] * d + j);
-        const V b = *reinterpret_cast<const V*>(y + (int64_t)dst[e] * d + j);
-        V o;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    // kEdgeUnroll groups per thread and iteration: all their edge ids, then all their gathers are in flight before the first use
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < total; i0 += stride * kEdgeUnroll) {
+        int64_t e[kEdgeUnroll], j[kEdgeUnroll];
+        int32_t s[kEdgeUnroll], t[kEdgeUnroll];
+        V a[kEdgeUnroll], b[kEdgeUnroll];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o.v[k] = mop_apply(a.v[k], b.v[k], mop);
-        *reinterpret_cast<V*>(out + e * d + j) = o;
+        for (int k = 0; k < kEdgeUnroll; ++k) {
+            const int64_t i = i0 + k * stride;
+            int64_t g;
+            split_group(i < total ? i : 0, per, log2per, e[k], g);
+            j[k] = g * VEC;
+            s[k] = stream_load(src + e[k]); t[k] = stream_load(dst + e[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kEdgeUnroll; ++k) {
+            a[k] = *reinterpret_cast<const V*>(x + (int64_t)s[k] * d + j[k]);
+            b[k] = *reinterpret_cast<const V*>(y + (int64_t)t[k] * d + j[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < kEdgeUnroll; ++k) {
+            if (i0 + k * stride >= total) continue;
+            V o;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) o[q] = mop_apply(a[k][q], b[k][q], mop);
+            stream_store(reinterpret_cast<V*>(out + e[k] * d + j[k]), o);
+        }
     }
 }
 
@@ -65,7 +116,7 @@ static int32_t send_uv_typed(const void* x, const void* y, int64_t dx, int64_t d
     constexpr int VEC = 16 / sizeof(T);
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out);
     if (dx == dout && dy == dout && dout % VEC == 0 && al % 16 == 0)
-        hipLaunchKernelGGL((send_uv_vec_kernel<T, VEC>), dim3(grid_for(E * (dout / VEC))), dim3(kBlock), 0, st, xp, yp, dout, src, dst, E, mop, op);
+        hipLaunchKernelGGL((send_uv_vec_kernel<T, VEC>), dim3(grid_for(ceil_div(E * (dout / VEC), (int64_t)kEdgeUnroll))), dim3(kBlock), 0, st, xp, yp, dout, src, dst, E, mop, log2_or_neg(dout / VEC), op);
     else
         hipLaunchKernelGGL(send_uv_generic_kernel<T>, dim3(grid_for(E * dout)), dim3(kBlock), 0, st, xp, yp, dx, dy, dout, src, dst, E, mop, op);
     PGLAMD_LAUNCH_CHECK();
@@ -89,26 +140,40 @@ template <> __device__ __forceinline__ double exp_t<double>(double v) { return e
 // MODE 0: exp(x - stat[seg])   1: x / stat[seg]   2: exp(x - max[seg]) / sum[seg] with stat = [n_seg, 2, d] (whole normalisation in one pass)
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(kBlock) void softmax_elem_kernel(const T* x, const T* __restrict__ stat,
-                                                              const int32_t* __restrict__ seg, int64_t n, int64_t d,
+                                                              const int32_t* __restrict__ seg, int64_t n, int64_t d, int log2per,
                                                               T* out) {   // x may alias out (in-place divide)
-    struct alignas(sizeof(T) * VEC) V { T v[VEC]; };
+    typedef T V __attribute__((ext_vector_type(VEC)));
     const int64_t per = d / VEC;
     const int64_t total = n * per;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int64_t e = i / per, j = (i - e * per) * VEC;
-        const V a = *reinterpret_cast<const V*>(x + e * d + j);
-        const int64_t so = (int64_t)seg[e] * (MODE == 2 ? 2 * d : d) + j;     // MODE 2: [n_seg, 2, d] maxima | sums
-        const V b = *reinterpret_cast<const V*>(stat + so);
-        V o;
-        if constexpr (MODE == 2) {
-            const V c = *reinterpret_cast<const V*>(stat + so + d);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < total; i0 += stride * kEdgeUnroll) {
+        int64_t off[kEdgeUnroll], so[kEdgeUnroll];
+        V a[kEdgeUnroll], b[kEdgeUnroll], c[kEdgeUnroll];
 #pragma unroll
-            for (int k = 0; k < VEC; ++k) o.v[k] = exp_t<T>(a.v[k] - b.v[k]) / c.v[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) o.v[k] = MODE == 1 ? a.v[k] / b.v[k] : exp_t<T>(a.v[k] - b.v[k]);
+        for (int k = 0; k < kEdgeUnroll; ++k) {
+            const int64_t i = i0 + k * stride;
+            int64_t e, g;
+            split_group(i < total ? i : 0, per, log2per, e, g);
+            off[k] = e * d + g * VEC;
+            so[k] = (int64_t)stream_load(seg + e) * (MODE == 2 ? 2 * d : d) + g * VEC;     // MODE 2: [n_seg, 2, d] maxima | sums
+            a[k] = stream_load(reinterpret_cast<const V*>(x + off[k]));
         }
-        *reinterpret_cast<V*>(out + e * d + j) = o;
+#pragma unroll
+        for (int k = 0; k < kEdgeUnroll; ++k) {
+            b[k] = *reinterpret_cast<const V*>(stat + so[k]);
+            if constexpr (MODE == 2) c[k] = *reinterpret_cast<const V*>(stat + so[k] + d);
+        }
+#pragma unroll
+        for (int k = 0; k < kEdgeUnroll; ++k) {
+            if (i0 + k * stride >= total) continue;
+            V o;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                if constexpr (MODE == 2) o[q] = exp_t<T>(a[k][q] - b[k][q]) / c[k][q];
+                else o[q] = MODE == 1 ? a[k][q] / b[k][q] : exp_t<T>(a[k][q] - b[k][q]);
+            }
+            stream_store(reinterpret_cast<V*>(out + off[k]), o);
+        }
     }
 }
 
@@ -116,12 +181,13 @@ template <typename T, int MODE>
 static int32_t softmax_elem(const T* x, const T* stat, const int32_t* seg, int64_t n, int64_t d, T* out, hipStream_t st) {
     constexpr int VMAX = 16 / sizeof(T);
     const uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(stat) | reinterpret_cast<uintptr_t>(out);
-    if (d % VMAX == 0 && al % 16 == 0)
-        hipLaunchKernelGGL((softmax_elem_kernel<T, VMAX, MODE>), dim3(grid_for(n * (d / VMAX))), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
-    else if (d % 2 == 0 && al % (2 * sizeof(T)) == 0)
-        hipLaunchKernelGGL((softmax_elem_kernel<T, 2, MODE>), dim3(grid_for(n * (d / 2))), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
-    else
-        hipLaunchKernelGGL((softmax_elem_kernel<T, 1, MODE>), dim3(grid_for(n * d)), dim3(kBlock), 0, st, x, stat, seg, n, d, out);
+#define SM(VEC)                                                                                                             \
+    hipLaunchKernelGGL((softmax_elem_kernel<T, VEC, MODE>), dim3(grid_for(ceil_div(n * (d / VEC), (int64_t)kEdgeUnroll))), \
+                       dim3(kBlock), 0, st, x, stat, seg, n, d, log2_or_neg(d / VEC), out)
+    if (d % VMAX == 0 && al % 16 == 0) SM(VMAX);
+    else if (d % 2 == 0 && al % (2 * sizeof(T)) == 0) SM(2);
+    else SM(1);
+#undef SM
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }

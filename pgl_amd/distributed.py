@@ -111,12 +111,37 @@ class AbiTransport(object):
             self.comm = self._ct.c_void_p()
 
 
+_OVERRIDE = {"flow": None, "transport": None}      # set_flow(): per-process choice that takes precedence over PGLAMD_FLOW / PGLAMD_TRANSPORT
+
+
+def _env_flow():
+    return _OVERRIDE["flow"] if _OVERRIDE["flow"] is not None else os.environ.get("PGLAMD_FLOW", "")
+
+
+def _env_transport():
+    return _OVERRIDE["transport"] if _OVERRIDE["transport"] is not None else os.environ.get("PGLAMD_TRANSPORT", "")
+
+
+def set_flow(flow=None, transport=None, graphs=()):
+    """Forces the data flow ("split" | "fold" | "accumulate" | "pipeline" | "" = the cost model's choice) and / or the transport
+    ("abi" = the library's own RCCL communicator on its side stream, pglamd_halo_exchange_*; "torch" = torch.distributed's
+    all_to_all_single) for every DistGraph of this process, taking precedence over PGLAMD_FLOW / PGLAMD_TRANSPORT; None leaves
+    a setting as it is.  Decisions already cached on `graphs` are dropped.  Every rank must make the same call."""
+    if flow is not None:
+        _OVERRIDE["flow"] = flow
+    if transport is not None:
+        _OVERRIDE["transport"] = "" if transport == "torch" else transport
+    for g in graphs:
+        for k in [k for k in g._idx if isinstance(k, tuple) and k and k[0] in ("mode", "mode_estimates", "pipelined", "ran")]:
+            del g._idx[k]
+
+
 def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
     """all-to-all-v of rows.  Returns an object with .wait()."""
     if not _group_ready(group):
         return _Done()
     backend = dist.get_backend(group)
-    if backend == "nccl" and os.environ.get("PGLAMD_TRANSPORT") == "abi":
+    if backend == "nccl" and _env_transport() == "abi":
         return AbiTransport.get(group).exchange(send_buf, send_splits, recv_buf, recv_splits)
     if backend == "nccl":
         return dist.all_to_all_single(recv_buf, send_buf, list(recv_splits), list(send_splits), group=group, async_op=True)
@@ -893,7 +918,7 @@ class DistGraph(object):
                 rem = H * 0.5 * e_rem / R + L
                 end_a = max(t_a, t_c) + rem
                 est["pipeline"] = max(end_a, t_a + half_x) + rem + rmw
-            forced = os.environ.get("PGLAMD_FLOW", "")
+            forced = _env_flow()
             if forced in est and forced != "pipeline":
                 hit = forced
             elif os.environ.get("PGLAMD_FOLD_INTERIOR"):              # (round-3 knob kept for the tests: fold below this interior share)
@@ -911,7 +936,7 @@ class DistGraph(object):
         PGLAMD_FLOW=pipeline forces it where eligible, any other PGLAMD_FLOW value rules it out."""
         if not (additive and x.dim() == 2 and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and int(x.shape[1]) % 32 == 0):
             return False
-        forced = os.environ.get("PGLAMD_FLOW", "")
+        forced = _env_flow()
         if forced or os.environ.get("PGLAMD_FOLD_INTERIOR"):
             return forced == "pipeline"
         key = ("pipelined", kind, transposed, row_bytes)

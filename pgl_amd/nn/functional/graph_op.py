@@ -12,10 +12,26 @@ def degree_norm(graph, mode="indegree"):
     """pgl/nn/functional/graph_op.py:29-55 -> [num_nodes, 1] in the default float dtype."""
     assert mode in ["indegree", "outdegree"], \
         "The degree_norm mode should be in ['indegree', 'outdegree']. But recieve mode=%s" % mode
-    degree = graph.indegree() if mode == "indegree" else graph.outdegree()
     dt = torch.get_default_dtype()
-    out = ops.degree_norm(degree, dt if dt in (torch.float32, torch.float64) else torch.float32)
+    dt = dt if dt in (torch.float32, torch.float64) else torch.float32
+    # One tensor per (graph, mode, dtype): a layer stack asks for it once per layer and step (pgl/nn/conv.py:240), and the
+    # aggregation keys its per-edge layout of the norm (ops.edge_scale) on the tensor it is handed.  The entry is dropped if
+    # somebody wrote into the tensor (version counter).
+    cache = getattr(graph, "_degree_norm_cache", None)
+    if cache is not None:
+        hit = cache.get((mode, dt))
+        if hit is not None and hit[0]._version == hit[1]:
+            return hit[0]
+    degree = graph.indegree() if mode == "indegree" else graph.outdegree()
+    out = ops.degree_norm(degree, dt)
     out._pglamd_positive = True          # clip(degree, 1)^-0.5 > 0 by construction: lets the k-hop layers skip their check
+    if torch.is_tensor(degree) and degree.is_cuda:
+        try:
+            if cache is None:
+                cache = graph._degree_norm_cache = {}
+            cache[(mode, dt)] = (out, out._version)
+        except AttributeError:
+            pass
     return out
 
 

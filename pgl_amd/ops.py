@@ -72,12 +72,48 @@ def _prod(shape):
 
 
 # ------------------------------------------------------------------------------------------------
+# feature slabs (pglamd_slab_alloc): device memory whose address-translation layout is known
+# ------------------------------------------------------------------------------------------------
+_TYPESTR = {torch.float32: "<f4", torch.float16: "<f2", torch.float64: "<f8", torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}
+
+
+class _Slab(object):
+    """Owner of one pglamd_slab_alloc allocation, exposed to torch through __cuda_array_interface__ (torch keeps this object
+    alive for as long as a tensor views the memory; the allocation is released when the last view is gone)."""
+
+    def __init__(self, shape, dtype, mode):
+        n = _prod(shape) * torch.empty((), dtype=dtype).element_size()
+        ptr, got = ctypes.c_void_p(0), ctypes.c_size_t(0)
+        _ffi.check(_ffi.lib().pglamd_slab_alloc(max(n, 1), int(mode), ctypes.cast(ctypes.pointer(ptr), ctypes.c_void_p),
+                                                ctypes.cast(ctypes.pointer(got), ctypes.c_void_p)), "slab_alloc")
+        self.ptr, self.nbytes, self.mode = int(ptr.value), int(got.value), int(mode)
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": _TYPESTR[dtype], "data": (self.ptr, False),
+                                         "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", 0):
+                _ffi.lib().pglamd_slab_free(ctypes.c_void_p(self.ptr))
+                self.ptr = 0
+        except Exception:                                            # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
+def slab_empty(shape, dtype=torch.float32, device=None, mode=1):
+    """An uninitialised tensor on memory from pglamd_slab_alloc (mode 1: one physical allocation mapped into a 1 GiB-aligned
+    virtual range; mode 0: hipMalloc) -- for feature matrices of several GB that are gathered row by row."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    with torch.cuda.device(device):
+        return torch.as_tensor(_Slab(tuple(shape), dtype, mode), device=device)
+
+
+# ------------------------------------------------------------------------------------------------
 # CSR build / segment ids
 # ------------------------------------------------------------------------------------------------
 class CSR(object):
     """Device-side result of csr_build: the reference's five int64 arrays + int32 engine copies."""
     __slots__ = ("degree", "sorted_v", "sorted_u", "sorted_eid", "indptr", "row32", "col32", "eid32",
-                 "num_nodes", "num_edges", "_pos_by_dst", "max_row", "y_rows")
+                 "num_nodes", "num_edges", "_pos_by_dst", "max_row", "y_rows", "_es")
 
 
 def csr_build(u, v, num_nodes, want_i64=True, check_range=True):
@@ -192,6 +228,27 @@ def _bcast(x, y):
 _GAT_BWD_EDGE_BUFFER = os.environ.get("PGLAMD_GAT_BWD_EDGE_BUFFER", "1") != "0"
 _GAT_POS_STATS = os.environ.get("PGLAMD_GAT_POS_STATS", "1") != "0"
 _PRESCALE_ROW_BYTES = int(os.environ.get("PGLAMD_PRESCALE_ROW_BYTES", "704"))
+_EDGE_SCALE = os.environ.get("PGLAMD_EDGE_SCALE", "1") != "0"
+
+
+def edge_scale(csr, scale):
+    """scale[col[p]] for every position p of the index's sorted stream ([E] fp32), cached on the index: the per-source scale of
+    an aggregation (GCN's degree norm, pgl/nn/conv.py:242) in the layout the kernels read sequentially.  The cache entry is keyed
+    by the scale vector's storage, offset, length and version counter and HOLDS the vector, so the address cannot be reused by
+    another tensor while the entry lives; an in-place update of the vector bumps the version and rebuilds the entry."""
+    scale = scale.reshape(-1)
+    if not scale.is_contiguous():
+        scale = scale.contiguous()
+    key = (scale.untyped_storage().data_ptr(), scale.storage_offset(), scale.numel(), scale._version)
+    hit = getattr(csr, "_es", None)
+    if hit is not None and hit[0] == key:
+        return hit[2]
+    es = gather_rows(scale.reshape(-1, 1), csr.col32).reshape(-1)
+    try:
+        csr._es = (key, scale, es)
+    except AttributeError:                                    # an index type without the slot: no caching
+        pass
+    return es
 
 
 def _row_strided(t):
@@ -227,6 +284,15 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
         x2 = x2.contiguous()
         if x2.dtype != x.dtype or tuple(x2.shape[1:]) != tuple(x.shape[1:]) or src_scale is not None:
             raise ValueError("aggregate: x2 must have x's dtype and row shape, and excludes src_scale")
+    es = None
+    if src_scale is not None and y is None and x2 is None and x.dim() >= 2 and x.dtype == torch.float32 and _EDGE_SCALE \
+            and reduce_op in ("sum", "mean") and _prod(x.shape[1:]) * 4 > 128 and src_scale.numel() == x.shape[0] \
+            and src_scale.dtype == torch.float32:
+        # fp32 rows wider than 128 bytes: the scale of every edge's source, laid out ALONG THE SORTED STREAM once per (index, scale
+        # vector) and cached on the index, rides in the kernel as 4 sequential bytes per edge (round 4) -- neither the pass over
+        # [N, d] below nor the random 4-byte read per edge of the node-indexed form
+        es = edge_scale(csr, src_scale)
+        src_scale = None
     if src_scale is not None and y is None and x.dim() >= 2 and x.is_floating_point() \
             and _prod(x.shape[1:]) * x.element_size() <= _PRESCALE_ROW_BYTES and src_scale.numel() == x.shape[0]:
         # The fused per-source scale costs one random 4-byte access per EDGE (+0.25 ms at 20 M edges, any row width);
@@ -263,16 +329,16 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     ws = _ws_hot(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
     if ext and src_scale is None:
         with torch.cuda.device(x.device):
-            _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(y), dy,
+            _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(y if es is None else es), dy if es is None else 1,
                                               _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
                                               _ptr(csr.indptr), _ptr(zero_indptr), max_row, csr.num_edges, csr.num_nodes, M, dout, ldo,
-                                              MSG[message_op], REDUCE[reduce_op], _ptr(dst_scale), int(accumulate), _ptr(out),
+                                              MSG[message_op if es is None else "mul"], REDUCE[reduce_op], _ptr(dst_scale), int(accumulate), _ptr(out),
                                               _ptr(ws), ws.numel(), _stream(x)), "aggregate_ext")
         return out
     with torch.cuda.device(x.device):
-        _ffi.check(L.pglamd_aggregate(_ptr(x), code, int(x.shape[0]), dx, _ptr(y), dy,
+        _ffi.check(L.pglamd_aggregate(_ptr(x), code, int(x.shape[0]), dx, _ptr(y if es is None else es), dy if es is None else 1,
                                       _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
-                                      _ptr(csr.indptr), csr.num_edges, csr.num_nodes, M, dout, MSG[message_op],
+                                      _ptr(csr.indptr), csr.num_edges, csr.num_nodes, M, dout, MSG[message_op if es is None else "mul"],
                                       REDUCE[reduce_op], _ptr(src_scale), _ptr(dst_scale), int(accumulate), _ptr(out), _ptr(ws),
                                       ws.numel(), _stream(x)), "aggregate")
     return out
@@ -284,10 +350,18 @@ def aggregate_dense_supported(x, d_out):
             and int(d_out) % 16 == 0 and 0 < int(d_out) <= 1024)
 
 
-def aggregate_dense(x, csr, w, bias=None, act=None, reduce_op="sum", dst_scale=None, out_size=None, keep_agg=False):
-    """act( (dst_scale * REDUCE_{u->v} x[u]) @ w + bias ) in one kernel (pglamd_aggregate_dense; GCNConv's aggregate ->
-    linear -> bias -> activation, pgl/nn/conv.py:242-254).  w: [d_in, d_out] row-major.  -> (out, agg or None)."""
-    _need_cuda(x, w, bias, dst_scale)
+def aggregate_dense(x, csr, w, bias=None, act=None, reduce_op="sum", dst_scale=None, out_size=None, keep_agg=False, src_scale=None):
+    """act( (dst_scale * REDUCE_{u->v} src_scale[u] * x[u]) @ w + bias ) in one kernel (pglamd_aggregate_dense; GCNConv's
+    aggregate -> linear -> bias -> activation, pgl/nn/conv.py:242-254).  w: [d_in, d_out] row-major.  src_scale (one value per
+    source node) travels as one value per edge position of the sorted stream, cached on the index (edge_scale).
+    -> (out, agg or None)."""
+    _need_cuda(x, w, bias, dst_scale, src_scale)
+    es = None
+    if src_scale is not None:
+        if _EDGE_SCALE and src_scale.numel() == x.shape[0]:
+            es = edge_scale(csr, src_scale.to(torch.float32))
+        else:
+            x = x * src_scale.reshape(-1, 1).to(x.dtype)
     x = x.contiguous(); w = w.contiguous()
     d_in, d_out = int(x.shape[1]), int(w.shape[1])
     if int(w.shape[0]) != d_in or w.dtype != torch.float32 or not aggregate_dense_supported(x, d_out):
@@ -306,7 +380,7 @@ def aggregate_dense(x, csr, w, bias=None, act=None, reduce_op="sum", dst_scale=N
     ds = None if dst_scale is None else dst_scale.to(torch.float32).contiguous()
     with torch.cuda.device(x.device):
         _ffi.check(L.pglamd_aggregate_dense(_ptr(x), d_in, _ptr(csr.row32), _ptr(csr.col32), _ptr(csr.indptr), csr.num_edges,
-                                            csr.num_nodes, M, REDUCE[reduce_op], _ptr(ds), _ptr(w), _ptr(b), 1 if act == "relu" else 0,
+                                            csr.num_nodes, M, REDUCE[reduce_op], _ptr(es), _ptr(ds), _ptr(w), _ptr(b), 1 if act == "relu" else 0,
                                             d_out, _ptr(agg), _ptr(out), _ptr(ws), ws.numel(), _stream(x)), "aggregate_dense")
     return out, agg
 

@@ -265,7 +265,17 @@ def cmd_noreuse(args):
     dst = torch.arange(n, device=dev).repeat_interleave(deg)
     g = pgl.Graph(edges=torch.stack([src, dst], 1), num_nodes=n); g.adj_dst_index
     del src, dst
-    x = torch.randn(n, d, generator=gen, device=dev)
+    slab = getattr(args, "slab", "torch")
+    if slab == "torch":
+        x = torch.randn(n, d, generator=gen, device=dev)
+    else:                                            # the feature matrix on pglamd_slab_alloc memory
+        x = pgl.ops.slab_empty((n, d), torch.float32, dev, mode=1 if slab == "vmm" else 0)
+        for lo in range(0, n, 1 << 21):
+            x[lo:lo + (1 << 21)] = torch.randn(min(1 << 21, n - lo), d, generator=gen, device=dev)
+    print("feature matrix [%d, %d] fp32 allocated through %s, base address 0x%x (2 MiB aligned: %s, 1 GiB aligned: %s)"
+          % (n, d, {"torch": "torch's caching allocator (hipMalloc)", "hipmalloc": "pglamd_slab_alloc mode 0 (hipMalloc)",
+                    "vmm": "pglamd_slab_alloc mode 1 (hipMemCreate + one mapping in a 1 GiB-aligned range)"}[slab],
+             x.data_ptr(), x.data_ptr() % (2 << 20) == 0, x.data_ptr() % (1 << 30) == 0))
     for _ in range(3):
         g.send_recv(x, "sum")
     torch.cuda.synchronize()
@@ -975,7 +985,7 @@ def main():
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     r.add_argument("--graph", default="rmat", choices=["rmat", "community"])
     r.add_argument("--flow", default="", choices=["", "split", "fold", "accumulate", "pipeline"], help="force one flow (PGLAMD_FLOW) instead of the cost model's")
-    sub.add_parser("noreuse")
+    nr = sub.add_parser("noreuse"); nr.add_argument("--slab", default="torch", choices=["torch", "hipmalloc", "vmm"])
     sub.add_parser("gcn")
     tr = sub.add_parser("traffic")
     tr.add_argument("--dir", required=True)

@@ -640,3 +640,60 @@ def test_degenerate_partitions_empty_ranks_and_no_cut_edges():
     p0 = HaloPlan(torch.zeros((0, 2), dtype=torch.int64), 6, np.array([0, 1, 0, 1, 0, 1]), 0, 2)
     dg0 = DistGraph(p0, backend=B)
     assert float(dg0.send_recv(torch.ones(3, 4), "sum").abs().sum()) == 0.0 and dg0.indegree().tolist() == [0, 0, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: the candidate ladder of bench.py (set_flow: forced flows one after the other on the SAME DistGraph, then back to the
+# cost model's choice) -- every rank takes the same flow at every rung and every rung yields the same rows
+# ------------------------------------------------------------------------------------------------
+def _ladder_worker(rank, world):
+    import pgl_amd.distributed as pd
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph(d=32)
+    dg = DistGraph.from_global(torch.from_numpy(edges), x.shape[0], rank, world, method="kway", backend=TorchBackend(), push="never")
+    x_own = dg.take_owned(torch.from_numpy(x))
+    outs, ran = [], []
+    try:
+        for flow, transport in (("fold", "torch"), ("", "torch"), ("", "abi"), ("accumulate", "torch"), ("split", None), ("pipeline", "torch"), ("", "torch")):
+            pd.set_flow(flow, transport, graphs=[dg])
+            outs.append(dg.send_recv(x_own, "sum").numpy())
+            ran.append(dg.stats()["flow"])
+    finally:
+        pd.set_flow("", "torch")
+        pd._OVERRIDE.update(flow=None, transport=None)
+    return (rank, dg.plan.own_global.numpy(), outs, ran)
+
+
+def test_set_flow_ladder_agrees_across_ranks_and_with_the_oracle():
+    got = _spawn(_ladder_worker, 2)
+    edges, x = _graph(d=32)
+    want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "sum")
+    assert got[0][3] == got[1][3], (got[0][3], got[1][3])              # the same flow on both ranks at every rung
+    assert got[0][3][0] == "fold" and got[0][3][3] == "accumulate" and got[0][3][4] == "split" and got[0][3][5] == "pipeline"
+    assert got[0][3][1] == got[0][3][6]                                # back to the cost model's own choice
+    for k in range(len(got[0][2])):
+        full = np.zeros_like(want)
+        for _, own, outs, _ in got:
+            full[own] = outs[k]
+        np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max(), err_msg="rung %d" % k)
+
+
+def test_bench_watchdog_prints_the_best_completed_record_and_exits_zero():
+    """bench.PhaseWatchdog: a phase past its limit ends the process with rc 0 and the fallback record on stdout (rank 0)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, time; sys.path.insert(0, %r); import bench\n"
+            "wd = bench.PhaseWatchdog(0, lambda rec: print(json.dumps(rec), flush=True))\n"
+            "wd.begin('quick', 30); wd.end()\n"
+            "wd.best = lambda: {'value': 42.0, 'metric': 'm'}\n"
+            "wd.begin('stuck collective', 0.5)\n"
+            "time.sleep(60)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["value"] == 42.0 and rec["aborted"]["phase"] == "stuck collective"
+    assert "phase 'quick' done" in r.stderr and "exceeded its limit" in r.stderr
+    # without any completed measurement there is nothing to report: non-zero exit, no JSON line
+    code2 = code.replace("wd.best = lambda: {'value': 42.0, 'metric': 'm'}\n", "")
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 3 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]

@@ -1349,7 +1349,7 @@ def test_bench_multi_rank_code_path_dry_run():
     env = dict(os.environ, PGLAMD_BENCH_DRYRUN="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29731", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--scale", "16", "--edges", "1000000", "--target-scale", "15", "--target-edges", "400000"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+                        "--scale", "16", "--edges", "1000000", "--target-scale", "15", "--target-edges", "400000", "--alternatives"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
@@ -1363,6 +1363,28 @@ def test_bench_multi_rank_code_path_dry_run():
     assert set(rec["halo"]["alternatives_ms_per_step"]) >= {"rows", "cols"}
     assert rec["halo"]["exchange_only_ms"] > 0 and len(rec["halo"]["recv_bytes_per_rank"]) == 2
     assert rec["halo"]["flow"] in ("split", "fold", "accumulate", "pipeline") and rec["target_size"]["flow"] in ("split", "fold", "accumulate", "pipeline")
+    # round 4: the candidates (fold / cost-model flow over torch.distributed, the cost-model flow over the library's transport) were
+    # all tried and timed, the timed region ran on the fastest, every phase reported its wall time on stderr
+    c = rec["halo"]["candidates"]
+    assert [(k["flow"], k["transport"]) for k in c] == [("fold", "torch"), ("cost-model", "torch"), ("cost-model", "abi")]
+    assert all(k["status"] == "ok" and k["trial_ms_per_step"] > 0 for k in c) and c[0]["ran_flow"] == "fold"
+    assert rec["halo"]["chosen"]["transport"] in ("torch", "abi") and "aborted" not in rec
+    assert "phase 'partition + halo plan' done" in r.stderr and "phase 'target size leg" in r.stderr
+
+
+def test_bench_phase_limit_ends_a_hung_run_with_the_best_completed_measurement():
+    """A phase that does not finish (here: every phase after the first candidate, by a 0.05 s limit on a 2-rank dry run) must end
+    the run with rc 0 and a JSON line that reports the last COMPLETED measurement, labelled -- not hang, not lose the number."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PGLAMD_BENCH_DRYRUN="1", PGLAMD_BENCH_HANG_AFTER="trial fold/torch")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--scale", "15", "--edges", "400000", "--phase-limit", "20"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["aborted"]["phase"].startswith("trial cost-model/torch") and rec["value"] > 0 and rec["n_gpus"] == 2
+    assert "trial of" in rec["timed"] and rec["halo"]["candidates"][0]["status"] == "ok"
 
 
 @pytest.mark.parametrize("H,D", [(4, 8), (8, 16), (1, 64), (3, 4)])

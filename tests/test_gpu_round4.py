@@ -68,8 +68,8 @@ def test_c2prime_build_index_bit_exact_vs_reference(pgl, c2prime, ref_native):
 
 def test_c2prime_gcn_spmm_vs_oracle(pgl, c2prime):
     """Full output of send_recv(sum) and (mean) at |E| = 100 M, d = 128 fp32 against the serial C port of the Paddle CPU
-    kernel walking the raw COO order (oracle/ref_ops.c), rtol 1e-5 of the data scale (north_star), then the per-element
-    fp32 reassociation bound of the fp64 result."""
+    kernel walking the raw COO order (oracle/ref_ops.c) and against the fp64 sum, rtol 1e-5 of the data scale (north_star), then
+    the per-element fp32 reassociation bound of the fp64 result."""
     g, x = c2prime
     e = host(g.edges)
     xh = host(x)
@@ -80,10 +80,23 @@ def test_c2prime_gcn_spmm_vs_oracle(pgl, c2prime):
         got = host(g.send_recv(x, op))
         want = R.c_send_u_recv(xh, src, dst, op)
         scale = float(np.abs(want).max())
-        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale, err_msg=op)
         w, a = (want64, abs64) if op == "sum" else (want64 / indeg.clamp(min=1), abs64 / indeg.clamp(min=1))
-        assert_within_fp32_reassociation(got, host(w), host(a), host(indeg.expand(-1, x.shape[1])) + (1 if op == "mean" else 0), slack=2.0)
-        del got, want
+        w = host(w)
+        # (1) north_star's bar against the EXACT result: 1e-5 relative, atol 1e-5 of the data scale
+        np.testing.assert_allclose(got, w, rtol=1e-5, atol=1e-5 * scale, err_msg=op + " vs fp64")
+        # (2) against the reference's serial fp32 loop: 1e-5, plus what that loop itself is away from the exact sum.  At this size
+        #     the graph has a row with ~10^5..10^6 in-edges whose SERIAL fp32 sum is 3e-5 off (one element of 5.4e8 in round 4's
+        #     first run); everywhere else the second term is far below the first.
+        own = np.abs(want.astype(np.float64) - w)
+        tol = 1e-5 * np.abs(want) + 1e-5 * scale + own
+        err = np.abs(got.astype(np.float64) - want)
+        bad = err > tol
+        assert not bad.any(), "%s: %d elements beyond 1e-5 + the oracle's own error (worst %.3e)" % (op, int(bad.sum()), float((err - tol).max()))
+        print("%s at |E| = 100 M: oracle elements farther than 1e-5 from the fp64 sum: %d; engine elements: %d"
+              % (op, int((own > 1e-5 * np.abs(w) + 1e-5 * scale).sum()), int((np.abs(got - w) > 1e-5 * np.abs(w) + 1e-5 * scale).sum())))
+        # (3) per element: inside the fp32 reassociation bound of the fp64 result
+        assert_within_fp32_reassociation(got, w, host(a), host(indeg.expand(-1, x.shape[1])) + (1 if op == "mean" else 0), slack=2.0)
+        del got, want, w, own, tol, err, bad
     # checksum of checksums in fp64: column sums of out == out-degree-weighted column sums of x
     out = g.send_recv(x, "sum")
     outdeg = torch.bincount(g.edges[:, 0], minlength=g.num_nodes).double()
@@ -137,3 +150,157 @@ def test_config5_fp16_features_two_layer_gcn_vs_fp64(pgl, c2prime):
     rel = float((got2.double() - w2).abs().max() / w2.abs().max())
     assert rel < 4e-3, rel
     assert torch.equal(got2, g.send_recv(xin2, "sum") * norm.to(x16.dtype))
+
+
+# ------------------------------------------------------------------------------------------------
+# GCN's source-side norm as one value per edge POSITION of the sorted stream (ops.edge_scale; flat kernel SS = 2, fused
+# layer kernel ES).  Reference: pgl/nn/conv.py:242-250 (h * norm -> send_recv(sum) -> * norm)
+# ------------------------------------------------------------------------------------------------
+def _hub_graph(pgl, n, e, seed, hub):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, e); dst = rng.integers(0, n, e)
+    dst[rng.choice(e, hub, replace=False)] = n // 3                # a row spanning many chunks (split-row fix-up)
+    src[rng.choice(e, hub // 2, replace=False)] = 5                # and a hub source (the transposed walk's long row)
+    edges = np.stack([src, dst], 1).astype(np.int64)
+    return pgl.Graph(edges=edges, num_nodes=n).tensor(), edges, rng
+
+
+@pytest.mark.parametrize("d", [48, 64, 128, 200, 256])
+def test_send_recv_scaled_edge_scale_vs_fp64(pgl, d):
+    n, e = 30000, 400000
+    g, edges, rng = _hub_graph(pgl, n, e, 31 + d, 60000)
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    ss = dev(rng.uniform(0.1, 2.0, n).astype(np.float32)); ds = dev(rng.uniform(0.1, 2.0, n).astype(np.float32))
+    got = g.send_recv_scaled(x, ss, ds)
+    et = dev(edges)
+    terms = x.double()[et[:, 0]] * ss.double()[et[:, 0], None]
+    want = torch.zeros(n, d, dtype=torch.float64, device="cuda").index_add_(0, et[:, 1], terms) * ds.double()[:, None]
+    absw = torch.zeros(n, d, dtype=torch.float64, device="cuda").index_add_(0, et[:, 1], terms.abs()) * ds.double()[:, None]
+    indeg = torch.bincount(et[:, 1], minlength=n).double()[:, None].expand(-1, d)
+    assert_within_fp32_reassociation(host(got), host(want), host(absw), host(indeg) + 2, slack=2.0)
+    np.testing.assert_allclose(host(got), host(want), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+    # the unfused composition of the reference, same kernels
+    ref = g.send_recv(x * ss[:, None], "sum") * ds[:, None]
+    np.testing.assert_allclose(host(got), host(ref), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    assert torch.equal(got, g.send_recv_scaled(x, ss, ds))                      # reproducible, cache hit
+    if d * 4 > 128:
+        es = g.adj_dst_index.csr._es
+        assert es is not None and torch.equal(es[2], ss[g.adj_dst_index.csr.col32.long()])
+        ss.mul_(2.0)                                                             # in-place update: the cached layout must follow
+        got2 = g.send_recv_scaled(x, ss, ds)
+        np.testing.assert_allclose(host(got2), 2.0 * host(got), rtol=2e-6, atol=1e-6)
+        other = dev(rng.uniform(0.1, 2.0, n).astype(np.float32))                 # another vector: another layout
+        got3 = g.send_recv_scaled(x, other, None)
+        ref3 = g.send_recv(x * other[:, None], "sum")
+        np.testing.assert_allclose(host(got3), host(ref3), rtol=1e-5, atol=1e-5 * float(ref3.abs().max()))
+
+
+def test_send_recv_scaled_gradient_through_edge_scale(pgl):
+    n, e, d = 20000, 250000, 128
+    g, edges, rng = _hub_graph(pgl, n, e, 77, 40000)
+    x = dev(rng.standard_normal((n, d)).astype(np.float32)).requires_grad_(True)
+    ss = dev(rng.uniform(0.1, 2.0, n).astype(np.float32)); ds = dev(rng.uniform(0.1, 2.0, n).astype(np.float32))
+    w = dev(rng.standard_normal((n, d)).astype(np.float32))
+    (g.send_recv_scaled(x, ss, ds) * w).sum().backward()
+    et = dev(edges)
+    x64 = x.detach().double().requires_grad_(True)
+    out64 = torch.zeros(n, d, dtype=torch.float64, device="cuda").index_add_(0, et[:, 1], x64[et[:, 0]] * ss.double()[et[:, 0], None]) * ds.double()[:, None]
+    (out64 * w.double()).sum().backward()
+    np.testing.assert_allclose(host(x.grad), host(x64.grad), rtol=1e-5, atol=1e-5 * float(x64.grad.abs().max()))
+
+
+@pytest.mark.parametrize("d_in,d_out,act", [(128, 128, "relu"), (64, 128, None), (128, 48, "relu"), (128, 512, None)])
+def test_fused_layer_kernel_with_edge_scale(pgl, d_in, d_out, act):
+    """Graph.send_recv_dense with both norms: act((ds * A (ss * x)) W^T + b), both forms of the kernel (W in LDS: form 2; 128 x 512:
+    form 1), forward and the three gradients against fp64 autograd."""
+    n, e = 25000, 300000
+    g, edges, rng = _hub_graph(pgl, n, e, 5 + d_out, 50000)
+    mk = lambda *s: dev(rng.standard_normal(s).astype(np.float32))
+    x, W, b = mk(n, d_in).requires_grad_(True), (mk(d_out, d_in) * 0.1).requires_grad_(True), mk(d_out).requires_grad_(True)
+    ss = dev(rng.uniform(0.2, 1.5, n).astype(np.float32)); ds = dev(rng.uniform(0.2, 1.5, n).astype(np.float32))
+    out = g.send_recv_dense(x, W, b, act, ss, ds)
+    wgt = mk(n, d_out)
+    (out * wgt).sum().backward()
+    et = dev(edges)
+    x64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    agg = torch.zeros(n, d_in, dtype=torch.float64, device="cuda").index_add_(0, et[:, 1], x64[et[:, 0]] * ss.double()[et[:, 0], None]) * ds.double()[:, None]
+    z = agg @ W64.t() + b64
+    o64 = torch.relu(z) if act == "relu" else z
+    (o64 * wgt.double()).sum().backward()
+    sc = float(o64.abs().max())
+    # relu kinks: an fp32 pre-activation within rounding of 0 may fall on the other side; compare away from the kink
+    safe = (z.abs() > 1e-4 * sc) if act == "relu" else torch.ones_like(z, dtype=torch.bool)
+    assert float(((out.double() - o64).abs() * safe).max()) <= 2e-5 * sc
+    for name, got, want in (("dx", x.grad, x64.grad), ("dW", W.grad, W64.grad), ("db", b.grad, b64.grad)):
+        err = float((got.double() - want).abs().max())
+        assert err <= 3e-5 * float(want.abs().max()), (name, err, float(want.abs().max()))
+    with torch.no_grad():                                      # inference path (no autograd Function), same values
+        assert torch.equal(g.send_recv_dense(x, W, b, act, ss, ds), out)
+
+
+def test_gcnconv_degree_norm_is_cached_per_graph_and_layers_agree(pgl):
+    """GF.degree_norm returns one tensor per graph (so the per-edge layout of the norm is built once), GCNConv with the fused
+    path equals the reference's three-op formulation, with and without the fused layer kernel."""
+    n, e, d = 20000, 200000, 128
+    g, edges, rng = _hub_graph(pgl, n, e, 9, 30000)
+    GF = pgl.nn.functional
+    n1, n2 = GF.degree_norm(g), GF.degree_norm(g)
+    assert n1 is n2 and GF.degree_norm(g, "outdegree") is not n1
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    torch.manual_seed(0)
+    layer = pgl.nn.GCNConv(d, d, activation="relu").cuda()
+    with torch.no_grad():
+        layer.bias.copy_(dev(rng.standard_normal(d).astype(np.float32) * 0.1))
+        y_fused = layer(g, x)
+        layer.fused_dense = False
+        y_two = layer(g, x)
+        norm = GF.degree_norm(g)
+        want = torch.relu(((g.send_recv(x * norm, "sum")) @ layer.linear.weight.t()) * norm + layer.bias)
+    sc = float(want.abs().max())
+    assert float((y_fused - want).abs().max()) <= 2e-5 * sc and float((y_two - want).abs().max()) <= 2e-5 * sc
+
+
+# ------------------------------------------------------------------------------------------------
+# send_uv / segment softmax kernels reworked in round 4 (several element groups in flight per thread, streamed operands
+# non-temporal): sizes around the unroll boundaries.  Reference: pgl/graph.py:939-966, pgl/math.py:181-224
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("e,d", [(1, 8), (255, 8), (1023, 4), (1025, 8), (4099, 12), (70001, 8), (300000, 6), (65536 * 4 + 3, 16)])
+def test_send_uv_and_edge_softmax_at_unroll_boundaries(pgl, e, d):
+    rng = np.random.default_rng(e + d)
+    n = max(2, e // 7)
+    src = rng.integers(0, n, e); dst = rng.integers(0, n, e)
+    edges = np.stack([src, dst], 1).astype(np.int64)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    a = rng.standard_normal((n, d)).astype(np.float32); b = rng.standard_normal((n, d)).astype(np.float32)
+    for mop in ("add", "sub", "mul", "div"):
+        bb = b if mop != "div" else np.abs(b) + 0.5
+        got = host(g.send_uv(dev(a), dev(bb), mop))
+        want = R.np_send_uv(a, bb, src, dst, mop)
+        np.testing.assert_allclose(got, want, rtol=2e-7, atol=1e-7)
+    logits = rng.standard_normal((e, d)).astype(np.float32) * 3
+    got = host(pgl.nn.functional.edge_softmax(g, dev(logits)))
+    want = R.np_edge_softmax(edges, n, logits)                  # the oracle's restatement of GF.edge_softmax (graph_op.py:117-123)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-7)
+    sums = np.zeros((n, d)); np.add.at(sums, dst, got)
+    assert np.allclose(sums[np.bincount(dst, minlength=n) > 0], 1.0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# pglamd_slab_alloc: feature slabs with a known address-translation layout (engine extension)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1])
+def test_feature_slab_allocation_is_a_normal_tensor(pgl, mode):
+    n, d = 50000, 128
+    g, edges, rng = _hub_graph(pgl, n, 300000, 3, 20000)
+    xh = rng.standard_normal((n, d)).astype(np.float32)
+    x = pgl.ops.slab_empty((n, d), torch.float32, "cuda:0", mode=mode)
+    assert x.is_cuda and tuple(x.shape) == (n, d) and x.is_contiguous()
+    if mode == 1:
+        assert x.data_ptr() % (1 << 30) == 0                   # the reserved range is 1 GiB aligned
+    x.copy_(dev(xh))
+    want = g.send_recv(dev(xh), "sum")
+    assert torch.equal(g.send_recv(x, "sum"), want)
+    y = x * 2.0                                                # ordinary torch ops read and write it
+    assert torch.equal(y, dev(xh) * 2.0)
+    del x, y
+    torch.cuda.synchronize()
