@@ -443,17 +443,6 @@ int32_t pglamd_row_epilogue_backward(const float* dy, const float* y, const floa
                                      float* dz, float* col_partials, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Feature slabs with a known address-translation layout (engine extension; in the reference Paddle's allocator owns device
- * memory behind Graph.tensor(), pgl/graph.py:1090-1123).  Random 512-byte row gathers over several GB miss the per-CU
- * translation cache on more than half of the rows, so the page-table fragment size of the slab matters:
- *   mode 0  hipMalloc (comparison partner)
- *   mode 1  ONE physical allocation (hipMemCreate) mapped into a 1 GiB-aligned virtual range in one piece
- * out_bytes (optional) = the mapped size (>= bytes).  pglamd_slab_free synchronises the device, then unmaps / frees.
- * ---------------------------------------------------------------------------------------------- */
-int32_t pglamd_slab_alloc(size_t bytes, int32_t mode, void** out_ptr, size_t* out_bytes);
-int32_t pglamd_slab_free(void* ptr);
-
-/* ------------------------------------------------------------------------------------------------
  * Multi-GPU exchange step of the row-partitioned path.  Replaces the collective of the reference's
  * DistGPUGraph -- all_reduce_sum_with_grad of the whole [N, d] output after every aggregation
  * (pgl/graph.py:1517-1553 -> pgl/utils/op.py:90-122, c_allreduce_sum) -- with one all-to-all-v of halo rows:

@@ -76,8 +76,6 @@ _SIGNATURES = {
     "pglamd_row_epilogue_partials": (c_i64, [c_i64]),
     "pglamd_row_epilogue": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.c_float, c_vp, c_vp, c_vp]),
     "pglamd_row_epilogue_backward": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
-    "pglamd_slab_alloc": (c_i32, [c_sz, c_i32, c_vp, c_vp]),
-    "pglamd_slab_free": (c_i32, [c_vp]),
     "pglamd_comm_unique_id": (c_i32, [c_vp]),
     "pglamd_comm_init": (c_i32, [c_i32, c_i32, c_vp, c_vp]),
     "pglamd_comm_destroy": (c_i32, [c_vp]),

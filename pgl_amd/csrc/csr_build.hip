@@ -17,8 +17,7 @@
 //      128-byte line per edge: 0.40 ms of the 1.04 at C2); the last kernel unpacks sequentially, widens to the
 //      reference's int64 arrays where asked, and keeps the int32 (row, col, eid) copies the aggregation kernels read.
 #include "common.hpp"
-
-#include <rocprim/rocprim.hpp>
+#include "scan.hpp"
 
 namespace pglamd {
 
@@ -458,13 +457,7 @@ static unsigned grid_for(int64_t n) {
     return (unsigned)(g < 256 * 16 ? g : 256 * 16);
 }
 
-static size_t scan_temp_bytes(int64_t N) {
-    size_t bytes = 0;
-    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), NonEmpty{nullptr});
-    int64_t* o = nullptr;
-    (void)rocprim::exclusive_scan(nullptr, bytes, it, o, int64_t(0), (size_t)(N > 0 ? N : 1), rocprim::plus<int64_t>(), (hipStream_t)0);
-    return bytes;
-}
+static size_t scan_temp_bytes(int64_t N) { return exclusive_scan64_temp_bytes(N); }
 
 }  // namespace pglamd
 
@@ -555,8 +548,8 @@ extern "C" int32_t pglamd_unique_segment(const int64_t* degree, const int64_t* s
     int64_t* rank = cv.take<int64_t>(N);
     size_t temp_bytes = scan_temp_bytes(N);
     void* temp = cv.take<char>(temp_bytes);
-    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), NonEmpty{degree});
-    PGLAMD_HIP_CHECK(rocprim::exclusive_scan(temp, temp_bytes, it, rank, int64_t(0), (size_t)N, rocprim::plus<int64_t>(), st));
+    (void)temp_bytes;
+    { const int32_t rc = exclusive_scan64(NonEmpty{degree}, N, rank, temp, st); if (rc != PGLAMD_OK) return rc; }   // rank of every non-empty row
     hipLaunchKernelGGL(uniq_scatter_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st, degree, rank, N, uniq_ind, num_uniq);
     PGLAMD_LAUNCH_CHECK();
     if (num_edges > 0) {

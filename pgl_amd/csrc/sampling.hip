@@ -15,7 +15,7 @@
 //   into new ids, a second lookup relabels every neighbour.
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "scan.hpp"
 
 namespace pglamd {
 
@@ -137,12 +137,7 @@ static uint64_t table_cap(int64_t total) {
     return c;
 }
 
-static size_t scan_bytes(int64_t total) {
-    size_t b = 0;
-    int64_t* p = nullptr;
-    (void)rocprim::exclusive_scan(nullptr, b, p, p, int64_t(0), (size_t)(total > 0 ? total : 1), rocprim::plus<int64_t>(), (hipStream_t)0);
-    return b;
-}
+static size_t scan_bytes(int64_t total) { return exclusive_scan64_temp_bytes(total); }
 
 }  // namespace pglamd
 
@@ -202,7 +197,7 @@ extern "C" int32_t pglamd_reindex(const int64_t* nodes, int64_t num_nodes, const
     PGLAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(reindex_first_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st, nodes, num_nodes, neighbors, num_neighbors, keys, minpos, cap - 1, is_first);
     PGLAMD_LAUNCH_CHECK();
-    PGLAMD_HIP_CHECK(rocprim::exclusive_scan(temp, tb, is_first, rank, int64_t(0), (size_t)total, rocprim::plus<int64_t>(), st));
+    { const int32_t rc = exclusive_scan64(LoadI64{is_first}, total, rank, temp, st); if (rc != PGLAMD_OK) return rc; }
     hipLaunchKernelGGL(reindex_assign_kernel, dim3(grid_for(total)), dim3(kBlock), 0, st, nodes, num_nodes, neighbors, num_neighbors, keys, minpos,
                        cap - 1, is_first, rank, reindex_src, out_nodes, num_out);
     PGLAMD_LAUNCH_CHECK();

@@ -72,42 +72,6 @@ def _prod(shape):
 
 
 # ------------------------------------------------------------------------------------------------
-# feature slabs (pglamd_slab_alloc): device memory whose address-translation layout is known
-# ------------------------------------------------------------------------------------------------
-_TYPESTR = {torch.float32: "<f4", torch.float16: "<f2", torch.float64: "<f8", torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}
-
-
-class _Slab(object):
-    """Owner of one pglamd_slab_alloc allocation, exposed to torch through __cuda_array_interface__ (torch keeps this object
-    alive for as long as a tensor views the memory; the allocation is released when the last view is gone)."""
-
-    def __init__(self, shape, dtype, mode):
-        n = _prod(shape) * torch.empty((), dtype=dtype).element_size()
-        ptr, got = ctypes.c_void_p(0), ctypes.c_size_t(0)
-        _ffi.check(_ffi.lib().pglamd_slab_alloc(max(n, 1), int(mode), ctypes.cast(ctypes.pointer(ptr), ctypes.c_void_p),
-                                                ctypes.cast(ctypes.pointer(got), ctypes.c_void_p)), "slab_alloc")
-        self.ptr, self.nbytes, self.mode = int(ptr.value), int(got.value), int(mode)
-        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": _TYPESTR[dtype], "data": (self.ptr, False),
-                                         "version": 2, "strides": None}
-
-    def __del__(self):
-        try:
-            if getattr(self, "ptr", 0):
-                _ffi.lib().pglamd_slab_free(ctypes.c_void_p(self.ptr))
-                self.ptr = 0
-        except Exception:                                            # noqa: BLE001 -- interpreter shutdown
-            pass
-
-
-def slab_empty(shape, dtype=torch.float32, device=None, mode=1):
-    """An uninitialised tensor on memory from pglamd_slab_alloc (mode 1: one physical allocation mapped into a 1 GiB-aligned
-    virtual range; mode 0: hipMalloc) -- for feature matrices of several GB that are gathered row by row."""
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    with torch.cuda.device(device):
-        return torch.as_tensor(_Slab(tuple(shape), dtype, mode), device=device)
-
-
-# ------------------------------------------------------------------------------------------------
 # CSR build / segment ids
 # ------------------------------------------------------------------------------------------------
 class CSR(object):

@@ -146,28 +146,6 @@ for k, (s, c) in sorted(dur.items()): print("%-62s grid %-9s duration under the 
 PY
         rm -rf $O/gatpmc_* )
       cat $F | cut -c1-200 ;;
-    noreuse_slabs)
-      # the known-bytes leg with the feature matrix on three allocations: torch's allocator, a bare hipMalloc,
-      # one physical allocation mapped into a 1 GiB-aligned range; then the translation counters of the first and the last
-      for SL in torch hipmalloc vmm; do
-        echo "== --slab $SL" >> $F; timeout 300 python scripts/prof.py noreuse --slab $SL 2>&1 | grep "feature matrix\|uniform\|our GPU\|<- ours" >> $F
-      done
-      ( cd /tmp && export TMPDIR=/tmp
-        for SL in torch vmm; do
-          rocprofv3 --kernel-trace --pmc TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum --output-format csv -d $O/tlb_$SL -o p -- python $R/scripts/prof.py noreuse --slab $SL > /dev/null 2>&1
-          rocprofv3 --kernel-trace --pmc TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_SERIALIZATION_STALL_sum TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS_sum --output-format csv -d $O/tlb2_$SL -o p -- python $R/scripts/prof.py noreuse --slab $SL > /dev/null 2>&1
-          python - <<PY >> $F
-import csv, glob, collections
-agg = collections.defaultdict(lambda: [0.0, 0])
-for f in glob.glob("$O/tlb_$SL/**/*counter_collection.csv", recursive=True) + glob.glob("$O/tlb2_$SL/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "agg_flat" in r.get("Kernel_Name", ""):
-            k = (r.get("Grid_Size"), r.get("Counter_Name")); agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
-for k, (s, n) in sorted(agg.items()): print("--slab $SL: agg_flat_kernel grid", k[0], k[1], "avg per dispatch %.0f" % (s / n), "n", n)
-PY
-          rm -rf $O/tlb_$SL $O/tlb2_$SL
-        done )
-      cat $F ;;
     noreuse_vec4)  PGLAMD_VEC=4 timeout 600 python scripts/prof.py noreuse > $F 2>&1; grep "uniform\|our GPU\|<- ours" $F ;;
     variants)
       # every experimental build under pgl_amd/csrc/variants (scripts/prof.py variant ...): CSR parity + CSR timing through PGLAMD_LIB

@@ -135,7 +135,7 @@ def cmd_rows(args):
         pull_c, push_c = HaloPlan.pair_counts(edges, N, part, P)
         choice = HaloPlan.choose_push(pull_c, push_c) if args.push == "auto" else torch.zeros((P, P), dtype=torch.bool)
         print("P=%d partition %s (%.1f s), edge cut %.3f, %d of %d pairs push, wire %s" % (P, how, tp, cut, int(choice.sum()), P * (P - 1), args.wire or "fp32"))
-        worst, rows = {"compute": 0.0, "pair_mb": 0.0, "ratio": 0.0}, []
+        worst, rows, preds = {"compute": 0.0, "pair_mb": 0.0, "ratio": 0.0}, [], []
         for r in range(P):
             plan = HaloPlan(edges, N, part, r, P)
             xplan = HaloPlan(edges, N, part, r, P, push=choice) if bool(choice.any()) else plan
@@ -175,9 +175,11 @@ def cmd_rows(args):
                 po1 = _t(lambda: (un1(), B.aggregate(in1, dg._index("xrecv"), "sum", plan.n_own, out=out[:, h:], accumulate=1)), it=10, warm=2)
                 pk, post = pk0 + pk1, po0 + po1
                 e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
-                t_a = pk0 + xch * h / d
-                end_a = max(t_a, pk + pre) + po0
-                pred = max(end_a, max(t_a, pk) + xch * (d - h) / d) + po1
+                def predict(x_ms, lat_ms, pk0=pk0, pk=pk, pre=pre, po0=po0, po1=po1, h=h):
+                    t_a = pk0 + lat_ms + x_ms * h / d
+                    end_a = max(t_a, pk + pre) + po0
+                    return max(end_a, max(t_a, pk) + lat_ms + x_ms * (d - h) / d) + po1
+                pred = predict(xch, 0.0)
             else:
                 mode = dg._mode("x", False, True, d * 4)
                 pk = _t(lambda: dg._start_exchange(x_own, "x", False), it=10, warm=2)
@@ -196,9 +198,12 @@ def cmd_rows(args):
                     un = (lambda: B.gather_rows_cast(dg._buf["inx0"], None, torch.float32, in_buf)) if args.wire else (lambda: None)
                     post = _t(lambda: (un(), B.aggregate(in_buf, dg._index("xrecv"), "sum", plan.n_own, out=out, accumulate=1)), it=10, warm=2)
                     e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecv").num_edges
-                pred = pk + max(pre, xch) + post
+                def predict(x_ms, lat_ms, pk=pk, pre=pre, post=post):
+                    return pk + max(pre, lat_ms + x_ms) + post
+                pred = predict(xch, 0.0)
             ideal = plan.local_edges / (E / t1)
             rows.append((r, plan.n_own, plan.local_edges, e_pre, e_post, xplan.n_send, xplan.n_recv, ms, pk, pre, post, ideal, pair_mb, enq, mode, pred))
+            preds.append((predict, xch))
             worst["compute"] = max(worst["compute"], ms); worst["pair_mb"] = max(worst["pair_mb"], pair_mb)
             worst["ratio"] = max(worst["ratio"], ms / ideal); worst["pred"] = max(worst.get("pred", 0.0), pred)
             del dg, plan, xplan, x_own, out
@@ -211,6 +216,16 @@ def cmd_rows(args):
         print("   predicted step (pack + max(work before the wait, exchange) + work after the wait; pipeline: block 1 travels under block 0's edges), slowest rank = %.3f ms = %.2fx of one GPU"
               "   [bounds: max(compute, exchange) = %.2fx, compute + exchange = %.2fx]"
               % (worst["pred"], t1 / worst["pred"], t1 / max(worst["compute"], t_link), t1 / (worst["compute"] + t_link)), flush=True)
+        # how much of that rides on the wire model: the same prediction with the links at 60 / 75 / 100 % of 153 GB/s and a fixed
+        # cost of 0 / 30 / 60 us per all-to-all-v; slowest rank, speed-up over one GPU
+        print("   sensitivity of the predicted step (ms, and x of one GPU) to the wire: link efficiency x latency per all-to-all-v")
+        print("      %-18s %s" % ("", "".join("%22s" % ("latency %d us" % l) for l in (0, 30, 60))))
+        for eff in (1.0, 0.75, 0.6):
+            cells = []
+            for lat in (0.0, 0.03, 0.06):
+                tt = max(f(xm / eff, lat) for f, xm in preds)
+                cells.append("%10.3f ms %6.2fx" % (tt, t1 / tt))
+            print("      links at %3.0f %%     %s" % (eff * 100, "  ".join(cells)), flush=True)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -265,17 +280,9 @@ def cmd_noreuse(args):
     dst = torch.arange(n, device=dev).repeat_interleave(deg)
     g = pgl.Graph(edges=torch.stack([src, dst], 1), num_nodes=n); g.adj_dst_index
     del src, dst
-    slab = getattr(args, "slab", "torch")
-    if slab == "torch":
-        x = torch.randn(n, d, generator=gen, device=dev)
-    else:                                            # the feature matrix on pglamd_slab_alloc memory
-        x = pgl.ops.slab_empty((n, d), torch.float32, dev, mode=1 if slab == "vmm" else 0)
-        for lo in range(0, n, 1 << 21):
-            x[lo:lo + (1 << 21)] = torch.randn(min(1 << 21, n - lo), d, generator=gen, device=dev)
-    print("feature matrix [%d, %d] fp32 allocated through %s, base address 0x%x (2 MiB aligned: %s, 1 GiB aligned: %s)"
-          % (n, d, {"torch": "torch's caching allocator (hipMalloc)", "hipmalloc": "pglamd_slab_alloc mode 0 (hipMalloc)",
-                    "vmm": "pglamd_slab_alloc mode 1 (hipMemCreate + one mapping in a 1 GiB-aligned range)"}[slab],
-             x.data_ptr(), x.data_ptr() % (2 << 20) == 0, x.data_ptr() % (1 << 30) == 0))
+    # (round 4 measured this leg with the matrix on a bare hipMalloc and on one hipMemCreate allocation mapped in one piece: same
+    #  time, same translation counters -- profiles/r04/noreuse_slab_allocations_slow_box.txt; the allocator experiment is at commit 420c49a)
+    x = torch.randn(n, d, generator=gen, device=dev)
     for _ in range(3):
         g.send_recv(x, "sum")
     torch.cuda.synchronize()
@@ -985,7 +992,7 @@ def main():
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     r.add_argument("--graph", default="rmat", choices=["rmat", "community"])
     r.add_argument("--flow", default="", choices=["", "split", "fold", "accumulate", "pipeline"], help="force one flow (PGLAMD_FLOW) instead of the cost model's")
-    nr = sub.add_parser("noreuse"); nr.add_argument("--slab", default="torch", choices=["torch", "hipmalloc", "vmm"])
+    sub.add_parser("noreuse")
     sub.add_parser("gcn")
     tr = sub.add_parser("traffic")
     tr.add_argument("--dir", required=True)

@@ -284,23 +284,3 @@ def test_send_uv_and_edge_softmax_at_unroll_boundaries(pgl, e, d):
     sums = np.zeros((n, d)); np.add.at(sums, dst, got)
     assert np.allclose(sums[np.bincount(dst, minlength=n) > 0], 1.0, atol=1e-5)
 
-
-# ------------------------------------------------------------------------------------------------
-# pglamd_slab_alloc: feature slabs with a known address-translation layout (engine extension)
-# ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("mode", [0, 1])
-def test_feature_slab_allocation_is_a_normal_tensor(pgl, mode):
-    n, d = 50000, 128
-    g, edges, rng = _hub_graph(pgl, n, 300000, 3, 20000)
-    xh = rng.standard_normal((n, d)).astype(np.float32)
-    x = pgl.ops.slab_empty((n, d), torch.float32, "cuda:0", mode=mode)
-    assert x.is_cuda and tuple(x.shape) == (n, d) and x.is_contiguous()
-    if mode == 1:
-        assert x.data_ptr() % (1 << 30) == 0                   # the reserved range is 1 GiB aligned
-    x.copy_(dev(xh))
-    want = g.send_recv(dev(xh), "sum")
-    assert torch.equal(g.send_recv(x, "sum"), want)
-    y = x * 2.0                                                # ordinary torch ops read and write it
-    assert torch.equal(y, dev(xh) * 2.0)
-    del x, y
-    torch.cuda.synchronize()
