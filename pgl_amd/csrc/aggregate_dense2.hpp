@@ -411,6 +411,9 @@ __global__ __launch_bounds__(kD2Threads, 6) void agg_dense2_kernel(AggParams p) 
 // and W straight from memory (a few thousand rows: W stays in L2), same MFMA tile and epilogue as the matrix waves.
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void dense_hub_kernel(AggParams p) {
+    // One wave = one (tile of 16 split rows, column tile of 16 outputs): n_tiles x (d_out / 16) independent tasks.  The first version
+    // gave a wave a whole tile and walked its column tiles one after the other -- eight dependent rounds of 32 loads + 32 MFMAs on
+    // a few hundred waves: 65 us at C2, 5 % of GCNConv's forward (profiles/r04/trace_layers_gcn_relu.txt).
     constexpr int DIN = kWave * VEC, KK = DIN / 4;
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & (kWave - 1);
@@ -418,34 +421,36 @@ __global__ __launch_bounds__(kBlock) void dense_hub_kernel(AggParams p) {
     const int n_tasks = p.long_count[0];
     const int dout = p.dout2, n_ct = dout >> 4;
     const float* __restrict__ pt = static_cast<const float*>(p.part_tail);
-    const int wave_g = (int)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = (int)gridDim.x * kWavesPerBlock;
-    for (int t0 = wave_g * 16; t0 < n_tasks; t0 += n_waves * 16) {
+    const int64_t wave_g = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+    const int64_t n_work = (int64_t)((n_tasks + 15) / 16) * n_ct;
+    for (int64_t wk = wave_g; wk < n_work; wk += n_waves) {
+        const int t0 = (int)(wk / n_ct) * 16, ct = (int)(wk % n_ct);
         const int n = n_tasks - t0 < 16 ? n_tasks - t0 : 16;
         const float* arow = pt + (int64_t)p.long_list[t0 + (l16 < n ? l16 : 0)] * p.tile_cols + q;
-        float a[KK];
+        const float* wc = p.w + (int64_t)q * dout + ct * 16 + l16;          // B operand: W[4 kk + l / 16][16 ct + l % 16]
+        float a[KK], b[KK];
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) a[kk] = arow[4 * kk];
+        for (int kk = 0; kk < KK; ++kk) { a[kk] = arow[4 * kk]; b[kk] = wc[(int64_t)4 * kk * dout]; }
         int rid[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ti = 4 * q + i < n ? 4 * q + i : 0;
             rid[i] = p.row[(int64_t)(p.long_list[t0 + ti] + 1) * p.chunk - 1];
         }
-#pragma unroll 1
-        for (int ct = 0; ct < n_ct; ++ct) {
-            const float* wc = p.w + (int64_t)q * dout + ct * 16 + l16;      // B operand: W[4 kk + l / 16][16 ct + l % 16]
-            f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+        f4 acc0 = f4{0.f, 0.f, 0.f, 0.f}, acc1 = f4{0.f, 0.f, 0.f, 0.f};       // two chains over the even / odd k-steps
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wc[(int64_t)4 * kk * dout], acc, 0, 0, 0);
-            const int colj = ct * 16 + l16;
-            const float bv = p.bias ? p.bias[colj] : 0.f;
+        for (int kk = 0; kk < KK; kk += 2) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], b[kk], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk + 1], b[kk + 1], acc1, 0, 0, 0);
+        }
+        const int colj = ct * 16 + l16;
+        const float bv = p.bias ? p.bias[colj] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (4 * q + i < n && rid[i] < p.out_rows) {
-                    float v = acc[i] + bv;
-                    if (p.act) v = v > 0.f ? v : 0.f;
-                    p.out2[(int64_t)rid[i] * dout + colj] = v;
-                }
+        for (int i = 0; i < 4; ++i) {
+            if (4 * q + i < n && rid[i] < p.out_rows) {
+                float v = acc0[i] + acc1[i] + bv;
+                if (p.act) v = v > 0.f ? v : 0.f;
+                p.out2[(int64_t)rid[i] * dout + colj] = v;
             }
         }
     }
@@ -453,8 +458,8 @@ __global__ __launch_bounds__(kBlock) void dense_hub_kernel(AggParams p) {
 
 template <int VEC>
 static int32_t launch_dense_hub(const AggParams& p, hipStream_t st) {
-    const int64_t tiles = ceil_div(p.n_chunks, 16);                       // (at most one split row starts per chunk)
-    hipLaunchKernelGGL((dense_hub_kernel<VEC>), dim3((unsigned)std::min<int64_t>(256, ceil_div(tiles, kWavesPerBlock))), dim3(kBlock), 0, st, p);
+    const int64_t work = ceil_div(p.n_chunks, 16) * (p.dout2 >> 4);      // (at most one split row starts per chunk; the real count is on the device)
+    hipLaunchKernelGGL((dense_hub_kernel<VEC>), dim3((unsigned)std::min<int64_t>(2048, ceil_div(work, kWavesPerBlock))), dim3(kBlock), 0, st, p);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }

@@ -527,6 +527,33 @@ class Graph(object):
         ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()                     #  cheaper than a 4-byte read per edge)
         return ag.aggregate_dense(feature.contiguous(), weight, bias, self._csr_dst(), self._csr_src, act, ds, reduce_op, ss)
 
+    def reorder(self, num_clusters=None, rows_per_cluster=4096, seed=0):
+        """-> (graph2, order): the same graph with its nodes RENUMBERED cluster by cluster (engine extension, opt-in; the
+        reference feeds node ids as they come, pgl/graph.py:859).  order[new_id] = old_id; graph2's node features are
+        self's rows taken in that order, edges keep their order (and their features), only their endpoints are relabelled.
+        The clusters come from the engine's own multilevel partitioner (pglamd_partition_edges) asked for N / rows_per_cluster
+        parts: a cluster's feature rows (4096 x 512 B = 2 MiB at d = 128 fp32) fit the 4 MiB L2 of one XCD, and consecutive
+        chunks of the destination-sorted stream then gather from the cluster they are walking, so that a source row is
+        fetched from HBM about once per cluster that reads it instead of once per edge.  Results on graph2 are results on
+        self up to this relabelling: out2[new] == out[order[new]].  Worth it only where the graph HAS clusters
+        (profiles/r04/locality.txt: planted communities yes, RMAT no)."""
+        n = self.num_nodes
+        k = int(num_clusters) if num_clusters else max(2, -(-n // int(rows_per_cluster)))
+        e = self._edges.detach().cpu().numpy() if check_is_tensor(self._edges) else np.asarray(self._edges)
+        part, _ = ops.host_partition_edges(e, n, k, None, None, 1.10, 1.10, seed)
+        order = np.argsort(part, kind="stable").astype(np.int64)
+        new_of_old = np.empty(n, np.int64)
+        new_of_old[order] = np.arange(n, dtype=np.int64)
+        if self._is_tensor:
+            dev = self._edges.device
+            order_t, map_t = torch.from_numpy(order).to(dev), torch.from_numpy(new_of_old).to(dev)
+            edges2 = map_t[self._edges]
+            nf = {key: ops.gather_rows(v, order_t) if v.is_cuda else v[order_t] for key, v in self._node_feat.items()}
+            g2 = self.__class__(edges=edges2, num_nodes=n, node_feat=nf, edge_feat=dict(self._edge_feat))
+            return g2, order_t
+        nf = {key: np.asarray(v)[order] for key, v in self._node_feat.items()}
+        return self.__class__(edges=new_of_old[e], num_nodes=n, node_feat=nf, edge_feat=dict(self._edge_feat)), order
+
     def propagate_step(self, feature, dst_scale, residual=None, residual_scale=0.0):
         """residual_scale * residual + dst_scale (.) (sum over in-edges of feature[src]) in one launch (engine extension
         for the k-hop propagation layers; fp32, dst_scale one value per node)."""

@@ -25,7 +25,7 @@ for STEP in "$@"; do
     rows_c2_pipe)  timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow pipeline --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     csr|noreuse|gcn|gat|ops|dtypes|gatsplit|model) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
-    edgeops)    timeout 600 python scripts/prof.py edgeops > $F 2>&1; grep -v amdgpu.ids $F ;;
+    edgeops)    timeout 600 python scripts/prof.py edgeops > $F 2>&1; timeout 600 python scripts/prof.py edgeops --sorted >> $F 2>&1; grep -v amdgpu.ids $F ;;
     pmc_edgeops)
       # rows a7 / a8 / a10 in original edge order: fetched / written bytes, L2 hit rate and memory-side request mix per KERNEL
       # (`prof.py edgeops --only pmc` runs the three ops three times each; one rocprofv3 --pmc pass per counter group)
@@ -59,6 +59,27 @@ for (k, g), v in dur.items(): print("%-72s grid %-9s duration under the counter 
 PY
         cat $F.fail >> $F 2>/dev/null; rm -rf $O/eopmc_* $F.*.log $F.fail )
       cat $F | cut -c1-200 ;;
+    locality)   timeout 900 python scripts/prof.py locality > $F 2>&1; grep -v amdgpu.ids $F ;;
+    pmc_locality)
+      # bytes fetched by the aggregation kernel before / after Graph.reorder (dispatches in the order prof.py prints)
+      ( cd /tmp && export TMPDIR=/tmp
+        rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/locpmc -o p -- python $R/scripts/prof.py locality --pmc > $F.run 2>&1
+        python - <<PY > $F
+import csv, glob
+print(open("$F.run").read().strip().splitlines()[-1])
+rows = []
+for f in glob.glob("$O/locpmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "agg_flat_kernel<float, 2, 1, 0, 0" in r.get("Kernel_Name", "") and r.get("Counter_Name") == "FETCH_SIZE":
+            rows.append((int(r["Dispatch_Id"]), r.get("Grid_Size"), float(r["Counter_Value"])))
+rows.sort()
+print("FETCH_SIZE per dispatch (KB as reported; gfx950 tallies 128-byte reads at 64: double for bytes), in dispatch order:")
+for k in range(0, len(rows), 3):
+    grp = rows[k:k + 3]
+    print("  dispatches %s grid %s: %s -> mean %.4g KB = %.2f GB (x2)" % ([g[0] for g in grp], grp[0][1], ["%.4g" % g[2] for g in grp], sum(g[2] for g in grp) / len(grp), 2 * sum(g[2] for g in grp) / len(grp) * 1024 / 1e9))
+PY
+        rm -rf $O/locpmc $F.run )
+      cat $F | cut -c1-220 ;;
     gcn_form1)  PGLAMD_DENSE_FORM=1 timeout 600 python scripts/prof.py gcn 2>&1 | grep -v amdgpu.ids | head -9 > $F; cat $F ;;
     train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
     trace:*)

@@ -605,6 +605,13 @@ def cmd_edgeops(args):
     (gpu_session.sh pmc_edgeops), otherwise one timing line per op with its byte model."""
     import torch
     pgl, dev, g = _c2(with_src_index=False, scale=args.scale, E=args.edges)
+    if getattr(args, "sorted", False):
+        # the same graph with its edge list ALREADY in destination order (sorted_eid = identity): what the ops cost when the caller's
+        # edge order is the engine's own -- every [E, ...] operand is then read and written sequentially
+        c = g.adj_dst_index.csr
+        g = pgl.Graph(edges=torch.stack([c.col32.long(), c.row32.long()], 1), num_nodes=g.num_nodes); g.adj_dst_index
+        assert bool((g.adj_dst_index.csr.eid32 == torch.arange(g.num_edges, device=dev, dtype=torch.int32)).all())
+        print("edge list pre-sorted by destination: sorted_eid is the identity")
     N, E, H = g.num_nodes, g.num_edges, 8
     gen = torch.Generator(device=dev); gen.manual_seed(7)
     a_s = torch.randn(N, H, generator=gen, device=dev); a_d = torch.randn(N, H, generator=gen, device=dev)
@@ -632,6 +639,60 @@ def cmd_edgeops(args):
         ms = _t(fn, it=10 if name != "gather_rows" else 3, warm=2)
         print("%-14s %8.3f ms   model %6.2f GB = %.3f of 8 TB/s   compulsory %6.2f GB = %.3f of 8 TB/s"
               % (name, ms, model / 1e9, model / ms / 1e6 / 8000.0, comp / 1e9, comp / ms / 1e6 / 8000.0), flush=True)
+
+
+def _planted(pgl, dev, N, E, C, gen):
+    import torch
+    src = torch.randint(0, N, (E,), generator=gen, device=dev)
+    inside = torch.rand(E, generator=gen, device=dev) < 0.9
+    dst = torch.where(inside, (src // (N // C)) * (N // C) + torch.randint(0, N // C, (E,), generator=gen, device=dev),
+                      torch.randint(0, N, (E,), generator=gen, device=dev))
+    perm = torch.randperm(N, generator=gen, device=dev)
+    return torch.stack([perm[src], perm[dst]], 1)
+
+
+def cmd_locality(args):
+    """does renumbering the nodes cluster by cluster (Graph.reorder: the engine's own partitioner asked for
+    N / 4096 parts) buy cache reuse on ONE GPU?  send_recv(sum), d = 128 fp32, before and after, on RMAT-20 (no clusters to find),
+    on 256 planted communities with permuted ids (clusters exist but the ids hide them) and on a products-sized graph of the same
+    kind.  --pmc: three launches of each case in a fixed order, for the FETCH_SIZE pass of gpu_session.sh pmc_locality."""
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    d = 128
+    cases = [("RMAT scale 20, 20 M edges", 1 << 20, lambda: rmat_edges(20, 20_000_000, seed=42, device=dev)),
+             ("256 planted communities, 2^20 nodes, 20 M edges, ids permuted", 1 << 20, lambda: _planted(pgl, dev, 1 << 20, 20_000_000, 256, gen)),
+             ("products-sized: 2 449 029 nodes -> 2^21 + ..., 598 communities, 61.9 M edges", 598 * 4096, lambda: _planted(pgl, dev, 598 * 4096, 61_859_140, 598, gen))]
+    if args.pmc:
+        cases = cases[:2]
+        print("dispatch order of agg_flat_kernel<float, 2, 1, 0, 0>: " + " | ".join("%s: 3 x original ids, 3 x reordered" % c[0] for c in cases))
+    for name, N, make in cases:
+        edges = make()
+        E = int(edges.shape[0])
+        x = torch.randn(N, d, generator=gen, device=dev)
+        g = pgl.Graph(edges=edges, num_nodes=N, node_feat={"x": x}); g.adj_dst_index
+        t0 = time.time()
+        g2, order = g.reorder()
+        t_re = time.time() - t0
+        g2.adj_dst_index
+        x2 = g2.node_feat["x"]
+        if args.pmc:
+            for gg, xx in ((g, x), (g2, x2)):
+                for _ in range(3):
+                    gg.send_recv(xx, "sum")
+                torch.cuda.synchronize()
+            continue
+        out = g.send_recv(x, "sum"); out2 = g2.send_recv(x2, "sum")
+        err = float((out2 - out[order]).abs().max() / out.abs().max())
+        inside = float(((g2.edges[:, 0] // 4096) == (g2.edges[:, 1] // 4096)).float().mean())
+        t_a = _t(lambda: g.send_recv(x, "sum")); t_b = _t(lambda: g2.send_recv(x2, "sum"))
+        comp = E * 4 + N * (2 * d * 4 + 8)
+        print("%s\n   original ids %.3f ms = %.2f G edges/s | reordered (%.1f s on the host, %.0f %% of the edges inside a 4096-row block) %.3f ms = %.2f G edges/s"
+              "   [x%.2f; results equal up to the relabelling: max rel diff %.1e; compulsory bytes %.2f GB = %.3f ms at 8 TB/s]"
+              % (name, t_a, E / t_a / 1e6, t_re, inside * 100, t_b, E / t_b / 1e6, t_a / t_b, err, comp / 1e9, comp / 8e9), flush=True)
+        del g, g2, x, x2, edges
 
 
 def _layer(pgl, which):
@@ -1008,8 +1069,10 @@ def main():
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
     dm.add_argument("--rank", type=int, default=0)
     sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
+    lo = sub.add_parser("locality"); lo.add_argument("--pmc", action="store_true")
     eo = sub.add_parser("edgeops"); eo.add_argument("--scale", type=int, default=20); eo.add_argument("--edges", type=int, default=20_000_000)
     eo.add_argument("--only", default="", choices=["", "pmc", "send_uv", "edge_softmax", "segment_sum", "gather_rows"])
+    eo.add_argument("--sorted", action="store_true", help="the graph's edge list pre-sorted by destination (sorted_eid = identity)")
     va = sub.add_parser("variant"); va.add_argument("name"); va.add_argument("defines", nargs="*")
     tc = sub.add_parser("trace"); tc.add_argument("csv"); tc.add_argument("filter", nargs="?", default="")
     args = ap.parse_args()
@@ -1019,6 +1082,8 @@ def main():
         cmd_rows(args)
     elif args.cmd == "edgeops":
         cmd_edgeops(args)
+    elif args.cmd == "locality":
+        cmd_locality(args)
     elif args.cmd in ("ops", "layers", "train", "model", "dense", "sizes", "distmodel", "gat", "dtypes", "variant", "trace", "gatsplit"):
         {"model": cmd_model, "dense": cmd_dense, "sizes": cmd_sizes, "distmodel": cmd_distmodel, "gatsplit": cmd_gatsplit, "ops": cmd_ops, "layers": cmd_layers, "train": cmd_train, "gat": cmd_gat, "dtypes": cmd_dtypes, "variant": cmd_variant,
          "trace": cmd_trace}[args.cmd](args)

@@ -284,3 +284,22 @@ def test_send_uv_and_edge_softmax_at_unroll_boundaries(pgl, e, d):
     sums = np.zeros((n, d)); np.add.at(sums, dst, got)
     assert np.allclose(sums[np.bincount(dst, minlength=n) > 0], 1.0, atol=1e-5)
 
+
+# ------------------------------------------------------------------------------------------------
+# Graph.reorder (engine extension): results on the renumbered graph are results on the original one, relabelled
+# ------------------------------------------------------------------------------------------------
+def test_reordered_graph_gives_the_same_rows(pgl):
+    n, e, d = 40000, 500000, 64
+    g, edges, rng = _hub_graph(pgl, n, e, 21, 30000)
+    x = dev(rng.standard_normal((n, d)).astype(np.float32))
+    g.node_feat["x"] = x
+    g2, order = g.reorder(rows_per_cluster=2048)
+    assert torch.equal(g2.node_feat["x"], x[order])
+    for op in ("sum", "mean", "max"):
+        a, b = g.send_recv(x, op), g2.send_recv(g2.node_feat["x"], op)
+        if op == "max":
+            assert torch.equal(b, a[order])
+        else:
+            np.testing.assert_allclose(host(b), host(a[order]), rtol=1e-5, atol=1e-5 * float(a.abs().max()))
+    want = R.c_send_u_recv(host(x), edges[:, 0], edges[:, 1], "sum")                # and against the oracle, through the relabelling
+    np.testing.assert_allclose(host(g2.send_recv(g2.node_feat["x"], "sum")), want[host(order)], rtol=1e-5, atol=1e-5 * np.abs(want).max())

@@ -371,3 +371,28 @@ def test_engine_cross_entropy_and_linear_equal_torch():
     assert torch.allclose(xin.grad, xref.grad, rtol=1e-5, atol=1e-6)
     assert torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-2)
     assert torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-2)
+
+
+def test_graph_reorder_is_a_consistent_relabelling():
+    """Graph.reorder (engine extension, round 4): order is a permutation, graph2's edge k is edge k with both endpoints renamed,
+    node features follow their nodes, edge features stay; a graph with planted clusters ends up with its clusters contiguous."""
+    import pgl_amd
+    rng = np.random.default_rng(5)
+    n, e, c = 8192, 120000, 8
+    src = rng.integers(0, n, e)
+    dst = np.where(rng.random(e) < 0.9, (src // (n // c)) * (n // c) + rng.integers(0, n // c, e), rng.integers(0, n, e))
+    perm = rng.permutation(n)
+    edges = np.stack([perm[src], perm[dst]], 1).astype(np.int64)
+    feat = rng.standard_normal((n, 3)).astype(np.float32)
+    w = rng.standard_normal((e, 1)).astype(np.float32)
+    g = pgl_amd.Graph(edges=edges, num_nodes=n, node_feat={"h": feat}, edge_feat={"w": w})
+    g2, order = g.reorder(num_clusters=c)
+    assert sorted(order.tolist()) == list(range(n))
+    new_of_old = np.empty(n, np.int64); new_of_old[order] = np.arange(n)
+    assert np.array_equal(g2.edges, new_of_old[edges])
+    assert np.array_equal(g2.node_feat["h"], feat[order]) and np.array_equal(g2.edge_feat["w"], w)
+    blk = n // c
+    before = ((edges[:, 0] // blk) == (edges[:, 1] // blk)).mean()
+    after = ((g2.edges[:, 0] // blk) == (g2.edges[:, 1] // blk)).mean()
+    assert before < 0.2 and after > 0.8, (before, after)
+    assert np.array_equal(g2.indegree(), g.indegree()[order])
