@@ -11,7 +11,7 @@ feature matrix already resident in HBM.  Workload (config.workload): BASELINE.js
 N = 1, one JSON line with the driver's contract fields plus
   roofline      PHYSICAL: achieved / frac come from the same kernel (agg_flat_kernel, d = 128 fp32 sum) on a graph whose gathered
                 bytes are KNOWN (uniform in-degree-19 graph over 8.6 GB of features: <= 3.5 % of the gathers can hit any cache),
-                timed with HIP events in this run; `traffic` = PMC bytes of that leg from profiles/r03/traffic.json, replayed only
+                timed with HIP events in this run; `traffic` = PMC bytes of that leg from profiles/r04/traffic.json, replayed only
                 when the file's stamp (kernel symbol + sha256 of the kernel sources) matches this tree, else null.  The headline
                 workload's own figures -- section 8(d) model bytes / kernel time, which is NOT a bandwidth on RMAT (hub rows live
                 in L2 / Infinity Cache) -- ride along under roofline.headline_workload, labelled; no ratio above 1 is printed.
@@ -52,7 +52,7 @@ def algorithmic_bytes(E, N, d, s):
     return E * (d * s + 4) + N * (d * s + 8)
 
 
-TRAFFIC_FILES = ("profiles/r03/traffic.json",)
+TRAFFIC_FILES = ("profiles/r04/traffic.json",)
 KERNEL_SOURCES = ("pgl_amd/csrc/aggregate_flat.hpp", "pgl_amd/csrc/aggregate.hpp", "pgl_amd/csrc/aggregate.hip", "pgl_amd/csrc/common.hpp")
 
 
@@ -68,7 +68,7 @@ def kernel_source_hash():
 def recorded_traffic(key, kernel):
     """(bytes, source) -- HBM-side bytes per launch of the dominant kernel as RECORDED in the committed PMC profile of this
     exact workload (separate rocprofv3 --pmc passes, FETCH/WRITE calibrated as MI355X_MICROARCH.md prescribes;
-    scripts/gpu_r03_profile.sh).  PMC counters cannot be collected from inside a timed run, so this is a replayed figure:
+    scripts/gpu_session.sh profile).  PMC counters cannot be collected from inside a timed run, so this is a replayed figure:
     it is returned only when the profile's stamp -- kernel symbol + sha256 of the kernel's sources -- matches what THIS run
     launched from THIS tree; otherwise (None, reason), and the line says traffic: null."""
     for rel in TRAFFIC_FILES:
