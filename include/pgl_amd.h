@@ -372,6 +372,13 @@ int32_t pglamd_sddmm(const float* x_by_col, const float* y_by_row, int64_t heads
                      const int32_t* row, const int32_t* col, const int32_t* eid, int64_t num_edges,
                      float* out, void* stream);
 
+/* out[i] = in[0] + ... + in[i-1] (int64; out may alias in).  The prefix sums the reference takes with paddle.cumsum
+ * (pgl/utils/edge_index.py:54 indptr from degrees; the offsets of a sampled block's neighbour lists, pgl/sampling/sage.py:144-147)
+ * as three small in-tree kernels (csrc/scan.hpp) -- no library primitive sits on the mini-batch path. */
+size_t pglamd_exclusive_scan_i64_workspace_bytes(int64_t n);
+int32_t pglamd_exclusive_scan_i64(const int64_t* in, int64_t n, int64_t* out, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* K4'  segment boundaries from sorted ids: seg_ptr[n_seg+1] (int64), n_seg = ids[E-1]+1 given by
  * the caller.  Used when segment_softmax is called with raw ids (pgl.math API). */
 int32_t pglamd_seg_ptr_from_ids(const void* ids, int32_t ids_i64, int64_t num_rows, int64_t n_seg,

@@ -25,6 +25,8 @@ _SIGNATURES = {
     "pglamd_unique_segment_workspace_bytes": (c_sz, [c_i64, c_i64]),
     "pglamd_unique_segment": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_narrow_i64": (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "pglamd_exclusive_scan_i64_workspace_bytes": (c_sz, [c_i64]),
+    "pglamd_exclusive_scan_i64": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_aggregate_workspace_bytes": (c_sz, [c_i64, c_i64, c_i32]),
     "pglamd_aggregate": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
                                   c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),

@@ -559,6 +559,15 @@ extern "C" int32_t pglamd_unique_segment(const int64_t* degree, const int64_t* s
     return PGLAMD_OK;
 }
 
+extern "C" size_t pglamd_exclusive_scan_i64_workspace_bytes(int64_t n) { return exclusive_scan64_temp_bytes(n) + 256; }
+
+extern "C" int32_t pglamd_exclusive_scan_i64(const int64_t* in, int64_t n, int64_t* out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(PGLAMD_E_ARG, "exclusive_scan_i64: bad argument");
+    if (n == 0) return PGLAMD_OK;
+    if (!workspace || workspace_bytes < pglamd_exclusive_scan_i64_workspace_bytes(n)) return fail(PGLAMD_E_WORKSPACE, "exclusive_scan_i64: workspace too small");
+    return exclusive_scan64(LoadI64{in}, n, out, workspace, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int32_t pglamd_narrow_i64(const int64_t* in, int64_t in_stride, int64_t n, int32_t* out, void* stream) {
     if (n < 0 || (n > 0 && (!in || !out))) return fail(PGLAMD_E_ARG, "narrow_i64: bad argument");
     if (n == 0) return PGLAMD_OK;

@@ -151,6 +151,20 @@ def unique_segment(degree, sorted_u):
     return uniq[:int(cnt.item())], seg
 
 
+def exclusive_scan_i64(t):
+    """out[i] = t[0] + ... + t[i-1] (int64) -- pglamd_exclusive_scan_i64 (stands where the reference calls paddle.cumsum)."""
+    _need_cuda(t)
+    t = t.to(torch.int64).contiguous()
+    n = int(t.shape[0])
+    out = torch.empty_like(t)
+    if n:
+        L = _ffi.lib()
+        ws = _ws_hot(L.pglamd_exclusive_scan_i64_workspace_bytes(n), t.device)
+        with torch.cuda.device(t.device):
+            _ffi.check(L.pglamd_exclusive_scan_i64(_ptr(t), n, _ptr(out), _ptr(ws), ws.numel(), _stream(t)), "exclusive_scan_i64")
+    return out
+
+
 def narrow_i64(t):
     """int64 (possibly strided) -> contiguous int32."""
     _need_cuda(t)
@@ -767,8 +781,8 @@ def sample_neighbors(csr, nodes, sample_size, seed=0, return_eids=False):
     with torch.cuda.device(dev):
         _ffi.check(L.pglamd_sample_neighbors_count(_ptr(csr.indptr), _ptr(nodes), n, int(sample_size), _ptr(count),
                                                    _stream(nodes)), "sample_neighbors_count")
-    offsets = torch.cumsum(count, 0) - count
-    total = int(count.sum().item()) if n else 0
+    offsets = exclusive_scan_i64(count)
+    total = int((offsets[-1] + count[-1]).item()) if n else 0
     nbr = torch.empty(total, dtype=torch.int64, device=dev)
     eids = torch.empty(total, dtype=torch.int64, device=dev) if return_eids else None
     if total:

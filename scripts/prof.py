@@ -735,7 +735,11 @@ def cmd_train(args):
             elif not fused:
                 continue
             x = x0.clone().requires_grad_(True)
-            ms = _t(lambda: layer(g, x).sum().backward(), 10, 3)
+
+            def step():                                              # (grads start empty every step: a step that ADDS into last step's
+                layer.zero_grad(set_to_none=True); x.grad = None    #  [N, d] gradient measures one more pass than the layer costs)
+                layer(g, x).sum().backward()
+            ms = _t(step, 10, 3)
             print("%-9s fused=%-5s %.3f ms / training step (fwd+bwd incl. d/dx)" % (which, fused, ms), flush=True)
 
 

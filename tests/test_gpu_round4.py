@@ -303,3 +303,14 @@ def test_reordered_graph_gives_the_same_rows(pgl):
             np.testing.assert_allclose(host(b), host(a[order]), rtol=1e-5, atol=1e-5 * float(a.abs().max()))
     want = R.c_send_u_recv(host(x), edges[:, 0], edges[:, 1], "sum")                # and against the oracle, through the relabelling
     np.testing.assert_allclose(host(g2.send_recv(g2.node_feat["x"], "sum")), want[host(order)], rtol=1e-5, atol=1e-5 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 2048, 2049, 1_000_003])
+def test_exclusive_scan_i64_equals_cumsum(pgl, n):
+    """pglamd_exclusive_scan_i64 (csrc/scan.hpp) where the reference calls paddle.cumsum: bit-exact integer work."""
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, 1000, n).astype(np.int64)
+    v[rng.integers(0, n)] = 3_000_000_000                        # sums beyond 32 bits
+    got = host(pgl.ops.exclusive_scan_i64(dev(v)))
+    want = np.cumsum(v) - v
+    assert np.array_equal(got, want)
