@@ -96,11 +96,9 @@ __device__ __forceinline__ float drop_factor(unsigned seed, int eid, int head, f
 // [E,H] d pre buffer of round 1 (0.64 GB written by the src-sorted walk, gathered back through a permutation by a 0.51 ms
 // segment sum) by one more [N, H*D] row written per destination in the forward.
 template <int VEC, int MODE, bool DROP, bool POS = false>
-#ifndef PGLAMD_GAT_BWD_WAVES        // (variant builds: scripts/prof.py variant NAME PGLAMD_GAT_BWD_WAVES=5)
-#define PGLAMD_GAT_BWD_WAVES 1
-#endif
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == 2 ? PGLAMD_GAT_BWD_WAVES : 1, 8)))
-void gat_flat_kernel(GatParams p) {
+// (MODE 2 needs 106 VGPRs = 4 waves per SIMD against the forward's 68 = 7.  Forcing 5 / 6 waves with amdgpu_waves_per_eu makes the
+//  compiler spill 11 / 32 VGPRs into the hot loop: fwd + bwd 5.09 -> 5.43 / 10.0 ms at C3, profiles/r04/gat_backward_occupancy_variants.txt.)
+__global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
     constexpr int U = 4;
     constexpr int PW = MODE == 0 ? (POS ? 5 : 3) : MODE == 2 ? 2 : 1;   // floats per column in a partial
     constexpr bool ATT = MODE >= 2;                     // accumulates the attention-score gradient of the row node
