@@ -593,6 +593,10 @@ def main():
                                halo=halo)
     if world > 1 and mode == "rows" and not args.no_extra_legs:
         wd.begin("target size leg (|E| = %d)" % args.target_edges, 6 * lim)
+        # the flow that won at the headline size need not be the one for 5x the edges: back to the cost model's own choice (on the
+        # transport that won) -- unless that candidate failed above, in which case the forced one stays
+        if any(k["flow"] == "cost-model" and k["status"] == "ok" and k["transport"] == halo["chosen"]["transport"] for k in cands):
+            pd.set_flow("", None)
         err = None
         try:
             target_rec = target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note)
