@@ -8,6 +8,7 @@ on the message-passing path.  The host_* functions are the CPU-side helpers of t
 Each function names the reference call site it stands in for (reference = PaddlePaddle/PGL 2.2.6).
 """
 import ctypes
+import threading
 
 import numpy as np
 import os
@@ -45,13 +46,15 @@ _WS_HOT_MAX = 1 << 30
 
 
 def _ws_hot(nbytes, device):
-    """Scratch of the per-step ops (aggregate, segment ops, the GAT kernels): one grow-only buffer per (device, stream)
+    """Scratch of the per-step ops (aggregate, segment ops, the GAT kernels): one grow-only buffer per (device, stream, thread)
     instead of an allocator round trip per call.  A kernel's scratch is consumed inside the call that filled it, so calls
     queued on ONE stream can share it; another stream gets its own.  Requests above 1 GiB are not held."""
     nbytes = max(int(nbytes), 256)
     if nbytes > _WS_HOT_MAX:
         return _ws(nbytes, device)
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    # (per thread as well: a library call enqueues its launches with the GIL released, so two threads feeding ONE stream could
+    #  interleave them -- thread A's kernel, thread B's kernel, thread A's fix-up reading B's partials)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     buf = _WS_HOT.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _WS_HOT[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
