@@ -80,6 +80,34 @@ for k in range(0, len(rows), 3):
 PY
         rm -rf $O/locpmc $F.run )
       cat $F | cut -c1-220 ;;
+    pmc_csr)
+      # the CSR build's kernels: bytes fetched / written and memory-side requests per launch (is the scatter byte-, request- or latency-bound?)
+      ( cd /tmp && export TMPDIR=/tmp
+        for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS"; do
+          N=$(echo $C | tr ' ' '_' | cut -c1-40)
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/csrpmc_$N -o p -- python $R/scripts/prof.py csr > $F.$N.log 2>&1 || echo "pass $C failed" >> $F.fail
+        done
+        python - <<PY > $F
+import csv, glob, collections
+agg = collections.OrderedDict(); dur = collections.OrderedDict()
+for f in sorted(glob.glob("$O/csrpmc_*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if not any(k in n for k in ("sort_", "scan_", "row_bounds", "degree_kernel")): continue
+        k = (n.replace("void ", "").split("(")[0][-60:], r.get("Grid_Size"), r.get("Counter_Name"))
+        a = agg.setdefault(k, [0.0, 0]); a[0] += float(r["Counter_Value"]); a[1] += 1
+for f in sorted(glob.glob("$O/csrpmc_FETCH_SIZE/**/*kernel_trace.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if not any(k in n for k in ("sort_", "scan_", "row_bounds", "degree_kernel")): continue
+        k = (n.replace("void ", "").split("(")[0][-60:], r.get("Grid_Size", r.get("Grid_Size_X")))
+        a = dur.setdefault(k, [0.0, 0]); a[0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; a[1] += 1
+print("CSR build kernels (prof.py csr: C2 20 M edges = grids 2502656, C2' 100 M edges = 12500992 ...); counters per launch")
+for (k, g, c), (s_, n) in agg.items(): print("%-62s grid %-9s %-24s avg %.5g (n=%d)" % (k, g, c, s_ / n, n))
+for (k, g), (s_, n) in dur.items(): print("%-62s grid %-9s duration under the counter pass avg %.1f us (n=%d)" % (k, g, s_ / n, n))
+PY
+        cat $F.fail >> $F 2>/dev/null; rm -rf $O/csrpmc_* $F.*.log $F.fail )
+      grep "2502656\|grid 1048576" $F | cut -c1-200 ;;
     gcn_form1)  PGLAMD_DENSE_FORM=1 timeout 600 python scripts/prof.py gcn 2>&1 | grep -v amdgpu.ids | head -9 > $F; cat $F ;;
     train)      timeout 600 python scripts/prof.py train gcn gcn_relu sage gat > $F 2>&1; grep -v amdgpu.ids $F ;;
     trace:*)
