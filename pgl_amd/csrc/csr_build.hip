@@ -12,12 +12,15 @@
 //      stability == ascending eid inside equal keys == the reference's order by construction;
 //   3. indptr from row boundaries in the sorted keys (no atomics, no scan): every position p with
 //      key[p] != key[p-1] writes indptr for the rows in (key[p-1], key[p]];  degree = diff;
-//   4. the neighbour id v rides THROUGH the sort packed with the edge id in one 64-bit value (v32 << 32 | eid32): 4 more
-//      bytes per element per pass, all sequential, instead of a random 8-byte gather v[eid] per edge afterwards (one
-//      128-byte line per edge: 0.40 ms of the 1.04 at C2); the last kernel unpacks sequentially, widens to the
-//      reference's int64 arrays where asked, and keeps the int32 (row, col, eid) copies the aggregation kernels read.
+//   4. the neighbour id v and the original edge id ride THROUGH the sort as two more int32 streams next to the key (12 B per item
+//      and pass, all sequential) instead of a random 8-byte gather v[eid] per edge afterwards (one 128-byte line per edge:
+//      0.40 ms of the 1.04 at C2); the last pass writes the int32 (row, col, eid) arrays the aggregation kernels read and,
+//      where asked, the reference's int64 arrays.
 #include "common.hpp"
 #include "scan.hpp"
+
+#include <atomic>
+#include <type_traits>
 
 namespace pglamd {
 
@@ -25,23 +28,6 @@ static int key_bits(int64_t n) {
     int b = 1;
     while (b < 32 && (int64_t(1) << b) < n) ++b;
     return b;
-}
-
-__global__ __launch_bounds__(kBlock) void narrow_keys_kernel(const int64_t* __restrict__ u, int64_t u_stride, const int64_t* __restrict__ v,
-                                                             int64_t v_stride, int64_t n, int64_t n_rows, int32_t* __restrict__ key,
-                                                             uint64_t* __restrict__ val, int32_t* __restrict__ range_flag) {
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        int64_t k = u[i * u_stride];
-        const int64_t nb = v[i * v_stride];
-        // a key outside [0, N) would be sorted on its low bits only and then race in row_bounds_kernel; a neighbour that
-        // does not fit 31 bits would alias another node.  Both are clamped (memory-safe) and reported through range_flag.
-        if ((uint64_t)k >= (uint64_t)n_rows) { k = 0; bad = true; }
-        if ((uint64_t)nb > (uint64_t)INT32_MAX) bad = true;
-        key[i] = (int32_t)k;
-        val[i] = ((uint64_t)(uint32_t)nb << 32) | (uint64_t)(uint32_t)i;       // (neighbour, original edge id)
-    }
-    if (range_flag && __any(bad)) { if ((threadIdx.x & (kWave - 1)) == 0) atomicOr(range_flag, 1); }
 }
 
 __global__ __launch_bounds__(kBlock) void narrow_i64_kernel(const int64_t* __restrict__ in, int64_t stride, int64_t n, int32_t* __restrict__ out) {
@@ -77,21 +63,6 @@ __global__ __launch_bounds__(kBlock) void row_bounds_kernel(const K* __restrict_
             const int64_t glo = __shfl(lo, l, kWave), ghi = __shfl(hi, l, kWave), gp = base + l;
             for (int64_t r = glo + lane; r <= ghi; r += kWave) indptr[r] = gp;
         }
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void finish_csr_kernel(const int32_t* __restrict__ row32, const uint64_t* __restrict__ val, int64_t n,
-                                                            int64_t* __restrict__ sorted_v, int64_t* __restrict__ sorted_u,
-                                                            int64_t* __restrict__ sorted_eid, int32_t* __restrict__ col32,
-                                                            int32_t* __restrict__ eid32) {
-    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (int64_t)gridDim.x * kBlock) {
-        const uint64_t w = val[p];
-        const int32_t e = (int32_t)(uint32_t)w, vv = (int32_t)(uint32_t)(w >> 32);
-        if (sorted_v) sorted_v[p] = vv;
-        if (sorted_u) sorted_u[p] = row32[p];
-        if (sorted_eid) sorted_eid[p] = e;
-        if (col32) col32[p] = vv;
-        if (eid32) eid32[p] = e;
     }
 }
 
@@ -153,8 +124,8 @@ constexpr int kSortMaxBits = 10;
 
 struct SortArgs {
     const int64_t* u; int64_t us; const int64_t* v; int64_t vs;      // FIRST: strided int64 key / neighbour columns
-    const int32_t* key_in; const uint64_t* val_in;                   // otherwise
-    int32_t* key_out; uint64_t* val_out;                             // not LAST
+    const int32_t* key_in; const int32_t* col_in; const int32_t* eid_in;     // otherwise: three int32 streams (key, neighbour, original edge id)
+    int32_t* key_out; int32_t* col_out; int32_t* eid_out;                   // not LAST
     int32_t* row32; int32_t* col32; int32_t* eid32;                  // LAST (any may be NULL)
     int64_t* sorted_u; int64_t* sorted_v; int64_t* sorted_eid;       // LAST, optional int64 copies (the reference's arrays)
     uint32_t* hist;                                                  // [bins][nblk]
@@ -264,38 +235,48 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(uint32_t* __restrict
 }
 
 // The scatter stages the tile through LDS in block-sorted order, so that consecutive lanes write consecutive slots of a
-// digit's run (a first version let every lane store its own pair where it belongs: correct, and 35 % SLOWER than the library
+// digit's run (a first version let every lane store its own triple where it belongs: correct, and 35 % SLOWER than the library
 // sort it replaced -- 64 partial cache lines per store instruction).
+// Round 4: the three 32-bit streams of an item (key, neighbour, edge id) go through ONE 16 KB stage one after the other instead
+// of through a 48 KB (key32 + value64) stage at once.  Counters had shown the kernel moving exactly its model bytes (FETCH 345 MB,
+// WRITE 262 MB at C2: the partial lines of neighbouring tiles do merge in the XCD's L2) at 2.8 TB/s -- it was neither byte- nor
+// request-bound but occupancy-bound: 57 KB of LDS = two blocks per CU, whose load / rank / scan / stage / store phases are separated
+// by barriers, so the memory pipes idled whenever both blocks were ranking (profiles/r04/pmc_csr_build.txt).  24 KB = four blocks.
+// Tried and removed in round 4: ranking with ONE returning LDS atomic per item on the wave's private counter instead of BITS ballots
+// (the ballot ranking is 900 of this kernel's 1 300 vector-ALU instructions per wave).  It was bit-exact and stable on every test
+// (the hardware serves the lanes of one ds_add_rtn in lane order; an on-device check of ascending edge ids inside every row guarded
+// it) and bought nothing: 0.576 -> 0.561 ms at C2, 2.39 -> 2.49 ms at C2' (profiles/r04/csr_build_variants.txt) -- the kernel is not
+// bound by its vector instructions either.
 template <int BITS, bool FIRST, bool LAST>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) {
     constexpr int BINS = 1 << BITS;
     constexpr int PER = BINS / kSortThreads > 0 ? BINS / kSortThreads : 1;     // digits per thread in the block-level scans
+    using CntT = uint16_t;
+    constexpr size_t kCntBytes = sizeof(CntT) * kSortWaves * BINS, kStageBytes = sizeof(int32_t) * kSortTile;
     __shared__ uint32_t gb[BINS];                         // global position of this block's first item of every digit
     __shared__ uint32_t dstart[BINS];                     // position of every digit's first item in the block-sorted tile
-    __shared__ int32_t skey[kSortTile];
-    __shared__ uint64_t sval[kSortTile];                  // (its first bytes double as the per-wave digit counters, see cnt)
+    __shared__ __align__(16) unsigned char lds_pool[kCntBytes > kStageBytes ? kCntBytes : kStageBytes];
     __shared__ uint32_t wave_tot[kSortWaves];
-    static_assert(sizeof(uint16_t) * kSortWaves * BINS <= sizeof(uint64_t) * kSortTile, "wave counters must fit the value stage");
-    uint16_t (*cnt)[BINS] = reinterpret_cast<uint16_t (*)[BINS]>(&sval[0]);   // [kSortWaves][BINS]: counts, then prefixes over waves
+    int32_t* stage = reinterpret_cast<int32_t*>(lds_pool);                     // one 32-bit stream of the tile at a time ...
+    CntT (*cnt)[BINS] = reinterpret_cast<CntT (*)[BINS]>(lds_pool);           // ... over the per-wave digit counters: [kSortWaves][BINS] counts, then prefixes over waves
     const int64_t tile = sort_tile(a.nblk);
     if (tile < 0) return;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
     for (int i = tid; i < BINS; i += kSortThreads) gb[i] = a.hist[(int64_t)i * a.nblk + tile];       // (already the global position: flat scan)
     {
         uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0]);
-        for (int i = tid; i < kSortWaves * BINS / 2; i += kSortThreads) z[i] = 0;
+        for (int i = tid; i < (int)(kCntBytes / 4); i += kSortThreads) z[i] = 0;
     }
     __syncthreads();
     const int64_t tbase = tile * kSortTile;
     const int64_t wbase = tbase + (int64_t)w * (kWave * kSortItems);
-    int32_t key[kSortItems];
-    uint64_t val[kSortItems];
+    int32_t key[kSortItems], col[kSortItems], eid[kSortItems];
     int pos[kSortItems];
     bool bad = false;
 #pragma unroll
     for (int s = 0; s < kSortItems; ++s) {
         const int64_t idx = wbase + s * kWave + lane;
-        key[s] = 0; val[s] = 0;
+        key[s] = 0; col[s] = 0; eid[s] = 0;
         if (idx < a.n) {
             if constexpr (FIRST) {
                 int64_t k, nb;
@@ -307,11 +288,9 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
                 }
                 if ((uint64_t)k >= (uint64_t)a.n_rows) { k = 0; bad = true; }              // clamped (memory-safe) and reported
                 if ((uint64_t)nb > (uint64_t)INT32_MAX) bad = true;
-                key[s] = (int32_t)k;
-                val[s] = ((uint64_t)(uint32_t)nb << 32) | (uint64_t)(uint32_t)idx;        // (neighbour, original edge id)
+                key[s] = (int32_t)k; col[s] = (int32_t)nb; eid[s] = (int32_t)idx;         // (neighbour, original edge id)
             } else {
-                key[s] = a.key_in[idx];
-                val[s] = a.val_in[idx];
+                key[s] = a.key_in[idx]; col[s] = a.col_in[idx]; eid[s] = a.eid_in[idx];
             }
         }
     }
@@ -346,7 +325,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
             uint32_t run = 0;
             if (d < BINS) {
 #pragma unroll
-                for (int ww = 0; ww < kSortWaves; ++ww) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (uint16_t)run; run += c; }
+                for (int ww = 0; ww < kSortWaves; ++ww) { const uint32_t c = cnt[ww][d]; cnt[ww][d] = (CntT)run; run += c; }
             }
             tot[j] = run; sum += run;
         }
@@ -369,30 +348,60 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
         pos[s] += (int)dstart[d] + (int)cnt[w][d];
     }
     __syncthreads();
+    const int n_tile = (int)min((int64_t)kSortTile, a.n - tbase);
+    // round 1: the keys.  Slot i of the block-sorted tile goes to dest[i]; the destinations stay in registers for rounds 2 and 3.
 #pragma unroll
     for (int s = 0; s < kSortItems; ++s)
-        if (wbase + s * kWave + lane < a.n) { skey[pos[s]] = key[s]; sval[pos[s]] = val[s]; }
+        if (wbase + s * kWave + lane < a.n) stage[pos[s]] = key[s];
     __syncthreads();
-    const int n_tile = (int)min((int64_t)kSortTile, a.n - tbase);
+    int32_t dest[kSortItems];
 #pragma unroll
     for (int s = 0; s < kSortItems; ++s) {
         const int i = s * kSortThreads + tid;
+        dest[s] = -1;
         if (i >= n_tile) continue;
-        const int32_t k = skey[i];
-        const uint64_t vv = sval[i];
+        const int32_t k = stage[i];
         const int d = (k >> a.shift) & (BINS - 1);
-        const int64_t dest = (int64_t)gb[d] + (i - (int)dstart[d]);
+        dest[s] = (int32_t)(gb[d] + (uint32_t)(i - (int)dstart[d]));
         if constexpr (LAST) {
-            const int32_t nb = (int32_t)(uint32_t)(vv >> 32), e = (int32_t)(uint32_t)vv;
-            if (a.row32) a.row32[dest] = k;
-            if (a.col32) a.col32[dest] = nb;
-            if (a.eid32) a.eid32[dest] = e;
-            if (a.sorted_u) a.sorted_u[dest] = k;
-            if (a.sorted_v) a.sorted_v[dest] = nb;
-            if (a.sorted_eid) a.sorted_eid[dest] = e;
+            if (a.row32) a.row32[dest[s]] = k;
+            if (a.sorted_u) a.sorted_u[dest[s]] = k;
         } else {
-            a.key_out[dest] = k;
-            a.val_out[dest] = vv;
+            a.key_out[dest[s]] = k;
+        }
+    }
+    __syncthreads();
+    // round 2: the neighbour ids
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s)
+        if (wbase + s * kWave + lane < a.n) stage[pos[s]] = col[s];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s) {
+        if (dest[s] < 0) continue;
+        const int32_t c = stage[s * kSortThreads + tid];
+        if constexpr (LAST) {
+            if (a.col32) a.col32[dest[s]] = c;
+            if (a.sorted_v) a.sorted_v[dest[s]] = c;
+        } else {
+            a.col_out[dest[s]] = c;
+        }
+    }
+    __syncthreads();
+    // round 3: the original edge ids
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s)
+        if (wbase + s * kWave + lane < a.n) stage[pos[s]] = eid[s];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kSortItems; ++s) {
+        if (dest[s] < 0) continue;
+        const int32_t e = stage[s * kSortThreads + tid];
+        if constexpr (LAST) {
+            if (a.eid32) a.eid32[dest[s]] = e;
+            if (a.sorted_eid) a.sorted_eid[dest[s]] = e;
+        } else {
+            a.eid_out[dest[s]] = e;
         }
     }
 }
@@ -465,9 +474,9 @@ using namespace pglamd;
 
 extern "C" size_t pglamd_csr_build_workspace_bytes(int64_t num_edges, int64_t num_nodes) {
     const int64_t E = num_edges > 0 ? num_edges : 1;
-    // two (key32, value64) ping-pong buffers, row32 when the caller does not keep it, block histograms + digit totals / bases
+    // two (key, neighbour, edge id) int32 ping-pong sets, row32 when the caller does not keep it, block histograms + digit totals / bases
     (void)num_nodes;
-    return 3 * align_up((size_t)E * 4, 256) + 2 * align_up((size_t)E * 8, 256) + align_up(sort_hist_entries(E) * 4, 256) +
+    return 7 * align_up((size_t)E * 4, 256) + align_up(sort_hist_entries(E) * 4, 256) +
            align_up((size_t)(ceil_div((int64_t)sort_hist_entries(E), (int64_t)kScanPiece) + 1) * 4, 256) + align_up(((size_t)1 << kSortMaxBits) * 4, 256) + 1024;
 }
 
@@ -487,8 +496,10 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
     int32_t* key_a = cv.take<int32_t>(E > 0 ? E : 1);
     int32_t* key_b = cv.take<int32_t>(E > 0 ? E : 1);
     int32_t* row_tmp = cv.take<int32_t>(E > 0 ? E : 1);
-    uint64_t* val_a = cv.take<uint64_t>(E > 0 ? E : 1);
-    uint64_t* val_b = cv.take<uint64_t>(E > 0 ? E : 1);
+    int32_t* col_a = cv.take<int32_t>(E > 0 ? E : 1);
+    int32_t* col_b = cv.take<int32_t>(E > 0 ? E : 1);
+    int32_t* eid_a = cv.take<int32_t>(E > 0 ? E : 1);
+    int32_t* eid_b = cv.take<int32_t>(E > 0 ? E : 1);
     uint32_t* hist = cv.take<uint32_t>(sort_hist_entries(E));
     uint32_t* totals = cv.take<uint32_t>(ceil_div((int64_t)sort_hist_entries(E), (int64_t)kScanPiece) + 1);
     uint32_t* dbase = cv.take<uint32_t>((size_t)1 << kSortMaxBits);
@@ -507,8 +518,8 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
         for (int p = 0; p < passes; ++p) {
             const bool first = p == 0, last = p == passes - 1;
             a.shift = shift;
-            a.key_in = (p & 1) ? key_a : key_b; a.val_in = (p & 1) ? val_a : val_b;      // pass 0 writes A, pass 1 reads A ...
-            a.key_out = (p & 1) ? key_b : key_a; a.val_out = (p & 1) ? val_b : val_a;
+            a.key_in = (p & 1) ? key_a : key_b; a.col_in = (p & 1) ? col_a : col_b; a.eid_in = (p & 1) ? eid_a : eid_b;      // pass 0 writes A, pass 1 reads A ...
+            a.key_out = (p & 1) ? key_b : key_a; a.col_out = (p & 1) ? col_b : col_a; a.eid_out = (p & 1) ? eid_b : eid_a;
             if (last) { a.row32 = rows; a.col32 = col32; a.eid32 = eid32; a.sorted_u = sorted_u; a.sorted_v = sorted_v; a.sorted_eid = sorted_eid; }
             int32_t rc;
             if (first && last) rc = sort_pass<true, true>(width[p], a, totals, st);

@@ -314,3 +314,4 @@ def test_exclusive_scan_i64_equals_cumsum(pgl, n):
     got = host(pgl.ops.exclusive_scan_i64(dev(v)))
     want = np.cumsum(v) - v
     assert np.array_equal(got, want)
+
