@@ -20,6 +20,7 @@ for STEP in "$@"; do
     rows_c2_p4) timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 4 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -8 $F ;;
     rows_c2_fp16) timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --wire fp16 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -4 $F ;;
     rows_community) timeout 900 python scripts/prof.py rows --graph community --scale 20 --edges 20000000 --parts 8 --partition kway > $F 2>&1; tail -14 $F ;;
+    rows_community_reorder) timeout 900 python scripts/prof.py rows --graph community --reorder --scale 20 --edges 20000000 --parts 8 --partition kway > $F 2>&1; tail -14 $F ;;
     rows_c2p_fp16) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --wire fp16 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_pipe) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow pipeline --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2_pipe)  timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow pipeline --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;

@@ -116,6 +116,14 @@ def cmd_rows(args):
     else:
         edges = rmat_edges(scale, E, seed=42, device=dev)
         gname = "RMAT scale %d" % scale
+    if getattr(args, "reorder", False):
+        # nodes renumbered cluster by cluster first (Graph.reorder): every rank then walks its rows in cluster order too
+        t0 = time.time()
+        g0 = pgl.Graph(edges=edges, num_nodes=N)
+        g0, _order = g0.reorder()
+        edges = g0.edges
+        gname += ", nodes renumbered by Graph.reorder() (%.1f s on the host)" % (time.time() - t0)
+        del g0
     x = torch.randn(N, d, generator=gen, device=dev)
     g = pgl.Graph(edges=edges, num_nodes=N); g.adj_dst_index
     t1 = _t(lambda: g.send_recv(x, "sum"))
@@ -1056,6 +1064,7 @@ def main():
     r.add_argument("--push", default="never", choices=["never", "auto"], help="never = the product default (pull everywhere)")
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     r.add_argument("--graph", default="rmat", choices=["rmat", "community"])
+    r.add_argument("--reorder", action="store_true", help="renumber the nodes with Graph.reorder() before partitioning")
     r.add_argument("--flow", default="", choices=["", "split", "fold", "accumulate", "pipeline"], help="force one flow (PGLAMD_FLOW) instead of the cost model's")
     sub.add_parser("noreuse")
     sub.add_parser("gcn")
