@@ -891,6 +891,12 @@ def cmd_model(args):
                 loss = head["loss"](model(g, x), y)
                 loss.backward()
                 opt.step()
+            if getattr(args, "infer_only", False):                   # rocprofv3 target: inference passes alone
+                with torch.no_grad():
+                    for _ in range(8):
+                        model(g, x)
+                torch.cuda.synchronize()
+                break
             with torch.no_grad():
                 inf = _t(lambda: model(g, x), 5, 2)
             print("%-5s 2 layers, hidden 128, 41 classes at C2, head = %s: inference %.3f ms, training step (loss + backward + Adam) %.3f ms"
@@ -1076,7 +1082,7 @@ def main():
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
-    mo = sub.add_parser("model"); mo.add_argument("which", nargs="*")
+    mo = sub.add_parser("model"); mo.add_argument("which", nargs="*"); mo.add_argument("--infer-only", action="store_true")
     sub.add_parser("dense")
     sub.add_parser("sizes")
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
