@@ -22,7 +22,7 @@ N = 1, one JSON line with the driver's contract fields plus
                 reference's own compiled build_index, an OpenMP CSR variant, scipy CSR @ dense and torch.index_add_ as sanity baselines
 
 N > 1 (strong scaling, the SAME global graph and features): north_star's layout -- row partition by the engine's own partitioner
-(pglamd_partition_edges: in-degree + 1 and rows balanced; --partition metis = the reference's METIS as an opt-in comparison), one
+(pglamd_partition_edges: in-degree + 1 and rows balanced; standing where north_star says "METIS-partitioned"), one
 RCCL halo all-to-all-v per step, interior rows aggregated while the rows travel, boundary rows afterwards from [owned | received]:
 every output row written once (DistGraph).  value = global |E| / max-rank time; halo bytes and the exchange-only time per rank ride
 along; target_size = the |E| = 100 M graph through the same flow.  The run is self-diagnosing (PhaseWatchdog): per-phase wall times
@@ -360,10 +360,9 @@ def main():
     ap.add_argument("--scale", type=int, default=20)
     ap.add_argument("--edges", type=int, default=20_000_000)
     ap.add_argument("--dim", type=int, default=128)
-    ap.add_argument("--partition", default="kway", choices=["kway", "metis", "random", "auto"],
+    ap.add_argument("--partition", default="kway", choices=["kway", "random", "auto"],
                     help="row partition for N > 1: 'kway' (default) = the engine's own multilevel partitioner (pglamd_partition_edges, "
-                         "balanced on in-degree + 1 and on rows), 'metis' = the reference's METIS as an opt-in comparison (helper library "
-                         "built from the reference checkout; k-way when absent), 'random' = balanced random, 'auto' = kway vs random, "
+                         "balanced on in-degree + 1 and on rows), 'random' = balanced random, 'auto' = kway vs random, "
                          "keep the plan whose slowest rank receives fewer rows")
     ap.add_argument("--parallel", default="rows", choices=["rows", "cols", "grid", "auto"],
                     help="N > 1 headline layout: 'rows' (default, north_star) = METIS row partition + one RCCL halo all-to-all-v "

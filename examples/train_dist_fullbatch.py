@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--hidden", type=int, default=128)
     ap.add_argument("--classes", type=int, default=47)
     ap.add_argument("--epochs", type=int, default=10)
-    ap.add_argument("--partition", default="metis", choices=["metis", "kway", "random"])
+    ap.add_argument("--partition", default="kway", choices=["kway", "random"])
     ap.add_argument("--lr", type=float, default=0.01)
     args = ap.parse_args()
 

@@ -121,7 +121,13 @@ int32_t pglamd_narrow_i64(const int64_t* in, int64_t in_stride, int64_t n, int32
  *   row, col   [E] int32, CSR order (row non-decreasing): destination row / source row per edge
  *   indptr     [n_csr_rows+1] int64 (the reference's indptr)
  *   y          NULL for send_u_recv; else edge features [E, dy] of `dtype` in ORIGINAL edge order
- *              when eid != NULL (yp = eid[p]) or already in CSR order when eid == NULL (yp = p)
+ *              when eid != NULL (yp = eid[p]) or already in CSR order when eid == NULL (yp = p).
+ *              Routing note: y = [E, 1] (dy == 1) with eid == NULL, message_op MUL, reduce SUM / MEAN, F32 and rows wider
+ *              than 128 bytes is one fp32 value per edge POSITION multiplied into the gathered row -- the library answers it
+ *              with the flat kernel's per-position scale slot (the `edge_scale` of pglamd_aggregate_dense: 4 sequential
+ *              bytes per edge) instead of the general edge-operand path.  Same result up to the order of one multiplication
+ *              (x * y summed, both ways); every accumulate mode and out_rows < n_csr_rows behave as documented below
+ *              (tests/test_gpu_round5.py::test_abi_edge_operand_e1_mul_reroute_equals_the_general_path).
  *   dx, dy, dout   trailing sizes.  Broadcast rule supported on the fast path: trailing-dim
  *              broadcast only, xj = j / (dout/dx), yj = j / (dout/dy)  (covers [H,D]x[H,1],
  *              [H,D]x[H,D], [D]x[1]); other numpy patterns must be expanded by the caller.
@@ -504,16 +510,11 @@ int32_t pglamd_halo_plan_fill(const int64_t* src, int64_t src_stride, const int6
  * pglamd_map_ids replaces graph_kernel.map_edges / map_nodes (pgl/graph_kernel.pyx:104-138):
  *     out[i] = value of key in[i] in the (keys -> vals) dictionary; missing key -> 0, like
  *     std::unordered_map::operator[] in the reference.
- * pglamd_partition_metis is pgl.partition.metis_partition's native call (pgl/partition.py:37-91 ->
- * graph_kernel.metis_partition, pgl/graph_kernel.pyx:434-472): METIS_PartGraphKway of the reference's
- * vendored METIS 5 (idx_t = int64), called exactly as the reference calls it (ncon = 1, vsize /
- * tpwgts / ubvec / options = NULL), so part ids are BIT-IDENTICAL to the reference's.  The METIS
- * code lives in the helper library libpglamd_metis.so (built from the reference checkout by
- * pgl_amd/_build_metis.py, opened with dlopen from the directory of this library or from
- * $PGLAMD_METIS_LIB); without it the call returns PGLAMD_E_UNAVAILABLE and
- * pglamd_metis_available() returns 0.
- * pglamd_partition_kway is the engine's own multilevel k-way partitioner: the documented fallback
- * when the helper is absent or METIS does not fit in host memory.  Same inputs (CSR xadj/adjncy
+ * pglamd_partition_kway stands behind pgl.partition.metis_partition (pgl/partition.py:37-91 ->
+ * graph_kernel.metis_partition, pgl/graph_kernel.pyx:434-472).  No METIS code is built into or opened by
+ * this library (round 5: the round-3/4 opt-in bridge pglamd_partition_metis / libpglamd_metis.so was removed from
+ * the product; the reference's METIS lives only in the test oracle, oracle/_ref).
+ * It is the engine's own multilevel k-way partitioner.  Same inputs as METIS_PartGraphKway as the reference calls it (CSR xadj/adjncy
  * int64, optional positive int64 vertex / edge weights), same output (part[N] int64 in
  * [0, nparts)); its ids are NOT METIS's -- parity there is on balance and edge cut.
  * ---------------------------------------------------------------------------------------------- */
@@ -526,10 +527,6 @@ int32_t pglamd_build_index_host(const int64_t* u, int64_t u_stride, const int64_
                                 int64_t* sorted_eid, int64_t* indptr);
 int32_t pglamd_map_ids(const int64_t* keys, const int64_t* vals, int64_t n_keys, const int64_t* in,
                        int64_t n_in, int64_t* out);
-int32_t pglamd_metis_available(void);
-int32_t pglamd_partition_metis(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
-                               const int64_t* vwgt, const int64_t* adjwgt, int64_t nparts,
-                               int64_t* part, int64_t* edgecut);
 int32_t pglamd_partition_kway(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy,
                               const int64_t* vwgt, const int64_t* adjwgt, int64_t nparts,
                               uint64_t seed, int64_t* part, int64_t* edgecut);

@@ -85,8 +85,6 @@ _SIGNATURES = {
     "pglamd_halo_exchange_wait": (c_i32, [c_vp, c_vp]),
     "pglamd_halo_plan_sizes": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_vp]),
     "pglamd_halo_plan_fill": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32] + [c_vp] * 13),
-    "pglamd_metis_available": (c_i32, []),
-    "pglamd_partition_metis": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
 }
 
 ABI_VERSION = 2

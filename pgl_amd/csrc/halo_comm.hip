@@ -124,17 +124,27 @@ extern "C" int32_t pglamd_halo_exchange_start(void* comm, const void* send_buf, 
     const char* sp = static_cast<const char*>(send_buf);
     char* rp = static_cast<char*>(recv_buf);
     PGLAMD_NCCL_CHECK(rccl().GroupStart());
-    for (int q = 0; q < c->world; ++q) {
+    // Between GroupStart and GroupEnd NOTHING returns early: a failure is remembered, the loop stops queueing, and the group is
+    // closed before the error is reported -- a communicator left with an open group would swallow every later call.
+    int32_t rc = PGLAMD_OK;
+    for (int q = 0; q < c->world && rc == PGLAMD_OK; ++q) {
         const size_t sb = (size_t)send_rows[q] * (size_t)row_bytes, rb = (size_t)recv_rows[q] * (size_t)row_bytes;
         if (q == c->rank) {                                           // own block (always empty for halo plans): a plain copy
-            if (sb) PGLAMD_HIP_CHECK(hipMemcpyAsync(rp, sp, sb, hipMemcpyDeviceToDevice, c->side));
+            if (sb) {
+                const hipError_t e = hipMemcpyAsync(rp, sp, sb, hipMemcpyDeviceToDevice, c->side);
+                if (e != hipSuccess) rc = fail(PGLAMD_E_HIP, "halo_exchange_start: own-block copy failed: %s", hipGetErrorString(e));
+            }
         } else {
-            if (sb) PGLAMD_NCCL_CHECK(rccl().Send(sp, sb, ncclInt8, q, c->nccl, c->side));
-            if (rb) PGLAMD_NCCL_CHECK(rccl().Recv(rp, rb, ncclInt8, q, c->nccl, c->side));
+            ncclResult_t r = ncclSuccess;
+            if (sb) r = rccl().Send(sp, sb, ncclInt8, q, c->nccl, c->side);
+            if (r == ncclSuccess && rb) r = rccl().Recv(rp, rb, ncclInt8, q, c->nccl, c->side);
+            if (r != ncclSuccess) rc = fail(PGLAMD_E_RCCL, "halo_exchange_start: send/recv with peer %d failed: %s", q, rccl().GetErrorString(r));
         }
         sp += sb; rp += rb;
     }
-    PGLAMD_NCCL_CHECK(rccl().GroupEnd());
+    const ncclResult_t end = rccl().GroupEnd();                      // always: closes the group on the error path too
+    if (rc != PGLAMD_OK) return rc;                                   // (the first failure's message stands)
+    if (end != ncclSuccess) return fail(PGLAMD_E_RCCL, "halo_exchange_start: ncclGroupEnd failed: %s", rccl().GetErrorString(end));
     PGLAMD_HIP_CHECK(hipEventRecord(c->done, c->side));
     c->in_flight = true;
     return PGLAMD_OK;

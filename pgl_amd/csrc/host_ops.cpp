@@ -1,10 +1,9 @@
-// host_ops.cpp -- CPU-side helpers of libpglamd (HOST pointers): the host CSR build, id relabel, the opt-in METIS bridge and
-// the halo plan of a row-partitioned graph.  (The engine's own partitioner lives in partition.cpp.)
+// host_ops.cpp -- CPU-side helpers of libpglamd (HOST pointers): the host CSR build, id relabel and the halo plan of a
+// row-partitioned graph.  (The engine's own partitioner -- what stands behind pgl.partition.metis_partition -- lives in
+// partition.cpp; no METIS code is linked, opened or built by the product.)
 //
 // pglamd_build_index_host <- graph_kernel.build_index (pgl/graph_kernel.pyx:59-88)
 // pglamd_map_ids          <- graph_kernel.map_edges / map_nodes (pgl/graph_kernel.pyx:104-138)
-// pglamd_partition_metis  <- METIS_PartGraphKway as driven by pgl.partition.metis_partition (pgl/partition.py:37-91 ->
-//                            pgl/graph_kernel.pyx:434-472): the reference's vendored METIS in a helper library, opt-in.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -16,8 +15,6 @@
 #include <vector>
 #include <mutex>
 #include <string>
-
-#include <dlfcn.h>
 
 #include "../../include/pgl_amd.h"
 
@@ -63,68 +60,6 @@ extern "C" int32_t pglamd_map_ids(const int64_t* keys, const int64_t* vals, int6
         auto it = m.find(in[i]);
         out[i] = it == m.end() ? 0 : it->second;   // reference: unordered_map::operator[] -> 0
     }
-    return PGLAMD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// METIS (the reference's vendored library, built by pgl_amd/_build_metis.py into libpglamd_metis.so next to this library)
-// ------------------------------------------------------------------------------------------------
-namespace {
-typedef int (*metis_kway_fn)(int64_t* nvtxs, int64_t* ncon, int64_t* xadj, int64_t* adjncy, int64_t* vwgt, int64_t* vsize,
-                             int64_t* adjwgt, int64_t* nparts, float* tpwgts, float* ubvec, int64_t* options,
-                             int64_t* edgecut, int64_t* part);
-struct MetisLib {
-    std::once_flag once;
-    metis_kway_fn kway = nullptr;
-    std::string why;
-};
-MetisLib& metis_lib() { static MetisLib m; return m; }
-
-void load_metis() {
-    MetisLib& m = metis_lib();
-    std::string path;
-    if (const char* e = getenv("PGLAMD_METIS_LIB")) path = e;
-    else {
-        Dl_info info;
-        if (dladdr((void*)&load_metis, &info) && info.dli_fname) {
-            path = info.dli_fname;
-            const size_t k = path.find_last_of('/');
-            path = (k == std::string::npos ? std::string(".") : path.substr(0, k)) + "/libpglamd_metis.so";
-        }
-    }
-    void* h = path.empty() ? nullptr : dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-    if (!h) {
-        const char* err = dlerror();               // ONE call: dlerror() clears the message it returns
-        m.why = "cannot open " + path + (err ? std::string(": ") + err : std::string());
-        return;
-    }
-    m.kway = (metis_kway_fn)dlsym(h, "METIS_PartGraphKway");
-    if (!m.kway) m.why = path + " has no METIS_PartGraphKway";
-}
-}  // namespace
-
-extern "C" int32_t pglamd_metis_available(void) {
-    std::call_once(metis_lib().once, load_metis);
-    return metis_lib().kway ? 1 : 0;
-}
-
-extern "C" int32_t pglamd_partition_metis(int64_t num_nodes, const int64_t* xadj, const int64_t* adjncy, const int64_t* vwgt,
-                                          const int64_t* adjwgt, int64_t nparts, int64_t* part, int64_t* edgecut) {
-    if (num_nodes < 0 || nparts < 1 || !part || (num_nodes > 0 && (!xadj || (xadj[num_nodes] > 0 && !adjncy))))
-        return pglamd::fail(PGLAMD_E_ARG, "partition_metis: bad argument");
-    std::call_once(metis_lib().once, load_metis);
-    if (!metis_lib().kway) return pglamd::fail(PGLAMD_E_UNAVAILABLE, "partition_metis: %s", metis_lib().why.c_str());
-    if (nparts == 1 || num_nodes == 0) {
-        std::fill(part, part + num_nodes, (int64_t)0);
-        if (edgecut) *edgecut = 0;
-        return PGLAMD_OK;
-    }
-    // exactly the reference's call (pgl/graph_kernel.pyx:468-471): ncon = 1, no vsize / tpwgts / ubvec, DEFAULT options
-    int64_t nv = num_nodes, ncon = 1, np_ = nparts, cut = -1;
-    const int rc = metis_lib().kway(&nv, &ncon, const_cast<int64_t*>(xadj), const_cast<int64_t*>(adjncy), const_cast<int64_t*>(vwgt),
-                                    nullptr, const_cast<int64_t*>(adjwgt), &np_, nullptr, nullptr, nullptr, &cut, part);
-    if (rc != 1) return pglamd::fail(PGLAMD_E_ARG, "partition_metis: METIS_PartGraphKway returned %d", rc);   // METIS_OK == 1
-    if (edgecut) *edgecut = cut;
     return PGLAMD_OK;
 }
 

@@ -462,8 +462,8 @@ class DistGraph(object):
         """Every rank holds the same global edge list (synthetic graphs are regenerated from the seed on each rank);
         rank 0 partitions and broadcasts the part vector.
         method: "kway" (default: the engine's own multilevel partitioner, balanced on aggregation work -- in-degree + 1 -- and
-                on rows), "metis" (opt-in comparison: the reference's METIS through pgl_amd.partition, k-way when its helper
-                library is absent), "random", "mod" (node id % world, the reference DistGPUGraph's rule), or "auto" (build
+                on rows; "metis" is accepted as a NAME for it -- north_star's "METIS-partitioned" role; no METIS code is in the
+                product), "random", "mod" (node id % world, the reference DistGPUGraph's rule), or "auto" (build
                 kway and random, keep the plan whose slowest rank receives fewer rows).
         push:   "never" (default) = pull everywhere: every edge is aggregated by its DESTINATION's owner, which is what the
                 partitioner balanced; "auto" = per rank pair the cheaper of pull / push for send_recv(sum | mean) -- 3-10 % fewer
@@ -497,9 +497,7 @@ class DistGraph(object):
             if best is None or float(cost) < best[0]:
                 best = (float(cost), m, plan, xplan)
         dg = cls(best[2], device=edges.device, group=group, backend=backend, exchange_plan=best[3])
-        dg.method = "given" if given else best[1]
-        if dg.method == "metis" and world > 1 and not ops.metis_available():   # say what actually ran (same answer on every rank)
-            dg.method = "kway (METIS helper library absent)"
+        dg.method = "given" if given else ("kway" if best[1] == "metis" else best[1])   # say what actually ran
         return dg
 
     @classmethod
@@ -529,16 +527,10 @@ class DistGraph(object):
                 # vertex weight = in-degree + 1 balances aggregation work (node_weights, pgl/partition.py:76-79); the adjacency is
                 # symmetrised (the reference warns METIS input should be undirected, pgl/partition.py:61)
                 vw = np.bincount(e[:, 1], minlength=num_nodes).astype(np.int64) + 1
-                p = None
-                if method == "metis" and ops.metis_available():       # opt-in comparison: the reference's METIS
-                    u = np.concatenate([e[:, 0], e[:, 1]]); v = np.concatenate([e[:, 1], e[:, 0]])
-                    _, sv, _, _, ip = ops.host_build_index(u, v, num_nodes)
-                    p = ops.host_partition_metis(num_nodes, ip, sv, world, vw)[0]
-                if p is None:
-                    # the engine's partitioner on the directed edge list (symmetrised inside, in parallel); second constraint =
-                    # rows, kept loose: on power-law graphs hubs and leaves cannot be spread evenly under a tight row bound,
-                    # and the isolated vertices, placed last, level the row counts anyway
-                    p, _ = ops.host_partition_edges(e, num_nodes, world, vw, np.ones(num_nodes, np.int64), 1.03, 1.6, seed)
+                # the engine's partitioner on the directed edge list (symmetrised inside, in parallel); second constraint =
+                # rows, kept loose: on power-law graphs hubs and leaves cannot be spread evenly under a tight row bound,
+                # and the isolated vertices, placed last, level the row counts anyway
+                p, _ = ops.host_partition_edges(e, num_nodes, world, vw, np.ones(num_nodes, np.int64), 1.03, 1.6, seed)
             part.copy_(torch.from_numpy(np.ascontiguousarray(p, dtype=np.int64)))
         if ready:
             buf = part.to(edges.device) if dist.get_backend(group) == "nccl" else part

@@ -91,6 +91,7 @@ class Graph(object):
         self._device = device
         self._is_tensor = True
         self._nodes = None
+        self._degree_norm_cache = None
 
     def tensor(self, inplace=True, device=None):
         """pgl/graph.py:227-267.  Moves edges, features and any already-built index to the GPU."""
@@ -126,6 +127,7 @@ class Graph(object):
             self._src32 = self._dst32 = None
             self._seg_cache = {}
             self._csr_views = None
+            self._degree_norm_cache = None           # (device tensors of the graph that was: ADVICE r4)
             return self
         return self.__class__(edges=edges, num_nodes=self._num_nodes, node_feat=nf, edge_feat=ef,
                               adj_src_index=None if self._adj_src_index is None else self._adj_src_index.numpy(False),

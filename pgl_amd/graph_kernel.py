@@ -25,12 +25,9 @@ def map_edges(eids, edges, reindex):
 
 def metis_partition(num_nodes, adj_indptr, sorted_v, nparts, node_weights=None, edge_weights=None, recursive=False):
     """pgl/graph_kernel.pyx:434-472 (K-way; the reference's wrapper never takes the recursive branch: pgl/partition.py:80-89).
-    Like pgl_amd.partition.metis_partition: the engine's own k-way partitioner answers unless PGLAMD_PARTITIONER=metis opted
-    into the reference's vendored METIS AND its helper library is built."""
+    Like pgl_amd.partition.metis_partition: the reference's NAME, answered by the engine's own k-way partitioner
+    (pglamd_partition_kway); no METIS code is reachable from the product."""
     if recursive:
         raise NotImplementedError("recursive METIS is not exposed (pgl/partition.py:80: 'recursive metis always core dump')")
-    from .partition import metis_kway_csr
-    part = metis_kway_csr(num_nodes, adj_indptr, sorted_v, nparts, node_weights, edge_weights)
-    if part is None:
-        part, _ = ops.host_partition_kway(num_nodes, adj_indptr, sorted_v, nparts, node_weights, edge_weights, 0)
+    part, _ = ops.host_partition_kway(num_nodes, adj_indptr, sorted_v, nparts, node_weights, edge_weights, 0)
     return part

@@ -14,22 +14,26 @@ def degree_norm(graph, mode="indegree"):
         "The degree_norm mode should be in ['indegree', 'outdegree']. But recieve mode=%s" % mode
     dt = torch.get_default_dtype()
     dt = dt if dt in (torch.float32, torch.float64) else torch.float32
-    # One tensor per (graph, mode, dtype): a layer stack asks for it once per layer and step (pgl/nn/conv.py:240), and the
+    # One tensor per (graph, mode, dtype, device): a layer stack asks for it once per layer and step (pgl/nn/conv.py:240), and the
     # aggregation keys its per-edge layout of the norm (ops.edge_scale) on the tensor it is handed.  The entry is dropped if
-    # somebody wrote into the tensor (version counter).
-    cache = getattr(graph, "_degree_norm_cache", None)
-    if cache is not None:
-        hit = cache.get((mode, dt))
-        if hit is not None and hit[0]._version == hit[1]:
-            return hit[0]
+    # somebody wrote into the tensor (version counter; writes through .data / set_() are not seen -- do not edit the result in
+    # place that way).  Tensors made under torch.inference_mode() track no version: nothing is cached for them.
     degree = graph.indegree() if mode == "indegree" else graph.outdegree()
+    on_gpu = torch.is_tensor(degree) and degree.is_cuda
+    cache = getattr(graph, "_degree_norm_cache", None)
+    key = (mode, dt, str(degree.device)) if on_gpu else None
+    if cache is not None and key is not None:
+        hit = cache.get(key)
+        if hit is not None and ops.tensor_version(hit[0]) == hit[1]:
+            return hit[0]
     out = ops.degree_norm(degree, dt)
     out._pglamd_positive = True          # clip(degree, 1)^-0.5 > 0 by construction: lets the k-hop layers skip their check
-    if torch.is_tensor(degree) and degree.is_cuda:
+    ver = ops.tensor_version(out) if on_gpu else None
+    if ver is not None:
         try:
             if cache is None:
                 cache = graph._degree_norm_cache = {}
-            cache[(mode, dt)] = (out, out._version)
+            cache[key] = (out, ver)
         except AttributeError:
             pass
     return out

@@ -7,6 +7,7 @@ on the message-passing path.  The host_* functions are the CPU-side helpers of t
 
 Each function names the reference call site it stands in for (reference = PaddlePaddle/PGL 2.2.6).
 """
+import collections
 import ctypes
 import threading
 
@@ -41,16 +42,28 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
-_WS_HOT = {}
-_WS_HOT_MAX = 1 << 30
+_WS_HOT = collections.OrderedDict()      # (device, stream, thread) -> buffer, least recently used first
+_WS_HOT_MAX = 1 << 29                    # largest request held (512 MiB: the aggregate scratch at |E| = 100 M, d = 128 fp32 is 400 MB)
+_WS_HOT_TOTAL = 1 << 30                  # bytes held over all entries; the least recently used ones are dropped beyond it
+_WS_HOT_ENTRIES = 16
+
+
+def release_workspaces():
+    """Drops every cached scratch buffer (they return to torch's caching allocator; torch.cuda.empty_cache() then gives the
+    memory back to the device).  Safe at any point: a buffer in use by queued kernels stays alive through the allocator's
+    stream ordering."""
+    _WS_HOT.clear()
 
 
 def _ws_hot(nbytes, device):
     """Scratch of the per-step ops (aggregate, segment ops, the GAT kernels): one grow-only buffer per (device, stream, thread)
     instead of an allocator round trip per call.  A kernel's scratch is consumed inside the call that filled it, so calls
-    queued on ONE stream can share it; another stream gets its own.  Requests above 1 GiB are not held."""
+    queued on ONE stream can share it; another stream gets its own.  Bounded: requests above 512 MiB are not held,
+    at most 16 entries / 1 GiB in total are kept (least recently used dropped first, so entries of finished threads and
+    streams age out), nothing is cached while the stream is being captured into a graph (the buffer would escape the
+    capture's private pool), and `release_workspaces()` empties the cache."""
     nbytes = max(int(nbytes), 256)
-    if nbytes > _WS_HOT_MAX:
+    if nbytes > _WS_HOT_MAX or torch.cuda.is_current_stream_capturing():
         return _ws(nbytes, device)
     # (per thread as well: a library call enqueues its launches with the GIL released, so two threads feeding ONE stream could
     #  interleave them -- thread A's kernel, thread B's kernel, thread A's fix-up reading B's partials)
@@ -58,7 +71,26 @@ def _ws_hot(nbytes, device):
     buf = _WS_HOT.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _WS_HOT[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        total = sum(b.numel() for b in _WS_HOT.values())
+        while len(_WS_HOT) > 1 and (total > _WS_HOT_TOTAL or len(_WS_HOT) > _WS_HOT_ENTRIES):
+            k0 = next(iter(_WS_HOT))
+            if k0 == key:
+                _WS_HOT.move_to_end(k0)
+                continue
+            total -= _WS_HOT.pop(k0).numel()
+    _WS_HOT.move_to_end(key)
     return buf
+
+
+def tensor_version(t):
+    """t._version, or None for a tensor that tracks none (created under torch.inference_mode(): reading the counter raises
+    RuntimeError there -- ADVICE r4).  Callers treat None as "do not cache"."""
+    try:
+        if t.is_inference():
+            return None
+        return t._version
+    except (RuntimeError, AttributeError):
+        return None
 
 
 def _code(dtype):
@@ -220,15 +252,17 @@ def edge_scale(csr, scale):
     scale = scale.reshape(-1)
     if not scale.is_contiguous():
         scale = scale.contiguous()
-    key = (scale.untyped_storage().data_ptr(), scale.storage_offset(), scale.numel(), scale._version)
+    ver = tensor_version(scale)
+    key = None if ver is None else (scale.untyped_storage().data_ptr(), scale.storage_offset(), scale.numel(), ver, str(scale.device))
     hit = getattr(csr, "_es", None)
-    if hit is not None and hit[0] == key:
+    if key is not None and hit is not None and hit[0] == key:
         return hit[2]
     es = gather_rows(scale.reshape(-1, 1), csr.col32).reshape(-1)
-    try:
-        csr._es = (key, scale, es)
-    except AttributeError:                                    # an index type without the slot: no caching
-        pass
+    if key is not None:                                       # (inference-mode tensors carry no version counter: not cached)
+        try:
+            csr._es = (key, scale, es)
+        except AttributeError:                                # an index type without the slot: no caching
+            pass
     return es
 
 
@@ -898,26 +932,6 @@ def host_partition_edges(edges, num_nodes, nparts, node_weights=None, node_weigh
     _ffi.check(_ffi.lib().pglamd_partition_edges(_np_ptr(src), st, _np_ptr(dst), st, E, int(num_nodes), _np_ptr(vw), _np_ptr(vw2),
                                                  int(nparts), float(ub), float(ub2), int(seed), int(threads), _np_ptr(part),
                                                  ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)), "partition_edges")
-    return part, int(cut.value)
-
-
-def metis_available():
-    """True when the METIS helper library (pgl_amd/_build_metis.py) can be opened."""
-    return bool(_ffi.lib().pglamd_metis_available())
-
-
-def host_partition_metis(num_nodes, indptr, adjncy, nparts, node_weights=None, edge_weights=None):
-    """graph_kernel.metis_partition(..., recursive=False) (pgl/graph_kernel.pyx:434-472): the reference's vendored METIS,
-    called as the reference calls it -> part ids bit-identical to the reference's.  Raises RuntimeError when the helper
-    library is absent (callers fall back to host_partition_kway)."""
-    indptr = _np_i64(indptr); adjncy = _np_i64(adjncy)
-    vw = None if node_weights is None else _np_i64(node_weights)
-    ew = None if edge_weights is None else _np_i64(edge_weights)
-    part = np.empty(int(num_nodes), np.int64)
-    cut = ctypes.c_int64(0)
-    _ffi.check(_ffi.lib().pglamd_partition_metis(int(num_nodes), _np_ptr(indptr), _np_ptr(adjncy), _np_ptr(vw), _np_ptr(ew),
-                                                 int(nparts), _np_ptr(part), ctypes.cast(ctypes.pointer(cut), ctypes.c_void_p)),
-               "partition_metis")
     return part, int(cut.value)
 
 

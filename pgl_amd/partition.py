@@ -1,14 +1,12 @@
 """pgl_amd.partition -- metis_partition / random_partition.  Mirrors pgl/partition.py:25-123.
 
-`metis_partition` keeps the reference's signature and pre-processing (dst-CSR input, min-max weight scaling to positive
+`metis_partition` keeps the reference's NAME, signature and pre-processing (dst-CSR input, min-max weight scaling to positive
 ints, K-way only).  The partitioner behind it is the ENGINE'S OWN (pglamd_partition_kway, csrc/partition.cpp: multi-threaded,
 deterministic label-propagation multilevel k-way; cut within 5 % of METIS's on the reference fixtures and on the benchmark
-graph, 15x faster) -- no code built from the reference sits on the product's default path.
-PGLAMD_PARTITIONER=metis opts into the reference's vendored METIS through pglamd_partition_metis -> libpglamd_metis.so
-(built from the reference checkout by pgl_amd/_build_metis.py): part ids then are bit-identical to
-pgl.partition.metis_partition's; it is the comparison the tests and scripts/prof.py use, not the product.
+graph, 15x faster).  Nothing built from the reference is reachable from the product: the round-3/4 opt-in METIS bridge
+(PGLAMD_PARTITIONER=metis -> pglamd_partition_metis -> libpglamd_metis.so) was removed in round 5; the reference's METIS is
+a comparison partner of the TESTS only (tests/test_host_logic.py, tests/test_golden_fixtures.py: the test oracle's build of it).
 """
-import os
 import math
 import warnings
 
@@ -45,34 +43,8 @@ def metis_partition(graph, npart, node_weights=None, edge_weights=None, seed=0):
         if check_is_tensor(node_weights):
             node_weights = node_weights.detach().cpu().numpy()
         node_weights = _metis_weight_scale(node_weights)
-    part = metis_kway_csr(graph.num_nodes, indptr, v, npart, node_weights, edge_weights)
-    if part is None:
-        part, _ = ops.host_partition_kway(graph.num_nodes, indptr, v, npart, node_weights, edge_weights, seed)
+    part, _ = ops.host_partition_kway(graph.num_nodes, indptr, v, npart, node_weights, edge_weights, seed)
     return part
-
-
-def use_metis():
-    """True when the caller opted into the reference's METIS (PGLAMD_PARTITIONER=metis) AND its helper library is built."""
-    return os.environ.get("PGLAMD_PARTITIONER", "kway") == "metis" and ops.metis_available()
-
-
-def metis_kway_csr(num_nodes, indptr, adjncy, npart, node_weights=None, edge_weights=None):
-    """METIS_PartGraphKway on a CSR as graph_kernel.metis_partition calls it -- only when PGLAMD_PARTITIONER=metis asks for it.
-    None = the caller runs the engine's own partitioner (the default; with a warning, once, when METIS was asked for but its
-    helper library is not built)."""
-    global _warned
-    if os.environ.get("PGLAMD_PARTITIONER", "kway") != "metis":
-        return None
-    if ops.metis_available():
-        return ops.host_partition_metis(num_nodes, indptr, adjncy, npart, node_weights, edge_weights)[0]
-    if not _warned:
-        warnings.warn("pgl_amd.partition: METIS helper library not available (python -m pgl_amd._build_metis needs the "
-                      "reference checkout); using the engine's own k-way partitioner -- part ids will differ from METIS's")
-        _warned = True
-    return None
-
-
-_warned = False
 
 
 def random_partition(graph, npart):

@@ -2,7 +2,7 @@
 """scripts/prof.py -- every measurement helper of this repository behind one entry point (run on the GPU box through gpurun).
 
     python scripts/prof.py diag                      box state a bandwidth number depends on (clocks, partition modes, VRAM)
-    python scripts/prof.py rows  [--scale 20 --edges 20000000 --parts 8 --partition kway|metis|random|FILE.npy]
+    python scripts/prof.py rows  [--scale 20 --edges 20000000 --parts 8 --partition kway|random|FILE.npy]
                                                      per-rank COMPUTE of the row-partitioned layout on ONE GPU, phase by phase,
                                                      next to the bytes each rank receives and what they cost on xGMI
     python scripts/prof.py ops                       one line per op of SURVEY 8(a) at C2 / C3 sizes
@@ -1066,7 +1066,7 @@ def main():
     r.add_argument("--edges", type=int, default=20_000_000)
     r.add_argument("--dim", type=int, default=128)
     r.add_argument("--parts", type=lambda s: [int(v) for v in s.split(",")], default=[2, 4, 8])
-    r.add_argument("--partition", default="kway", help="kway | metis | random | path/with{P}.npy")
+    r.add_argument("--partition", default="kway", help="kway | random | path/with{P}.npy")
     r.add_argument("--push", default="never", choices=["never", "auto"], help="never = the product default (pull everywhere)")
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     r.add_argument("--graph", default="rmat", choices=["rmat", "community"])

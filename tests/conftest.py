@@ -26,16 +26,3 @@ def ref_native():
     if m is None:
         pytest.skip("oracle/_ref not built and /root/reference absent")
     return m
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _metis_comparison_partner():
-    """The opt-in METIS bridge (PGLAMD_PARTITIONER=metis) is a comparison partner of the tests, not part of the product
-    build: __graft_entry__.build() no longer compiles it, the test session does when the reference checkout is present
-    (here; on the GPU box the prebuilt helper travels with the snapshot, or the METIS tests skip)."""
-    try:
-        from pgl_amd import _build_metis
-        _build_metis.build()
-    except Exception as e:                                   # the METIS tests skip through ops.metis_available()
-        print("METIS helper not built: %s" % e)
-    yield

@@ -1,0 +1,252 @@
+"""GPU tests added in round 5 (-m gpu): the parity holes VERDICT r4 names -- K1' (COO scatter-add) against the ORACLE, BASELINE
+config 4 (ogbn-products size, GraphSAGE mean, d = 100: a 400-byte row) with its FULL output against the oracle, the 8-way
+partitioned flow at that size with the ENGINE'S partitioner against the oracle -- and the ADVICE r4 items."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import ref_ops as R
+from test_gpu_round2 import assert_within_fp32_reassociation
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pgl():
+    import pgl_amd
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    arch = pgl_amd._ffi.lib().pglamd_device_arch().decode()
+    assert arch.startswith("gfx950"), "libpglamd sees %r, expected gfx950" % arch
+    return pgl_amd
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# (a) K1': paddle.geometric.send_u_recv straight from raw COO (pgl/graph.py:859-861; the Paddle-free fallback
+#     pgl/utils/helper.py:163-210) -- against the oracle's serial COO loop, not against the engine's CSR kernel
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [128, 100, 8, 64, 256])
+@pytest.mark.parametrize("shape", ["hub", "uniform", "sorted"])
+def test_scatter_add_coo_vs_oracle(pgl, d, shape):
+    rng = np.random.default_rng(100 + d)
+    n, e = 6000, 150000
+    src = rng.integers(0, n, e).astype(np.int64)
+    dst = (rng.integers(0, n // 2, e) * 2).astype(np.int64)             # odd rows stay empty -> exactly 0
+    if shape == "hub":
+        dst[rng.choice(e, 40000, replace=False)] = 10                    # one row takes a quarter of the edges
+        dst[rng.choice(e, 9000, replace=False)] = 4000
+    elif shape == "sorted":
+        o = np.argsort(dst, kind="stable"); src, dst = src[o], dst[o]    # destination-grouped input (sampled blocks)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    got = host(pgl.ops.scatter_add_coo(dev(x), dev(src.astype(np.int32)), dev(dst.astype(np.int32)), n))
+    want = R.c_send_u_recv(x, src, dst, "sum")
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5 * scale)
+    assert (got[1::2] == 0).all()
+    # per element, inside the fp32 re-association bound of the exact (fp64) sum: the atomic order is arbitrary
+    w64 = np.zeros((n, d)); a64 = np.zeros((n, d))
+    np.add.at(w64, dst, x[src].astype(np.float64)); np.add.at(a64, dst, np.abs(x[src]).astype(np.float64))
+    assert_within_fp32_reassociation(got, w64, a64, np.bincount(dst, minlength=n)[:, None].astype(np.float64), slack=2.0)
+
+
+def test_scatter_add_coo_edge_cases(pgl):
+    x = dev(np.arange(40, dtype=np.float32).reshape(5, 8))
+    z = torch.zeros(0, dtype=torch.int32, device="cuda")
+    assert (host(pgl.ops.scatter_add_coo(x, z, z, 5)) == 0).all()                       # no edges
+    one = pgl.ops.scatter_add_coo(x, dev(np.array([2], np.int32)), dev(np.array([3], np.int32)), 9)
+    assert one.shape == (9, 8) and torch.equal(one[3], x[2]) and float(one.abs().sum()) == float(x[2].abs().sum())
+    with pytest.raises(RuntimeError):
+        pgl.ops.scatter_add_coo(x.cpu(), z.cpu(), z.cpu(), 5)                           # no CPU fallback
+
+
+# ------------------------------------------------------------------------------------------------
+# (b), (c) BASELINE config 4 at its stated size: N = 2 449 029, E = 123 718 280 directed, d = 100, mean.
+# Reference: pgl/graph.py:834-861 (send_recv), pgl/nn/conv.py:81-115 (GraphSageConv), pgl/partition.py:37-91.
+# Real OGB files are not available offline: the topology is an RMAT stand-in folded onto N nodes.
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config4(pgl):
+    from pgl_amd.utils.rmat import rmat_edges
+    N, E, d = 2_449_029, 123_718_280, 100
+    edges = rmat_edges(22, E, seed=42, device="cuda") % N
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    x = torch.randn(N, d, generator=gen, device="cuda")
+    e = host(edges)
+    src, dst = np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+    want = R.c_send_u_recv(host(x), src, dst, "mean")                 # the serial C port of the Paddle CPU kernel, raw COO order
+    # the exact result and the per-element magnitude of its terms, in fp64 on the GPU
+    w64 = torch.zeros(N, d, dtype=torch.float64, device="cuda"); a64 = torch.zeros_like(w64)
+    for lo in range(0, E, 4_000_000):
+        s, t = edges[lo:lo + 4_000_000, 0], edges[lo:lo + 4_000_000, 1]
+        xs = x[s].double()
+        w64.index_add_(0, t, xs); a64.index_add_(0, t, xs.abs())
+    indeg = torch.bincount(edges[:, 1], minlength=N).double()[:, None]
+    w64 /= indeg.clamp(min=1); a64 /= indeg.clamp(min=1)
+    return dict(N=N, E=E, d=d, edges=edges, x=x, want=want, w64=host(w64), a64=host(a64), indeg=host(indeg), e_host=e)
+
+
+def _check_full_output(got, c, what):
+    want, w = c["want"], c["w64"]
+    scale = float(np.abs(want).max())
+    # (1) north_star's bar against the EXACT result
+    np.testing.assert_allclose(got, w, rtol=1e-5, atol=1e-5 * scale, err_msg=what + " vs fp64")
+    # (2) against the reference's serial fp32 loop: 1e-5, plus what that loop itself is away from the exact result on rows with
+    #     10^5+ in-edges (tests/test_gpu_round4.py::test_c2prime_gcn_spmm_vs_oracle explains the term)
+    own = np.abs(want.astype(np.float64) - w)
+    tol = 1e-5 * np.abs(want) + 1e-5 * scale + own
+    err = np.abs(got.astype(np.float64) - want)
+    assert not (err > tol).any(), "%s: %d elements beyond 1e-5 + the oracle's own error (worst %.3e)" % (what, int((err > tol).sum()), float((err - tol).max()))
+    print("%s: all %d x %d outputs compared; oracle elements farther than 1e-5 from fp64: %d, engine elements: %d"
+          % (what, got.shape[0], got.shape[1], int((own > 1e-5 * np.abs(w) + 1e-5 * scale).sum()),
+             int((np.abs(got - w) > 1e-5 * np.abs(w) + 1e-5 * scale).sum())))
+    # (3) per element: inside the fp32 re-association bound of the fp64 result
+    assert_within_fp32_reassociation(got, w, c["a64"], np.broadcast_to(c["indeg"] + 1, got.shape), slack=2.0)
+
+
+def test_config4_full_output_mean_vs_oracle(pgl, config4):
+    """All 2 449 029 x 100 outputs of send_recv(mean) -- the one headline config with a non-power-of-two row (400 bytes)."""
+    c = config4
+    g = pgl.Graph(edges=c["edges"], num_nodes=c["N"])
+    out = g.send_recv(c["x"], "mean")
+    assert torch.equal(out, g.send_recv(c["x"], "mean"))                 # bit-reproducible
+    _check_full_output(host(out), c, "config 4 send_recv(mean), one GPU")
+
+
+def test_config4_eight_way_engine_partition_vs_oracle(pgl, config4):
+    """The config-4 data flow as north_star states it: the graph row-partitioned 8 ways by the ENGINE'S partitioner (what stands
+    where the reference calls METIS, pgl/partition.py:37-91), each rank packing the rows its peers pull, the all-to-all-v
+    emulated in-process (one GPU), interior rows first and boundary rows from [owned | received] afterwards -- and the result
+    compared with the ORACLE (not with the single-GPU engine)."""
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    c = config4
+    N, world, edges, x = c["N"], 8, c["edges"], c["x"]
+    part = DistGraph.partition(edges, N, world, "kway")
+    sizes = torch.bincount(part, minlength=world)
+    assert int(sizes.min()) > 0
+    pe = part.to(edges.device)[edges[:, 1]]
+    work = torch.bincount(pe, minlength=world).double() + sizes.to(edges.device).double()      # in-degree + 1 per owned row
+    assert float(work.max() / work.mean()) <= 1.05, work
+    dgs = [DistGraph(HaloPlan(edges, N, part, r, world)) for r in range(world)]
+    packs = [dg.pack(dg.take_owned(x)) for dg in dgs]
+    full = torch.empty_like(x)
+    cut = 0
+    for r, dg in enumerate(dgs):
+        recv = torch.cat([packs[q][sum(dq.plan.pull_splits[:r]):sum(dq.plan.pull_splits[:r + 1])] for q, dq in enumerate(dgs)], 0)
+        assert recv.shape[0] == dg.plan.n_halo
+        full[dg.plan.own_global] = dg.aggregate_with_halo(dg.take_owned(x), recv, "mean")
+        cut += int(dg.plan.hal_rows.shape[0])
+    assert sum(dg.plan.local_edges for dg in dgs) == c["E"]
+    print("config 4, engine partitioner, P = 8: edge cut %.3f, rows per rank %s" % (cut / c["E"], sizes.tolist()))
+    _check_full_output(host(full), c, "config 4 send_recv(mean), 8-way partitioned flow")
+
+
+# ------------------------------------------------------------------------------------------------
+# ADVICE r4
+# ------------------------------------------------------------------------------------------------
+def test_gcnconv_under_inference_mode(pgl):
+    """medium: tensors created under torch.inference_mode() track no version counter; the degree_norm / edge_scale caches read it."""
+    rng = np.random.default_rng(3)
+    n, e, d = 3000, 40000, 128
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    layer = pgl.nn.GCNConv(d, 64).cuda()
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    want = layer(g, dev(x)).detach()
+    with torch.inference_mode():
+        g2 = pgl.Graph(edges=edges, num_nodes=n).tensor()
+        xt = dev(x)
+        a = layer(g2, xt); b = layer(g2, xt)                              # twice: the second call is where a cache would be read
+        nrm = pgl.nn.functional.degree_norm(g2)
+        s = g2.send_recv_scaled(xt, nrm, nrm) if hasattr(g2, "send_recv_scaled") else None
+    assert torch.allclose(a, want, rtol=1e-5, atol=1e-5) and torch.equal(a, b)
+    if s is not None:
+        ref = (g.send_recv(dev(x) * pgl.nn.functional.degree_norm(g), "sum") * pgl.nn.functional.degree_norm(g))
+        assert torch.allclose(s, ref, rtol=1e-5, atol=1e-4)
+
+
+def test_degree_norm_cache_follows_the_graph(pgl):
+    """low: the cached norm is dropped by Graph.numpy(inplace) / a move back to the device, and is keyed by device."""
+    g = pgl.Graph(edges=np.array([[0, 1], [1, 2], [2, 1]], np.int64), num_nodes=3).tensor()
+    a = pgl.nn.functional.degree_norm(g)
+    assert pgl.nn.functional.degree_norm(g) is a
+    g.numpy(inplace=True)
+    assert getattr(g, "_degree_norm_cache", None) is None
+    h = pgl.nn.functional.degree_norm(g)
+    assert isinstance(h, np.ndarray) or not h.is_cuda
+    g.tensor(inplace=True)
+    b = pgl.nn.functional.degree_norm(g)
+    assert b is not a and torch.equal(a, b)
+
+
+def test_workspace_cache_is_bounded_and_releasable(pgl):
+    """low: _ws_hot keeps at most 16 entries / 1 GiB, never a request above 512 MiB, and release_workspaces() empties it."""
+    ops = pgl.ops
+    ops.release_workspaces()
+    dev0 = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream() for _ in range(24)]
+    for s in streams:
+        with torch.cuda.stream(s):
+            ops._ws_hot(1 << 20, dev0)
+    assert len(ops._WS_HOT) <= ops._WS_HOT_ENTRIES
+    big = ops._ws_hot(ops._WS_HOT_MAX + 1, dev0)
+    assert all(b is not big for b in ops._WS_HOT.values())
+    for s in streams[:6]:
+        with torch.cuda.stream(s):
+            ops._ws_hot(300 << 20, dev0)
+    assert sum(b.numel() for b in ops._WS_HOT.values()) <= ops._WS_HOT_TOTAL
+    ops.release_workspaces()
+    assert len(ops._WS_HOT) == 0
+
+
+@pytest.mark.parametrize("accumulate,out_rows", [(0, None), (1, None), (2, None), (0, 2500)])
+def test_abi_edge_operand_e1_mul_reroute_equals_the_general_path(pgl, accumulate, out_rows):
+    """low: pglamd_aggregate with y = [E, 1], eid = NULL, MUL, sum, fp32, rows wider than 128 B is answered by the per-position
+    scale slot of the flat kernel (documented in include/pgl_amd.h next to the eid == NULL semantics).  Called straight through
+    ctypes here and compared with the SAME call carrying an identity eid (the general edge-operand path) and with the oracle,
+    including accumulate = 1 / 2 and out_rows < n_csr_rows."""
+    from pgl_amd import _ffi
+    ops = pgl.ops
+    rng = np.random.default_rng(8)
+    n, e, d = 4000, 60000, 128
+    src = rng.integers(0, n, e).astype(np.int64)
+    dst = np.sort(rng.integers(0, (out_rows or n) // 2, e) * 2).astype(np.int64)     # already in destination order: position p == edge p
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    y = rng.standard_normal((e, 1)).astype(np.float32)
+    csr = ops.csr_build(dev(dst), dev(src), n, want_i64=False)
+    assert torch.equal(csr.eid32.long(), torch.arange(e, device="cuda"))
+    rows = out_rows or n
+    before = rng.standard_normal((rows, d)).astype(np.float32)
+    ident = torch.arange(e, dtype=torch.int32, device="cuda")
+
+    def call(eid):
+        out = dev(before.copy())
+        xt, yt = dev(x), dev(y)
+        L = _ffi.lib()
+        ws_bytes = L.pglamd_aggregate_workspace_bytes(e, d, 1)
+        ws = torch.empty(max(int(ws_bytes), 256), dtype=torch.uint8, device="cuda")
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        rc = L.pglamd_aggregate(p(xt), 1, n, d, p(yt), 1, p(eid), p(csr.row32), p(csr.col32), p(csr.indptr), e, n, rows, d, 2, 0,
+                                None, None, accumulate, p(out), p(ws), ws.numel(), st)
+        _ffi.check(rc, "aggregate")
+        torch.cuda.synchronize()
+        return host(out)
+
+    a, b = call(None), call(ident)
+    np.testing.assert_allclose(a, b, rtol=2e-6, atol=2e-6 * np.abs(b).max())
+    want = R.c_send_ue_recv(x, y, src, dst, "mul", "sum", out_size=rows)
+    has = np.bincount(dst, minlength=rows) > 0
+    if accumulate == 1:
+        want = want + before                                             # rows without edges: 0 + their old contents
+    elif accumulate == 2:
+        want = np.where(has[:, None], want, before)
+    np.testing.assert_allclose(a, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())

@@ -158,7 +158,6 @@ def test_partitioner_balance_and_cut_vs_metis(ref_native, nparts, monkeypatch):
     """Engine's own partitioner (the product default) vs the reference's METIS (oracle/_ref) on a graph with planted
     communities: valid ids, balanced within 3 %, edge cut within 1.05x of METIS and far below random."""
     import pgl_amd
-    monkeypatch.delenv("PGLAMD_PARTITIONER", raising=False)
     n = 4000
     edges = _sym_simple(n, 40000, 4, communities=16)
     g = pgl_amd.Graph(edges=edges, num_nodes=n)
@@ -181,28 +180,29 @@ def test_partitioner_balance_and_cut_vs_metis(ref_native, nparts, monkeypatch):
 
 
 @pytest.mark.parametrize("nparts", [2, 3, 8])
-@pytest.mark.parametrize("weighted", [False, True])
-def test_metis_partition_equals_the_reference_module(ref_native, nparts, weighted, monkeypatch):
-    """The opt-in METIS bridge (PGLAMD_PARTITIONER=metis) against the reference's own compiled graph_kernel.metis_partition on
-    the same CSR (and the same min-max scaled weights): identical part ids."""
+def test_weighted_partition_vs_the_reference_metis(ref_native, nparts):
+    """pgl.partition.metis_partition with node and edge weights (pgl/partition.py:63-79: min-max scaled to positive ints): the
+    engine's partitioner against the reference's compiled graph_kernel.metis_partition (oracle/_ref, the comparison partner --
+    nothing of it is reachable from the product) on the same CSR and the same scaled weights: weighted cut <= 1.10x METIS's,
+    weighted balance <= 1.05."""
     import pgl_amd
-    monkeypatch.setenv("PGLAMD_PARTITIONER", "metis")
-    if not pgl_amd.ops.metis_available():
-        pytest.skip("libpglamd_metis.so not built")
     n = 3000
     edges = _sym_simple(n, 30000, 21 + nparts, communities=12)
     g = pgl_amd.Graph(edges=edges, num_nodes=n)
     ix = g.adj_dst_index
     rng = np.random.default_rng(nparts)
-    nw = rng.random(n) if weighted else None
+    nw = rng.random(n)
     lo_, hi_ = np.minimum(edges[:, 0], edges[:, 1]), np.maximum(edges[:, 0], edges[:, 1])
-    ew = ((lo_ * 7919 + hi_ * 104729) % 1000 / 1000.0) if weighted else None      # symmetric: METIS checks w(u,v) == w(v,u)
+    ew = (lo_ * 7919 + hi_ * 104729) % 1000 / 1000.0                  # symmetric: METIS checks w(u,v) == w(v,u)
     with pytest.warns(UserWarning):
         part = pgl_amd.partition.metis_partition(g, nparts, node_weights=nw, edge_weights=ew)
     scale = pgl_amd.partition._metis_weight_scale
-    want = ref_native.metis_partition(n, ix._indptr, ix._sorted_v, nparts, None if nw is None else scale(nw),
-                                      None if ew is None else scale(ew[ix._sorted_eid]), False)
-    assert np.array_equal(part, want)
+    snw, sew = scale(nw), scale(ew)
+    want = ref_native.metis_partition(n, ix._indptr, ix._sorted_v, nparts, snw, scale(ew[ix._sorted_eid]), False)
+    wcut = lambda p_: float(sew[p_[edges[:, 0]] != p_[edges[:, 1]]].sum())
+    assert wcut(part) <= 1.10 * wcut(want), (wcut(part), wcut(want))
+    w = np.bincount(part, weights=snw, minlength=nparts)
+    assert w.max() / w.mean() <= 1.05, w
 
 
 def test_partition_weights_and_trivial_cases():
@@ -270,33 +270,26 @@ def test_bench_and_entry_scripts_import_cleanly():
     assert callable(ge.build) and callable(ge.smoke)
 
 
-def test_missing_metis_helper_falls_back_without_crashing(tmp_path):
-    """with the helper library absent load_metis() used to call dlerror() twice and crash the interpreter.  A
-    fresh process (the loader result is cached per process) pointed at a path that does not exist must report 'unavailable' and
-    partition through the engine's own partitioner with a warning."""
+def test_no_metis_code_reachable_from_the_product():
+    """the round-3/4 opt-in METIS bridge is gone -- libpglamd exports no METIS entry point, the header declares
+    none, no helper library is built or opened, and PGLAMD_PARTITIONER has no effect (the reference's METIS is a comparison
+    partner of the tests through oracle/_ref only)."""
     import subprocess
-    import sys
-    code = r'''
-import warnings, numpy as np
-import pgl_amd
-from pgl_amd import ops
-assert ops.metis_available() is False
-try:
-    ops.host_partition_metis(4, np.array([0, 1, 2, 3, 4]), np.array([1, 0, 3, 2]), 2)
-    raise SystemExit("host_partition_metis did not raise")
-except RuntimeError as ex:
-    assert "cannot open" in str(ex), ex
-g = pgl_amd.Graph(edges=np.array([[0, 1], [1, 0], [2, 3], [3, 2], [1, 2], [2, 1]]), num_nodes=4)
-with warnings.catch_warnings(record=True) as w:
-    warnings.simplefilter("always")
-    part = pgl_amd.partition.metis_partition(g, 2)
-assert any("METIS helper library not available" in str(m.message) for m in w), [str(m.message) for m in w]
-assert sorted(np.bincount(part, minlength=2).tolist()) == [2, 2]
-print("fallback ok")
-'''
-    env = dict(os.environ, PGLAMD_METIS_LIB=str(tmp_path / "no_such_libmetis.so"), PGLAMD_PARTITIONER="metis")   # the opt-in, helper absent
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=120)
-    assert r.returncode == 0 and "fallback ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    import pgl_amd
+    lib = os.path.join(ROOT, "pgl_amd", "csrc", "libpglamd.so")
+    syms = subprocess.run(["nm", "-D", lib], capture_output=True, text=True).stdout.lower()
+    assert "metis" not in syms
+    assert "metis_partition" not in open(os.path.join(ROOT, "include", "pgl_amd.h")).read().replace("pgl.partition.metis_partition", "").replace("graph_kernel.metis_partition", "")
+    assert not os.path.exists(os.path.join(ROOT, "pgl_amd", "_build_metis.py"))
+    assert not hasattr(pgl_amd.ops, "host_partition_metis") and not hasattr(pgl_amd.ops, "metis_available")
+    g = pgl_amd.Graph(edges=np.array([[0, 1], [1, 0], [2, 3], [3, 2], [1, 2], [2, 1]]), num_nodes=4)
+    os.environ["PGLAMD_PARTITIONER"] = "metis"
+    try:
+        with pytest.warns(UserWarning):
+            part = pgl_amd.partition.metis_partition(g, 2)
+    finally:
+        del os.environ["PGLAMD_PARTITIONER"]
+    assert sorted(np.bincount(part, minlength=2).tolist()) == [2, 2]
 
 
 def test_engine_partitioner_degenerate_inputs():
