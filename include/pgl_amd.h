@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PGLAMD_ABI_VERSION 2
+#define PGLAMD_ABI_VERSION 3
 
 /* status codes */
 #define PGLAMD_OK 0
@@ -181,6 +181,41 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
                              int64_t out_rows, int64_t dout, int64_t ldout, int32_t message_op, int32_t reduce_op,
                              const float* dst_scale, int32_t accumulate, void* out, void* workspace,
                              size_t workspace_bytes, void* stream);
+
+/* K1w  pglamd_aggregate_ext whose finished rows ALSO land in the halo send buffer of the NEXT aggregation (ABI 3).
+ * A row-partitioned layer stack (pgl_amd/distributed.py; the reference's DistGPUGraph, pgl/graph.py:1509-1553, all-reduces
+ * [N, d] instead) starts every aggregation by packing the owned rows its peers pull into a contiguous send buffer -- a gather
+ * that re-reads rows the previous layer has just written (0.18 of 1.15 ms per rank at |E| = 100 M, P = 8).  With a wire
+ * descriptor the producing launch writes each finished row to `out` and, in the same store, to its slots of that buffer
+ * (a row pulled by k peers has k slots), so layer L+1's exchange starts with no pack launch at all.
+ *   slot_ptr [out_rows+1], slot_pos   CSR over output rows: wire rows of row r are slot_pos[slot_ptr[r] .. slot_ptr[r+1])
+ *   wire, ldw          the send buffer [n_wire_rows, ldw] in the SAME dtype as out (ldw elements per row, 0 = row length);
+ *                      for a column-block launch pass the address of the block's first column, as for out
+ *   scale              optional fp32 [out_rows] (floating dtypes): the wire copy is scale[r] * row -- GCN's source-side degree
+ *                      norm of the next layer (pgl/nn/conv.py:242) applied while the row is in registers
+ *   scaled_out, ld_scaled   optional dense [out_rows, ld_scaled] copy of scale[r] * row: what the next layer's LOCAL edges read
+ *   wire2, ldw2, split      optional: columns [split, d) of every row go to a second buffer (at column j - split)
+ * The mirror follows every store to `out`: with accumulate 0 all rows the launch writes (zero-filled ones included, as
+ * zeros), with accumulate 1 / 2 the rows that receive edges -- a sequence of launches that together finalise `out` (interior
+ * + boundary, or local edges + received edges) finalises the wire when each carries the descriptor.  SUM / MEAN, no edge
+ * operand; the launch takes the flat kernel whatever the row width (the lane-per-edge kernels have no mirror).  Deterministic. */
+typedef struct pglamd_wire_out {
+    const int32_t* slot_ptr;
+    const int32_t* slot_pos;
+    void* wire;
+    int64_t ldw;
+    const float* scale;
+    void* scaled_out;
+    int64_t ld_scaled;
+    void* wire2;          /* optional second buffer: columns >= split of a row go to wire2 at column (j - split) -- the column- */
+    int64_t ldw2;         /* pipelined exchange sends the rows as two contiguous column blocks, one all-to-all-v each          */
+    int64_t split;        /* 0 = one buffer; otherwise a multiple of 16 elements                                              */
+} pglamd_wire_out;
+int32_t pglamd_aggregate_wire(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx, int64_t ldx,
+                              const int32_t* row, const int32_t* col, const int64_t* indptr, const int64_t* zero_indptr,
+                              int64_t max_row_edges, int64_t num_edges, int64_t n_csr_rows, int64_t out_rows,
+                              int64_t ldout, int32_t reduce_op, const float* dst_scale, int32_t accumulate, void* out,
+                              const pglamd_wire_out* wire, void* workspace, size_t workspace_bytes, void* stream);
 
 /* K1d  aggregation feeding a dense layer inside ONE kernel (row f1: "SpMM -> GEMM epilogue"; GCNConv's
  * send_recv(sum) -> linear -> + bias -> activation, pgl/nn/conv.py:242-254, when input_size <= output_size):
@@ -451,6 +486,12 @@ int32_t pglamd_reindex(const int64_t* nodes, int64_t num_nodes, const int64_t* n
 int64_t pglamd_row_epilogue_partials(int64_t n_rows);
 int32_t pglamd_row_epilogue(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act,
                             int32_t normalize, float eps, float* y, float* inv_norm, void* stream);
+/* the same with a wire descriptor (see pglamd_aggregate_wire): a conv layer's OUTPUT row is the next layer's input, so the row
+ * kernel that finishes it also writes it -- times wire->scale[r] if given -- into the halo send buffer slots of the peers
+ * that pull it and, optionally, into a dense scaled copy (GraphSageConv: wire = y; GCNConv: wire = norm * y). */
+int32_t pglamd_row_epilogue_wire(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act,
+                                 int32_t normalize, float eps, float* y, float* inv_norm,
+                                 const pglamd_wire_out* wire, void* stream);
 int32_t pglamd_row_epilogue_backward(const float* dy, const float* y, const float* inv_norm,
                                      int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
                                      float* dz, float* col_partials, void* stream);

@@ -44,6 +44,15 @@ struct AggParams {
     int dout2, act;                       // act: 0 none, 1 relu
     int max_row_edges;                    // host-side hint: longest row of the index (0 = unknown).  Rows of <= chunk edges are never
                                           // split (chunk_cut), so when it is <= chunk no partial exists and the fix-up launches are skipped
+    // ---- wire out (pglamd_aggregate_wire): every row this launch stores to `out` ALSO goes to its slots of the halo send buffer ----
+    const int* wslot_ptr;                 // [out_rows + 1] or NULL: row r's wire rows are wslot_pos[wslot_ptr[r] .. wslot_ptr[r+1])
+    const int* wslot_pos;
+    void* wire;                           // [n_wire_rows, ldw], same element type as out, ALREADY offset to this launch's column block
+    int64_t ldw;
+    void* wire2; int64_t ldw2; int wsplit;   // columns >= wsplit (of the whole row) go to wire2 at column (j - wsplit); wsplit 0 = one buffer
+    const float* wscale;                  // optional [out_rows]: the wire (and wscaled) copies hold wscale[r] * row
+    void* wscaled;                        // optional dense [out_rows, ldws] copy of wscale[r] * row (the next layer's local-edge input)
+    int64_t ldws;
 };
 
 // true when this launch can leave split-row partials behind (=> the counter reset and the two fix-up launches are needed)
@@ -64,6 +73,34 @@ template <typename T> __device__ __forceinline__ T from_acc(typename AccT<T>::ty
 template <> __device__ __forceinline__ __half from_acc<__half>(float v) { return __float2half(v); }
 template <> __device__ __forceinline__ __hip_bfloat16 from_acc<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 
+// Mirrors one finished piece of output row r (columns j .. j+VEC-1 of the launch's block, already converted to T) into the row's
+// wire slots (at column jw of the buffer it belongs to) and, if asked for, into the scaled dense copy.  Called from the store
+// paths only (once per row and tile).
+template <typename T, int VEC, typename VT>
+__device__ __forceinline__ void wire_mirror_to(const int* __restrict__ wptr, const int* __restrict__ wpos, void* wire, int64_t ldw,
+                                               const float* __restrict__ wscale, void* wscaled, int64_t ldws, int64_t r, int j,
+                                               int jw, const VT& o) {
+    VT w = o;
+    if constexpr (std::is_floating_point_v<typename AccT<T>::type>) {
+        if (wscale) {
+            const float s = wscale[r];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) w.v[k] = from_acc<T>(to_acc<T>(o.v[k]) * (typename AccT<T>::type)s);
+        }
+    }
+    if (wscaled) *reinterpret_cast<VT*>(static_cast<T*>(wscaled) + r * ldws + j) = w;
+    const int s0 = wptr[r], s1 = wptr[r + 1];
+    for (int s = s0; s < s1; ++s) *reinterpret_cast<VT*>(static_cast<T*>(wire) + (int64_t)wpos[s] * ldw + jw) = w;
+}
+// Q: a pointer to the launch parameters (generic or constant address space)
+template <typename T, int VEC, typename Q, typename VT>
+__device__ __forceinline__ void wire_mirror(Q q, int64_t r, int j, const VT& o) {
+    const int split = q->wsplit;
+    const bool second = split > 0 && j >= split;          // column-pipelined exchange: columns >= split live in the second buffer
+    wire_mirror_to<T, VEC>(q->wslot_ptr, q->wslot_pos, second ? q->wire2 : q->wire, second ? q->ldw2 : q->ldw, q->wscale, q->wscaled,
+                           q->ldws, r, j, second ? j - split : j, o);
+}
+
 template <typename T> struct Limits;
 template <> struct Limits<float> { static __device__ float lo() { return -INFINITY; } static __device__ float hi() { return INFINITY; } };
 template <> struct Limits<double> { static __device__ double lo() { return -INFINITY; } static __device__ double hi() { return INFINITY; } };
@@ -82,7 +119,7 @@ template <typename T> __device__ __forceinline__ T apply_mop(T a, T b, int mop) 
 // Zero-fills the columns [j_base, j_base+tile_cols) of output rows that receive no edge: rows
 // r < n_csr_rows with indptr[r]==indptr[r+1], and rows in [n_csr_rows, out_rows).  One wave
 // inspects 64 rows (coalesced indptr read) and clears the empty ones, lanes across the columns.
-template <typename T>
+template <typename T, bool WIRE = false>
 __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t zb, int lane) {
     const int64_t w = zb * kWavesPerBlock + (threadIdx.x >> 6);
     const int64_t r0 = w * kWave;
@@ -102,6 +139,11 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
             for (int j = lane * 2; j < p.tile_cols; j += kWave * 2) *reinterpret_cast<VecT<T, 2>*>(dst + j) = VecT<T, 2>{};
         } else {
             for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = from_acc<T>(typename AccT<T>::type(0));
+        }
+        if constexpr (WIRE) {                   // an empty row travels as zeros (scale * 0 = 0: no scale needed)
+            const VecT<T, 1> z{{from_acc<T>(typename AccT<T>::type(0))}};
+            for (int j = lane; j < p.tile_cols; j += kWave)
+                wire_mirror<T, 1>(&p, r0 + l, p.j_base + j, z);
         }
     }
 }

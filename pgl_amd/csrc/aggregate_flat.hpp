@@ -29,8 +29,12 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 //     the shadow of the row gathers (the kernel is HBM-bound; the MFMA pipe was idle).
 // SS: 0 no per-source scale, 1 src_scale[col] (one random 4-byte read per edge), 2 src_scale[p] by edge POSITION (the scale of every
 //     edge's source laid out along the sorted stream once per graph: 4 sequential bytes per edge)
-template <typename T, int VEC, int NT, int RCLS, int YMODE, int SS = 0, bool PIPE3 = true, int UB = 0, int SINK = 0, bool TWO = false>
+// WIRE: every row this launch stores ALSO goes to its slots of the halo send buffer of the next aggregation (pglamd_aggregate_wire).
+//     A template variant, not a run-time test: the test alone cost the 256-byte-row kernel 16 SGPRs (70 -> 86: one resident workgroup
+//     per CU fewer) although the code sits in the once-per-row store path.
+template <typename T, int VEC, int NT, int RCLS, int YMODE, int SS = 0, bool PIPE3 = true, int UB = 0, int SINK = 0, bool TWO = false, bool WIRE = false>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
+    static_assert(!WIRE || (RCLS == 0 && YMODE == 0 && SS == 0 && SINK == 0), "the wire mirror rides with plain sum / mean rows");
     constexpr int U = 8;
     constexpr int kTileRows = 16;                      // rows per MFMA tile (v_mfma_f32_16x16x4_f32)
     constexpr int kTileStride = kWave * VEC + 4;       // floats per parked row: +4 keeps the A-operand reads bank-conflict free
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
             if (p.out) zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
             dense_empty_rows_role(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
         } else {
-            zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
+            zero_empty_rows_role<T, WIRE>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
         }
         return;
     }
@@ -230,6 +234,8 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                     if (q->out) *reinterpret_cast<V*>(dst + j0[t]) = o;
                 } else {
                     *reinterpret_cast<V*>(dst + j0[t]) = o;
+                    if constexpr (WIRE)          // halo send buffer of the NEXT aggregation: the finished row goes there in the same store
+                        wire_mirror<T, VEC>(q, r, j0[t], o);
                 }
             }
         if constexpr (SINK == 1) {
@@ -463,7 +469,7 @@ constexpr int kFixWaves = 16;
 constexpr int kFixGridShort = 2048;
 constexpr int kFixGridLong = 512;
 
-template <typename T, int VEC, int NT, int RCLS, bool LONG>
+template <typename T, int VEC, int NT, int RCLS, bool LONG, bool WIRE = false>
 __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_kernel(AggParams p) {
     using A = typename AccT<T>::type;
     using V = VecT<A, VEC>;     // partials are stored in the accumulator type
@@ -630,6 +636,8 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
                 *reinterpret_cast<VO*>(dst + j0[t]) = o;
+                if constexpr (WIRE)
+                    wire_mirror<T, VEC>(&p, r, p.j_base + j0[t], o);
             }
     }
 }
@@ -732,10 +740,24 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     // workgroups/CU) measured 4 % faster there; everywhere else the three-deep one wins (up to 20 % on [E,8]).
     const size_t row_bytes = (size_t)p.tile_cols * sizeof(T);
     const bool two = p.x_split != INT32_MAX;
+    constexpr bool can_wire = RCLS == 0 && YMODE == 0 && (std::is_same_v<T, float> || sizeof(T) == 2);
+    const bool wire = p.wslot_ptr != nullptr;
+    if (wire && (!can_wire || p.src_scale)) return fail(PGLAMD_E_ARG, "aggregate_wire: fp32 / fp16 / bf16 rows, sum or mean, no source scale");
 #define PGLAMD_LAUNCH_FLAT(...)                                                                                                          \
     do {                                                                                                                                 \
-        if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p); \
-        else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, false>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);    \
+        const dim3 grid_((unsigned)(p.n_grid_chunks + zb));                                                                              \
+        bool done_ = false;                                                                                                              \
+        if constexpr (can_wire) {                                                                                                        \
+            if (wire) {                                                                                                                  \
+                if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, true, true>), grid_, dim3(kBlock), 0, st, p);   \
+                else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, false, true>), grid_, dim3(kBlock), 0, st, p);      \
+                done_ = true;                                                                                                            \
+            }                                                                                                                            \
+        }                                                                                                                                \
+        if (!done_) {                                                                                                                    \
+            if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, true>), grid_, dim3(kBlock), 0, st, p);  \
+            else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, false>), grid_, dim3(kBlock), 0, st, p);     \
+        }                                                                                                                                \
         PGLAMD_LAUNCH_CHECK();                                                                                                           \
     } while (0)
     if constexpr (NT == 1 && YMODE == 0) {
@@ -774,9 +796,21 @@ launched:
         prof().ev.emplace_back(e0, e1);
     }
     if (fixups) {
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), dim3((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), dim3(kBlock), 0, st, p);
-        PGLAMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), dim3((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks)), dim3(kFixWaves * kWave), 0, st, p);
+        const dim3 gs((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), gl((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks));
+        bool done = false;
+        if constexpr (can_wire) {
+            if (wire) {
+                hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false, true>), gs, dim3(kBlock), 0, st, p);
+                PGLAMD_LAUNCH_CHECK();
+                hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true, true>), gl, dim3(kFixWaves * kWave), 0, st, p);
+                done = true;
+            }
+        }
+        if (!done) {
+            hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), gs, dim3(kBlock), 0, st, p);
+            PGLAMD_LAUNCH_CHECK();
+            hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), gl, dim3(kFixWaves * kWave), 0, st, p);
+        }
     }
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
@@ -864,6 +898,7 @@ template <typename T> int max_tiles(int vec) { return (sizeof(T) == 2 && vec == 
 struct AggExtra {
     const void* x2 = nullptr; int64_t x_split = 0; const int64_t* zero_indptr = nullptr; int64_t max_row_edges = 0;
     int64_t ldx = 0, ldo = 0;
+    const pglamd_wire_out* wire = nullptr;       // pglamd_aggregate_wire: mirror every stored row into the halo send buffer
 };
 
 // argument list of aggregate_typed<T> for the explicit instantiations (aggregate*.hip)
@@ -884,13 +919,32 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     const int64_t ldx = ex.ldx ? ex.ldx : dx, ldo = ex.ldo ? ex.ldo : dout;
     if (ldx < dx || ldo < dout) return fail(PGLAMD_E_SHAPE, "aggregate_ext: row stride shorter than the row (ldx %lld < %lld or ldout %lld < %lld)",
                                             (long long)ldx, (long long)dx, (long long)ldo, (long long)dout);
+    const pglamd_wire_out* wo = ex.wire && ex.wire->slot_ptr ? ex.wire : nullptr;
+    if (wo) {
+        if (!wo->slot_pos || !wo->wire) return fail(PGLAMD_E_ARG, "aggregate_wire: slot_pos / wire missing");
+        if (dout != dx || y) return fail(PGLAMD_E_ARG, "aggregate_wire: plain send_u_recv rows only (no edge operand, no source-side broadcast)");
+        if ((wo->scale || wo->scaled_out) && !std::is_floating_point_v<typename AccT<T>::type>)
+            return fail(PGLAMD_E_DTYPE, "aggregate_wire: a wire scale needs a floating dtype");
+        if (wo->scaled_out && !wo->scale) return fail(PGLAMD_E_ARG, "aggregate_wire: scaled_out without scale");
+    }
     if (E == 0) {
         if (accumulate) return PGLAMD_OK;
+        if (wo) return fail(PGLAMD_E_ARG, "aggregate_wire: an index without edges (the stand-alone zero-fill has no wire mirror)");
         if (ldo != dout) return fail(PGLAMD_E_ARG, "aggregate_ext: an index without edges cannot zero-fill a strided output");
         return zero_empty_rows(zip, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
     }
 
     AggParams p{};
+    if (wo) {
+        p.wslot_ptr = wo->slot_ptr; p.wslot_pos = wo->slot_pos; p.wire = wo->wire; p.ldw = wo->ldw ? wo->ldw : dout;
+        p.wscale = wo->scale; p.wscaled = wo->scaled_out; p.ldws = wo->ld_scaled ? wo->ld_scaled : dout;
+        if (wo->split) {
+            if (wo->split < 0 || wo->split >= dout || wo->split % 16 != 0 || !wo->wire2 || wo->ldw2 < 0)
+                return fail(PGLAMD_E_ARG, "aggregate_wire: split must be a multiple of 16 inside the row, with a second buffer");
+            p.wire2 = wo->wire2; p.wsplit = (int)wo->split; p.ldw2 = wo->ldw2 ? wo->ldw2 : dout - wo->split;
+            if (!wo->ldw) p.ldw = wo->split;
+        }
+    }
     // A one-value edge operand given IN THE ORDER OF THE SORTED STREAM (eid NULL) and multiplied into fp32 rows that are summed
     // is a per-edge scale read sequentially: it rides in the flat kernel's scale slot (SS = 2: one coalesced 4-byte load per
     // edge) instead of the general edge-operand path.  This is how GCN's source-side degree norm is applied (pgl/nn/conv.py:242):
@@ -926,8 +980,10 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     int vmax = max_vec<T>();
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
                                  (y && gy == 1 ? reinterpret_cast<uintptr_t>(y) : 0) |
-                                 reinterpret_cast<uintptr_t>(ws);
-    while (vmax > 1 && (dout % vmax != 0 || ldx % vmax != 0 || ldo % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0)) vmax >>= 1;
+                                 reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(p.wire) | reinterpret_cast<uintptr_t>(p.wscaled) |
+                                 reinterpret_cast<uintptr_t>(p.wire2);
+    while (vmax > 1 && (dout % vmax != 0 || ldx % vmax != 0 || ldo % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0 ||
+                        (p.wire && p.ldw % vmax != 0) || (p.wscaled && p.ldws % vmax != 0) || (p.wire2 && p.ldw2 % vmax != 0))) vmax >>= 1;
     int ymode = 0;
     if (y) {
         if (gy == 1) ymode = 2;
@@ -973,7 +1029,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
             const int64_t rb = (int64_t)((size_t)dout * sizeof(T));
             const bool narrow_ok = dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u;
             const int64_t gmin = (rcls == 1 || !narrow_ok) ? std::min<int64_t>(32, group_min_bytes()) : group_min_bytes();
-            if (ymode == 0 && !src_scale && rb > gmin && rb <= group_row_bytes()) {
+            if (ymode == 0 && !src_scale && !p.wslot_ptr && rb > gmin && rb <= group_row_bytes()) {
                 AggParams q = p;
                 q.j_base = 0; q.tile_cols = (int)dout;
                 bool handled = false;
@@ -983,7 +1039,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         }
         // measured at C2 sizes: the lane-per-edge kernel wins up to 32 B of accumulator per row for every reduce op
         // (2.6-3.4x at d <= 8 fp32) and up to 64 B for sum / mean (1.3x at d = 16 fp32)
-        if (dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {
+        if (!p.wslot_ptr && dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {   // (the wire mirror lives in the flat kernel's stores)
             AggParams q = p;
             const int nk = std::max(K, narrow_chunk_edges());                   // fewer, longer chunks: the carved arrays still fit
             q.chunk = nk; q.n_chunks = (int)ceil_div(E, nk);
@@ -1007,6 +1063,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         if (fast) return PGLAMD_OK;
     }
     // generic fallback: rewrites every row < out_rows (rows without edges get 0)
+    if (p.wslot_ptr) return fail(PGLAMD_E_SHAPE, "aggregate_wire: this shape takes the generic kernel, which has no wire mirror");
     p.tile_cols = (int)dout; p.j_base = 0;
     p.is_max = rop == PGLAMD_MAX ? 1 : rop == PGLAMD_MIN ? 2 : 0;
     if (src_scale || dst_scale) return fail(PGLAMD_E_SHAPE, "scales unsupported with this broadcast pattern");

@@ -214,9 +214,13 @@ class _EngineBackend(object):
         return c
 
     def aggregate(self, x, index, reduce_op, n_rows, y=None, message_op="add", src_scale=None, dst_scale=None, out=None,
-                  accumulate=0, x2=None, zero_indptr=None):
+                  accumulate=0, x2=None, zero_indptr=None, wire=None):
         return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
-                             x2=x2, zero_indptr=zero_indptr)
+                             x2=x2, zero_indptr=zero_indptr, wire=wire)
+
+    def row_epilogue(self, z, bias, act, normalize, wire=None):
+        from . import autograd as ag
+        return ag.row_epilogue(z, bias, act, normalize, wire=wire)
 
     def gather_rows(self, x, idx):
         return ops.gather_rows(x, idx)
@@ -388,13 +392,13 @@ class _HaloAggregate(torch.autograd.Function):
     Backward: the transposed indices, splits swapped: gx = A_loc^T g' + S^T (exchange^T (R^T g')), g' = dst_scale * g."""
 
     @staticmethod
-    def forward(ctx, x_own, dg, scale):
+    def forward(ctx, x_own, dg, scale, emit_in=None, emit_out=None):
         ctx.dg, ctx.scale = dg, scale
-        return dg._flow(x_own, scale, transposed=False)
+        return dg._flow(x_own, scale, transposed=False, emit_in=emit_in, emit_out=emit_out)
 
     @staticmethod
     def backward(ctx, grad):
-        return ctx.dg._flow(grad.contiguous(), ctx.scale, transposed=True), None, None
+        return ctx.dg._flow(grad.contiguous(), ctx.scale, transposed=True), None, None, None, None
 
 
 class _HaloExtend(torch.autograd.Function):
@@ -428,6 +432,31 @@ class _AllGatherRows(torch.autograd.Function):
         if _group_ready(dg.group):
             _all_reduce_sum(g, dg.group)
         return g[dg.plan.own_global.to(g.device)].contiguous(), None
+
+
+class Emission(object):
+    """One fused pack: the ops.Wire a producing launch mirrors its rows into, and what identifies the tensor it produced."""
+    __slots__ = ("graph", "kind", "wire", "epoch", "scale", "piped", "d", "dtype", "version", "shape")
+
+    def __init__(self, graph, kind, wire, epoch, scale, piped, d, dtype):
+        self.graph, self.kind, self.wire, self.epoch, self.scale, self.piped, self.d, self.dtype = graph, kind, wire, epoch, scale, piped, d, dtype
+        self.version, self.shape = None, None
+
+
+def _version_of(t):
+    """Version counter of a tensor; -1 for tensors made under torch.inference_mode() (they track none: taken as unmodified)."""
+    v = ops.tensor_version(t)
+    if v is None:
+        try:
+            return -1 if t.is_inference() else None
+        except Exception:                                            # noqa: BLE001
+            return None
+    return v
+
+
+def _wk(wire):
+    """keyword of a backend.aggregate call that mirrors its rows (nothing when there is no wire: other backends need not know it)."""
+    return {} if wire is None else {"wire": wire}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -723,8 +752,87 @@ class DistGraph(object):
         w = self.wire_dtype
         return w if (w is not None and dtype == torch.float32 and w in (torch.float16, torch.bfloat16)) else dtype
 
+    # ---- fused pack: the producer of a layer's output rows writes them into the NEXT aggregation's send buffer ----------------
+    def wire(self, like, scale=None, scaled=False, kind="x"):
+        """-> an Emission for rows shaped / typed like `like` ([n_own, d]), or None when this graph cannot take one.
+        Hand `emission.wire` to the launch that produces a layer's output (ops.aggregate / ag.row_epilogue / DistGraph.send_recv(...,
+        emit=True)): every finished row is then ALSO written into the halo send buffer of the next aggregation, in the slots of
+        the peers that pull it -- so that aggregation starts its exchange with no pack launch (the pack re-read
+        rows the previous layer had just written, 0.18 of 1.15 ms per rank at |E| = 100 M / P = 8).  `mark(y, emission)` then tags
+        the produced tensor; send_recv / send_recv_scaled recognise the tag.
+        scale: optional fp32 [n_own] -- the wire copy is scale[r] * row (GCN's source-side norm of the NEXT layer);
+        scaled: also keep a dense [n_own, d] copy of the scaled rows (what the next layer's local edges read).
+        Eligible: world > 1, pull plan (every send row is one owned row), the rows travel in their own dtype (no 16-bit wire cast),
+        fp32 / fp16 / bf16, 2-D.  Two send buffers alternate, so the emission of step k+1 never writes what exchange k+1 still sends."""
+        p = self.plan
+        xp = self.xplan if kind == "x" else p
+        if p.world == 1 or int(xp.pushed_pairs) != 0 or like.dim() != 2 or not xp.n_send:
+            return None
+        if like.dtype not in (torch.float32, torch.float16, torch.bfloat16) or self._wire(like.dtype) != like.dtype:
+            return None
+        if scale is not None and (scale.dtype != torch.float32 or scale.numel() != p.n_own):
+            return None
+        if int(like.shape[0]) != p.n_own:
+            return None
+        d, dev = int(like.shape[1]), like.device
+        key = "wslots" + kind
+        slots = self._idx.get(key)
+        if slots is None:                                            # CSR over owned rows -> their positions in the send buffer
+            cols = xp.send_cols.to(dev)
+            order = torch.argsort(cols, stable=True)
+            ptr = torch.zeros(p.n_own + 1, dtype=torch.int64, device=dev)
+            ptr[1:] = torch.cumsum(torch.bincount(cols, minlength=p.n_own), 0)
+            slots = self._idx[key] = (ptr.to(torch.int32), order.to(torch.int32))
+        row_bytes = d * like.element_size()
+        piped = self._pipelined(kind, False, True, like, row_bytes)
+        self._emit_epoch = getattr(self, "_emit_epoch", 0) + 1
+        par = self._emit_epoch & 1
+        if piped:
+            h = (d // 2 + 15) // 16 * 16
+            b0 = self._buffer("emit%s%d_0" % (kind, par), (xp.n_send, h), like.dtype, dev)
+            b1 = self._buffer("emit%s%d_1" % (kind, par), (xp.n_send, d - h), like.dtype, dev)
+            bufs, split = (b0, b1), h
+        else:
+            bufs, split = (self._buffer("emit%s%d" % (kind, par), (xp.n_send, d), like.dtype, dev), None), 0
+        sc = None if scale is None else scale.reshape(-1).contiguous()
+        so = self._buffer("emits%s%d" % (kind, par), (p.n_own, d), like.dtype, dev) if (scaled and sc is not None) else None
+        w = ops.Wire(slots[0], slots[1], bufs[0], sc, so, bufs[1], split)
+        return Emission(self, kind, w, self._emit_epoch, scale, piped, d, like.dtype)
+
+    def can_wire(self, d, dtype, kind="x"):
+        """True when wire() would hand out an emission for [n_own, d] rows of `dtype` (no side effects)."""
+        xp = self.xplan if kind == "x" else self.plan
+        return bool(self.plan.world > 1 and int(xp.pushed_pairs) == 0 and xp.n_send and
+                    dtype in (torch.float32, torch.float16, torch.bfloat16) and self._wire(dtype) == dtype)
+
+    def mark(self, tensor, emission):
+        """Tags `tensor` as the rows `emission` mirrored into the send buffer (valid until the tensor is written to or a newer
+        emission of the same kind is produced two steps later)."""
+        if emission is not None:
+            emission.version = _version_of(tensor)
+            emission.shape = tuple(tensor.shape)
+            try:
+                tensor._pglamd_emission = emission
+            except Exception:                                        # noqa: BLE001 -- a tensor type that takes no attributes
+                pass
+        return tensor
+
+    def _emission_of(self, x, kind, scale=None):
+        """The valid emission carried by x for this graph / plan / scale, else None."""
+        em = getattr(x, "_pglamd_emission", None)
+        if em is None or em.graph is not self or em.kind != kind:
+            return None
+        if em.version is None or _version_of(x) != em.version or tuple(x.shape) != em.shape or x.dtype != em.dtype:
+            return None
+        if getattr(self, "_emit_epoch", 0) - em.epoch > 1:            # its buffer has been handed to a newer emission
+            return None
+        if (scale is None) != (em.scale is None) or (scale is not None and scale is not em.scale and
+                                                     not (scale.data_ptr() == em.scale.data_ptr() and scale.numel() == em.scale.numel())):
+            return None
+        return em
+
     # ---- the exchange: pack -> all-to-all-v (asynchronous) ------------------------------------------------------------
-    def _start_exchange(self, x, kind, transposed, cols=None):
+    def _start_exchange(self, x, kind, transposed, cols=None, emit=None):
         """-> (work, in_buf, unpack) or None when this plan moves nothing.  Pack = ONE launch: a row gather straight into
         the wire buffer (in the wire dtype) when every send row is a single owned row, otherwise the aggregation kernel over
         the send index (pushed partial rows; the transposed flow's pre-summed gradients) followed by the wire cast.
@@ -745,8 +853,17 @@ class DistGraph(object):
         tail = tuple(x.shape[1:])
         wire = self._wire(x.dtype)
         tag = "%s%d%s" % (kind, transposed, blk)
-        out_buf = self._buffer("out" + tag, (n_out,) + tail, wire, x.device)
-        if n_out:
+        out_buf = None
+        if emit is not None and not transposed:
+            # the producer of x already wrote these rows into the send buffer (DistGraph.wire): no pack launch
+            w = emit.wire
+            out_buf = w.buf if (cols is None or cols[0] == 0) else w.buf2
+            if cols is None and w.split:
+                raise RuntimeError("DistGraph: a column-split emission met a single-block exchange")
+            self._packs_skipped = getattr(self, "_packs_skipped", 0) + 1
+        if out_buf is None:
+            out_buf = self._buffer("out" + tag, (n_out,) + tail, wire, x.device)
+        if n_out and not (emit is not None and not transposed):
             plain = (not transposed) and int(xp.pushed_pairs) == 0
             if plain and x.dtype in (torch.float32, torch.float16, torch.bfloat16):
                 B.gather_rows_cast(x, self._send_cols32(kind), wire, out_buf)    # (same-dtype "casts" too: the persistent wire buffer is written in place)
@@ -776,7 +893,7 @@ class DistGraph(object):
         return s
 
     # ---- the overlapped two-phase flow (forward and, with the indices transposed, backward) --------------------------------
-    def _flow(self, x, scale, transposed, reduce="sum", kind="x"):
+    def _flow(self, x, scale, transposed, reduce="sum", kind="x", emit_in=None, emit_out=None):
         """out[v] = scale[v] * REDUCE over ALL in-edges of owned row v (transposed: the gradient of that).  SURVEY 8e steps
         1-4: pack -> all-to-all-v on the side stream -> work that needs no received row while the rows travel -> wait -> the rest.
         WHAT runs under the exchange is chosen per plan (`_mode`, `_pipelined`): "split" -- INTERIOR rows (every source local)
@@ -795,7 +912,15 @@ class DistGraph(object):
         sfx = "_t" if transposed else ""
         additive = reduce in ("sum", "mean")
         row_bytes = max(1, x.element_size() * int(np.prod(tail)) if tail else x.element_size())
-        if p.world > 1 and self._pipelined(kind, transposed, additive, x, row_bytes):
+        if transposed or post is not None or not additive:
+            emit_in = emit_out = None
+        wo = None if emit_out is None else emit_out.wire             # every launch that stores output rows mirrors them
+        piped = p.world > 1 and self._pipelined(kind, transposed, additive, x, row_bytes)
+        if emit_in is not None and bool(emit_in.piped) != bool(piped):
+            emit_in = None                                           # (cannot happen for one plan and row width; be safe)
+        if wo is not None and bool(emit_out.piped) != bool(piped):
+            wo = None
+        if piped:
             # COLUMN-PIPELINED (all ranks agreed on it): the rows travel in two column blocks, one all-to-all-v each.  While block
             # 0 is on the wire block 1 is packed and the local-source edges run; the received rows' edges of block 0 are added
             # while block 1 is still travelling.  Same arithmetic as "accumulate" (every output element: local edges first, then
@@ -803,8 +928,8 @@ class DistGraph(object):
             d = int(x.shape[1])
             h = (d // 2 + 15) // 16 * 16
             blocks = [(0, h), (h, d)]
-            started = [self._start_exchange(x, kind, transposed, cols=c) for c in blocks]
-            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k)
+            started = [self._start_exchange(x, kind, transposed, cols=c, emit=emit_in) for c in blocks]
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo))
             recv = kind + ("send_t" if transposed else "recv")
             for st, (c0, c1) in zip(started, blocks):
                 if st is None:
@@ -814,12 +939,15 @@ class DistGraph(object):
                 if (xp.n_send if transposed else xp.n_recv):
                     if unpack is not None:
                         unpack()
-                    B.aggregate(in_buf, self._index(recv), reduce, p.n_own, dst_scale=scale_k, out=out[:, c0:c1], accumulate=1)
+                    B.aggregate(in_buf, self._index(recv), reduce, p.n_own, dst_scale=scale_k, out=out[:, c0:c1], accumulate=1,
+                                **_wk(None if wo is None else wo.block(c0, c1)))
             self._idx[("ran", kind, transposed)] = "pipeline"
             if post is not None:
                 out = out * post
+            if wo is not None:
+                self.mark(out, emit_out)
             return out
-        started = self._start_exchange(x, kind, transposed)
+        started = self._start_exchange(x, kind, transposed, emit=emit_in)
         n_in = (xp.n_send if transposed else xp.n_recv) if started is not None else 0
         mode = self._mode(kind, transposed, additive=additive, row_bytes=row_bytes) if n_in else "split"
         self._idx[("ran", kind, transposed)] = mode
@@ -830,20 +958,20 @@ class DistGraph(object):
             work.wait()
             if unpack is not None:
                 unpack()
-            out = B.aggregate(x, self._index(kind + "all" + sfx), reduce, p.n_own, dst_scale=scale_k, x2=in_buf)
+            out = B.aggregate(x, self._index(kind + "all" + sfx), reduce, p.n_own, dst_scale=scale_k, x2=in_buf, **_wk(wo))
         elif mode == "accumulate":
             # most edges are local, most rows have a few remote sources: ALL local-source edges run under the exchange, the
             # received rows' edges are added on top afterwards (their rows are read-modify-written)
-            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k)
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo))
             work, in_buf, unpack = started
             work.wait()
             if unpack is not None:
                 unpack()
             B.aggregate(in_buf, self._index(kind + ("send_t" if transposed else "recv")), reduce, p.n_own, dst_scale=scale_k, out=out,
-                        accumulate=1)
+                        accumulate=1, **_wk(wo))
         else:
             out = B.aggregate(x, self._index(kind + "int" + sfx), reduce, p.n_own, dst_scale=scale_k,
-                              zero_indptr=self._zero_indptr(transposed) if n_in else None)    # overlaps the exchange
+                              zero_indptr=self._zero_indptr(transposed) if n_in else None, **_wk(wo))    # overlaps the exchange
             if started is not None:
                 work, in_buf, unpack = started
                 work.wait()
@@ -851,9 +979,11 @@ class DistGraph(object):
                     if unpack is not None:
                         unpack()
                     B.aggregate(x, self._index(kind + "bnd" + sfx), reduce, p.n_own, dst_scale=scale_k, out=out, accumulate=2,
-                                x2=in_buf)
+                                x2=in_buf, **_wk(wo))
         if post is not None:
             out = out * post
+        if wo is not None:
+            self.mark(out, emit_out)
         return out
 
     # edges / s of the aggregation kernel on a rank-sized problem, fixed cost of one aggregation launch (counter reset, kernel ramp
@@ -946,14 +1076,20 @@ class DistGraph(object):
             self._idx[key] = hit
         return hit
 
-    def _sum_like(self, x_own, reduce_func, extra_dst_scale=None):
+    def _sum_like(self, x_own, reduce_func, extra_dst_scale=None, emit_in=None, emit=False, emit_scale=None, emit_scaled=False):
+        """emit_in: the valid Emission of x_own (its rows already sit in the send buffer: no pack).  emit: mirror the OUTPUT rows
+        into the send buffer of the next aggregation (times emit_scale) and tag the result."""
         scale = self._scale(reduce_func)
         if extra_dst_scale is not None:
             scale = extra_dst_scale if scale is None else scale * extra_dst_scale
         x_own = x_own.contiguous()
+        emit_out = self.wire(x_own, emit_scale, emit_scaled) if emit else None
         if torch.is_grad_enabled() and x_own.requires_grad:
-            return _HaloAggregate.apply(x_own, self, scale)
-        return self._flow(x_own, scale, transposed=False)
+            out = _HaloAggregate.apply(x_own, self, scale, emit_in, emit_out)
+            if emit_out is not None and emit_out.version is not None:
+                self.mark(out, emit_out)                               # (the Function returned a fresh tensor object)
+            return out
+        return self._flow(x_own, scale, transposed=False, emit_in=emit_in, emit_out=emit_out)
 
     # ---- halo extension (pull), differentiable ------------------------------------------------------------------------
     def _extend(self, x_own, work_out=None):
@@ -1021,21 +1157,23 @@ class DistGraph(object):
         return self.local_graph._edge_cols32()
 
     # ---- the reference's method set (pgl/graph.py:1509-1553), on owned rows -----------------------------------------------
-    def send_recv(self, feature, reduce_func="sum", out_size=None):
-        """pgl/graph.py:1534-1538 role; Graph.send_recv semantics (pgl/graph.py:834-861).  feature: [n_own, ...]."""
+    def send_recv(self, feature, reduce_func="sum", out_size=None, emit=False):
+        """pgl/graph.py:1534-1538 role; Graph.send_recv semantics (pgl/graph.py:834-861).  feature: [n_own, ...].
+        emit=True (sum / mean): the result's rows are also written into the send buffer of the NEXT aggregation on this graph
+        (a propagation chain h <- A h: every step after the first starts its exchange without a pack launch)."""
         assert reduce_func in ("sum", "mean", "max", "min"), \
             "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
         if out_size is not None and int(out_size) not in (0, self.plan.n_own):
             raise ValueError("DistGraph: out_size must equal the number of owned rows (%d)" % self.plan.n_own)
         if reduce_func in ("sum", "mean"):
-            return self._sum_like(feature, reduce_func)
+            return self._sum_like(feature, reduce_func, emit_in=self._emission_of(feature, "x"), emit=emit)
         if torch.is_grad_enabled() and feature.requires_grad:
             return self.local_graph.send_recv(self.halo_extend(feature), reduce_func)[:self.plan.n_own]
         return self._minmax(feature.contiguous(), reduce_func)
 
-    def send_u_recv(self, feature, reduce_op="sum", out_size=None):
+    def send_u_recv(self, feature, reduce_op="sum", out_size=None, emit=False):
         """pgl/graph.py:1540-1544."""
-        return self.send_recv(feature, reduce_op, out_size)
+        return self.send_recv(feature, reduce_op, out_size, emit=emit)
 
     def _minmax(self, x_own, reduce_func):
         """Interior rows while the halo is in flight, boundary rows afterwards from [owned | received] (pull plan: max / min
@@ -1099,13 +1237,23 @@ class DistGraph(object):
         return self.local_graph.recv(reduce_func, msg, recv_mode)[:self.plan.n_own]
 
     # ---- engine extensions the pgl_amd.nn layers look for ---------------------------------------------------------------
-    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None):
+    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None, emit=False, emit_scale=None):
         """out[v] = dst_scale[v] * sum_{u->v} src_scale[u] * feature[u] (GCN's symmetric norm, pgl/nn/conv.py:242-250): the
-        source scale is applied to the owned rows before they travel, the destination scale inside the kernels."""
+        source scale is applied to the owned rows before they travel, the destination scale inside the kernels.
+        A `feature` that carries an emission made with THIS src_scale (DistGraph.wire(..., scale=src_scale, scaled=True): the layer
+        that produced it wrote scale * row into the send buffer and into a dense scaled copy) needs neither the scaling pass nor the
+        pack.  emit / emit_scale: mirror the result (times emit_scale, keeping the dense scaled copy) for the next aggregation."""
+        em = self._emission_of(feature, "x", src_scale) if src_scale is not None else self._emission_of(feature, "x")
         if src_scale is not None:
-            feature = feature * src_scale.reshape((-1,) + (1,) * (feature.dim() - 1)).to(feature.dtype)
+            if em is not None and em.wire.scaled_out is not None and not (torch.is_grad_enabled() and feature.requires_grad):
+                feature = em.wire.scaled_out                          # scale * row, written by the producer: no scaling pass either
+            else:
+                # (training: the product stays an autograd op; the send buffer already holds the same values, so the pack is
+                #  skipped all the same)
+                feature = feature * src_scale.reshape((-1,) + (1,) * (feature.dim() - 1)).to(feature.dtype)
         ds = None if dst_scale is None else dst_scale.reshape(-1).to(torch.float32).contiguous()
-        return self._sum_like(feature, "sum", extra_dst_scale=ds)
+        return self._sum_like(feature, "sum", extra_dst_scale=ds, emit_in=em, emit=emit, emit_scale=emit_scale,
+                              emit_scaled=emit_scale is not None)
 
     def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2, attn_drop=0.0, seed=0):
         """The fused GAT attention of Graph.gat_aggregate over the partitioned graph: a_src rides with the halo feature

@@ -272,8 +272,48 @@ def _row_strided(t):
     return t.dim() == 2 and t.shape[1] > 0 and t.stride(1) == 1 and t.stride(0) > t.shape[1] and not t.is_contiguous()
 
 
+class Wire(object):
+    """Where a producing launch mirrors its finished rows (struct pglamd_wire_out): `buf` = the halo send buffer of the NEXT
+    aggregation ([n_send, d]; or, for the column-pipelined exchange, `buf` = columns [0, split) and `buf2` = columns [split, d) as
+    two contiguous buffers), `ptr32` / `pos32` = CSR over output rows listing each row's slots in it, `scale` (optional fp32
+    [n_rows]) = multiplier of the wire copy, `scaled_out` (optional [n_rows, d]) = dense copy of the scaled rows.
+    Built by pgl_amd.distributed.DistGraph.wire()."""
+    __slots__ = ("ptr32", "pos32", "buf", "scale", "scaled_out", "buf2", "split")
+
+    def __init__(self, ptr32, pos32, buf, scale=None, scaled_out=None, buf2=None, split=0):
+        self.ptr32, self.pos32, self.buf, self.scale, self.scaled_out = ptr32, pos32, buf, scale, scaled_out
+        self.buf2, self.split = buf2, int(split)
+
+    def block(self, c0, c1):
+        """The wire of a launch that writes only columns [c0, c1) of the rows (the pipelined flow aggregates block by block)."""
+        if self.split:
+            if c0 == 0 and c1 == self.split:
+                buf = self.buf
+            elif c0 == self.split:
+                buf = self.buf2
+            else:
+                raise ValueError("wire: column block [%d, %d) does not match the split at %d" % (c0, c1, self.split))
+        else:
+            buf = self.buf[:, c0:c1]
+        return Wire(self.ptr32, self.pos32, buf, self.scale, None if self.scaled_out is None else self.scaled_out[:, c0:c1])
+
+    def struct(self, d):
+        for t, w in ((self.buf, self.split or d), (self.scaled_out, d), (self.buf2, d - self.split)):
+            if t is not None and not (t.dim() == 2 and int(t.shape[1]) == w and t.stride(1) == 1):
+                raise ValueError("wire: buffers must be [rows, %d] with contiguous rows (got %s)" % (w, tuple(t.shape)))
+        p = lambda t: None if t is None else t.data_ptr()
+        return _ffi.WireOut(p(self.ptr32), p(self.pos32), p(self.buf), int(self.buf.stride(0)), p(self.scale), p(self.scaled_out),
+                            0 if self.scaled_out is None else int(self.scaled_out.stride(0)),
+                            p(self.buf2), 0 if self.buf2 is None else int(self.buf2.stride(0)), self.split)
+
+    def zero_(self):
+        for t in (self.buf, self.buf2, self.scaled_out):
+            if t is not None:
+                t.zero_()
+
+
 def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None,
-              out=None, accumulate=False, x2=None, zero_indptr=None):
+              out=None, accumulate=False, x2=None, zero_indptr=None, wire=None):
     """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
     graph's cached dst-CSR.  y (if given) is in ORIGINAL edge order, shape [E, ...].
     accumulate: False / 0 write every row of `out`; True / 1 combine the rows that receive edges with their old contents;
@@ -282,8 +322,12 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     x2 (the rows received from peers); rows are zero-filled where zero_indptr -- not the index's own indptr -- says they
     have no edge.  An index carrying `max_row` (longest row) lets the library skip the split-row fix-up launches.
     x and out may be COLUMN BLOCKS of wider matrices (m[:, a:b]; no edge operand, no src_scale, no x2): the kernels walk them
-    with the parent's row stride, nothing is copied."""
+    with the parent's row stride, nothing is copied.
+    wire (ops.Wire; pglamd_aggregate_wire): every row this launch stores also goes to its slots of the halo send buffer of the
+    next aggregation -- sum / mean of fp32 / fp16 / bf16 rows, no edge operand, no source scale."""
     _need_cuda(x, y, src_scale, dst_scale, x2, zero_indptr)
+    if wire is not None and (y is not None or src_scale is not None or reduce_op not in ("sum", "mean") or x.dim() != 2):
+        raise ValueError("aggregate: a wire mirror goes with plain sum / mean over 2-D rows (no edge operand, no source scale)")
     L = _ffi.lib()
     ldx = ldo = 0
     if y is None and src_scale is None and x2 is None:
@@ -337,11 +381,22 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
             raise ValueError("out must be a contiguous %s tensor of dtype %s" % ((M,) + tuple(tail), x.dtype))
     if M == 0 or dout == 0:
         return out
-    if ldo and not accumulate and csr.num_edges == 0:
-        out.zero_()
+    if (ldo or wire is not None) and csr.num_edges == 0:
+        if not accumulate:
+            out.zero_()
+            if wire is not None:                       # (an index without edges: every row is an empty row -- zeros travel)
+                wire.zero_()
         return out
     code = _code(x.dtype)
     ws = _ws_hot(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
+    if wire is not None:
+        wo = wire.struct(dout)
+        with torch.cuda.device(x.device):
+            _ffi.check(L.pglamd_aggregate_wire(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(csr.row32), _ptr(csr.col32),
+                                               _ptr(csr.indptr), _ptr(zero_indptr), max_row, csr.num_edges, csr.num_nodes, M, ldo,
+                                               REDUCE[reduce_op], _ptr(dst_scale), int(accumulate), _ptr(out), ctypes.byref(wo),
+                                               _ptr(ws), ws.numel(), _stream(x)), "aggregate_wire")
+        return out
     if ext and src_scale is None:
         with torch.cuda.device(x.device):
             _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(y if es is None else es), dy if es is None else 1,
@@ -979,7 +1034,7 @@ def row_epilogue_supported(z, width=None):
     return row_epilogue_width_ok(z.shape[-1] if width is None else width)
 
 
-def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12):
+def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12, wire=None):
     """y = normalize_L2(act(z + bias)) -> (y, inv_norm or None).  act: None | "relu".  GraphSageConv's epilogue
     (pgl/nn/conv.py:109-115) and GCNConv's (pgl/nn/conv.py:250-254) in one kernel."""
     _need_cuda(z, bias)
@@ -994,9 +1049,15 @@ def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12):
     inv = torch.empty(n, dtype=torch.float32, device=z.device) if normalize else None
     if n:
         with torch.cuda.device(z.device):
-            _ffi.check(_ffi.lib().pglamd_row_epilogue(_ptr(z), _ptr(None if bias is None else bias.contiguous()), n, d,
-                                                      1 if act == "relu" else 0, int(bool(normalize)), float(eps), _ptr(y), _ptr(inv),
-                                                      _stream(z)), "row_epilogue")
+            if wire is not None:       # the finished row is the next aggregation's input: it goes to the halo send buffer in the same store
+                wo = wire.struct(d)
+                _ffi.check(_ffi.lib().pglamd_row_epilogue_wire(_ptr(z), _ptr(None if bias is None else bias.contiguous()), n, d,
+                                                               1 if act == "relu" else 0, int(bool(normalize)), float(eps), _ptr(y),
+                                                               _ptr(inv), ctypes.byref(wo), _stream(z)), "row_epilogue_wire")
+            else:
+                _ffi.check(_ffi.lib().pglamd_row_epilogue(_ptr(z), _ptr(None if bias is None else bias.contiguous()), n, d,
+                                                          1 if act == "relu" else 0, int(bool(normalize)), float(eps), _ptr(y), _ptr(inv),
+                                                          _stream(z)), "row_epilogue")
     return y, inv
 
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU session = a list of steps, run on the GPU box through gpurun:
 #     gpurun --timeout 3000 -- 'bash scripts/gpu_session.sh TAG step [step ...]'
-# Every step writes gpurun_out/r04/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r04/.
+# Every step writes gpurun_out/r05/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r05/.
 # Steps: diag tests tests:<pytest -k expr> bench rows_c2 rows_c2_p4 rows_c2_fp16 rows_c2p csr noreuse tlb gcn train gat ops dtypes profile
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r04}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r05}; mkdir -p $O
 TAG=$1; shift
 PARTS="scratch/parts"
 cd $R
@@ -15,6 +15,7 @@ for STEP in "$@"; do
     smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $F 2>&1; echo "smoke rc=$?" >> $F; tail -3 $F ;;
     tests)      timeout 1500 python -m pytest tests -m gpu -q > $F 2>&1; echo "pytest rc=$?" >> $F; tail -6 $F ;;
     tests:*)    timeout 1500 python -m pytest tests -m gpu -q -x -k "${STEP#tests:}" > $F 2>&1; echo "pytest rc=$?" >> $F; tail -25 $F ;;
+    file:*)     timeout 1500 python -m pytest "tests/${STEP#file:}" -m gpu -q -x -s > $F 2>&1; echo "pytest rc=$?" >> $F; grep -E "compared|edge cut|passed|failed|rc=|Error|error" $F | tail -25 ;;
     bench)      timeout 600 python bench.py > $O/bench_n1_$TAG.json 2> $F; echo "bench rc=$?"; head -c 600 $O/bench_n1_$TAG.json; echo ;;
     rows_c2)    timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 2,8 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -14 $F ;;
     rows_c2_p4) timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 4 --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -8 $F ;;
@@ -25,7 +26,7 @@ for STEP in "$@"; do
     rows_c2p_pipe) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow pipeline --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2_pipe)  timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow pipeline --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
-    csr|noreuse|gcn|gat|ops|dtypes|gatsplit|model) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
+    csr|coo|noreuse|gcn|gat|ops|dtypes|gatsplit|model) timeout 600 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     edgeops)    timeout 600 python scripts/prof.py edgeops > $F 2>&1; timeout 600 python scripts/prof.py edgeops --sorted >> $F 2>&1; grep -v amdgpu.ids $F ;;
     pmc_edgeops)
       # rows a7 / a8 / a10 in original edge order: fetched / written bytes, L2 hit rate and memory-side request mix per KERNEL

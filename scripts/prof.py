@@ -7,6 +7,7 @@
                                                      next to the bytes each rank receives and what they cost on xGMI
     python scripts/prof.py ops                       one line per op of SURVEY 8(a) at C2 / C3 sizes
     python scripts/prof.py csr                       CSR build (a1) at C2 / C2' / sampled-block sizes
+    python scripts/prof.py coo                       K1' (COO scatter-add, a graph used once) against csr_build + aggregate, five sizes
     python scripts/prof.py gcn                       GCNConv forward / training step through the fused aggregate -> dense kernel and without
     python scripts/prof.py train [gcn sage gat ...]  ms per training step of one layer, fused paths on / off
     python scripts/prof.py model [gcn sage gat]      the reference examples' MODELS at C2: inference and one whole training step
@@ -143,7 +144,7 @@ def cmd_rows(args):
         pull_c, push_c = HaloPlan.pair_counts(edges, N, part, P)
         choice = HaloPlan.choose_push(pull_c, push_c) if args.push == "auto" else torch.zeros((P, P), dtype=torch.bool)
         print("P=%d partition %s (%.1f s), edge cut %.3f, %d of %d pairs push, wire %s" % (P, how, tp, cut, int(choice.sum()), P * (P - 1), args.wire or "fp32"))
-        worst, rows, preds = {"compute": 0.0, "pair_mb": 0.0, "ratio": 0.0}, [], []
+        worst, rows, preds, chains = {"compute": 0.0, "pair_mb": 0.0, "ratio": 0.0}, [], [], []
         for r in range(P):
             plan = HaloPlan(edges, N, part, r, P)
             xplan = HaloPlan(edges, N, part, r, P, push=choice) if bool(choice.any()) else plan
@@ -152,6 +153,16 @@ def cmd_rows(args):
                 dg.wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.wire]
             x_own = dg.take_owned(x)
             ms = _t(lambda: dg.send_recv(x_own, "sum"), it=10, warm=3)
+            # layers >= 2 of a stack: the step's input is the previous step's output, whose rows the producing launches already
+            # mirrored into the send buffer (pglamd_aggregate_wire): no pack launch.  mean (= sum with the fused 1 / degree scale)
+            # keeps the values bounded over the timed steps; the unfused mean step is timed beside it
+            chain = [x_own]
+            def chained():
+                chain[0] = dg.send_recv(chain[0], "mean", emit=True)
+            ms_mean = _t(lambda: dg.send_recv(x_own, "mean"), it=10, warm=3)
+            k0 = getattr(dg, "_packs_skipped", 0)
+            ms_chain = _t(chained, it=10, warm=3)
+            fused_ok = getattr(dg, "_packs_skipped", 0) - k0 >= 12
             torch.cuda.synchronize()
             t_cpu = time.perf_counter()
             for _ in range(20):
@@ -211,6 +222,7 @@ def cmd_rows(args):
                 pred = predict(xch, 0.0)
             ideal = plan.local_edges / (E / t1)
             rows.append((r, plan.n_own, plan.local_edges, e_pre, e_post, xplan.n_send, xplan.n_recv, ms, pk, pre, post, ideal, pair_mb, enq, mode, pred))
+            chains.append((r, ms_mean, ms_chain, ideal, fused_ok))
             preds.append((predict, xch))
             worst["compute"] = max(worst["compute"], ms); worst["pair_mb"] = max(worst["pair_mb"], pair_mb)
             worst["ratio"] = max(worst["ratio"], ms / ideal); worst["pred"] = max(worst.get("pred", 0.0), pred)
@@ -218,6 +230,14 @@ def cmd_rows(args):
         for r, n_own, le, e_pre, e_post, ns, nr, ms, pk, pre, post, ideal, pmb, enq, mode, pred in rows:
             print("   rank %d: %7d rows %9d edges, flow %-10s (%8d edges before the wait, %9d after) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms (host enqueue %.3f); alone: pack %.3f, before %.3f, after %.3f | ideal %.3f ms -> x%.2f | with the exchange: %.3f ms"
                   % (r, n_own, le, mode, e_pre, e_post, ns, nr, pmb, ms, enq, pk, pre, post, ideal, ms / ideal, pred))
+        print("   layers >= 2 (input = the previous step's output; its rows were mirrored into the send buffer by the launches that "
+              "produced them: no pack):")
+        for r, mm, mc, ideal, ok in chains:
+            print("   rank %d: mean step with pack %.3f ms | chained step, fused pack %.3f ms (%s) | ideal %.3f ms -> x%.2f"
+                  % (r, mm, mc, "pack skipped every step" if ok else "PACK NOT SKIPPED", ideal, mc / ideal))
+        wc = max(c[2] for c in chains)
+        print("   slowest rank, layers >= 2: compute %.3f ms (worst compute/ideal x%.2f) -> bound %.2fx of one GPU with the exchange fully hidden"
+              % (wc, max(c[2] / c[3] for c in chains), t1 / wc))
         t_link = worst["pair_mb"] / 1e3 / LINK * 1e3
         print("   slowest rank compute %.3f ms (worst compute/ideal x%.2f; ideal = E/P at the 1-GPU rate = %.3f ms) | exchange >= %.3f ms (largest pair block at %.0f GB/s per link)"
               % (worst["compute"], worst["ratio"], t1 / P, t_link, LINK))
@@ -537,6 +557,36 @@ def cmd_csr(args):
         ms = _t(lambda: pgl.ops.csr_from_sorted(u_sorted, v_sorted, N), it=10, warm=3)
         print("%-14s %-9s |E|=%-10d N=2^%-2d csr_from_sorted %.3f ms (keys already grouped: no sort)" % (name, "sorted", E, scale, ms), flush=True)
         del edges, c, u_sorted, v_sorted
+
+
+def cmd_coo(args):
+    """K1' (row n1): paddle.geometric.send_u_recv straight from raw COO for a graph used ONCE (pgl/graph.py:859-861) --
+    pglamd_scatter_add_coo against the engine's default for the same call: csr_build + aggregate (+ the int32 narrowing of the edge
+    columns both need).  One line per graph size; `once` = everything a single call costs, `cached` = the aggregation alone."""
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    d = args.dim
+    for name, scale, E in (("C2", 20, 20_000_000), ("4 M edges", 18, 4_000_000), ("sampled block", 17, 600_000), ("100 k edges", 14, 100_000), ("Cora-sized", 12, 13_264)):
+        N = 1 << scale
+        gen = torch.Generator(device=dev); gen.manual_seed(7)
+        x = torch.randn(N, d, generator=gen, device=dev)
+        for order in ("raw", "dst-grouped"):
+            edges = rmat_edges(scale, E, seed=42, device=dev)
+            if order == "dst-grouped":
+                edges = edges[torch.argsort(edges[:, 1], stable=True)]
+            src32, dst32 = edges[:, 0].to(torch.int32).contiguous(), edges[:, 1].to(torch.int32).contiguous()
+            t_coo = _t(lambda: pgl.ops.scatter_add_coo(x, src32, dst32, N), it=10, warm=3)
+            t_build = _t(lambda: pgl.ops.csr_build(edges[:, 1], edges[:, 0], N, want_i64=False, check_range=False), it=10, warm=3)
+            c = pgl.ops.csr_build(edges[:, 1], edges[:, 0], N, want_i64=False, check_range=False)
+            t_agg = _t(lambda: pgl.ops.aggregate(x, c, "sum", N), it=10, warm=3)
+            a, b = pgl.ops.scatter_add_coo(x, src32, dst32, N), pgl.ops.aggregate(x, c, "sum", N)
+            err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+            print("%-14s %-11s |E|=%-9d d=%d  scatter_add_coo %.3f ms | csr_build %.3f + aggregate %.3f = %.3f ms once (cached: %.3f) | "
+                  "COO / CSR-once = %.2f | max rel diff %.1e" % (name, order, E, d, t_coo, t_build, t_agg, t_build + t_agg, t_agg,
+                                                               t_coo / (t_build + t_agg), err), flush=True)
+            del edges, src32, dst32, c, a, b
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1078,6 +1128,7 @@ def main():
     tr.add_argument("--dir", required=True)
     tr.add_argument("--out", required=True)
     sub.add_parser("csr")
+    co = sub.add_parser("coo"); co.add_argument("--dim", type=int, default=128)
     o = sub.add_parser("ops"); o.add_argument("--scale", type=int, default=20); o.add_argument("--edges", type=int, default=20_000_000)
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
@@ -1108,6 +1159,8 @@ def main():
          "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
+    elif args.cmd == "coo":
+        cmd_coo(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
     elif args.cmd == "gcn":

@@ -697,3 +697,108 @@ def test_bench_watchdog_prints_the_best_completed_record_and_exits_zero():
     code2 = code.replace("wd.best = lambda: {'value': 42.0, 'metric': 'm'}\n", "")
     r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 3 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: the fused pack -- a layer's output rows are written into the NEXT aggregation's halo send buffer by the launch that
+# produces them (pglamd_aggregate_wire / pglamd_row_epilogue_wire; DistGraph.wire / mark / send_recv(emit=True))
+# ------------------------------------------------------------------------------------------------
+def _nan_buffers(dg):
+    """Every buffer DistGraph creates starts as NaN: a send-buffer slot that no launch mirrored fails the comparison."""
+    orig = dg._buffer
+
+    def make(name, shape, dtype, device):
+        fresh = name not in dg._buf or tuple(dg._buf[name].shape) != tuple(shape) or dg._buf[name].dtype != dtype
+        b = orig(name, shape, dtype, device)
+        if fresh and b.is_floating_point():
+            b.fill_(float("nan"))
+        return b
+    dg._buffer = make
+
+
+def _chain_worker(rank, world, steps, scaled, grad):
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph(d=32)
+    n = x.shape[0]
+    dg = DistGraph.from_global(torch.from_numpy(edges), n, rank, world, method="random", backend=TorchBackend(), push="never")
+    _nan_buffers(dg)
+    h = dg.take_owned(torch.from_numpy(x))
+    if grad:
+        h = h.clone().requires_grad_(True)
+    h0 = h
+    deg = dg.indegree().clamp(min=1).to(torch.float32)
+    norm = deg.pow(-0.5).reshape(-1, 1)
+    outs = []
+    for k in range(steps):
+        if scaled:                                          # GCN-style propagation: norm * A (norm * h), the next step's norm * h mirrored
+            h = dg.send_recv_scaled(h, norm, norm, emit=True, emit_scale=norm)
+        else:
+            h = dg.send_recv(h, "mean", emit=True)
+        outs.append(h.detach().numpy().copy())
+    skipped = getattr(dg, "_packs_skipped", 0)
+    flow = dg.stats()["flow"]
+    # a tensor that was written to after it was produced must NOT be taken for its mirrored copy
+    h2 = dg.send_recv(torch.from_numpy(outs[-2]).clone(), "mean", emit=True)
+    h2.mul_(2.0)
+    tampered = dg.send_recv(h2, "mean").numpy()
+    g = None
+    if grad:
+        (h * h).sum().backward()
+        g = h0.grad.numpy()
+    return (rank, dg.plan.own_global.numpy(), {"outs": outs, "skipped": skipped, "flow": flow, "tampered": tampered, "grad": g,
+                                                 "tampered_in": outs[-2]})
+
+
+@pytest.mark.parametrize("world,flow,scaled,grad", [(2, "", False, False), (3, "fold", False, False), (2, "accumulate", True, False),
+                                                    (3, "split", True, False), (2, "pipeline", False, False), (3, "pipeline", True, False),
+                                                    (2, "split", False, True), (2, "pipeline", True, True)])
+def test_gloo_fused_pack_chain(monkeypatch, world, flow, scaled, grad):
+    """h <- A h four times with emit=True: every step after the first starts its exchange from rows the previous step's launches
+    mirrored into the send buffer (no pack), under every flow; the values equal the single-graph chain, the gradient too."""
+    if flow:
+        monkeypatch.setenv("PGLAMD_FLOW", flow)
+    steps = 4
+    got = _spawn(_chain_worker, world, steps, scaled, grad)
+    edges, x = _graph(d=32)
+    n = x.shape[0]
+    src, dst = torch.from_numpy(edges[:, 0]), torch.from_numpy(edges[:, 1])
+    deg = torch.bincount(dst, minlength=n).clamp(min=1).float()
+    norm = deg.pow(-0.5).reshape(-1, 1)
+    h = torch.from_numpy(x).clone().requires_grad_(grad)
+    h0, want = h, []
+
+    def step(t):
+        if scaled:
+            return torch.zeros_like(t).index_add(0, dst, (t * norm)[src]) * norm
+        return torch.zeros_like(t).index_add(0, dst, t[src]) / deg.reshape(-1, 1)
+    for k in range(steps):
+        h = step(h)
+        want.append(h.detach().numpy())
+    for k in range(steps):
+        full = np.full_like(want[k], np.nan)
+        for _, own, res in got:
+            full[own] = res["outs"][k]
+        assert np.isfinite(full).all(), "step %d" % k
+        np.testing.assert_allclose(full, want[k], rtol=2e-5, atol=2e-5 * np.abs(want[k]).max(), err_msg="step %d" % k)
+    per_step = 2 if flow == "pipeline" else 1                          # (the pipelined flow starts two exchanges per step)
+    for _, _, res in got:
+        assert res["skipped"] == (steps - 1) * per_step, (res["skipped"], res["flow"])
+        if flow:
+            assert res["flow"] == flow
+    # the tampered tensor went through the ordinary pack
+    t_in = np.full_like(want[0], np.nan)
+    for _, own, res in got:
+        t_in[own] = res["tampered_in"]
+    t_want = step(step(torch.from_numpy(t_in)) * 2.0).numpy() if not scaled else None
+    if t_want is not None:
+        full = np.full_like(t_want, np.nan)
+        for _, own, res in got:
+            full[own] = res["tampered"]
+        np.testing.assert_allclose(full, t_want, rtol=2e-5, atol=2e-5 * np.abs(t_want).max())
+    if grad:
+        (h * h).sum().backward()
+        gw = h0.grad.numpy()
+        full = np.full_like(gw, np.nan)
+        for _, own, res in got:
+            full[own] = res["grad"]
+        np.testing.assert_allclose(full, gw, rtol=1e-4, atol=1e-5 * np.abs(gw).max())

@@ -1373,17 +1373,19 @@ def test_bench_multi_rank_code_path_dry_run():
 
 
 def test_bench_phase_limit_ends_a_hung_run_with_the_best_completed_measurement():
-    """A phase that does not finish (here: every phase after the first candidate, by a 0.05 s limit on a 2-rank dry run) must end
-    the run with rc 0 and a JSON line that reports the last COMPLETED measurement, labelled -- not hang, not lose the number."""
+    """A phase that does not finish (here: every phase after the first candidate) must end the run instead of hanging it, with a
+    JSON line that reports the last COMPLETED measurement.  Ending BEFORE the timed region is a failed run: rc != 0 and
+    the line's `metric` says it is a candidate trial, so a driver cannot take it for the headline."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PGLAMD_BENCH_DRYRUN="1", PGLAMD_BENCH_HANG_AFTER="trial fold/torch")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29741", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--scale", "15", "--edges", "400000", "--phase-limit", "20"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.returncode != 0, (r.stdout[-1500:], r.stderr[-3000:])
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["aborted"]["phase"].startswith("trial cost-model/torch") and rec["value"] > 0 and rec["n_gpus"] == 2
+    assert rec["metric"].startswith("ABORTED before the timed region")
     assert "trial of" in rec["timed"] and rec["halo"]["candidates"][0]["status"] == "ok"
 
 

@@ -250,3 +250,116 @@ def test_abi_edge_operand_e1_mul_reroute_equals_the_general_path(pgl, accumulate
     elif accumulate == 2:
         want = np.where(has[:, None], want, before)
     np.testing.assert_allclose(a, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# the fused pack: pglamd_aggregate_wire / pglamd_row_epilogue_wire -- every row a launch stores also lands in
+# its slots of the next aggregation's halo send buffer.  Kernel-level contract here; the multi-rank flow in test_gpu_distributed.py
+# ------------------------------------------------------------------------------------------------
+def _random_slots(rng, n_rows, n_slots_max=3):
+    """CSR over rows -> wire positions: row r has 0..n_slots_max slots, positions are a permutation of [0, total)."""
+    cnt = rng.integers(0, n_slots_max + 1, n_rows)
+    ptr = np.zeros(n_rows + 1, np.int32); ptr[1:] = np.cumsum(cnt)
+    pos = rng.permutation(int(ptr[-1])).astype(np.int32)
+    return ptr, pos
+
+
+def _mirror_reference(ptr, pos, written, values, scale, buf):
+    """what the wire must hold afterwards: slots of stored rows = scale[r] * row, all other slots untouched"""
+    want = buf.copy()
+    for r in np.nonzero(written)[0]:
+        for s in range(ptr[r], ptr[r + 1]):
+            want[pos[s]] = values[r] * (1.0 if scale is None else scale[r])
+    return want
+
+
+@pytest.mark.parametrize("d,dt", [(128, torch.float32), (64, torch.float32), (100, torch.float32), (8, torch.float32), (256, torch.float32),
+                                  (128, torch.float16), (64, torch.bfloat16), (32, torch.float32)])
+@pytest.mark.parametrize("mode", ["write", "accumulate", "overwrite", "zero_indptr", "split", "scaled"])
+def test_aggregate_wire_mirror_contract(pgl, d, dt, mode):
+    if mode == "split" and d < 32:
+        pytest.skip("a split needs two blocks of >= 16 columns")
+    ops = pgl.ops
+    rng = np.random.default_rng(d * 7 + len(mode))
+    n, e = 5000, 90000
+    src = rng.integers(0, n, e).astype(np.int64)
+    dst = (rng.integers(0, n // 2, e) * 2).astype(np.int64)                 # odd rows empty
+    dst[rng.choice(e, 20000, replace=False)] = 10                            # a hub row: the split-row fix-up path stores it
+    dst[rng.choice(e, 3000, replace=False)] = 512
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    xt = dev(x).to(dt)
+    csr = ops.csr_build(dev(dst), dev(src), n, want_i64=False)
+    ptr, pos = _random_slots(rng, n)
+    n_wire = int(ptr[-1])
+    scale = (rng.random(n).astype(np.float32) + 0.5) if mode == "scaled" else None
+    split = ((d // 2 + 15) // 16 * 16) if mode == "split" else 0
+    sentinel = -777.0
+    buf = torch.full((n_wire, d), sentinel, dtype=dt, device="cuda")
+    b0 = torch.full((n_wire, split), sentinel, dtype=dt, device="cuda") if split else None
+    b1 = torch.full((n_wire, d - split), sentinel, dtype=dt, device="cuda") if split else None
+    so = torch.full((n, d), sentinel, dtype=dt, device="cuda") if scale is not None else None
+    wire = ops.Wire(dev(ptr), dev(pos), b0 if split else buf, None if scale is None else dev(scale), so, b1, split)
+    has = np.bincount(dst, minlength=n) > 0
+    before = rng.standard_normal((n, d)).astype(np.float32)
+    kw, written = {}, np.ones(n, bool)
+    if mode == "accumulate":
+        kw, written = dict(out=dev(before).to(dt), accumulate=1), has
+    elif mode == "overwrite":
+        kw, written = dict(out=dev(before).to(dt), accumulate=2), has
+    elif mode == "zero_indptr":
+        # the interior launch of a partition: rows 1, 5, 9, ... are empty here but not in the zero-fill's indptr -> left untouched
+        deg_all = np.bincount(dst, minlength=n); deg_all[1::4] += 1
+        zi = np.zeros(n + 1, np.int64); zi[1:] = np.cumsum(deg_all)
+        kw, written = dict(zero_indptr=dev(zi)), has | (deg_all == 0)
+    out = ops.aggregate(xt, csr, "sum", n, wire=wire, **kw)
+    kw2 = dict(kw)
+    if "out" in kw2:
+        kw2["out"] = dev(before).to(dt)
+    plain = ops.aggregate(xt, csr, "sum", n, **kw2)                            # the same launch without the mirror
+    torch.cuda.synchronize()
+    got_out = host(out.float())
+    if mode != "zero_indptr":
+        assert np.array_equal(got_out, host(plain.float())), "the mirror must not change the result"
+    vals = got_out                                                          # the wire holds exactly what went to `out` (times scale)
+    wbuf = host((torch.cat([b0, b1], 1) if split else buf).float())
+    want = _mirror_reference(ptr, pos, written, vals, scale, np.full((n_wire, d), sentinel, np.float32))
+    if scale is None:
+        assert np.array_equal(wbuf, want)
+    else:
+        tol = 1e-6 if dt == torch.float32 else 1e-2
+        np.testing.assert_allclose(wbuf, want, rtol=tol, atol=tol)
+        ws = host(so.float())
+        np.testing.assert_allclose(ws[written], (vals * scale[:, None])[written], rtol=tol, atol=tol)
+        assert (ws[~written] == sentinel).all()
+    # the oracle on the rows themselves (the mirror test above is relative to `out`)
+    ref = R.c_send_u_recv(host(xt.float()), src, dst, "sum")
+    if mode == "write":
+        tol = 1e-5 if dt == torch.float32 else (4e-3 if dt == torch.float16 else 3e-2)
+        np.testing.assert_allclose(got_out, ref, rtol=tol, atol=tol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("d,split,scaled", [(128, 0, False), (128, 64, True), (100, 0, True), (64, 32, False), (32, 16, True)])
+def test_row_epilogue_wire_mirror_contract(pgl, d, split, scaled):
+    ops = pgl.ops
+    rng = np.random.default_rng(d + split)
+    n = 7000
+    z = rng.standard_normal((n, d)).astype(np.float32)
+    bias = rng.standard_normal(d).astype(np.float32)
+    ptr, pos = _random_slots(rng, n)
+    n_wire = int(ptr[-1])
+    scale = (rng.random(n).astype(np.float32) + 0.5) if scaled else None
+    sentinel = -777.0
+    b0 = torch.full((n_wire, split or d), sentinel, device="cuda")
+    b1 = torch.full((n_wire, d - split), sentinel, device="cuda") if split else None
+    so = torch.full((n, d), sentinel, device="cuda") if scaled else None
+    wire = ops.Wire(dev(ptr), dev(pos), b0, None if scale is None else dev(scale), so, b1, split)
+    y, inv = ops.row_epilogue(dev(z), dev(bias), "relu", True, wire=wire)
+    y0, _ = ops.row_epilogue(dev(z), dev(bias), "relu", True)
+    assert torch.equal(y, y0)
+    want_y = np.maximum(z + bias, 0.0); want_y = want_y / np.maximum(np.linalg.norm(want_y, axis=1, keepdims=True), 1e-12)
+    np.testing.assert_allclose(host(y), want_y, rtol=1e-5, atol=1e-6)
+    wbuf = host(torch.cat([b0, b1], 1) if split else b0)
+    want = _mirror_reference(ptr, pos, np.ones(n, bool), host(y), scale, np.full((n_wire, d), sentinel, np.float32))
+    np.testing.assert_allclose(wbuf, want, rtol=1e-6, atol=1e-7)
+    if scaled:
+        np.testing.assert_allclose(host(so), host(y) * scale[:, None], rtol=1e-6, atol=1e-7)

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert sorted(pgl_amd._ffi.exported_symbols()) == declared
-    assert L.pglamd_abi_version() == 2
+    assert L.pglamd_abi_version() == 3
 
 
 def test_ctypes_signatures_match_the_header_prototypes():
