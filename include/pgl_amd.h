@@ -188,7 +188,10 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
  * that re-reads rows the previous layer has just written (0.18 of 1.15 ms per rank at |E| = 100 M, P = 8).  With a wire
  * descriptor the producing launch writes each finished row to `out` and, in the same store, to its slots of that buffer
  * (a row pulled by k peers has k slots), so layer L+1's exchange starts with no pack launch at all.
- *   slot_ptr [out_rows+1], slot_pos   CSR over output rows: wire rows of row r are slot_pos[slot_ptr[r] .. slot_ptr[r+1])
+ *   slot_desc [out_rows][4], slot_more   where row r goes: slot_desc[r] = {count, p0, p1, p2} (int32 x 4, 16-byte aligned) --
+ *                      count <= 3: the wire rows are p0 .. p(count-1); count > 3: p0, p1 and slot_more[p2 .. p2 + count - 2).
+ *                      One 16-byte scalar load per stored row, issued before the row's last arithmetic, instead of a dependent
+ *                      chain through a CSR (which cost more than the pack launch it replaced: profiles/r05)
  *   wire, ldw          the send buffer [n_wire_rows, ldw] in the SAME dtype as out (ldw elements per row, 0 = row length);
  *                      for a column-block launch pass the address of the block's first column, as for out
  *   scale              optional fp32 [out_rows] (floating dtypes): the wire copy is scale[r] * row -- GCN's source-side degree
@@ -200,8 +203,8 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
  * + boundary, or local edges + received edges) finalises the wire when each carries the descriptor.  SUM / MEAN, no edge
  * operand; the launch takes the flat kernel whatever the row width (the lane-per-edge kernels have no mirror).  Deterministic. */
 typedef struct pglamd_wire_out {
-    const int32_t* slot_ptr;
-    const int32_t* slot_pos;
+    const int32_t* slot_desc;
+    const int32_t* slot_more;
     void* wire;
     int64_t ldw;
     const float* scale;

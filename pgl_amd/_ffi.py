@@ -17,7 +17,7 @@ c_i32, c_i64, c_sz, c_vp, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_
 class WireOut(ctypes.Structure):
     """struct pglamd_wire_out (include/pgl_amd.h): where a producing launch mirrors its finished rows -- the halo send buffer of the
     next aggregation (slot CSR + buffer), an optional per-row scale and an optional dense scaled copy."""
-    _fields_ = [("slot_ptr", c_vp), ("slot_pos", c_vp), ("wire", c_vp), ("ldw", c_i64), ("scale", c_vp), ("scaled_out", c_vp),
+    _fields_ = [("slot_desc", c_vp), ("slot_more", c_vp), ("wire", c_vp), ("ldw", c_i64), ("scale", c_vp), ("scaled_out", c_vp),
                 ("ld_scaled", c_i64), ("wire2", c_vp), ("ldw2", c_i64), ("split", c_i64)]
 
 

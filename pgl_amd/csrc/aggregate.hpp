@@ -45,8 +45,8 @@ struct AggParams {
     int max_row_edges;                    // host-side hint: longest row of the index (0 = unknown).  Rows of <= chunk edges are never
                                           // split (chunk_cut), so when it is <= chunk no partial exists and the fix-up launches are skipped
     // ---- wire out (pglamd_aggregate_wire): every row this launch stores to `out` ALSO goes to its slots of the halo send buffer ----
-    const int* wslot_ptr;                 // [out_rows + 1] or NULL: row r's wire rows are wslot_pos[wslot_ptr[r] .. wslot_ptr[r+1])
-    const int* wslot_pos;
+    const int* wdesc;                     // [out_rows][4] or NULL: {count, p0, p1, p2} -- the wire rows of output row r (count <= 3), or
+    const int* wmore;                     //   p0, p1 and wmore[p2 .. p2 + count - 2) (count > 3)
     void* wire;                           // [n_wire_rows, ldw], same element type as out, ALREADY offset to this launch's column block
     int64_t ldw;
     void* wire2; int64_t ldw2; int wsplit;   // columns >= wsplit (of the whole row) go to wire2 at column (j - wsplit); wsplit 0 = one buffer
@@ -73,32 +73,40 @@ template <typename T> __device__ __forceinline__ T from_acc(typename AccT<T>::ty
 template <> __device__ __forceinline__ __half from_acc<__half>(float v) { return __float2half(v); }
 template <> __device__ __forceinline__ __hip_bfloat16 from_acc<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 
-// Mirrors one finished piece of output row r (columns j .. j+VEC-1 of the launch's block, already converted to T) into the row's
-// wire slots (at column jw of the buffer it belongs to) and, if asked for, into the scaled dense copy.  Called from the store
-// paths only (once per row and tile).
-template <typename T, int VEC, typename VT>
-__device__ __forceinline__ void wire_mirror_to(const int* __restrict__ wptr, const int* __restrict__ wpos, void* wire, int64_t ldw,
-                                               const float* __restrict__ wscale, void* wscaled, int64_t ldws, int64_t r, int j,
-                                               int jw, const VT& o) {
+// The wire slots of one output row, fetched with ONE 16-byte scalar load (wave-uniform row) at the top of a store path.
+struct WDesc { int n, p0, p1, p2; };
+__device__ __forceinline__ WDesc wire_desc(const int* wdesc, int64_t r) {
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    const i4 v = *reinterpret_cast<const i4 __attribute__((address_space(4)))*>((unsigned long long)(wdesc + 4 * r));
+    return WDesc{v.x, v.y, v.z, v.w};
+}
+// Mirrors one finished piece of output row r (columns j .. j+VEC-1 of the whole row, already converted to T) into the row's wire
+// slots and, if asked for, into the scaled dense copy.  Called from the store paths only (once per row and tile).
+// Q: a pointer to the launch parameters (generic or constant address space).
+template <typename T, int VEC, typename Q, typename VT>
+__device__ __forceinline__ void wire_mirror(Q q, const WDesc& dsc, int64_t r, int j, const VT& o) {
     VT w = o;
     if constexpr (std::is_floating_point_v<typename AccT<T>::type>) {
-        if (wscale) {
-            const float s = wscale[r];
+        const float* ws = q->wscale;
+        if (ws) {
+            const float s = ws[r];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) w.v[k] = from_acc<T>(to_acc<T>(o.v[k]) * (typename AccT<T>::type)s);
         }
     }
-    if (wscaled) *reinterpret_cast<VT*>(static_cast<T*>(wscaled) + r * ldws + j) = w;
-    const int s0 = wptr[r], s1 = wptr[r + 1];
-    for (int s = s0; s < s1; ++s) *reinterpret_cast<VT*>(static_cast<T*>(wire) + (int64_t)wpos[s] * ldw + jw) = w;
-}
-// Q: a pointer to the launch parameters (generic or constant address space)
-template <typename T, int VEC, typename Q, typename VT>
-__device__ __forceinline__ void wire_mirror(Q q, int64_t r, int j, const VT& o) {
+    if (q->wscaled) *reinterpret_cast<VT*>(static_cast<T*>(q->wscaled) + r * q->ldws + j) = w;
+    if (dsc.n <= 0) return;
     const int split = q->wsplit;
     const bool second = split > 0 && j >= split;          // column-pipelined exchange: columns >= split live in the second buffer
-    wire_mirror_to<T, VEC>(q->wslot_ptr, q->wslot_pos, second ? q->wire2 : q->wire, second ? q->ldw2 : q->ldw, q->wscale, q->wscaled,
-                           q->ldws, r, j, second ? j - split : j, o);
+    T* base = static_cast<T*>(second ? q->wire2 : q->wire) + (second ? j - split : j);
+    const int64_t ld = second ? q->ldw2 : q->ldw;
+    *reinterpret_cast<VT*>(base + (int64_t)dsc.p0 * ld) = w;
+    if (dsc.n > 1) *reinterpret_cast<VT*>(base + (int64_t)dsc.p1 * ld) = w;
+    if (dsc.n == 3) *reinterpret_cast<VT*>(base + (int64_t)dsc.p2 * ld) = w;
+    else if (dsc.n > 3) {
+        const int* more = q->wmore + dsc.p2;
+        for (int i = 0; i < dsc.n - 2; ++i) *reinterpret_cast<VT*>(base + (int64_t)more[i] * ld) = w;
+    }
 }
 
 template <typename T> struct Limits;
@@ -140,10 +148,11 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
         } else {
             for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = from_acc<T>(typename AccT<T>::type(0));
         }
-        if constexpr (WIRE) {                   // an empty row travels as zeros (scale * 0 = 0: no scale needed)
+        if constexpr (WIRE) {                   // an empty row travels as zeros
             const VecT<T, 1> z{{from_acc<T>(typename AccT<T>::type(0))}};
+            const WDesc dsc = wire_desc(p.wdesc, r0 + l);
             for (int j = lane; j < p.tile_cols; j += kWave)
-                wire_mirror<T, 1>(&p, r0 + l, p.j_base + j, z);
+                wire_mirror<T, 1>(&p, dsc, r0 + l, p.j_base + j, z);
         }
     }
 }

@@ -192,6 +192,8 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         const cptr<AggParams> q = cold();
         if (r >= q->out_rows) return;
         T* dst = static_cast<T*>(q->out) + (int64_t)r * q->ldo;
+        WDesc wdsc{};
+        if constexpr (WIRE) wdsc = wire_desc(q->wdesc, r);       // issued first: its latency hides behind the row's scale / old-value loads
         const float* dsp = q->dst_scale;
         const bool is_mean = q->is_mean != 0, accumulate = q->accumulate == 1;
         float ds = 1.f;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                 } else {
                     *reinterpret_cast<V*>(dst + j0[t]) = o;
                     if constexpr (WIRE)          // halo send buffer of the NEXT aggregation: the finished row goes there in the same store
-                        wire_mirror<T, VEC>(q, r, j0[t], o);
+                        wire_mirror<T, VEC>(q, wdsc, r, j0[t], o);
                 }
             }
         if constexpr (SINK == 1) {
@@ -593,6 +595,8 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
                 }
         }
         if (r >= p.out_rows) continue;
+        WDesc wdsc{};
+        if constexpr (WIRE) wdsc = wire_desc(p.wdesc, r);
         T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
         float ds = 1.f;
         if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
                 for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
                 *reinterpret_cast<VO*>(dst + j0[t]) = o;
                 if constexpr (WIRE)
-                    wire_mirror<T, VEC>(&p, r, p.j_base + j0[t], o);
+                    wire_mirror<T, VEC>(&p, wdsc, r, p.j_base + j0[t], o);
             }
     }
 }
@@ -741,7 +745,7 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     const size_t row_bytes = (size_t)p.tile_cols * sizeof(T);
     const bool two = p.x_split != INT32_MAX;
     constexpr bool can_wire = RCLS == 0 && YMODE == 0 && (std::is_same_v<T, float> || sizeof(T) == 2);
-    const bool wire = p.wslot_ptr != nullptr;
+    const bool wire = p.wdesc != nullptr;
     if (wire && (!can_wire || p.src_scale)) return fail(PGLAMD_E_ARG, "aggregate_wire: fp32 / fp16 / bf16 rows, sum or mean, no source scale");
 #define PGLAMD_LAUNCH_FLAT(...)                                                                                                          \
     do {                                                                                                                                 \
@@ -919,9 +923,9 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     const int64_t ldx = ex.ldx ? ex.ldx : dx, ldo = ex.ldo ? ex.ldo : dout;
     if (ldx < dx || ldo < dout) return fail(PGLAMD_E_SHAPE, "aggregate_ext: row stride shorter than the row (ldx %lld < %lld or ldout %lld < %lld)",
                                             (long long)ldx, (long long)dx, (long long)ldo, (long long)dout);
-    const pglamd_wire_out* wo = ex.wire && ex.wire->slot_ptr ? ex.wire : nullptr;
+    const pglamd_wire_out* wo = ex.wire && ex.wire->slot_desc ? ex.wire : nullptr;
     if (wo) {
-        if (!wo->slot_pos || !wo->wire) return fail(PGLAMD_E_ARG, "aggregate_wire: slot_pos / wire missing");
+        if (!wo->wire || reinterpret_cast<uintptr_t>(wo->slot_desc) % 16 != 0) return fail(PGLAMD_E_ARG, "aggregate_wire: wire missing or slot_desc not 16-byte aligned");
         if (dout != dx || y) return fail(PGLAMD_E_ARG, "aggregate_wire: plain send_u_recv rows only (no edge operand, no source-side broadcast)");
         if ((wo->scale || wo->scaled_out) && !std::is_floating_point_v<typename AccT<T>::type>)
             return fail(PGLAMD_E_DTYPE, "aggregate_wire: a wire scale needs a floating dtype");
@@ -936,7 +940,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
 
     AggParams p{};
     if (wo) {
-        p.wslot_ptr = wo->slot_ptr; p.wslot_pos = wo->slot_pos; p.wire = wo->wire; p.ldw = wo->ldw ? wo->ldw : dout;
+        p.wdesc = wo->slot_desc; p.wmore = wo->slot_more; p.wire = wo->wire; p.ldw = wo->ldw ? wo->ldw : dout;
         p.wscale = wo->scale; p.wscaled = wo->scaled_out; p.ldws = wo->ld_scaled ? wo->ld_scaled : dout;
         if (wo->split) {
             if (wo->split < 0 || wo->split >= dout || wo->split % 16 != 0 || !wo->wire2 || wo->ldw2 < 0)
@@ -1029,7 +1033,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
             const int64_t rb = (int64_t)((size_t)dout * sizeof(T));
             const bool narrow_ok = dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u;
             const int64_t gmin = (rcls == 1 || !narrow_ok) ? std::min<int64_t>(32, group_min_bytes()) : group_min_bytes();
-            if (ymode == 0 && !src_scale && !p.wslot_ptr && rb > gmin && rb <= group_row_bytes()) {
+            if (ymode == 0 && !src_scale && !p.wdesc && rb > gmin && rb <= group_row_bytes()) {
                 AggParams q = p;
                 q.j_base = 0; q.tile_cols = (int)dout;
                 bool handled = false;
@@ -1039,7 +1043,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         }
         // measured at C2 sizes: the lane-per-edge kernel wins up to 32 B of accumulator per row for every reduce op
         // (2.6-3.4x at d <= 8 fp32) and up to 64 B for sum / mean (1.3x at d = 16 fp32)
-        if (!p.wslot_ptr && dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {   // (the wire mirror lives in the flat kernel's stores)
+        if (!p.wdesc && dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {   // (the wire mirror lives in the flat kernel's stores)
             AggParams q = p;
             const int nk = std::max(K, narrow_chunk_edges());                   // fewer, longer chunks: the carved arrays still fit
             q.chunk = nk; q.n_chunks = (int)ceil_div(E, nk);
@@ -1063,7 +1067,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         if (fast) return PGLAMD_OK;
     }
     // generic fallback: rewrites every row < out_rows (rows without edges get 0)
-    if (p.wslot_ptr) return fail(PGLAMD_E_SHAPE, "aggregate_wire: this shape takes the generic kernel, which has no wire mirror");
+    if (p.wdesc) return fail(PGLAMD_E_SHAPE, "aggregate_wire: this shape takes the generic kernel, which has no wire mirror");
     p.tile_cols = (int)dout; p.j_base = 0;
     p.is_max = rop == PGLAMD_MAX ? 1 : rop == PGLAMD_MIN ? 2 : 0;
     if (src_scale || dst_scale) return fail(PGLAMD_E_SHAPE, "scales unsupported with this broadcast pattern");

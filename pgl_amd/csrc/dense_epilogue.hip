@@ -39,6 +39,8 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(const float* __res
     for (int64_t r = wave; r < n_rows; r += n_waves) {
         V v[NT];
         float ss = 0.f;
+        int4 dsc = {0, 0, 0, 0};
+        if (wo.slot_desc) dsc = *reinterpret_cast<const int4*>(wo.slot_desc + 4 * r);   // {count, p0, p1, p2}: issued with the row's own loads
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int j = (t * kWave + lane) * VEC;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(const float* __res
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = v[t].v[k] * inv;
                 *reinterpret_cast<V*>(y + r * d + j) = o;
-                if (wo.slot_ptr) {
+                if (wo.slot_desc) {
                     // the finished row is the next aggregation's input: its (scaled) copy goes straight into the halo send buffer
                     // (one store per peer that pulls the row) and, if asked for, into the dense scaled matrix the local edges read
                     if (wo.scale) {
@@ -77,12 +79,16 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(const float* __res
                         for (int k = 0; k < VEC; ++k) o.v[k] *= sc;
                     }
                     if (wo.scaled_out) *reinterpret_cast<V*>(static_cast<float*>(wo.scaled_out) + r * wo.ld_scaled + j) = o;
-                    const bool second = wo.split > 0 && j >= wo.split;          // (the column-pipelined exchange: two contiguous blocks)
-                    float* wb = static_cast<float*>(second ? wo.wire2 : wo.wire);
-                    const int64_t wl = second ? wo.ldw2 : wo.ldw;
-                    const int jw = second ? j - (int)wo.split : j;
-                    const int s0 = wo.slot_ptr[r], s1 = wo.slot_ptr[r + 1];
-                    for (int s = s0; s < s1; ++s) *reinterpret_cast<V*>(wb + (int64_t)wo.slot_pos[s] * wl + jw) = o;
+                    if (dsc.x > 0) {
+                        const bool second = wo.split > 0 && j >= wo.split;          // (the column-pipelined exchange: two contiguous blocks)
+                        float* wb = static_cast<float*>(second ? wo.wire2 : wo.wire) + (second ? j - (int)wo.split : j);
+                        const int64_t wl = second ? wo.ldw2 : wo.ldw;
+                        *reinterpret_cast<V*>(wb + (int64_t)dsc.y * wl) = o;
+                        if (dsc.x > 1) *reinterpret_cast<V*>(wb + (int64_t)dsc.z * wl) = o;
+                        if (dsc.x == 3) *reinterpret_cast<V*>(wb + (int64_t)dsc.w * wl) = o;
+                        else if (dsc.x > 3)
+                            for (int i = 0; i < dsc.x - 2; ++i) *reinterpret_cast<V*>(wb + (int64_t)wo.slot_more[dsc.w + i] * wl) = o;
+                    }
                 }
             }
         }
@@ -173,9 +179,9 @@ static int32_t row_epilogue_entry(const float* z, const float* bias, int64_t n_r
     if (n_rows < 0 || d <= 0 || !z || !y || (normalize && !inv_norm) || act < 0 || act > 1)
         return fail(PGLAMD_E_ARG, "row_epilogue: bad argument");
     pglamd_wire_out wo{};
-    if (wire && wire->slot_ptr) {
+    if (wire && wire->slot_desc) {
         wo = *wire;
-        if (!wo.slot_pos || !wo.wire || wo.ldw < 0 || wo.ld_scaled < 0 || (wo.scaled_out && !wo.scale))
+        if (!wo.wire || reinterpret_cast<uintptr_t>(wo.slot_desc) % 16 != 0 || wo.ldw < 0 || wo.ld_scaled < 0 || (wo.scaled_out && !wo.scale))
             return fail(PGLAMD_E_ARG, "row_epilogue_wire: incomplete wire descriptor");
         if (wo.split) {
             if (wo.split < 0 || wo.split >= d || wo.split % 16 != 0 || !wo.wire2 || wo.ldw2 < 0)

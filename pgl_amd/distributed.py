@@ -436,11 +436,11 @@ class _AllGatherRows(torch.autograd.Function):
 
 class Emission(object):
     """One fused pack: the ops.Wire a producing launch mirrors its rows into, and what identifies the tensor it produced."""
-    __slots__ = ("graph", "kind", "wire", "epoch", "scale", "piped", "d", "dtype", "version", "shape")
+    __slots__ = ("graph", "kind", "wire", "wire_first", "epoch", "scale", "piped", "d", "dtype", "version", "shape")
 
     def __init__(self, graph, kind, wire, epoch, scale, piped, d, dtype):
         self.graph, self.kind, self.wire, self.epoch, self.scale, self.piped, self.d, self.dtype = graph, kind, wire, epoch, scale, piped, d, dtype
-        self.version, self.shape = None, None
+        self.version, self.shape, self.wire_first = None, None, wire
 
 
 def _version_of(t):
@@ -777,12 +777,14 @@ class DistGraph(object):
         d, dev = int(like.shape[1]), like.device
         key = "wslots" + kind
         slots = self._idx.get(key)
-        if slots is None:                                            # CSR over owned rows -> their positions in the send buffer
+        if slots is None:
+            # per owned row: its positions in the send buffer ({count, p0, p1, p2} records, ops.wire_slots).  Two sets: `all`, and
+            # `first` with the rows that also receive remote edges emptied -- in the two-launch flows that store such a row twice
+            # (accumulate, pipeline) only the second store is the final value, so only that launch mirrors it
             cols = xp.send_cols.to(dev)
-            order = torch.argsort(cols, stable=True)
-            ptr = torch.zeros(p.n_own + 1, dtype=torch.int64, device=dev)
-            ptr[1:] = torch.cumsum(torch.bincount(cols, minlength=p.n_own), 0)
-            slots = self._idx[key] = (ptr.to(torch.int32), order.to(torch.int32))
+            d_all, more = ops.wire_slots(cols, p.n_own)
+            d_first, _ = ops.wire_slots(cols, p.n_own, drop_rows=torch.unique(xp.recv_rows.to(dev)))
+            slots = self._idx[key] = (d_all, d_first, more)
         row_bytes = d * like.element_size()
         piped = self._pipelined(kind, False, True, like, row_bytes)
         self._emit_epoch = getattr(self, "_emit_epoch", 0) + 1
@@ -796,8 +798,10 @@ class DistGraph(object):
             bufs, split = (self._buffer("emit%s%d" % (kind, par), (xp.n_send, d), like.dtype, dev), None), 0
         sc = None if scale is None else scale.reshape(-1).contiguous()
         so = self._buffer("emits%s%d" % (kind, par), (p.n_own, d), like.dtype, dev) if (scaled and sc is not None) else None
-        w = ops.Wire(slots[0], slots[1], bufs[0], sc, so, bufs[1], split)
-        return Emission(self, kind, w, self._emit_epoch, scale, piped, d, like.dtype)
+        w = ops.Wire(slots[0], slots[2], bufs[0], sc, so, bufs[1], split)
+        em = Emission(self, kind, w, self._emit_epoch, scale, piped, d, like.dtype)
+        em.wire_first = w.with_desc(slots[1])
+        return em
 
     def can_wire(self, d, dtype, kind="x"):
         """True when wire() would hand out an emission for [n_own, d] rows of `dtype` (no side effects)."""
@@ -914,12 +918,13 @@ class DistGraph(object):
         row_bytes = max(1, x.element_size() * int(np.prod(tail)) if tail else x.element_size())
         if transposed or post is not None or not additive:
             emit_in = emit_out = None
-        wo = None if emit_out is None else emit_out.wire             # every launch that stores output rows mirrors them
+        wo = None if emit_out is None else emit_out.wire             # every launch that stores output rows mirrors them ...
+        wo1 = None if emit_out is None else emit_out.wire_first      # ... but a row two launches store is mirrored by the second only
         piped = p.world > 1 and self._pipelined(kind, transposed, additive, x, row_bytes)
         if emit_in is not None and bool(emit_in.piped) != bool(piped):
             emit_in = None                                           # (cannot happen for one plan and row width; be safe)
         if wo is not None and bool(emit_out.piped) != bool(piped):
-            wo = None
+            wo = wo1 = None
         if piped:
             # COLUMN-PIPELINED (all ranks agreed on it): the rows travel in two column blocks, one all-to-all-v each.  While block
             # 0 is on the wire block 1 is packed and the local-source edges run; the received rows' edges of block 0 are added
@@ -929,7 +934,7 @@ class DistGraph(object):
             h = (d // 2 + 15) // 16 * 16
             blocks = [(0, h), (h, d)]
             started = [self._start_exchange(x, kind, transposed, cols=c, emit=emit_in) for c in blocks]
-            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo))
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo1))
             recv = kind + ("send_t" if transposed else "recv")
             for st, (c0, c1) in zip(started, blocks):
                 if st is None:
@@ -962,7 +967,7 @@ class DistGraph(object):
         elif mode == "accumulate":
             # most edges are local, most rows have a few remote sources: ALL local-source edges run under the exchange, the
             # received rows' edges are added on top afterwards (their rows are read-modify-written)
-            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo))
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo1))
             work, in_buf, unpack = started
             work.wait()
             if unpack is not None:

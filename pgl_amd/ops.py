@@ -272,17 +272,52 @@ def _row_strided(t):
     return t.dim() == 2 and t.shape[1] > 0 and t.stride(1) == 1 and t.stride(0) > t.shape[1] and not t.is_contiguous()
 
 
+def wire_slots(row_of_pos, n_rows, drop_rows=None):
+    """Slot descriptors of pglamd_wire_out from `row_of_pos` (send-buffer position i holds output row row_of_pos[i]):
+    -> (desc int32 [n_rows, 4] = {count, p0, p1, p2}, more int32 [*]): count <= 3 -> the positions themselves; count > 3 -> p0, p1 and
+    more[p2 : p2 + count - 2].  drop_rows: rows whose descriptor is emptied (count 0) -- rows a LATER launch of the same flow
+    stores again, so that only their last store is mirrored."""
+    dev = row_of_pos.device
+    cols = row_of_pos.long()
+    order = torch.argsort(cols, stable=True)
+    cnt = torch.bincount(cols, minlength=n_rows)
+    start = torch.cumsum(cnt, 0) - cnt
+    desc = torch.zeros((n_rows, 4), dtype=torch.int64, device=dev)
+    desc[:, 0] = cnt
+    n_pos = int(order.shape[0])
+    pad = torch.cat([order, order.new_zeros(3)]) if n_pos else order.new_zeros(3)
+    for k in range(3):
+        desc[:, 1 + k] = torch.where(cnt > k, pad[(start + k).clamp(max=n_pos + 2)], torch.zeros_like(cnt))
+    big = cnt > 3
+    more = torch.zeros(1, dtype=torch.int32, device=dev)
+    if bool(big.any()):
+        extra = (cnt - 2) * big
+        off = torch.cumsum(extra, 0) - extra
+        desc[:, 3] = torch.where(big, off, desc[:, 3])
+        rows_big = torch.nonzero(big).reshape(-1)
+        rep = torch.repeat_interleave(rows_big, extra[rows_big])
+        within = torch.arange(int(rep.shape[0]), device=dev) - off[rep]
+        more = order[start[rep] + 2 + within].to(torch.int32).contiguous()
+    if drop_rows is not None:
+        desc[drop_rows.long(), 0] = 0
+    return desc.to(torch.int32).contiguous(), more
+
+
 class Wire(object):
     """Where a producing launch mirrors its finished rows (struct pglamd_wire_out): `buf` = the halo send buffer of the NEXT
     aggregation ([n_send, d]; or, for the column-pipelined exchange, `buf` = columns [0, split) and `buf2` = columns [split, d) as
-    two contiguous buffers), `ptr32` / `pos32` = CSR over output rows listing each row's slots in it, `scale` (optional fp32
-    [n_rows]) = multiplier of the wire copy, `scaled_out` (optional [n_rows, d]) = dense copy of the scaled rows.
+    two contiguous buffers), `desc` / `more` = per-row slot descriptors (wire_slots), `scale` (optional fp32 [n_rows]) =
+    multiplier of the wire copy, `scaled_out` (optional [n_rows, d]) = dense copy of the scaled rows.
     Built by pgl_amd.distributed.DistGraph.wire()."""
-    __slots__ = ("ptr32", "pos32", "buf", "scale", "scaled_out", "buf2", "split")
+    __slots__ = ("desc", "more", "buf", "scale", "scaled_out", "buf2", "split")
 
-    def __init__(self, ptr32, pos32, buf, scale=None, scaled_out=None, buf2=None, split=0):
-        self.ptr32, self.pos32, self.buf, self.scale, self.scaled_out = ptr32, pos32, buf, scale, scaled_out
+    def __init__(self, desc, more, buf, scale=None, scaled_out=None, buf2=None, split=0):
+        self.desc, self.more, self.buf, self.scale, self.scaled_out = desc, more, buf, scale, scaled_out
         self.buf2, self.split = buf2, int(split)
+
+    def with_desc(self, desc):
+        """The same buffers under other slot descriptors (the first launch of a two-launch flow mirrors only the rows it finishes)."""
+        return Wire(desc, self.more, self.buf, self.scale, self.scaled_out, self.buf2, self.split)
 
     def block(self, c0, c1):
         """The wire of a launch that writes only columns [c0, c1) of the rows (the pipelined flow aggregates block by block)."""
@@ -295,14 +330,14 @@ class Wire(object):
                 raise ValueError("wire: column block [%d, %d) does not match the split at %d" % (c0, c1, self.split))
         else:
             buf = self.buf[:, c0:c1]
-        return Wire(self.ptr32, self.pos32, buf, self.scale, None if self.scaled_out is None else self.scaled_out[:, c0:c1])
+        return Wire(self.desc, self.more, buf, self.scale, None if self.scaled_out is None else self.scaled_out[:, c0:c1])
 
     def struct(self, d):
         for t, w in ((self.buf, self.split or d), (self.scaled_out, d), (self.buf2, d - self.split)):
             if t is not None and not (t.dim() == 2 and int(t.shape[1]) == w and t.stride(1) == 1):
                 raise ValueError("wire: buffers must be [rows, %d] with contiguous rows (got %s)" % (w, tuple(t.shape)))
         p = lambda t: None if t is None else t.data_ptr()
-        return _ffi.WireOut(p(self.ptr32), p(self.pos32), p(self.buf), int(self.buf.stride(0)), p(self.scale), p(self.scaled_out),
+        return _ffi.WireOut(p(self.desc), p(self.more), p(self.buf), int(self.buf.stride(0)), p(self.scale), p(self.scaled_out),
                             0 if self.scaled_out is None else int(self.scaled_out.stride(0)),
                             p(self.buf2), 0 if self.buf2 is None else int(self.buf2.stride(0)), self.split)
 

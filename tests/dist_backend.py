@@ -30,18 +30,23 @@ class TorchBackend(object):
         (`written`) goes -- times wire.scale -- to its slots of the send buffer (two buffers when the descriptor is split) and to
         the dense scaled copy.  Slots of rows that were not stored keep their contents."""
         n_rows = int(values.shape[0])
-        ptr, pos = wire.ptr32.long(), wire.pos32.long()
-        row_of_slot = torch.repeat_interleave(torch.arange(n_rows), ptr[1:] - ptr[:-1])
-        sel = written[row_of_slot]
-        r = row_of_slot[sel]
+        desc, more = wire.desc.long(), wire.more.long()
+        rows, poss = [], []
+        for r in torch.nonzero(written & (desc[:, 0] > 0)).reshape(-1).tolist():   # {count, p0, p1, p2}: include/pgl_amd.h
+            c = int(desc[r, 0])
+            ps = desc[r, 1:1 + c].tolist() if c <= 3 else desc[r, 1:3].tolist() + more[int(desc[r, 3]):int(desc[r, 3]) + c - 2].tolist()
+            rows += [r] * c
+            poss += ps
+        r = torch.tensor(rows, dtype=torch.long)
+        pos = torch.tensor(poss, dtype=torch.long)
         v = values[r]
         if wire.scale is not None:
             v = v * wire.scale[r].reshape(-1, 1).to(v.dtype)
         if wire.split:
-            wire.buf[pos[sel]] = v[:, :wire.split]
-            wire.buf2[pos[sel]] = v[:, wire.split:]
+            wire.buf[pos] = v[:, :wire.split]
+            wire.buf2[pos] = v[:, wire.split:]
         else:
-            wire.buf[pos[sel]] = v
+            wire.buf[pos] = v
         if wire.scaled_out is not None:
             wire.scaled_out[written] = values[written] * wire.scale[written].reshape(-1, 1).to(values.dtype)
 

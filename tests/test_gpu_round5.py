@@ -179,9 +179,7 @@ def test_degree_norm_cache_follows_the_graph(pgl):
     a = pgl.nn.functional.degree_norm(g)
     assert pgl.nn.functional.degree_norm(g) is a
     g.numpy(inplace=True)
-    assert getattr(g, "_degree_norm_cache", None) is None
-    h = pgl.nn.functional.degree_norm(g)
-    assert isinstance(h, np.ndarray) or not h.is_cuda
+    assert getattr(g, "_degree_norm_cache", None) is None               # (degree_norm itself is a device op: no numpy-mode form)
     g.tensor(inplace=True)
     b = pgl.nn.functional.degree_norm(g)
     assert b is not a and torch.equal(a, b)
@@ -256,21 +254,38 @@ def test_abi_edge_operand_e1_mul_reroute_equals_the_general_path(pgl, accumulate
 # the fused pack: pglamd_aggregate_wire / pglamd_row_epilogue_wire -- every row a launch stores also lands in
 # its slots of the next aggregation's halo send buffer.  Kernel-level contract here; the multi-rank flow in test_gpu_distributed.py
 # ------------------------------------------------------------------------------------------------
-def _random_slots(rng, n_rows, n_slots_max=3):
-    """CSR over rows -> wire positions: row r has 0..n_slots_max slots, positions are a permutation of [0, total)."""
+def _random_slots(rng, n_rows, n_slots_max=5):
+    """row_of_pos: send-buffer position i holds output row row_of_pos[i]; every row has 0..n_slots_max positions (more than three
+    exercises the overflow list of the slot descriptors), positions shuffled."""
     cnt = rng.integers(0, n_slots_max + 1, n_rows)
-    ptr = np.zeros(n_rows + 1, np.int32); ptr[1:] = np.cumsum(cnt)
-    pos = rng.permutation(int(ptr[-1])).astype(np.int32)
-    return ptr, pos
+    return rng.permutation(np.repeat(np.arange(n_rows), cnt)).astype(np.int64)
 
 
-def _mirror_reference(ptr, pos, written, values, scale, buf):
+def _mirror_reference(row_of_pos, written, values, scale, buf):
     """what the wire must hold afterwards: slots of stored rows = scale[r] * row, all other slots untouched"""
     want = buf.copy()
-    for r in np.nonzero(written)[0]:
-        for s in range(ptr[r], ptr[r + 1]):
-            want[pos[s]] = values[r] * (1.0 if scale is None else scale[r])
+    sel = written[row_of_pos]
+    r = row_of_pos[sel]
+    want[sel] = values[r] * (1.0 if scale is None else scale[r][:, None])
     return want
+
+
+def test_wire_slot_descriptors(pgl):
+    rng = np.random.default_rng(0)
+    n = 3000
+    rop = _random_slots(rng, n, 7)
+    desc, more = pgl.ops.wire_slots(dev(rop), n, drop_rows=dev(np.array([5, 6, 7], np.int64)))
+    desc, more = host(desc), host(more)
+    assert desc.shape == (n, 4) and desc.dtype == np.int32
+    for r in range(n):
+        want = np.sort(np.nonzero(rop == r)[0])
+        c = desc[r, 0]
+        if r in (5, 6, 7):
+            assert c == 0
+            continue
+        assert c == len(want)
+        got = list(desc[r, 1:1 + c]) if c <= 3 else list(desc[r, 1:3]) + list(more[desc[r, 3]:desc[r, 3] + c - 2])
+        assert sorted(got) == list(want), r
 
 
 @pytest.mark.parametrize("d,dt", [(128, torch.float32), (64, torch.float32), (100, torch.float32), (8, torch.float32), (256, torch.float32),
@@ -289,8 +304,9 @@ def test_aggregate_wire_mirror_contract(pgl, d, dt, mode):
     x = rng.standard_normal((n, d)).astype(np.float32)
     xt = dev(x).to(dt)
     csr = ops.csr_build(dev(dst), dev(src), n, want_i64=False)
-    ptr, pos = _random_slots(rng, n)
-    n_wire = int(ptr[-1])
+    rop = _random_slots(rng, n)
+    n_wire = len(rop)
+    desc, more = ops.wire_slots(dev(rop), n)
     scale = (rng.random(n).astype(np.float32) + 0.5) if mode == "scaled" else None
     split = ((d // 2 + 15) // 16 * 16) if mode == "split" else 0
     sentinel = -777.0
@@ -298,7 +314,7 @@ def test_aggregate_wire_mirror_contract(pgl, d, dt, mode):
     b0 = torch.full((n_wire, split), sentinel, dtype=dt, device="cuda") if split else None
     b1 = torch.full((n_wire, d - split), sentinel, dtype=dt, device="cuda") if split else None
     so = torch.full((n, d), sentinel, dtype=dt, device="cuda") if scale is not None else None
-    wire = ops.Wire(dev(ptr), dev(pos), b0 if split else buf, None if scale is None else dev(scale), so, b1, split)
+    wire = ops.Wire(desc, more, b0 if split else buf, None if scale is None else dev(scale), so, b1, split)
     has = np.bincount(dst, minlength=n) > 0
     before = rng.standard_normal((n, d)).astype(np.float32)
     kw, written = {}, np.ones(n, bool)
@@ -322,7 +338,7 @@ def test_aggregate_wire_mirror_contract(pgl, d, dt, mode):
         assert np.array_equal(got_out, host(plain.float())), "the mirror must not change the result"
     vals = got_out                                                          # the wire holds exactly what went to `out` (times scale)
     wbuf = host((torch.cat([b0, b1], 1) if split else buf).float())
-    want = _mirror_reference(ptr, pos, written, vals, scale, np.full((n_wire, d), sentinel, np.float32))
+    want = _mirror_reference(rop, written, vals, scale, np.full((n_wire, d), sentinel, np.float32))
     if scale is None:
         assert np.array_equal(wbuf, want)
     else:
@@ -345,21 +361,22 @@ def test_row_epilogue_wire_mirror_contract(pgl, d, split, scaled):
     n = 7000
     z = rng.standard_normal((n, d)).astype(np.float32)
     bias = rng.standard_normal(d).astype(np.float32)
-    ptr, pos = _random_slots(rng, n)
-    n_wire = int(ptr[-1])
+    rop = _random_slots(rng, n)
+    n_wire = len(rop)
+    desc, more = ops.wire_slots(dev(rop), n)
     scale = (rng.random(n).astype(np.float32) + 0.5) if scaled else None
     sentinel = -777.0
     b0 = torch.full((n_wire, split or d), sentinel, device="cuda")
     b1 = torch.full((n_wire, d - split), sentinel, device="cuda") if split else None
     so = torch.full((n, d), sentinel, device="cuda") if scaled else None
-    wire = ops.Wire(dev(ptr), dev(pos), b0, None if scale is None else dev(scale), so, b1, split)
+    wire = ops.Wire(desc, more, b0, None if scale is None else dev(scale), so, b1, split)
     y, inv = ops.row_epilogue(dev(z), dev(bias), "relu", True, wire=wire)
     y0, _ = ops.row_epilogue(dev(z), dev(bias), "relu", True)
     assert torch.equal(y, y0)
     want_y = np.maximum(z + bias, 0.0); want_y = want_y / np.maximum(np.linalg.norm(want_y, axis=1, keepdims=True), 1e-12)
     np.testing.assert_allclose(host(y), want_y, rtol=1e-5, atol=1e-6)
     wbuf = host(torch.cat([b0, b1], 1) if split else b0)
-    want = _mirror_reference(ptr, pos, np.ones(n, bool), host(y), scale, np.full((n_wire, d), sentinel, np.float32))
+    want = _mirror_reference(rop, np.ones(n, bool), host(y), scale, np.full((n_wire, d), sentinel, np.float32))
     np.testing.assert_allclose(wbuf, want, rtol=1e-6, atol=1e-7)
     if scaled:
         np.testing.assert_allclose(host(so), host(y) * scale[:, None], rtol=1e-6, atol=1e-7)
