@@ -194,9 +194,10 @@ int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int
  *                      chain through a CSR (which cost more than the pack launch it replaced: profiles/r05)
  *   wire, ldw          the send buffer [n_wire_rows, ldw] in the SAME dtype as out (ldw elements per row, 0 = row length);
  *                      for a column-block launch pass the address of the block's first column, as for out
- *   scale              optional fp32 [out_rows] (floating dtypes): the wire copy is scale[r] * row -- GCN's source-side degree
- *                      norm of the next layer (pgl/nn/conv.py:242) applied while the row is in registers
- *   scaled_out, ld_scaled   optional dense [out_rows, ld_scaled] copy of scale[r] * row: what the next layer's LOCAL edges read
+ *   scale              optional fp32 [out_rows]: the wire copy is scale[r] * row -- GCN's source-side degree norm of the next
+ *                      layer (pgl/nn/conv.py:242) applied while the row is in registers       } pglamd_row_epilogue_wire only:
+ *   scaled_out, ld_scaled   optional dense [out_rows, ld_scaled] copy of scale[r] * row: what  } pglamd_aggregate_wire refuses them
+ *                      the next layer's LOCAL edges read                                       } (its store paths are short of SGPRs)
  *   wire2, ldw2, split      optional: columns [split, d) of every row go to a second buffer (at column j - split)
  * The mirror follows every store to `out`: with accumulate 0 all rows the launch writes (zero-filled ones included, as
  * zeros), with accumulate 1 / 2 the rows that receive edges -- a sequence of launches that together finalise `out` (interior

@@ -50,9 +50,6 @@ struct AggParams {
     void* wire;                           // [n_wire_rows, ldw], same element type as out, ALREADY offset to this launch's column block
     int64_t ldw;
     void* wire2; int64_t ldw2; int wsplit;   // columns >= wsplit (of the whole row) go to wire2 at column (j - wsplit); wsplit 0 = one buffer
-    const float* wscale;                  // optional [out_rows]: the wire (and wscaled) copies hold wscale[r] * row
-    void* wscaled;                        // optional dense [out_rows, ldws] copy of wscale[r] * row (the next layer's local-edge input)
-    int64_t ldws;
 };
 
 // true when this launch can leave split-row partials behind (=> the counter reset and the two fix-up launches are needed)
@@ -84,17 +81,10 @@ __device__ __forceinline__ WDesc wire_desc(const int* wdesc, int64_t r) {
 // slots and, if asked for, into the scaled dense copy.  Called from the store paths only (once per row and tile).
 // Q: a pointer to the launch parameters (generic or constant address space).
 template <typename T, int VEC, typename Q, typename VT>
-__device__ __forceinline__ void wire_mirror(Q q, const WDesc& dsc, int64_t r, int j, const VT& o) {
-    VT w = o;
-    if constexpr (std::is_floating_point_v<typename AccT<T>::type>) {
-        const float* ws = q->wscale;
-        if (ws) {
-            const float s = ws[r];
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) w.v[k] = from_acc<T>(to_acc<T>(o.v[k]) * (typename AccT<T>::type)s);
-        }
-    }
-    if (q->wscaled) *reinterpret_cast<VT*>(static_cast<T*>(q->wscaled) + r * q->ldws + j) = w;
+__device__ __forceinline__ void wire_mirror(Q q, const WDesc& dsc, int64_t r, int j, const VT& w) {
+    // (no scale / scaled dense copy here: the aggregation kernels' store paths are short of SGPRs -- every pointer this touches is
+    //  re-read from the kernarg segment at the store and still counts towards the kernel's allocation; the row kernel that ends a
+    //  conv layer, pglamd_row_epilogue_wire, has both)
     if (dsc.n <= 0) return;
     const int split = q->wsplit;
     const bool second = split > 0 && j >= split;          // column-pipelined exchange: columns >= split live in the second buffer

@@ -927,9 +927,8 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     if (wo) {
         if (!wo->wire || reinterpret_cast<uintptr_t>(wo->slot_desc) % 16 != 0) return fail(PGLAMD_E_ARG, "aggregate_wire: wire missing or slot_desc not 16-byte aligned");
         if (dout != dx || y) return fail(PGLAMD_E_ARG, "aggregate_wire: plain send_u_recv rows only (no edge operand, no source-side broadcast)");
-        if ((wo->scale || wo->scaled_out) && !std::is_floating_point_v<typename AccT<T>::type>)
-            return fail(PGLAMD_E_DTYPE, "aggregate_wire: a wire scale needs a floating dtype");
-        if (wo->scaled_out && !wo->scale) return fail(PGLAMD_E_ARG, "aggregate_wire: scaled_out without scale");
+        if (wo->scale || wo->scaled_out)
+            return fail(PGLAMD_E_ARG, "aggregate_wire: scale / scaled_out belong to pglamd_row_epilogue_wire (the aggregation mirrors rows as they are)");
     }
     if (E == 0) {
         if (accumulate) return PGLAMD_OK;
@@ -941,7 +940,6 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     AggParams p{};
     if (wo) {
         p.wdesc = wo->slot_desc; p.wmore = wo->slot_more; p.wire = wo->wire; p.ldw = wo->ldw ? wo->ldw : dout;
-        p.wscale = wo->scale; p.wscaled = wo->scaled_out; p.ldws = wo->ld_scaled ? wo->ld_scaled : dout;
         if (wo->split) {
             if (wo->split < 0 || wo->split >= dout || wo->split % 16 != 0 || !wo->wire2 || wo->ldw2 < 0)
                 return fail(PGLAMD_E_ARG, "aggregate_wire: split must be a multiple of 16 inside the row, with a second buffer");
@@ -984,10 +982,9 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     int vmax = max_vec<T>();
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
                                  (y && gy == 1 ? reinterpret_cast<uintptr_t>(y) : 0) |
-                                 reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(p.wire) | reinterpret_cast<uintptr_t>(p.wscaled) |
-                                 reinterpret_cast<uintptr_t>(p.wire2);
+                                 reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(p.wire) | reinterpret_cast<uintptr_t>(p.wire2);
     while (vmax > 1 && (dout % vmax != 0 || ldx % vmax != 0 || ldo % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0 ||
-                        (p.wire && p.ldw % vmax != 0) || (p.wscaled && p.ldws % vmax != 0) || (p.wire2 && p.ldw2 % vmax != 0))) vmax >>= 1;
+                        (p.wire && p.ldw % vmax != 0) || (p.wire2 && p.ldw2 % vmax != 0))) vmax >>= 1;
     int ymode = 0;
     if (y) {
         if (gy == 1) ymode = 2;

@@ -1081,14 +1081,14 @@ class DistGraph(object):
             self._idx[key] = hit
         return hit
 
-    def _sum_like(self, x_own, reduce_func, extra_dst_scale=None, emit_in=None, emit=False, emit_scale=None, emit_scaled=False):
+    def _sum_like(self, x_own, reduce_func, extra_dst_scale=None, emit_in=None, emit=False):
         """emit_in: the valid Emission of x_own (its rows already sit in the send buffer: no pack).  emit: mirror the OUTPUT rows
-        into the send buffer of the next aggregation (times emit_scale) and tag the result."""
+        into the send buffer of the next aggregation and tag the result."""
         scale = self._scale(reduce_func)
         if extra_dst_scale is not None:
             scale = extra_dst_scale if scale is None else scale * extra_dst_scale
         x_own = x_own.contiguous()
-        emit_out = self.wire(x_own, emit_scale, emit_scaled) if emit else None
+        emit_out = self.wire(x_own) if emit else None
         if torch.is_grad_enabled() and x_own.requires_grad:
             out = _HaloAggregate.apply(x_own, self, scale, emit_in, emit_out)
             if emit_out is not None and emit_out.version is not None:
@@ -1242,12 +1242,13 @@ class DistGraph(object):
         return self.local_graph.recv(reduce_func, msg, recv_mode)[:self.plan.n_own]
 
     # ---- engine extensions the pgl_amd.nn layers look for ---------------------------------------------------------------
-    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None, emit=False, emit_scale=None):
+    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None, emit=False):
         """out[v] = dst_scale[v] * sum_{u->v} src_scale[u] * feature[u] (GCN's symmetric norm, pgl/nn/conv.py:242-250): the
         source scale is applied to the owned rows before they travel, the destination scale inside the kernels.
-        A `feature` that carries an emission made with THIS src_scale (DistGraph.wire(..., scale=src_scale, scaled=True): the layer
-        that produced it wrote scale * row into the send buffer and into a dense scaled copy) needs neither the scaling pass nor the
-        pack.  emit / emit_scale: mirror the result (times emit_scale, keeping the dense scaled copy) for the next aggregation."""
+        A `feature` that carries an emission made with THIS src_scale (DistGraph.wire(..., scale=src_scale, scaled=True): the row
+        kernel that finished the previous layer wrote scale * row into the send buffer and into a dense scaled copy) needs neither
+        the scaling pass nor the pack.  emit: mirror the result's rows AS THEY ARE for the next aggregation (a propagation chain
+        h <- norm * A (norm * h) runs as g <- norm^2 * A g on g = norm * h: no source scale, so every step can feed the next)."""
         em = self._emission_of(feature, "x", src_scale) if src_scale is not None else self._emission_of(feature, "x")
         if src_scale is not None:
             if em is not None and em.wire.scaled_out is not None and not (torch.is_grad_enabled() and feature.requires_grad):
@@ -1257,8 +1258,7 @@ class DistGraph(object):
                 #  skipped all the same)
                 feature = feature * src_scale.reshape((-1,) + (1,) * (feature.dim() - 1)).to(feature.dtype)
         ds = None if dst_scale is None else dst_scale.reshape(-1).to(torch.float32).contiguous()
-        return self._sum_like(feature, "sum", extra_dst_scale=ds, emit_in=em, emit=emit, emit_scale=emit_scale,
-                              emit_scaled=emit_scale is not None)
+        return self._sum_like(feature, "sum", extra_dst_scale=ds, emit_in=em, emit=emit)
 
     def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2, attn_drop=0.0, seed=0):
         """The fused GAT attention of Graph.gat_aggregate over the partitioned graph: a_src rides with the halo feature

@@ -145,6 +145,7 @@ def cmd_rows(args):
         choice = HaloPlan.choose_push(pull_c, push_c) if args.push == "auto" else torch.zeros((P, P), dtype=torch.bool)
         print("P=%d partition %s (%.1f s), edge cut %.3f, %d of %d pairs push, wire %s" % (P, how, tp, cut, int(choice.sum()), P * (P - 1), args.wire or "fp32"))
         worst, rows, preds, chains = {"compute": 0.0, "pair_mb": 0.0, "ratio": 0.0}, [], [], []
+        stack_layers = None
         for r in range(P):
             plan = HaloPlan(edges, N, part, r, P)
             xplan = HaloPlan(edges, N, part, r, P, push=choice) if bool(choice.any()) else plan
@@ -163,6 +164,23 @@ def cmd_rows(args):
             k0 = getattr(dg, "_packs_skipped", 0)
             ms_chain = _t(chained, it=10, warm=3)
             fused_ok = getattr(dg, "_packs_skipped", 0) - k0 >= 12
+            # a conv-layer stack (3 x GraphSageConv(d, d, mean), inference): the row kernel that finishes a layer writes its rows into
+            # the next layer's send buffer (pglamd_row_epilogue_wire) -- against the same stack with a pack launch per layer
+            if stack_layers is None:
+                torch.manual_seed(0)
+                stack_layers = [pgl.nn.GraphSageConv(d, d, "mean").to(dev) for _ in range(3)]
+            def stack():
+                h = x_own
+                for L in stack_layers:
+                    h = L(dg, h, act="relu")
+                return h
+            with torch.no_grad():
+                dg.emit_outputs = False
+                ms_stack_pack = _t(stack, it=6, warm=2)
+                dg.emit_outputs = True
+                k1 = getattr(dg, "_packs_skipped", 0)
+                ms_stack_fused = _t(stack, it=6, warm=2)
+                stack_ok = getattr(dg, "_packs_skipped", 0) - k1 >= 2 * 8
             torch.cuda.synchronize()
             t_cpu = time.perf_counter()
             for _ in range(20):
@@ -222,7 +240,7 @@ def cmd_rows(args):
                 pred = predict(xch, 0.0)
             ideal = plan.local_edges / (E / t1)
             rows.append((r, plan.n_own, plan.local_edges, e_pre, e_post, xplan.n_send, xplan.n_recv, ms, pk, pre, post, ideal, pair_mb, enq, mode, pred))
-            chains.append((r, ms_mean, ms_chain, ideal, fused_ok))
+            chains.append((r, ms_mean, ms_chain, ideal, fused_ok, ms_stack_pack, ms_stack_fused, stack_ok))
             preds.append((predict, xch))
             worst["compute"] = max(worst["compute"], ms); worst["pair_mb"] = max(worst["pair_mb"], pair_mb)
             worst["ratio"] = max(worst["ratio"], ms / ideal); worst["pred"] = max(worst.get("pred", 0.0), pred)
@@ -232,9 +250,11 @@ def cmd_rows(args):
                   % (r, n_own, le, mode, e_pre, e_post, ns, nr, pmb, ms, enq, pk, pre, post, ideal, ms / ideal, pred))
         print("   layers >= 2 (input = the previous step's output; its rows were mirrored into the send buffer by the launches that "
               "produced them: no pack):")
-        for r, mm, mc, ideal, ok in chains:
-            print("   rank %d: mean step with pack %.3f ms | chained step, fused pack %.3f ms (%s) | ideal %.3f ms -> x%.2f"
-                  % (r, mm, mc, "pack skipped every step" if ok else "PACK NOT SKIPPED", ideal, mc / ideal))
+        for r, mm, mc, ideal, ok, sp, sf, sok in chains:
+            print("   rank %d: mean step with pack %.3f ms | chained step, aggregation mirrors its rows %.3f ms (%s) | ideal %.3f ms -> x%.2f || "
+                  "3 x GraphSageConv forward: pack per layer %.3f ms | row kernel mirrors its rows %.3f ms (%s)"
+                  % (r, mm, mc, "pack skipped every step" if ok else "PACK NOT SKIPPED", ideal, mc / ideal, sp, sf,
+                     "layers 2, 3 without pack" if sok else "PACK NOT SKIPPED"))
         wc = max(c[2] for c in chains)
         print("   slowest rank, layers >= 2: compute %.3f ms (worst compute/ideal x%.2f) -> bound %.2fx of one GPU with the exchange fully hidden"
               % (wc, max(c[2] / c[3] for c in chains), t1 / wc))

@@ -729,12 +729,14 @@ def _chain_worker(rank, world, steps, scaled, grad):
     deg = dg.indegree().clamp(min=1).to(torch.float32)
     norm = deg.pow(-0.5).reshape(-1, 1)
     outs = []
+    if scaled:                                              # GCN-style propagation h <- norm * A (norm * h), run on g = norm * h:
+        h = h * norm                                        # g <- norm^2 * A g (no source scale: every step's rows feed the next as they are)
     for k in range(steps):
-        if scaled:                                          # GCN-style propagation: norm * A (norm * h), the next step's norm * h mirrored
-            h = dg.send_recv_scaled(h, norm, norm, emit=True, emit_scale=norm)
+        if scaled:
+            h = dg.send_recv_scaled(h, None, norm * norm, emit=True)
         else:
             h = dg.send_recv(h, "mean", emit=True)
-        outs.append(h.detach().numpy().copy())
+        outs.append((h / norm if scaled else h).detach().numpy().copy())
     skipped = getattr(dg, "_packs_skipped", 0)
     flow = dg.stats()["flow"]
     # a tensor that was written to after it was produced must NOT be taken for its mirrored copy
@@ -743,7 +745,8 @@ def _chain_worker(rank, world, steps, scaled, grad):
     tampered = dg.send_recv(h2, "mean").numpy()
     g = None
     if grad:
-        (h * h).sum().backward()
+        hh = h / norm if scaled else h
+        (hh * hh).sum().backward()
         g = h0.grad.numpy()
     return (rank, dg.plan.own_global.numpy(), {"outs": outs, "skipped": skipped, "flow": flow, "tampered": tampered, "grad": g,
                                                  "tampered_in": outs[-2]})
@@ -751,7 +754,7 @@ def _chain_worker(rank, world, steps, scaled, grad):
 
 @pytest.mark.parametrize("world,flow,scaled,grad", [(2, "", False, False), (3, "fold", False, False), (2, "accumulate", True, False),
                                                     (3, "split", True, False), (2, "pipeline", False, False), (3, "pipeline", True, False),
-                                                    (2, "split", False, True), (2, "pipeline", True, True)])
+                                                    (2, "split", False, True), (2, "pipeline", True, True), (3, "split", False, True), (3, "accumulate", True, True)])
 def test_gloo_fused_pack_chain(monkeypatch, world, flow, scaled, grad):
     """h <- A h four times with emit=True: every step after the first starts its exchange from rows the previous step's launches
     mirrored into the send buffer (no pack), under every flow; the values equal the single-graph chain, the gradient too."""

