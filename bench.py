@@ -530,6 +530,22 @@ def main():
             halo.update(exchange_only_ms=t_x, recv_bytes_per_rank=allp[:, 0].tolist(), send_bytes_per_rank=allp[:, 1].tolist(),
                         flow=dg.stats()["flow"])                     # the flow that RAN: DESIGN section 5
             wd.end()
+            # per-rank compute phases (pack / work before the wait / work after it), each alone, no collective: the line can then be
+            # read against the single-GPU per-rank measurements of scripts/prof.py rows (profiles/r04, r05 rows_c2p.txt) column by
+            # column, and the cost model's constants (_LINK, _LAT, _RMW) calibrated from exchange_only_ms and these
+            wd.begin("per-rank phases", lim)
+            try:
+                ph = dg.phase_times(x_own, iters=max(n_trial, 5))
+                allq = torch.zeros((world, 3), dtype=torch.float64, device=dev)
+                allq[rank, 0], allq[rank, 1], allq[rank, 2] = ph["pack_ms"], ph["before_ms"], ph["after_ms"]
+                dist.all_reduce(allq)
+                halo["phases_ms_per_rank"] = {"flow": ph["flow"], "pack": allq[:, 0].tolist(), "before_the_wait": allq[:, 1].tolist(),
+                                              "after_the_wait": allq[:, 2].tolist(),
+                                              "what": "each phase alone on its rank (HIP events, no collective); exchange_only_ms = pack + all-to-all-v + wait"}
+            except Exception as ex:                                  # noqa: BLE001 -- a diagnostic: never lose the headline over it
+                print("[bench] per-rank phases failed on rank %d: %r" % (rank, ex), file=sys.stderr, flush=True)
+                dist.all_reduce(torch.zeros((world, 3), dtype=torch.float64, device=dev))
+            wd.end()
             if args.alternatives:                                    # the feature-column layout as a secondary field (not by default:
                 wd.begin("alternative layout: feature columns", 2 * lim)   # the first hardware run spends its minutes on rows + target size)
                 try:

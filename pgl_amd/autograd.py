@@ -8,6 +8,7 @@ out-edges.  Fused backward kernels (SDDMM for d/d(edge feature), softmax-backwar
 import torch
 
 from . import ops
+from . import edge_tensor as _et
 
 
 def _unbroadcast(g, shape):
@@ -132,6 +133,7 @@ def _edge_csr(c):
 def aggregate(x, csr, csr_t, reduce_op="sum", out_size=None, y=None, message_op="add", src32=None, dst32=None,
               src_scale=None, dst_scale=None):
     """src_scale / dst_scale ([N] fp32, no gradient): fused row scalings, only with y=None and sum."""
+    y = _et.materialize(y)                 # (an EdgeTensor reaching this level is read in original edge order)
     if torch.is_grad_enabled() and (x.requires_grad or (y is not None and y.requires_grad)):
         return _Aggregate.apply(x, y, csr, csr_t, reduce_op, message_op, out_size, src32, dst32, src_scale, dst_scale)
     return ops.aggregate(x, csr, reduce_op, out_size, y, message_op, src_scale, dst_scale)
@@ -155,6 +157,7 @@ class _GatherRows(torch.autograd.Function):
 def gather_rows(x, index, index_csr=None):
     """Differentiable paddle.gather(x, index, axis=0).  index_csr: CSR keyed by `index` (the graph
     passes adj_src/adj_dst so the backward is one aggregation, no sort)."""
+    x = _et.materialize(x)
     if torch.is_grad_enabled() and x.requires_grad:
         return _GatherRows.apply(x, index, index_csr)
     return ops.gather_rows(x, index)
@@ -220,6 +223,7 @@ class _SegmentReduce(torch.autograd.Function):
 
 
 def segment_reduce(data, ids, pool="sum", num_segments=None):
+    data = _et.materialize(data)
     if torch.is_grad_enabled() and data.requires_grad:
         return _SegmentReduce.apply(data, ids, pool, num_segments)
     return ops.segment_reduce(data, ids, pool, num_segments)
@@ -253,6 +257,7 @@ class _SegmentSoftmax(torch.autograd.Function):
 
 
 def segment_softmax(data, view):
+    data = _et.materialize(data)
     if torch.is_grad_enabled() and data.requires_grad:
         return _SegmentSoftmax.apply(data, view)
     return ops.segment_softmax(data, view)
@@ -390,6 +395,7 @@ class _ScatterRows(torch.autograd.Function):
 
 def scatter_into_zeros(n_rows, index, x):
     """zeros([n_rows, ...]) with rows `index` (unique) overwritten by x (pgl/graph.py:828-830)."""
+    x = _et.materialize(x)
     if torch.is_grad_enabled() and x.requires_grad:
         return _ScatterRows.apply(n_rows, index, x)
     out = torch.zeros((n_rows,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)

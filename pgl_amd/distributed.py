@@ -479,6 +479,12 @@ class DistGraph(object):
         self._inv_deg = None
         self._all_ids = None
         self.method = "given"
+        # True: the row kernel that finishes a GraphSageConv / GCNConv layer also writes its rows into the next layer's halo send
+        # buffer (wire / mark below), so that layer starts its exchange without a pack launch.  OFF by default: measured at
+        # |E| = 100 M, P = 8 (profiles/r05/rows_c2p.txt) it does not beat the pack launch it removes -- the pack's reads are served
+        # by the Infinity Cache (the rows were written by the launch before it), what it costs is the 0.5 GB of send-buffer
+        # writes, and the mirror pays those too
+        self.emit_outputs = False
         # halo rows of fp32 features travel as fp16 / bf16 when set (half the xGMI bytes; ~1e-3 relative error on the
         # remote contributions, so OFF by default: north_star's 1e-5 parity holds only with the features' own dtype);
         # PGLAMD_WIRE=fp16|bf16 sets the default
@@ -1283,6 +1289,56 @@ class DistGraph(object):
         if unpack is not None:
             unpack()
         return in_buf
+
+    def phase_times(self, x_own, iters=10, warm=3):
+        """Measurement hook (bench.py --gpus N, scripts/prof.py rows): this rank's COMPUTE phases of send_recv(sum) for the flow its
+        plan runs, each alone between a pair of events on the current stream, no collective involved (the receive buffer holds
+        whatever the last exchange left: timing only) -> {"flow", "pack_ms", "before_ms", "after_ms"} -- what the exchange has to
+        hide (`before`) and what it cannot (`pack`, `after`); read next to exchange_only()."""
+        p, B, xp = self.plan, self._b, self.xplan
+        x_own = x_own.contiguous()
+        d = int(x_own.shape[1])
+        row_bytes = d * x_own.element_size()
+
+        def timed(fn):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize(x_own.device)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize(x_own.device)
+            return a.elapsed_time(b) / iters
+        if p.world == 1 or not (xp.n_send or xp.n_recv):
+            return {"flow": "single rank", "pack_ms": 0.0, "before_ms": timed(lambda: self.send_recv(x_own, "sum")), "after_ms": 0.0}
+        wire = self._wire(x_own.dtype)
+        send_buf = self._buffer("phase_out", (xp.n_send, d), wire, x_own.device)
+        in_buf = self._buffer("phase_in", (xp.n_recv, d), x_own.dtype, x_own.device)
+        pack = (lambda: B.gather_rows_cast(x_own, self._send_cols32("x"), wire, send_buf)) if (xp.n_send and int(xp.pushed_pairs) == 0 and
+               x_own.dtype in (torch.float32, torch.float16, torch.bfloat16)) else (lambda: B.aggregate(x_own, self._index("xsend"), "sum", xp.n_send)) if xp.n_send else (lambda: None)
+        out = torch.empty_like(x_own)
+        if self._pipelined("x", False, True, x_own, row_bytes):
+            flow, h = "pipeline", (d // 2 + 15) // 16 * 16
+            before = lambda: B.aggregate(x_own, self._index("loc"), "sum", p.n_own, out=out)
+            b0 = self._buffer("phase_in0", (xp.n_recv, h), x_own.dtype, x_own.device)
+            b1 = self._buffer("phase_in1", (xp.n_recv, d - h), x_own.dtype, x_own.device)
+            after = lambda: (B.aggregate(b0, self._index("xrecv"), "sum", p.n_own, out=out[:, :h], accumulate=1),
+                             B.aggregate(b1, self._index("xrecv"), "sum", p.n_own, out=out[:, h:], accumulate=1))
+        else:
+            flow = self._mode("x", False, True, row_bytes) if xp.n_recv else "split"
+            if flow == "fold":
+                before = lambda: None
+                after = lambda: B.aggregate(x_own, self._index("xall"), "sum", p.n_own, out=out, x2=in_buf)
+            elif flow == "accumulate":
+                before = lambda: B.aggregate(x_own, self._index("loc"), "sum", p.n_own, out=out)
+                after = lambda: B.aggregate(in_buf, self._index("xrecv"), "sum", p.n_own, out=out, accumulate=1)
+            else:
+                zi = self._zero_indptr(False) if xp.n_recv else None
+                before = lambda: B.aggregate(x_own, self._index("xint"), "sum", p.n_own, out=out, zero_indptr=zi)
+                after = (lambda: B.aggregate(x_own, self._index("xbnd"), "sum", p.n_own, out=out, accumulate=2, x2=in_buf)) if xp.n_recv else (lambda: None)
+        return {"flow": flow, "pack_ms": timed(pack), "before_ms": timed(before), "after_ms": timed(after)}
 
     # ---- in-process simulation helpers (single-GPU tests of the compute path) ---------------------------------------------
     def pack(self, x_own):

@@ -20,6 +20,7 @@ import torch
 
 from . import autograd as ag
 from . import ops
+from . import edge_tensor as _et
 from .message import Message
 from .utils import op
 from .utils.edge_index import EdgeIndex
@@ -378,6 +379,19 @@ class Graph(object):
     def _csr_src(self):
         return self.adj_src_index.csr
 
+    def _csr_dst_view(self):
+        """The dst-keyed half of _csr_order_views alone (no src index is built for it)."""
+        if getattr(self, "_csr_views", None) is not None:
+            return self._csr_views[0]
+        if getattr(self, "_csr_dview", None) is None:
+            c, v = self._csr_dst(), ops.CSR()
+            v.degree, v.indptr, v.row32, v.col32 = c.degree, c.indptr, c.row32, c.col32
+            v.num_nodes, v.num_edges = c.num_nodes, c.num_edges
+            v.sorted_v = v.sorted_u = v.sorted_eid = None
+            v.eid32 = None
+            self._csr_dview = v
+        return self._csr_dview
+
     def _csr_order_views(self):
         """Index views for edge tensors kept in DST-SORTED (CSR) order instead of original edge order: the dst-keyed view
         has no eid indirection at all (position p of the walk is row p of the tensor), the src-keyed view maps each of
@@ -435,7 +449,7 @@ class Graph(object):
         edge_feat_temp = {}
         if edge_feat is not None:
             assert isinstance(edge_feat, dict), "The input edge_feat must be a dict"
-            edge_feat_temp.update(edge_feat)
+            edge_feat_temp.update({k: _et.materialize(v) for k, v in edge_feat.items()})
         src32, dst32 = self._edge_cols32()
         src_reader = _GraphRowReader(src_feat_temp, src32, self._csr_src)
         dst_reader = _GraphRowReader(dst_feat_temp, dst32, self._csr_dst)
@@ -455,6 +469,7 @@ class Graph(object):
             raise TypeError("reduce_func should be callable")
         src, dst, eid = self.sorted_edges(sort_by=recv_mode)
         csr = self._csr_dst() if recv_mode == "dst" else self._csr_src()
+        msg = {k: _et.materialize(v) for k, v in msg.items()}
         msg = op.RowReader(msg, csr.eid32)
         uniq_ind, segment_ids = self.get_segment_ids(src, dst, segment_by=recv_mode)
         bucketed_msg = Message(msg, segment_ids, num_segments=int(uniq_ind.shape[0]))
@@ -481,15 +496,29 @@ class Graph(object):
             raise ValueError("You must call Graph.tensor()")
         assert message_op in _MSGOP, "Only support 'add', 'sub', 'max', 'min' build-in message functions."
         assert reduce_op in _REDUCE, "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
-        return self._aggregate(feature, edge_feature, message_op, reduce_op, out_size)
+        rows = _et.sorted_rows(edge_feature, self)
+        if rows is not None:                                     # the operand is already in the order the kernel walks: no eid indirection
+            return self.edge_order("dst").send_ue_recv(feature, rows, message_op, reduce_op, out_size)
+        return self._aggregate(feature, _et.materialize(edge_feature), message_op, reduce_op, out_size)
 
     def send_uv(self, src_feature, dst_feature, message_op="add"):
         """pgl/graph.py:939-966."""
         if not self._is_tensor:
             raise ValueError("You must call Graph.tensor()")
         assert message_op in _MSGOP, "Only support 'add', 'sub', 'max', 'min' build-in message functions."
+        if self._lazy_edges(src_feature):
+            # rows produced in the engine's own (destination-sorted) edge order and tagged: leaky_relu / dropout / edge_softmax /
+            # send_ue_recv downstream then never touch the eid permutation; whoever READS the values gets original edge order
+            view = self.edge_order("dst")
+            return _et.EdgeTensor(view.send_uv(src_feature, dst_feature, message_op), view)
         src32, dst32 = self._edge_cols32()
         return ag.send_uv(src_feature, dst_feature, src32, dst32, message_op, self._csr_dst, self._csr_src)
+
+    def _lazy_edges(self, like):
+        """True when [E, ...] results of this graph are handed out as EdgeTensors (pgl_amd/edge_tensor.py): a tensor graph on the
+        GPU, floating rows, the mechanism not switched off (graph.lazy_edge_order = False / PGLAMD_EDGE_TENSOR=0)."""
+        return (_et.ENABLED and getattr(self, "lazy_edge_order", True) and self._is_tensor and isinstance(like, torch.Tensor)
+                and like.is_cuda and like.is_floating_point())
 
     def send_ue(self, feature, edge_feature, message_op="add"):
         raise NotImplementedError
@@ -503,6 +532,9 @@ class Graph(object):
         if (src_feature.dim() == 3 and src_feature.dtype == torch.float32 and dst_feature.dtype == torch.float32
                 and tuple(src_feature.shape[1:]) == tuple(dst_feature.shape[1:])
                 and ops.sddmm_supported(int(src_feature.shape[1]), int(src_feature.shape[2]))):
+            if self._lazy_edges(src_feature):
+                view = self.edge_order("dst")
+                return _et.EdgeTensor(view.sddmm(src_feature, dst_feature), view)
             return ag.sddmm(src_feature.contiguous(), dst_feature.contiguous(), self._csr_dst(), self._csr_src)
         return self.send_uv(src_feature, dst_feature, "mul").sum(-1)
 
@@ -589,7 +621,8 @@ class _DstOrderedEdges(object):
 
     def __init__(self, graph):
         self.graph = graph
-        self._cd, self._cs = graph._csr_order_views()
+        self._cd = graph._csr_dst_view()                       # (the src-keyed view -- backward only -- is built on first use: `_cs`)
+        self._cs_view = None
         full = graph._csr_dst()
         self.eid = full.eid32                                  # original edge id of position p
         self.src, self.dst = full.col32, full.row32            # endpoints of position p (int32)
@@ -602,6 +635,12 @@ class _DstOrderedEdges(object):
         cdi.eid32 = iota
         self._cd_iota = cdi
         self._inv = None
+
+    @property
+    def _cs(self):
+        if self._cs_view is None:
+            self._cs_view = self.graph._csr_order_views()[1]
+        return self._cs_view
 
     def to_order(self, edge_tensor):
         """original edge order -> this order (differentiable)."""

@@ -136,7 +136,7 @@ class GraphSageConv(nn.Module):
             z = ag.dual_linear(feature[1].contiguous(), neigh_feature, self.self_linear.weight, self.neigh_linear.weight)
             # on a row-partitioned graph the finished rows are the next layer's send_recv input: the row kernel also writes them into
             # that aggregation's halo send buffer (DistGraph.wire), which then starts its exchange without a pack launch
-            em = graph.wire(z) if (hasattr(graph, "can_wire") and getattr(graph, "emit_outputs", True)) else None
+            em = graph.wire(z) if (hasattr(graph, "can_wire") and getattr(graph, "emit_outputs", False)) else None
             y = ag.row_epilogue(z, self.self_linear.bias + self.neigh_linear.bias, act, self.normalize, wire=None if em is None else em.wire)
             return y if em is None else graph.mark(y, em)
         neigh_feature = self.neigh_linear(neigh_feature)
@@ -192,7 +192,7 @@ class GCNConv(nn.Module):
             if self.input_size <= self.output_size:
                 tall = output.shape[0] >= 65536 and torch.is_grad_enabled()
                 em = None
-                if hasattr(graph, "can_wire") and getattr(graph, "emit_outputs", True) and self.activation in (None, F.relu) \
+                if hasattr(graph, "can_wire") and getattr(graph, "emit_outputs", False) and self.activation in (None, F.relu) \
                         and ops.row_epilogue_supported(output, self.output_size) and self.linear.weight.dtype == torch.float32 \
                         and output.dtype == torch.float32 and graph.can_wire(self.output_size, torch.float32):
                     # row-partitioned graph: finish the layer with the row kernel, which also writes norm * row into the next layer's

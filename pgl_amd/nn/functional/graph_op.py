@@ -60,6 +60,14 @@ def edge_softmax(graph, logits, norm_by="dst"):
         if norm_by != "dst":
             raise ValueError("edge_softmax on a DistGraph supports norm_by='dst' only")
         graph = graph.local_graph
+    from ... import edge_tensor as _et
+    rows = _et.sorted_rows(logits, graph) if norm_by == "dst" else None
+    if rows is not None:
+        # logits that never left the engine's destination-sorted order (Graph.send_uv / sddmm -> element-wise ops): the segments
+        # are contiguous runs, no permutation on the way in or out; the result keeps the tag and reads back in ORIGINAL edge order
+        view = graph.edge_order("dst")
+        return _et.EdgeTensor(view.edge_softmax(rows), view)
+    logits = _et.materialize(logits)
     ix = graph.adj_dst_index if norm_by == "dst" else graph.adj_src_index
     csr = ix.csr
     src32, dst32 = graph._edge_cols32()

@@ -588,7 +588,8 @@ def cmd_coo(args):
     from pgl_amd.utils.rmat import rmat_edges
     dev = torch.device("cuda:0")
     d = args.dim
-    for name, scale, E in (("C2", 20, 20_000_000), ("4 M edges", 18, 4_000_000), ("sampled block", 17, 600_000), ("100 k edges", 14, 100_000), ("Cora-sized", 12, 13_264)):
+    for name, scale, E in (("C2", 20, 20_000_000), ("4 M edges", 18, 4_000_000), ("sampled block", 17, 600_000), ("100 k edges", 14, 100_000),
+                           ("50 k edges", 14, 50_000), ("32 k edges", 13, 32_768), ("Cora-sized", 12, 13_264)):
         N = 1 << scale
         gen = torch.Generator(device=dev); gen.manual_seed(7)
         x = torch.randn(N, d, generator=gen, device=dev)
@@ -603,10 +604,50 @@ def cmd_coo(args):
             t_agg = _t(lambda: pgl.ops.aggregate(x, c, "sum", N), it=10, warm=3)
             a, b = pgl.ops.scatter_add_coo(x, src32, dst32, N), pgl.ops.aggregate(x, c, "sum", N)
             err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+            t_rule = _t(lambda: pgl.ops.send_u_recv(x, edges[:, 0], edges[:, 1], "sum"), it=10, warm=3)
+            rule = "atomic" if 0 < E * d <= pgl.ops._COO_ONCE_MAX else "csr"
             print("%-14s %-11s |E|=%-9d d=%d  scatter_add_coo %.3f ms | csr_build %.3f + aggregate %.3f = %.3f ms once (cached: %.3f) | "
-                  "COO / CSR-once = %.2f | max rel diff %.1e" % (name, order, E, d, t_coo, t_build, t_agg, t_build + t_agg, t_agg,
-                                                               t_coo / (t_build + t_agg), err), flush=True)
+                  "COO / CSR-once = %.2f | ops.send_u_recv (rule: %s) %.3f ms | max rel diff %.1e"
+                  % (name, order, E, d, t_coo, t_build, t_agg, t_build + t_agg, t_agg, t_coo / (t_build + t_agg), rule, t_rule, err), flush=True)
             del edges, src32, dst32, c, a, b
+
+
+def cmd_chains(args):
+    """the un-fused attention compositions (the reference's own op sequences: send_uv -> element-wise -> edge_softmax
+    -> send_ue_recv) at C3 size with their [E, H] tensors kept in the engine's destination-sorted order (EdgeTensor, the default)
+    against the same layers with the mechanism off (every op permutes through the eid array)."""
+    import torch
+    import pgl_amd as pgl
+    import pgl_amd.nn as nn_
+    pgl_, dev, g = _c2(scale=args.scale, E=args.edges)
+    N = g.num_nodes
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, 128, generator=gen, device=dev)
+    torch.manual_seed(0)
+    cases = [("GATConv(fused=False) H=8 D=16   (pgl/nn/conv.py:331-339)", nn_.GATConv(128, 16, feat_drop=0.0, attn_drop=0.0, num_heads=8), True),
+             ("FAConv d=128                     (gate = tanh(send_uv) * send_uv)", nn_.FAConv(128, drop=0.0), False),
+             ("TransformerConv H=8 D=12 generic (pgl/nn/conv.py:796-834)", nn_.TransformerConv(128, 12, num_heads=8, feat_drop=0.0, attn_drop=0.0), False),
+             ("GATv2Conv H=4 D=12 generic       (pgl/nn/conv.py:421-424)", nn_.GATv2Conv(128, 12, feat_drop=0.0, attn_drop=0.0, num_heads=4), False)]
+    print("C3 size: RMAT scale %d, %d edges, 128 input columns; ms per call" % (args.scale, args.edges))
+    for name, L, unfuse in cases:
+        L = L.to(dev)
+        if unfuse:
+            L.fused = False
+        res = {}
+        for lazy in (False, True):
+            g.lazy_edge_order = lazy
+            with torch.no_grad():
+                fwd = _t(lambda: L(g, x), it=5, warm=2)
+            xt = x.clone().requires_grad_(True)
+            def step():
+                L.zero_grad(); xt.grad = None
+                L(g, xt).square().mean().backward()
+            trn = _t(step, it=3, warm=1)
+            res[lazy] = (fwd, trn)
+            torch.cuda.empty_cache()
+        print("%-66s forward %.3f -> %.3f ms (x%.2f) | forward + backward %.3f -> %.3f ms (x%.2f)   [original edge order -> engine order]"
+              % (name, res[False][0], res[True][0], res[False][0] / res[True][0], res[False][1], res[True][1], res[False][1] / res[True][1]), flush=True)
+        del L
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -1149,6 +1190,7 @@ def main():
     tr.add_argument("--out", required=True)
     sub.add_parser("csr")
     co = sub.add_parser("coo"); co.add_argument("--dim", type=int, default=128)
+    ch = sub.add_parser("chains"); ch.add_argument("--scale", type=int, default=20); ch.add_argument("--edges", type=int, default=20_000_000)
     o = sub.add_parser("ops"); o.add_argument("--scale", type=int, default=20); o.add_argument("--edges", type=int, default=20_000_000)
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
@@ -1181,6 +1223,8 @@ def main():
         cmd_csr(args)
     elif args.cmd == "coo":
         cmd_coo(args)
+    elif args.cmd == "chains":
+        cmd_chains(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
     elif args.cmd == "gcn":

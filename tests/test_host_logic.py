@@ -389,3 +389,73 @@ def test_graph_reorder_is_a_consistent_relabelling():
     after = ((g2.edges[:, 0] // blk) == (g2.edges[:, 1] // blk)).mean()
     assert before < 0.2 and after > 0.8, (before, after)
     assert np.array_equal(g2.indegree(), g.indegree()[order])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: EdgeTensor (pgl_amd/edge_tensor.py) -- the wrapper's own logic, on CPU with a stand-in view (the kernels that
+# produce / consume the sorted rows are covered by the GPU tests)
+# ------------------------------------------------------------------------------------------------
+class _FakeView(object):
+    def __init__(self, perm):
+        import torch
+        self.graph = object()
+        self.eid = torch.as_tensor(perm)                    # original edge id of sorted position p
+        self.inv = torch.empty_like(self.eid)
+        self.inv[self.eid] = torch.arange(len(perm))
+        self.calls = 0
+
+    def from_order(self, rows):
+        self.calls += 1
+        return rows[self.inv]
+
+
+def test_edge_tensor_keeps_the_tag_through_elementwise_work_and_reads_back_in_original_order():
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from pgl_amd.edge_tensor import EdgeTensor
+    rng = np.random.default_rng(0)
+    E, H, D = 50, 4, 3
+    orig = torch.as_tensor(rng.standard_normal((E, H, D)).astype(np.float32))
+    view = _FakeView(rng.permutation(E))
+    et = EdgeTensor(orig[view.eid], view)                   # rows in "sorted" order
+    attn = torch.as_tensor(rng.standard_normal((1, H, D)).astype(np.float32))
+    # the GATv2-style chain (pgl/nn/conv.py:421-424): leaky_relu -> * attn -> sum over the last dim -> reshape -> dropout(p=0)
+    a = nn.LeakyReLU(0.2)(et)
+    a = torch.sum(a * attn, dim=-1)
+    a = (2.0 * a + 1.0).reshape(-1, H, 1)
+    a = nn.Dropout(p=0.0)(a)
+    a = torch.tanh(a) * torch.exp(-a.abs())
+    assert isinstance(a, EdgeTensor) and view.calls == 0 and tuple(a.shape) == (E, H, 1)
+    ref = (2.0 * torch.sum(F.leaky_relu(orig, 0.2) * attn, dim=-1) + 1.0).reshape(-1, H, 1)
+    ref = torch.tanh(ref) * torch.exp(-ref.abs())
+    assert torch.allclose(a.materialize(), ref) and view.calls == 1
+    assert torch.allclose(a.materialize(), ref) and view.calls == 1        # cached
+    # tensor-on-the-left arithmetic and EdgeTensor (x) EdgeTensor of the same view keep the tag
+    b = attn.reshape(1, H, D) * et + et
+    assert isinstance(b, EdgeTensor) and torch.allclose(b.materialize(), attn * orig + orig)
+    # anything that looks at rows by position gets ORIGINAL order: indexing, sum over the edge dimension, cat, cpu / numpy, comparison
+    assert torch.equal(et[3], orig[3]) and torch.equal(et[5:9], orig[5:9])
+    assert torch.allclose(et.sum(0), orig.sum(0)) and torch.allclose(torch.sum(et), orig.sum()) and torch.allclose(et.sum(), orig.sum())
+    assert torch.equal(torch.cat([et, et], 0), torch.cat([orig, orig], 0))
+    assert np.array_equal(et.detach().cpu().numpy(), orig.numpy()) and np.array_equal(np.asarray(et), orig.numpy())
+    assert bool((et == orig).all()) and torch.equal(et.reshape(E * H, D), orig.reshape(E * H, D))
+    assert not isinstance(et.reshape(E * H, D), EdgeTensor) and isinstance(et.reshape(E, -1), EdgeTensor) and isinstance(et.reshape(-1, H * D), EdgeTensor)
+    # a per-EDGE operand (size E in dim 0) cannot be combined without knowing the order: the result is an ordinary original-order tensor
+    w = torch.as_tensor(rng.standard_normal((E, 1, 1)).astype(np.float32))
+    c = et * w
+    assert not isinstance(c, EdgeTensor) and torch.allclose(c, orig * w)
+    # two views never mix silently
+    other = EdgeTensor(orig[view.eid], _FakeView(rng.permutation(E)))
+    assert not isinstance(et + other, EdgeTensor)
+    # gradients flow through the permutation
+    leaf = orig.clone().requires_grad_(True)
+    e2 = EdgeTensor(leaf[view.eid], view)
+    (torch.tanh(e2) * 3.0).materialize().square().sum().backward()
+    l2 = orig.clone().requires_grad_(True)
+    (torch.tanh(l2) * 3.0).square().sum().backward()
+    assert torch.allclose(leaf.grad, l2.grad)
+    # the engine's kernels refuse the wrapper instead of reading sorted rows as if they were in original order
+    import pgl_amd
+    with pytest.raises(TypeError, match="EdgeTensor"):
+        pgl_amd.ops.gather_rows(et, torch.zeros(1, dtype=torch.int64))
