@@ -245,42 +245,25 @@ __global__ __launch_bounds__(kBlock) void degree_norm_kernel(const int64_t* __re
 
 // K1' edge-parallel COO scatter-add with hardware fp32 atomics (global_atomic_add_f32): what answers
 // paddle.geometric.send_u_recv(x, src, dst) on a SMALL edge list used once (pgl/graph.py:859-861), where the launches of a CSR
-// build would cost more than the whole aggregation.  A wave takes 8 edges per step: their ids are one vector load each (lane l:
-// edge l), the 8 source rows are issued back to back (lanes span the columns, 8 bytes per lane where the row allows), then their
-// atomics -- 8 independent gather -> atomic chains in flight per wave instead of one.  Order-nondeterministic in the last bits.
+// build would cost more than the whole aggregation.  One edge per wave step, lanes across the columns: a wave's 64 atomics hit
+// one 256-byte row segment.  Order-nondeterministic in the last bits.
 // NOT the path for large graphs: at |E| = 20 M, d = 128 every atomic row is a read-modify-write of a 512-byte line at the memory
 // side (the destination matrix does not fit in L2) -- measured 9.96 ms against 0.58 + 1.11 ms for csr_build + the flat kernel
-// (profiles/r05/coo.txt).  Staging destination rows in LDS needs the edges grouped by destination tile, i.e. a sorting pass --
-// which is what csr_build is; so above the crossover (ops.send_u_recv: |E| * d <= 4 M elements) the engine sorts.
-template <int VEC>
+// (profiles/r05/coo.txt).  A variant that walks 8 edges per wave step (ids by one vector load, the 8 row gathers issued back to
+// back) was built and measured SLOWER at every size (19.4 ms at C2, 0.041 vs 0.023 ms at 13 k edges: an eighth of the waves, and
+// the kernel is bound by the atomics, not by the gathers) and dropped.  Staging destination rows in LDS needs the edges grouped
+// by destination tile, i.e. a sorting pass -- which is what csr_build is; so above the crossover (ops.send_u_recv: |E| * d <= 4 M
+// elements) the engine sorts.
 __global__ __launch_bounds__(kBlock) void scatter_add_coo_kernel(const float* __restrict__ x, int64_t d,
                                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                                  int64_t E, float* __restrict__ out) {
-    constexpr int U = 8;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * kWavesPerBlock;
-    for (int64_t e0 = wave * U; e0 < E; e0 += nw * U) {
-        const int n = (int)(E - e0 < U ? E - e0 : U);
-        int sv = 0, tv = 0;
-        if (lane < n) { sv = src[e0 + lane]; tv = dst[e0 + lane]; }
-        for (int64_t j = (int64_t)lane * VEC; j < d; j += kWave * VEC) {
-            float v[U][VEC];
-#pragma unroll
-            for (int i = 0; i < U; ++i)
-                if (i < n) {
-                    const float* xr = x + (int64_t)__builtin_amdgcn_readlane(sv, i) * d + j;
-                    if constexpr (VEC == 2) { const float2 t = *reinterpret_cast<const float2*>(xr); v[i][0] = t.x; v[i][1] = t.y; }
-                    else v[i][0] = xr[0];
-                }
-#pragma unroll
-            for (int i = 0; i < U; ++i)
-                if (i < n) {
-                    float* o = out + (int64_t)__builtin_amdgcn_readlane(tv, i) * d + j;
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) unsafeAtomicAdd(o + k, v[i][k]);
-                }
-        }
+    for (int64_t e = wave; e < E; e += nw) {
+        const int s = wave_uniform(src[e]);
+        const int t = wave_uniform(dst[e]);
+        for (int64_t j = lane; j < d; j += kWave) unsafeAtomicAdd(out + (int64_t)t * d + j, x[(int64_t)s * d + j]);
     }
 }
 
@@ -477,11 +460,9 @@ extern "C" int32_t pglamd_scatter_add_coo(const float* x, int64_t d, const int32
     hipStream_t st = static_cast<hipStream_t>(stream);
     PGLAMD_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)out_rows * d * sizeof(float), st));
     if (num_edges == 0) return PGLAMD_OK;
-    int64_t g = ceil_div(ceil_div(num_edges, (int64_t)8), kWavesPerBlock);     // a wave walks 8 edges per step
-    if (d % 2 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0)
-        hipLaunchKernelGGL(scatter_add_coo_kernel<2>, dim3((unsigned)(g < 256 * 32 ? g : 256 * 32)), dim3(kBlock), 0, st, x, d, src, dst, num_edges, out);
-    else
-        hipLaunchKernelGGL(scatter_add_coo_kernel<1>, dim3((unsigned)(g < 256 * 32 ? g : 256 * 32)), dim3(kBlock), 0, st, x, d, src, dst, num_edges, out);
+    int64_t g = ceil_div(num_edges, kWavesPerBlock);
+    hipLaunchKernelGGL(scatter_add_coo_kernel, dim3((unsigned)(g < 256 * 32 ? g : 256 * 32)), dim3(kBlock), 0, st, x, d, src, dst,
+                       num_edges, out);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
 }

@@ -332,6 +332,95 @@ class HaloPlan(object):
         self.n_send = int(scnt.sum())
         self.pushed_pairs = int(push.sum())
 
+    @classmethod
+    def from_edge_slabs(cls, slabs, num_nodes, rank, world, part=None, device=None):
+        """The pull plan of one rank built from the edge list handed over SLAB BY SLAB (an iterable of int64 [k, 2] (src, dst)
+        tensors that together are the global edge list, in order) -- what BASELINE config 5 needs: at |E| = 1.6 B the global COO is
+        25.8 GB of int64, and no rank should hold more of it than one slab plus its own share (SURVEY 8d:
+        "generated per-partition on device").  Same arrays, element for element, as HaloPlan(edges, ...) on the concatenated list.
+        part: int64 [N] part vector, or None = RANGE partition of the node ids as they are (rank p owns ids [p N / P, (p+1) N / P):
+        the documented fallback where a partitioner's input does not fit in host memory, pgl/partition.py:94-123 / SURVEY 8e --
+        RMAT ids are randomly permuted already, so this is a balanced random partition that needs no [N] array at all).
+        Kept per slab: the slab's edges into owned rows (relabelled), a [world, n_own] bitmap of which peer reads which owned row,
+        and the owned rows' out-degree counts."""
+        N, P, rank = int(num_nodes), int(world), int(rank)
+        it = iter(slabs)
+        first = next(it)
+        dev = torch.device(device) if device is not None else first.device
+        if part is None:
+            bounds = [(p * N) // P for p in range(P + 1)]
+            off = torch.tensor(bounds, dtype=torch.int64, device=dev)
+            new_id, order = None, None
+        else:
+            part = torch.as_tensor(part, device=dev).to(torch.int64)
+            order = torch.argsort(part, stable=True)
+            new_id = torch.empty_like(order)
+            new_id[order] = torch.arange(N, device=dev)
+            counts = torch.bincount(part, minlength=P)
+            off = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+            off[1:] = torch.cumsum(counts, 0)
+        offsets = off.cpu().tolist()
+        lo, hi = offsets[rank], offsets[rank + 1]
+        n_own = hi - lo
+        reads = torch.zeros((P, max(n_own, 1)), dtype=torch.bool, device=dev)      # reads[p, r]: peer p has an edge from my row r
+        out_deg = torch.zeros(max(n_own, 1), dtype=torch.int64, device=dev)
+        loc, inc = [], []                                                            # per slab: (rows, cols, eid) / (rows, src_new, eid)
+        base = 0
+        import itertools
+        for edges in itertools.chain([first], it):
+            edges = edges.to(dev)
+            k = int(edges.shape[0])
+            src, dst = edges[:, 0], edges[:, 1]
+            if new_id is not None:
+                src, dst = new_id[src], new_id[dst]
+            s_mine = (src >= lo) & (src < hi)
+            d_mine = (dst >= lo) & (dst < hi)
+            if n_own:
+                sm = src[s_mine] - lo
+                out_deg += torch.bincount(sm, minlength=n_own)
+                outg = s_mine & ~d_mine
+                if bool(outg.any()):
+                    owner = torch.searchsorted(off, dst[outg], right=True) - 1
+                    reads[owner, src[outg] - lo] = True
+            eid = torch.arange(base, base + k, device=dev)
+            both = d_mine & s_mine
+            loc.append((dst[both] - lo, src[both] - lo, eid[both]))
+            rem = d_mine & ~s_mine
+            inc.append((dst[rem] - lo, src[rem], eid[rem]))
+            base += k
+            del edges, src, dst, s_mine, d_mine, eid, both, rem
+        cat = lambda parts, i: torch.cat([p_[i] for p_ in parts]) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+        plan = cls.__new__(cls)
+        plan.rank, plan.world, plan.num_nodes, plan.offsets, plan.n_own = rank, P, N, offsets, n_own
+        plan.own_global = torch.arange(lo, hi, device=dev) if order is None else order[lo:hi]
+        plan.loc_rows, plan.loc_cols = cat(loc, 0), cat(loc, 1)
+        hd, hs = cat(inc, 0), cat(inc, 1)
+        plan.edge_global = torch.cat([cat(loc, 2), cat(inc, 2)])
+        del loc, inc
+        plan.in_degree = torch.bincount(torch.cat([plan.loc_rows, hd]), minlength=n_own) if n_own else torch.zeros(0, dtype=torch.int64, device=dev)
+        plan.out_degree = out_deg[:n_own]
+        plan.local_edges = int(plan.loc_rows.shape[0] + hd.shape[0])
+        halo_ids, inv = torch.unique(hs, sorted=True, return_inverse=True)
+        plan.hal_rows, plan.hal_cols = hd, inv
+        plan.n_halo = int(halo_ids.shape[0])
+        plan.halo_global = halo_ids
+        b = torch.searchsorted(halo_ids, off)
+        plan.halo_splits = (b[1:] - b[:-1]).cpu().tolist()
+        reads[rank] = False
+        nz = torch.nonzero(reads[:, :n_own]) if n_own else torch.zeros((0, 2), dtype=torch.int64, device=dev)   # peer-major, rows ascending
+        plan.send_idx = nz[:, 1].contiguous()
+        plan.pull_splits = torch.bincount(nz[:, 0], minlength=P).cpu().tolist()
+        # exchange plan = the pull plan (no push decisions without the global pair counts)
+        plan.push = torch.zeros((P, P), dtype=torch.bool)
+        plan.recv_rows, plan.recv_cols = plan.hal_rows, plan.hal_cols
+        plan.recv_splits, plan.n_recv = list(plan.halo_splits), plan.n_halo
+        plan.n_send = int(plan.send_idx.shape[0])
+        plan.send_rows = torch.arange(plan.n_send, device=dev)
+        plan.send_cols = plan.send_idx
+        plan.send_splits = list(plan.pull_splits)
+        plan.pushed_pairs = 0
+        return plan
+
     # ---- the pair decision, identical on every rank ----------------------------------------------------------------
     @staticmethod
     def pair_counts(edges, num_nodes, part, world):

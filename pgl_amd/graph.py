@@ -449,7 +449,7 @@ class Graph(object):
         edge_feat_temp = {}
         if edge_feat is not None:
             assert isinstance(edge_feat, dict), "The input edge_feat must be a dict"
-            edge_feat_temp.update({k: _et.materialize(v) for k, v in edge_feat.items()})
+            edge_feat_temp.update(edge_feat)
         src32, dst32 = self._edge_cols32()
         src_reader = _GraphRowReader(src_feat_temp, src32, self._csr_src)
         dst_reader = _GraphRowReader(dst_feat_temp, dst32, self._csr_dst)
@@ -469,7 +469,6 @@ class Graph(object):
             raise TypeError("reduce_func should be callable")
         src, dst, eid = self.sorted_edges(sort_by=recv_mode)
         csr = self._csr_dst() if recv_mode == "dst" else self._csr_src()
-        msg = {k: _et.materialize(v) for k, v in msg.items()}
         msg = op.RowReader(msg, csr.eid32)
         uniq_ind, segment_ids = self.get_segment_ids(src, dst, segment_by=recv_mode)
         bucketed_msg = Message(msg, segment_ids, num_segments=int(uniq_ind.shape[0]))

@@ -33,7 +33,10 @@ class RowReader(dict):
 
     def __getitem__(self, key):
         if key not in self.loaded_nfeat:
-            self.loaded_nfeat[key] = read_rows(self.nfeat[key], self.index)
+            val = self.nfeat[key]
+            if type(val).__name__ == "EdgeTensor":          # (pgl_amd/edge_tensor.py: read in original edge order)
+                val = val.materialize()
+            self.loaded_nfeat[key] = read_rows(val, self.index)
         return self.loaded_nfeat[key]
 
     def __contains__(self, key):

@@ -805,3 +805,43 @@ def test_gloo_fused_pack_chain(monkeypatch, world, flow, scaled, grad):
         for _, own, res in got:
             full[own] = res["grad"]
         np.testing.assert_allclose(full, gw, rtol=1e-4, atol=1e-5 * np.abs(gw).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: the halo plan from an edge list handed over slab by slab (BASELINE config 5: nobody holds the global COO)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("given_part", [False, True])
+def test_plan_from_edge_slabs_equals_the_plan_from_the_whole_list(given_part):
+    from pgl_amd.distributed import DistGraph, HaloPlan, _PLAN_ARRAYS, _PLAN_META
+    from pgl_amd.utils.rmat import rmat_edges, rmat_slabs
+    rng = np.random.default_rng(0)
+    n, e, P = 300, 5000, 4
+    edges = torch.from_numpy(np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64))
+    edges[:40, 0] = 299; edges[40:90, 1] = 0                          # rows at the range boundaries, a source read by every peer
+    if given_part:
+        part = torch.from_numpy(rng.integers(0, P, n))
+        pv = part
+    else:
+        part = None                                                    # range partition: rank p owns ids [p n / P, (p + 1) n / P)
+        pv = torch.from_numpy(np.searchsorted(np.array([(p * n) // P for p in range(P + 1)]), np.arange(n), side="right") - 1)
+    x = torch.from_numpy(rng.standard_normal((n, 6)).astype(np.float32))
+    for r in range(P):
+        a = HaloPlan(edges, n, pv, r, P)
+        for slab in (5000, 777, 100):
+            chunks = [edges[i:i + slab] for i in range(0, e, slab)] + [edges[:0]]          # (an empty slab is legal)
+            b = HaloPlan.from_edge_slabs(chunks, n, r, P, part=part)
+            for k in _PLAN_ARRAYS:
+                assert torch.equal(getattr(a, k).cpu(), getattr(b, k).cpu()), (k, r, slab)
+            for k in _PLAN_META:
+                assert getattr(a, k) == getattr(b, k), (k, r, slab)
+        # and the plan works: the compute half of send_recv on it
+        dg = DistGraph(b, backend=TorchBackend())
+        got = dg.aggregate_with_halo(dg.take_owned(x), x[b.halo_global if part is None else torch.argsort(pv, stable=True)[b.halo_global]], "sum")
+        want = torch.zeros_like(x).index_add_(0, edges[:, 1], x[edges[:, 0]])[b.own_global]
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+    # the slab generator: slabs concatenate to a graph of the same kind every time, any slab can be regenerated on its own
+    s1 = list(rmat_slabs(10, 10000, 3000, seed=5))
+    s2 = list(rmat_slabs(10, 10000, 3000, seed=5, fold=1000))
+    assert [int(t.shape[0]) for t in s1] == [3000, 3000, 3000, 1000]
+    assert torch.equal(torch.cat(s1) % 1000, torch.cat(s2)) and int(torch.cat(s1).max()) < 1024
+    assert torch.equal(list(rmat_slabs(10, 10000, 3000, seed=5))[2], s1[2])

@@ -309,7 +309,7 @@ def test_aggregate_wire_mirror_contract(pgl, d, dt, mode):
     desc, more = ops.wire_slots(dev(rop), n)
     scale = (rng.random(n).astype(np.float32) + 0.5) if mode == "scaled" else None
     split = ((d // 2 + 15) // 16 * 16) if mode == "split" else 0
-    sentinel = -777.0
+    sentinel = -512.0                                                    # (exact in bf16 too)
     buf = torch.full((n_wire, d), sentinel, dtype=dt, device="cuda")
     b0 = torch.full((n_wire, split), sentinel, dtype=dt, device="cuda") if split else None
     b1 = torch.full((n_wire, d - split), sentinel, dtype=dt, device="cuda") if split else None
@@ -368,7 +368,7 @@ def test_row_epilogue_wire_mirror_contract(pgl, d, split, scaled):
     n_wire = len(rop)
     desc, more = ops.wire_slots(dev(rop), n)
     scale = (rng.random(n).astype(np.float32) + 0.5) if scaled else None
-    sentinel = -777.0
+    sentinel = -512.0                                                    # (exact in bf16 too)
     b0 = torch.full((n_wire, split or d), sentinel, device="cuda")
     b1 = torch.full((n_wire, d - split), sentinel, device="cuda") if split else None
     so = torch.full((n, d), sentinel, device="cuda") if scaled else None
@@ -487,3 +487,83 @@ def test_edge_tensor_layers_equal_original_order_composition(pgl, layer):
     np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=2e-5 * float(gx0.abs().max()))
     for a, b in zip(gp1, gp0):
         np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=5e-5 * float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 5 at ONE RANK'S REAL SHARE: ogbn-papers100M-sized synthetic (N = 111 059 956,
+# |E| = 1 615 685 872, 8 parts, fp16 features), the plan built from the edge list handed over slab by slab -- no global COO
+# anywhere -- then one aggregation of the rank's ~200 M in-edges against fp64 on sampled rows.  pgl/partition.py:94-123 (the
+# range / random fallback where a partitioner's input does not fit), pgl/graph.py:1509-1553 (what it replaces).
+# ------------------------------------------------------------------------------------------------
+def _node_features(ids, d, dtype):
+    """Deterministic pseudo-random features of GLOBAL node ids ([len(ids), d]): any rank can produce any node's row."""
+    col = torch.arange(d, device=ids.device, dtype=torch.float64)
+    out = torch.empty((int(ids.shape[0]), d), dtype=dtype, device=ids.device)
+    for lo in range(0, int(ids.shape[0]), 1 << 21):                    # (in slabs: the fp64 phase of 60 M rows would be 61 GB)
+        ph = (ids[lo:lo + (1 << 21)].double().unsqueeze(1) * 0.6180339887498949 + col.unsqueeze(0) * 0.7548776662466927) % 1.0
+        out[lo:lo + (1 << 21)] = (torch.sin(ph * 6.283185307179586 * 3.0) * 0.5).to(dtype)
+    return out
+
+
+def test_config5_one_rank_share_streamed_plan_fp16(pgl):
+    import time
+    from pgl_amd.distributed import DistGraph, HaloPlan
+    from pgl_amd.utils.rmat import rmat_slabs
+    N, E, P, d, rank = 111_059_956, 1_615_685_872, 8, 128, 3
+    slab = 48_000_000                                                   # 1/34 of the global list
+    torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    base_mem = torch.cuda.memory_allocated()
+    t0 = time.time()
+    plan = HaloPlan.from_edge_slabs(rmat_slabs(27, E, slab, seed=42, device="cuda", fold=N), N, rank, P)
+    torch.cuda.synchronize()
+    t_plan = time.time() - t0
+    peak_plan = torch.cuda.max_memory_allocated() - base_mem
+    assert plan.n_own == (N * (rank + 1)) // P - (N * rank) // P
+    assert 0.5 * E / P < plan.local_edges < 2.0 * E / P and plan.local_edges <= E // 4        # a rank holds its share, never a quarter of the list
+    assert slab * 16 <= E * 16 // 32
+    assert int(plan.in_degree.sum()) == plan.local_edges
+    assert sum(plan.halo_splits) == plan.n_halo and plan.halo_splits[rank] == 0 and sum(plan.pull_splits) == plan.n_send
+    t0 = time.time()
+    dg = DistGraph(plan)
+    x_own = _node_features(plan.own_global, d, torch.float16)
+    halo = _node_features(plan.halo_global, d, torch.float16)          # what the all-to-all-v would deliver (pull layout)
+    out = dg.aggregate_with_halo(x_own, halo, "mean")
+    torch.cuda.synchronize()
+    t_first = time.time() - t0                                          # includes the two index builds (interior / boundary)
+    t0 = time.time()
+    for _ in range(3):
+        out = dg.aggregate_with_halo(x_own, halo, "mean")
+    torch.cuda.synchronize()
+    t_step = (time.time() - t0) / 3
+    peak_all = torch.cuda.max_memory_allocated() - base_mem
+    assert out.dtype == torch.float16 and tuple(out.shape) == (plan.n_own, d)
+    # sampled rows against fp64 on the same fp16-quantised inputs: reassociation bound + one fp16 rounding of the result
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    rows = torch.randint(0, plan.n_own, (96,), generator=gen, device="cuda").unique()
+    hub = torch.argmax(plan.in_degree).reshape(1)
+    rows = torch.cat([rows, hub]).unique()
+    src_of = torch.cat([plan.own_global[plan.loc_cols], plan.halo_global[plan.hal_cols]])      # global source of every local edge
+    row_of = torch.cat([plan.loc_rows, plan.hal_rows])
+    worst = 0.0
+    for r in rows.tolist():
+        srcs = src_of[row_of == r]
+        deg = int(srcs.shape[0])
+        assert deg == int(plan.in_degree[r])
+        if deg == 0:
+            assert float(out[r].abs().max()) == 0.0
+            continue
+        f = _node_features(srcs, d, torch.float16).double()
+        want = f.sum(0) / deg
+        bound = (2.0 * deg * 2.0 ** -24 * f.abs().sum(0) / deg) + 2.0 ** -11 * want.abs() + 1e-7
+        err = (out[r].double() - want).abs()
+        assert bool((err <= bound).all()), (r, deg, float(err.max()), float(bound.max()))
+        worst = max(worst, float((err / bound).max()))
+    msg = ("config 5, rank %d of %d: %d owned rows, %d in-edges (%.3f of |E|), %d halo rows, %d rows sent | plan from %d slabs of %d edges: "
+           "%.1f s, peak device memory %.2f GB | first aggregation incl. index builds %.2f s, then %.1f ms / aggregation (fp16 rows, "
+           "fp32 accumulation) | peak device memory overall %.2f GB | sampled rows incl. the hub (in-degree %d): worst error / bound = %.2f"
+           % (rank, P, plan.n_own, plan.local_edges, plan.local_edges / E, plan.n_halo, plan.n_send, -(-E // slab), slab, t_plan, peak_plan / 1e9,
+              t_first, t_step * 1e3, peak_all / 1e9, int(plan.in_degree.max()), worst))
+    print(msg)
+    import os
+    os.makedirs("gpurun_out/r05", exist_ok=True)
+    open("gpurun_out/r05/config5_one_rank_share.txt", "w").write(msg + "\n")
