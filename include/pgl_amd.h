@@ -280,7 +280,7 @@ const char* pglamd_profile_last_kernel(void);
 
 /* K1'  un-indexed COO variant (edges in arbitrary order, hardware float atomics; SUM only, F32): what answers
  * paddle.geometric.send_u_recv(x, src, dst) (pgl/graph.py:859-861; Paddle-free fallback pgl/utils/helper.py:163-210) on a SMALL
- * edge list used once, where the launches of a CSR build cost more than the aggregation: |E| * d <= 4 M elements (measured on
+ * edge list used once, where the launches of a CSR build cost more than the aggregation: |E| * d <= 6.4 M elements (measured on
  * MI355X, profiles/r05/coo.txt: 0.023 vs 0.074 ms at 13 k edges, d = 128; break-even near 50 k edges).  Above that the memory-side
  * read-modify-write of every 512-byte destination row makes it 3-7 x slower than pglamd_csr_build + pglamd_aggregate, which is
  * what pgl_amd.ops.send_u_recv runs there.  Result is order-nondeterministic in the last bits, unlike pglamd_aggregate.  `out`

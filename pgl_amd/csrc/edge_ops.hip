@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void degree_norm_kernel(const int64_t* __re
 // (profiles/r05/coo.txt).  A variant that walks 8 edges per wave step (ids by one vector load, the 8 row gathers issued back to
 // back) was built and measured SLOWER at every size (19.4 ms at C2, 0.041 vs 0.023 ms at 13 k edges: an eighth of the waves, and
 // the kernel is bound by the atomics, not by the gathers) and dropped.  Staging destination rows in LDS needs the edges grouped
-// by destination tile, i.e. a sorting pass -- which is what csr_build is; so above the crossover (ops.send_u_recv: |E| * d <= 4 M
+// by destination tile, i.e. a sorting pass -- which is what csr_build is; so above the crossover (ops.send_u_recv: |E| * d <= 6.4 M
 // elements) the engine sorts.
 __global__ __launch_bounds__(kBlock) void scatter_add_coo_kernel(const float* __restrict__ x, int64_t d,
                                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ dst,

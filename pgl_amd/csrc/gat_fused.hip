@@ -332,7 +332,17 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             if constexpr (MODE == 2) a_held = prow[(int64_t)cur * p.H + head];
             else p_held = pk[(int64_t)cur * p.H + head];
         }
-        auto consume_att = [&](int r, int ed, int pos, const V& xv, const F4& pc, float ac, const V& yo, const F4& po, float ao) {
+        // Round 5: what belongs to the ROW node is no longer prefetched per batch element "in case this edge opens a row" (three to
+        // seven VGPRs per element and stage: 106 VGPRs = 4 waves per SIMD) but fetched at the row change itself -- a row change
+        // happens once per ~19 edges at C3, the fetch is a vector load of consecutive rows (the walk's own row order), and the 24
+        // registers it frees buy two more resident waves per SIMD.
+        auto open_row = [&](int r) {
+            if (!act) return;
+            y_held = *reinterpret_cast<const V*>(rvec + (int64_t)r * p.d + j0);
+            if constexpr (MODE == 2) a_held = prow[(int64_t)r * p.H + head];
+            else p_held = pk[(int64_t)r * p.H + head];
+        };
+        auto consume_att = [&](int r, int ed, int pos, const V& xv, const F4& pc, float ac) {
             if (r != cur) {
                 if (head_open) store_partial(true); else store_final(cur);
                 head_open = false;
@@ -340,8 +350,7 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
                 acc_a = 0.f;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-                y_held = yo;
-                if constexpr (MODE == 2) a_held = ao; else p_held = po;
+                open_row(r);
             }
             const F4 q = MODE == 2 ? pc : p_held;                  // (a_dst, m, s, t) of the destination v
             const float pre = q.a + (MODE == 2 ? a_held : ac);     // + a_src[u]
@@ -364,49 +373,50 @@ __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
             // line per edge, and the caller's reduction by destination gathers through a permutation either way)
             if (dpre_out && (lane & (lph - 1)) == 0 && act) dpre_out[(int64_t)pos * p.H + head] = dp;
         };
-        auto load_att = [&](const int (&cc)[U], const int (&rr)[U], V (&vx)[U], F4 (&pc)[U], float (&ac)[U], V (&yo)[U],
-                            F4 (&po)[U], float (&ao)[U]) {
+        auto load_att = [&](const int (&cc)[U], V (&vx)[U], F4 (&pc)[U], float (&ac)[U]) {
             if (!act) return;
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 vx[i] = *reinterpret_cast<const V*>(x + (int64_t)cc[i] * p.d + j0);
                 if constexpr (MODE == 2) pc[i] = pk[(int64_t)cc[i] * p.H + head];
                 else ac[i] = pcol[(int64_t)cc[i] * p.H + head];
-                if (i == 0 || rr[i] != rr[i - 1]) {                // wave-uniform: this edge may open a row
-                    yo[i] = *reinterpret_cast<const V*>(rvec + (int64_t)rr[i] * p.d + j0);
-                    if constexpr (MODE == 2) ao[i] = prow[(int64_t)rr[i] * p.H + head];
-                    else po[i] = pk[(int64_t)rr[i] * p.H + head];
-                }
             }
         };
-        int cA[U], rA[U], eA[U]; V xA[U], yA[U]; F4 pcA[U], poA[U]; float acA[U], aoA[U];
-        if (n_full > 0) { load_idx(e, cA, rA, eA); load_att(cA, rA, xA, pcA, acA, yA, poA, aoA); }
+        // three stages deep, as the forward walk: rows of batch g consumed, rows of g+1 in flight, (scalar) indices of g+2 being fetched
+        int cA[U], rA[U], eA[U]; V xA[U]; F4 pcA[U]; float acA[U];
+        int cB[U], rB[U], eB[U];
+        if (n_full > 0) { load_idx(e, cA, rA, eA); load_att(cA, xA, pcA, acA); }
+        if (n_full > 1) load_idx(e + U, cB, rB, eB);
         for (int g = 0; g < n_full; ++g) {
-            int cB[U], rB[U], eB[U]; V xB[U], yB[U]; F4 pcB[U], poB[U]; float acB[U], aoB[U];
-            const bool more = g + 1 < n_full;
-            if (more) { load_idx(e + U, cB, rB, eB); load_att(cB, rB, xB, pcB, acB, yB, poB, aoB); }
+            int cC[U], rC[U], eC[U]; V xB[U]; F4 pcB[U]; float acB[U];
+            const bool more = g + 1 < n_full, more2 = g + 2 < n_full;
+            if (more) load_att(cB, xB, pcB, acB);
+            if (more2) load_idx(e + 2 * U, cC, rC, eC);
 #pragma unroll
-            for (int i = 0; i < U; ++i) consume_att(rA[i], eA[i], e + i, xA[i], pcA[i], acA[i], yA[i], poA[i], aoA[i]);
+            for (int i = 0; i < U; ++i) consume_att(rA[i], eA[i], e + i, xA[i], pcA[i], acA[i]);
             if (more) {
 #pragma unroll
                 for (int i = 0; i < U; ++i) {
-                    rA[i] = rB[i]; eA[i] = eB[i]; xA[i] = xB[i]; yA[i] = yB[i];
-                    if constexpr (MODE == 2) { pcA[i] = pcB[i]; aoA[i] = aoB[i]; } else { acA[i] = acB[i]; poA[i] = poB[i]; }
+                    rA[i] = rB[i]; eA[i] = eB[i]; xA[i] = xB[i];
+                    if constexpr (MODE == 2) pcA[i] = pcB[i]; else acA[i] = acB[i];
                 }
+            }
+            if (more2) {
+#pragma unroll
+                for (int i = 0; i < U; ++i) { cB[i] = cC[i]; rB[i] = rC[i]; eB[i] = eC[i]; }
             }
             e += U;
         }
         for (; e < e1; ++e) {
             const int r = rowp[e], cc = colp[e];
             const int ed = need_eid ? eidp[e] : 0;
-            V xv{}, yo{}; F4 pc{}, po{}; float ac = 0.f, ao = 0.f;
+            V xv{}; F4 pc{}; float ac = 0.f;
             if (act) {
                 xv = *reinterpret_cast<const V*>(x + (int64_t)cc * p.d + j0);
-                yo = *reinterpret_cast<const V*>(rvec + (int64_t)r * p.d + j0);
-                if constexpr (MODE == 2) { pc = pk[(int64_t)cc * p.H + head]; ao = prow[(int64_t)r * p.H + head]; }
-                else { ac = pcol[(int64_t)cc * p.H + head]; po = pk[(int64_t)r * p.H + head]; }
+                if constexpr (MODE == 2) pc = pk[(int64_t)cc * p.H + head];
+                else ac = pcol[(int64_t)cc * p.H + head];
             }
-            consume_att(r, ed, e, xv, pc, ac, yo, po, ao);
+            consume_att(r, ed, e, xv, pc, ac);
         }
     }
     const bool tail_open = e1 < p.E && rowp[e1] == cur;

@@ -583,13 +583,13 @@ def scatter_add_coo(x, src32, dst32, out_rows):
     return out
 
 
-_COO_ONCE_MAX = int(os.environ.get("PGLAMD_COO_ONCE_ELEMENTS", str(4 << 20)))
+_COO_ONCE_MAX = int(os.environ.get("PGLAMD_COO_ONCE_ELEMENTS", str(6_400_000)))       # 50 k edges at d = 128 (profiles/r05/coo.txt)
 
 
 def send_u_recv(x, src_index, dst_index, reduce_op="sum", out_size=None):
     """paddle.geometric.send_u_recv(x, src_index, dst_index, reduce_op, out_size) on RAW index arrays -- the call behind
     Graph.send_recv in the reference (pgl/graph.py:859-861), for an edge list that is used once and has no cached index.
-    Dispatch rule (measured, profiles/r05/coo.txt): fp32 sum with |E| * d <= 4 M elements -> the edge-parallel atomic kernel
+    Dispatch rule (measured, profiles/r05/coo.txt): fp32 sum with |E| * d <= 6.4 M elements (50 k edges at d = 128) -> the edge-parallel atomic kernel
     (pglamd_scatter_add_coo: one launch, no sort; last bits depend on the atomics' order); everything else -> csr_build +
     the flat aggregation kernel (deterministic; 0.58 + 1.11 ms at |E| = 20 M, d = 128 where the atomic kernel takes 10 ms)."""
     _need_cuda(x, src_index, dst_index)

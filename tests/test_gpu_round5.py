@@ -554,7 +554,9 @@ def test_config5_one_rank_share_streamed_plan_fp16(pgl):
             continue
         f = _node_features(srcs, d, torch.float16).double()
         want = f.sum(0) / deg
-        bound = (2.0 * deg * 2.0 ** -24 * f.abs().sum(0) / deg) + 2.0 ** -11 * want.abs() + 1e-7
+        # fp32 reassociation of the sum + THREE fp16 roundings: the sum is stored in fp16, 1 / degree is an fp16 value, so is their product
+        # (a 16-bit mean applies its scale after the kernel: pgl_amd/distributed.py, aggregate_with_halo)
+        bound = (2.0 * deg * 2.0 ** -24 * f.abs().sum(0) / deg) + 3.0 * 2.0 ** -11 * want.abs() + 1e-7
         err = (out[r].double() - want).abs()
         assert bool((err <= bound).all()), (r, deg, float(err.max()), float(bound.max()))
         worst = max(worst, float((err / bound).max()))
