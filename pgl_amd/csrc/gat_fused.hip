@@ -99,7 +99,10 @@ template <int VEC, int MODE, bool DROP, bool POS = false>
 // (MODE 2 needs 106 VGPRs = 4 waves per SIMD against the forward's 68 = 7.  Forcing 5 / 6 waves with amdgpu_waves_per_eu makes the
 //  compiler spill 11 / 32 VGPRs into the hot loop: fwd + bwd 5.09 -> 5.43 / 10.0 ms at C3, profiles/r04/gat_backward_occupancy_variants.txt.)
 __global__ __launch_bounds__(kBlock) void gat_flat_kernel(GatParams p) {
-    constexpr int U = 4;
+#ifndef PGLAMD_GAT_ATT_U
+#define PGLAMD_GAT_ATT_U 4                                  // edges per batch of the attention-gradient walks (variant builds: 3, 2)
+#endif
+    constexpr int U = MODE >= 2 ? PGLAMD_GAT_ATT_U : 4;
     constexpr int PW = MODE == 0 ? (POS ? 5 : 3) : MODE == 2 ? 2 : 1;   // floats per column in a partial
     constexpr bool ATT = MODE >= 2;                     // accumulates the attention-score gradient of the row node
     constexpr bool FEAT = MODE != 3;                    // accumulates / writes a feature row
