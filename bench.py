@@ -52,7 +52,7 @@ def algorithmic_bytes(E, N, d, s):
     return E * (d * s + 4) + N * (d * s + 8)
 
 
-TRAFFIC_FILES = ("profiles/r04/traffic.json",)
+TRAFFIC_FILES = ("profiles/r05/traffic.json", "profiles/r04/traffic.json",)
 KERNEL_SOURCES = ("pgl_amd/csrc/aggregate_flat.hpp", "pgl_amd/csrc/aggregate.hpp", "pgl_amd/csrc/aggregate.hip", "pgl_amd/csrc/common.hpp")
 
 
