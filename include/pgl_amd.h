@@ -528,6 +528,16 @@ int32_t pglamd_halo_exchange_start(void* comm, const void* send_buf, const int64
                                    void* recv_buf, const int64_t* recv_rows, int64_t row_bytes,
                                    void* compute_stream);
 int32_t pglamd_halo_exchange_wait(void* comm, void* compute_stream);
+/* The exchange WITHOUT a send buffer (ABI 3): with the owner's rows ordered by the set of peers that pull them
+ * (pgl_amd.distributed.HaloPlan(row_order="peers")) every peer's rows are a few contiguous ranges of the feature matrix `x` itself;
+ * they are sent from where they lie (one ncclSend per range) into the matching ranges of recv_buf -- no pack launch, no send-buffer
+ * traffic.  send_ptr / recv_ptr [world + 1] delimit each peer's ranges in send_first / send_cnt (rows of x) and recv_first /
+ * recv_cnt (rows of recv_buf); range k of a pair has the same length on both ends.  Several exchanges (up to 8) may be in flight;
+ * pglamd_halo_exchange_wait retires them in start order. */
+int32_t pglamd_halo_exchange_start_ranges(void* comm, const void* x, const int64_t* send_ptr,
+                                          const int64_t* send_first, const int64_t* send_cnt, void* recv_buf,
+                                          const int64_t* recv_ptr, const int64_t* recv_first,
+                                          const int64_t* recv_cnt, int64_t row_bytes, void* compute_stream);
 
 /* Halo plan of one rank (HOST pointers; every rank derives its own share from the global edge list and the part vector,
  * so no negotiation is needed).  Relabelling and layout follow apps/GNNAutoScale/graph_partition.py:70-101 (owned ids

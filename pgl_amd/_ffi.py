@@ -93,6 +93,7 @@ _SIGNATURES = {
     "pglamd_comm_destroy": (c_i32, [c_vp]),
     "pglamd_halo_exchange_start": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pglamd_halo_exchange_wait": (c_i32, [c_vp, c_vp]),
+    "pglamd_halo_exchange_start_ranges": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pglamd_halo_plan_sizes": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_vp]),
     "pglamd_halo_plan_fill": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32] + [c_vp] * 13),
 }

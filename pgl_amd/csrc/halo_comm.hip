@@ -56,8 +56,11 @@ struct Comm {
     int rank = 0, world = 1;
     hipStream_t side = nullptr;          // library-owned: the exchange never queues behind the caller's kernels
     hipEvent_t ready = nullptr;          // compute stream -> side stream: the send buffer is complete
-    hipEvent_t done = nullptr;           // side stream -> compute stream: the receive buffer is complete
-    bool in_flight = false;
+    // side stream -> compute stream: "this exchange's receive buffer is complete".  A small ring, so that several exchanges can be
+    // in flight at once (the pipelined flows start block / half B while A is still travelling); waits retire them in start order.
+    static constexpr int kRing = 8;
+    hipEvent_t done[kRing] = {};
+    unsigned started = 0, waited = 0;    // exchanges started / waited for (in flight: started - waited, at most kRing)
 };
 
 #define PGLAMD_NCCL_CHECK(expr)                                                                          \
@@ -95,7 +98,7 @@ extern "C" int32_t pglamd_comm_init(int32_t rank, int32_t world, const void* uni
     if (r != ncclSuccess) { delete c; return fail(PGLAMD_E_RCCL, "ncclCommInitRank failed: %s", rccl().GetErrorString(r)); }
     PGLAMD_HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     PGLAMD_HIP_CHECK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
-    PGLAMD_HIP_CHECK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    for (int i = 0; i < Comm::kRing; ++i) PGLAMD_HIP_CHECK(hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming));
     *comm_out = c;
     return PGLAMD_OK;
 }
@@ -106,7 +109,7 @@ extern "C" int32_t pglamd_comm_destroy(void* comm) {
     if (c->side) (void)hipStreamSynchronize(c->side);
     if (c->nccl) (void)rccl().CommDestroy(c->nccl);
     if (c->ready) (void)hipEventDestroy(c->ready);
-    if (c->done) (void)hipEventDestroy(c->done);
+    for (int i = 0; i < Comm::kRing; ++i) if (c->done[i]) (void)hipEventDestroy(c->done[i]);
     if (c->side) (void)hipStreamDestroy(c->side);
     delete c;
     return PGLAMD_OK;
@@ -117,7 +120,7 @@ extern "C" int32_t pglamd_halo_exchange_start(void* comm, const void* send_buf, 
                                               const int64_t* recv_rows, int64_t row_bytes, void* compute_stream) {
     Comm* c = static_cast<Comm*>(comm);
     if (!c || !send_rows || !recv_rows || row_bytes <= 0) return fail(PGLAMD_E_ARG, "halo_exchange_start: bad argument");
-    if (c->in_flight) return fail(PGLAMD_E_ARG, "halo_exchange_start: the previous exchange has not been waited for");
+    if (c->started - c->waited >= (unsigned)Comm::kRing) return fail(PGLAMD_E_ARG, "halo_exchange_start: %d exchanges are in flight, wait for one first", Comm::kRing);
     hipStream_t cs = static_cast<hipStream_t>(compute_stream);
     PGLAMD_HIP_CHECK(hipEventRecord(c->ready, cs));                   // everything queued so far (the pack kernel) ...
     PGLAMD_HIP_CHECK(hipStreamWaitEvent(c->side, c->ready, 0));       // ... happens before the transfers
@@ -145,16 +148,58 @@ extern "C" int32_t pglamd_halo_exchange_start(void* comm, const void* send_buf, 
     const ncclResult_t end = rccl().GroupEnd();                      // always: closes the group on the error path too
     if (rc != PGLAMD_OK) return rc;                                   // (the first failure's message stands)
     if (end != ncclSuccess) return fail(PGLAMD_E_RCCL, "halo_exchange_start: ncclGroupEnd failed: %s", rccl().GetErrorString(end));
-    PGLAMD_HIP_CHECK(hipEventRecord(c->done, c->side));
-    c->in_flight = true;
+    PGLAMD_HIP_CHECK(hipEventRecord(c->done[c->started % Comm::kRing], c->side));
+    ++c->started;
+    return PGLAMD_OK;
+}
+
+// The same exchange WITHOUT a send buffer (round 5): every peer's rows are a few contiguous RANGES of the owner's feature matrix
+// (HaloPlan(row_order="peers"): rows pulled by the same set of peers lie together), so they are sent from where they are -- one
+// ncclSend per range -- and land in the matching ranges of the receive buffer.  Range k of a pair has the same length on both ends.
+//   send_ptr / recv_ptr  [world + 1]: ranges of peer q are send_first / send_cnt [send_ptr[q] .. send_ptr[q+1])  (rows of x),
+//                                      recv_first / recv_cnt [recv_ptr[q] .. recv_ptr[q+1])                      (rows of recv_buf)
+extern "C" int32_t pglamd_halo_exchange_start_ranges(void* comm, const void* x, const int64_t* send_ptr, const int64_t* send_first,
+                                                     const int64_t* send_cnt, void* recv_buf, const int64_t* recv_ptr,
+                                                     const int64_t* recv_first, const int64_t* recv_cnt, int64_t row_bytes,
+                                                     void* compute_stream) {
+    Comm* c = static_cast<Comm*>(comm);
+    if (!c || !send_ptr || !recv_ptr || !send_first || !send_cnt || !recv_first || !recv_cnt || row_bytes <= 0)
+        return fail(PGLAMD_E_ARG, "halo_exchange_start_ranges: bad argument");
+    if (c->started - c->waited >= (unsigned)Comm::kRing) return fail(PGLAMD_E_ARG, "halo_exchange_start_ranges: %d exchanges are in flight, wait for one first", Comm::kRing);
+    hipStream_t cs = static_cast<hipStream_t>(compute_stream);
+    PGLAMD_HIP_CHECK(hipEventRecord(c->ready, cs));                   // the rows of x are complete ...
+    PGLAMD_HIP_CHECK(hipStreamWaitEvent(c->side, c->ready, 0));       // ... before they travel
+    const char* xb = static_cast<const char*>(x);
+    char* rb = static_cast<char*>(recv_buf);
+    PGLAMD_NCCL_CHECK(rccl().GroupStart());
+    int32_t rc = PGLAMD_OK;                                           // (nothing returns between GroupStart and GroupEnd)
+    for (int q = 0; q < c->world && rc == PGLAMD_OK; ++q) {
+        if (q == c->rank) continue;
+        for (int64_t k = send_ptr[q]; k < send_ptr[q + 1] && rc == PGLAMD_OK; ++k) {
+            if (send_cnt[k] <= 0) continue;
+            const ncclResult_t r = rccl().Send(xb + (size_t)send_first[k] * (size_t)row_bytes, (size_t)send_cnt[k] * (size_t)row_bytes, ncclInt8, q, c->nccl, c->side);
+            if (r != ncclSuccess) rc = fail(PGLAMD_E_RCCL, "halo_exchange_start_ranges: send to peer %d failed: %s", q, rccl().GetErrorString(r));
+        }
+        for (int64_t k = recv_ptr[q]; k < recv_ptr[q + 1] && rc == PGLAMD_OK; ++k) {
+            if (recv_cnt[k] <= 0) continue;
+            const ncclResult_t r = rccl().Recv(rb + (size_t)recv_first[k] * (size_t)row_bytes, (size_t)recv_cnt[k] * (size_t)row_bytes, ncclInt8, q, c->nccl, c->side);
+            if (r != ncclSuccess) rc = fail(PGLAMD_E_RCCL, "halo_exchange_start_ranges: recv from peer %d failed: %s", q, rccl().GetErrorString(r));
+        }
+    }
+    const ncclResult_t end = rccl().GroupEnd();
+    if (rc != PGLAMD_OK) return rc;
+    if (end != ncclSuccess) return fail(PGLAMD_E_RCCL, "halo_exchange_start_ranges: ncclGroupEnd failed: %s", rccl().GetErrorString(end));
+    PGLAMD_HIP_CHECK(hipEventRecord(c->done[c->started % Comm::kRing], c->side));
+    ++c->started;
     return PGLAMD_OK;
 }
 
 extern "C" int32_t pglamd_halo_exchange_wait(void* comm, void* compute_stream) {
     Comm* c = static_cast<Comm*>(comm);
     if (!c) return fail(PGLAMD_E_ARG, "halo_exchange_wait: NULL communicator");
-    if (!c->in_flight) return PGLAMD_OK;
-    PGLAMD_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(compute_stream), c->done, 0));   // no host sync
-    c->in_flight = false;
+    if (c->started == c->waited) return PGLAMD_OK;
+    // the OLDEST exchange still in flight (exchanges complete in start order: they share the side stream); no host sync
+    PGLAMD_HIP_CHECK(hipStreamWaitEvent(static_cast<hipStream_t>(compute_stream), c->done[c->waited % Comm::kRing], 0));
+    ++c->waited;
     return PGLAMD_OK;
 }

@@ -105,25 +105,61 @@ class AbiTransport(object):
                 outer._ffi.check(L.pglamd_halo_exchange_wait(outer.comm, st), "halo_exchange_wait")
         return _W()
 
+    def exchange_ranges(self, x, send_ranges, recv_buf, recv_ranges):
+        """send_ranges[q] = [(first row of x, rows), ...]; recv_ranges[q] = [(first row of recv_buf, rows), ...] (see _exchange_ranges)."""
+        ct, L = self._ct, self._ffi.lib()
+        row_bytes = x.element_size()
+        for s_ in x.shape[1:]:
+            row_bytes *= int(s_)
+        def flat(rr):
+            ptr, first, cnt = [0], [], []
+            for q in range(self.world):
+                for a, n in rr[q]:
+                    first.append(int(a)); cnt.append(int(n))
+                ptr.append(len(first))
+            mk = lambda v: (ct.c_int64 * max(len(v), 1))(*v)
+            return mk(ptr), mk(first), mk(cnt)
+        sp, sf, sc = flat(send_ranges)
+        rp, rf, rc = flat(recv_ranges)
+        stream = ct.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        self._ffi.check(L.pglamd_halo_exchange_start_ranges(self.comm, ct.c_void_p(x.data_ptr()), sp, sf, sc, ct.c_void_p(recv_buf.data_ptr()),
+                                                            rp, rf, rc, row_bytes, stream), "halo_exchange_start_ranges")
+        keep = (x, recv_buf)
+        outer = self
+
+        class _W(object):
+            def wait(self_inner):
+                st = ct.c_void_p(torch.cuda.current_stream(keep[0].device).cuda_stream)
+                outer._ffi.check(L.pglamd_halo_exchange_wait(outer.comm, st), "halo_exchange_wait")
+        return _W()
+
     def close(self):
         if self.comm:
             self._ffi.lib().pglamd_comm_destroy(self.comm)
             self.comm = self._ct.c_void_p()
 
 
-_OVERRIDE = {"flow": None, "transport": None}      # set_flow(): per-process choice that takes precedence over PGLAMD_FLOW / PGLAMD_TRANSPORT
+_OVERRIDE = {"flow": None, "transport": None, "pipe": None}      # set_flow(): per-process choice that takes precedence over PGLAMD_FLOW / PGLAMD_TRANSPORT
 
 
 def _env_flow():
     return _OVERRIDE["flow"] if _OVERRIDE["flow"] is not None else os.environ.get("PGLAMD_FLOW", "")
 
 
+def _pipe_kind():
+    """How a pipelined exchange is cut: "rows" (two halves of the rows, flow "rows2") or "cols" (two column blocks, flow "pipeline").
+    PGLAMD_PIPE / set_flow(pipe=...); every rank must use the same."""
+    v = _OVERRIDE.get("pipe")
+    return v if v else os.environ.get("PGLAMD_PIPE", "cols")
+
+
 def _env_transport():
     return _OVERRIDE["transport"] if _OVERRIDE["transport"] is not None else os.environ.get("PGLAMD_TRANSPORT", "")
 
 
-def set_flow(flow=None, transport=None, graphs=()):
-    """Forces the data flow ("split" | "fold" | "accumulate" | "pipeline" | "" = the cost model's choice) and / or the transport
+def set_flow(flow=None, transport=None, graphs=(), pipe=None):
+    """Forces the data flow ("split" | "fold" | "accumulate" | "pipeline" (two column blocks) | "rows2" (two halves of the rows) |
+    "" = the cost model's choice) and / or the transport
     ("abi" = the library's own RCCL communicator on its side stream, pglamd_halo_exchange_*; "torch" = torch.distributed's
     all_to_all_single) for every DistGraph of this process, taking precedence over PGLAMD_FLOW / PGLAMD_TRANSPORT; None leaves
     a setting as it is.  Decisions already cached on `graphs` are dropped.  Every rank must make the same call."""
@@ -131,6 +167,8 @@ def set_flow(flow=None, transport=None, graphs=()):
         _OVERRIDE["flow"] = flow
     if transport is not None:
         _OVERRIDE["transport"] = "" if transport == "torch" else transport
+    if pipe is not None:                                  # "rows" | "cols": how a pipelined exchange is cut (see _pipe_kind)
+        _OVERRIDE["pipe"] = pipe
     for g in graphs:
         for k in [k for k in g._idx if isinstance(k, tuple) and k and k[0] in ("mode", "mode_estimates", "pipelined", "ran")]:
             del g._idx[k]
@@ -164,6 +202,58 @@ def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
             reqs.append(dist.irecv(dst[ro[q]:ro[q + 1]], src=peer(q), group=group))
         if send_splits[q]:
             reqs.append(dist.isend(src[so[q]:so[q + 1]].contiguous(), dst=peer(q), group=group))
+
+    class _W(object):
+        def wait(self_inner):
+            for r in reqs:
+                r.wait()
+            if staged:
+                recv_buf.copy_(dst)
+    return _W()
+
+
+def _exchange_ranges(x, send_ranges, recv_buf, recv_ranges, group=None, tag0=0):
+    """The halo exchange WITHOUT a send buffer: for every peer q the rows x[first : first + n] of each (first, n) in send_ranges[q]
+    travel from where they lie (x = the owner's feature matrix, rows contiguous) into recv_buf[pos : pos + n] for the matching
+    (pos, n) of the peer's recv_ranges -- range k of a pair has the same length on both ends (HaloPlan.range_plan).  Returns an
+    object with .wait().  Transports: the library's own RCCL communicator (pglamd_halo_exchange_start_ranges: grouped ncclSend /
+    ncclRecv per range on its side stream), torch.distributed point-to-point on RCCL, or gloo (tests; staged through the host)."""
+    if not _group_ready(group):
+        return _Done()
+    backend = dist.get_backend(group)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if backend == "nccl" and _env_transport() == "abi":
+        return AbiTransport.get(group).exchange_ranges(x, send_ranges, recv_buf, recv_ranges)
+    peer = (lambda q: q) if group is None else (lambda q: dist.get_global_rank(group, q))
+    if backend == "nccl":
+        ops_ = []
+        for q in range(world):
+            if q == rank:
+                continue
+            for first, n in send_ranges[q]:
+                ops_.append(dist.P2POp(dist.isend, x[first:first + n], peer(q), group))
+            for pos, n in recv_ranges[q]:
+                ops_.append(dist.P2POp(dist.irecv, recv_buf[pos:pos + n], peer(q), group))
+        reqs = dist.batch_isend_irecv(ops_) if ops_ else []
+
+        class _Wn(object):
+            def wait(self_inner):
+                for r in reqs:
+                    r.wait()
+        return _Wn()
+    staged = x.is_cuda
+    dst = torch.empty(recv_buf.shape, dtype=recv_buf.dtype) if staged else recv_buf
+    reqs, keep = [], []
+    for q in range(world):
+        if q == rank:
+            continue
+        for k, (pos, n) in enumerate(recv_ranges[q]):
+            reqs.append(dist.irecv(dst[pos:pos + n], src=peer(q), group=group, tag=tag0 + k))
+        for k, (first, n) in enumerate(send_ranges[q]):
+            piece = x[first:first + n]
+            piece = piece.cpu() if staged else piece.contiguous()
+            keep.append(piece)
+            reqs.append(dist.isend(piece, dst=peer(q), group=group, tag=tag0 + k))
 
     class _W(object):
         def wait(self_inner):
@@ -246,11 +336,34 @@ class HaloPlan(object):
         recv  (recv_rows, recv_cols), n_recv  out[rows] += recv_buf[cols]   (pull: the halo edges; push: one edge per row)
     """
 
-    def __init__(self, edges, num_nodes, part, rank, world, push=None):
+    def __init__(self, edges, num_nodes, part, rank, world, push=None, row_order="id"):
+        """row_order: how a rank's owned rows are ordered -- "id" (by original node id, the default) or "peers": rows pulled by the
+        same SET of peers lie together (sets in Gray-code order), so that the rows any one peer pulls are a few contiguous RANGES of
+        the owner's feature matrix and can be sent from where they are, without a pack into a send buffer (DistGraph, flow "rows2")."""
         dev = edges.device
         part = torch.as_tensor(part, device=dev).to(torch.int64)
         N, P = int(num_nodes), int(world)
-        order = torch.argsort(part, stable=True)                      # new id -> old id
+        self.row_order = row_order
+        if row_order == "peers" and P > 1:
+            if P > 40:
+                raise ValueError("row_order='peers' keys rows by a bit mask of the reading peers: world <= 40")
+            ps_, pd_ = part[edges[:, 0]], part[edges[:, 1]]
+            cut_ = ps_ != pd_
+            mask = torch.zeros(N, dtype=torch.int64, device=dev)
+            for q in range(P):                                            # bit q: some row of rank q reads this node
+                flag = torch.zeros(N, dtype=torch.bool, device=dev)
+                flag[edges[cut_ & (pd_ == q), 0]] = True
+                mask |= flag.to(torch.int64) << q
+            k, sh = mask.clone(), 1
+            while sh < P:                                                 # position of the mask in the reflected Gray sequence:
+                k ^= k >> sh                                              # neighbouring sets differ in one peer, so a peer's rows
+                sh <<= 1                                                  # form about half as many runs as in binary order
+            order = torch.argsort(part * (1 << P) + k, stable=True)
+            del ps_, pd_, cut_, mask, k
+        elif row_order not in ("id", "peers"):
+            raise ValueError("row_order must be 'id' or 'peers'")
+        else:
+            order = torch.argsort(part, stable=True)                      # new id -> old id
         new_id = torch.empty_like(order)
         new_id[order] = torch.arange(N, device=dev)
         counts = torch.bincount(part, minlength=P)
@@ -332,6 +445,39 @@ class HaloPlan(object):
         self.n_send = int(scnt.sum())
         self.pushed_pairs = int(push.sum())
 
+    @staticmethod
+    def _runs(ids):
+        """[(first, length), ...] of the maximal runs of consecutive values in an ascending id list (host list of ints)."""
+        if int(ids.shape[0]) == 0:
+            return []
+        v = ids.cpu()
+        brk = torch.nonzero(v[1:] != v[:-1] + 1).reshape(-1) + 1
+        starts = torch.cat([brk.new_zeros(1), brk])
+        ends = torch.cat([brk, brk.new_full((1,), int(v.shape[0]))])
+        return [(int(v[a]), int(b - a)) for a, b in zip(starts.tolist(), ends.tolist())]
+
+    def range_plan(self):
+        """-> (send, recv): for every peer q the contiguous ranges of OWNED rows it pulls -- send[q] = [(first local row, rows), ...] --
+        and the matching runs on the receiving side -- recv[q] = [(first position inside q's block of the receive buffer, rows), ...].
+        Both sides derive the same run structure from their own arrays (the rows rank q sends to rank p ARE p's halo rows owned by q,
+        in the same order), so range k of a pair has the same length on both ends.  With row_order="peers" a peer's rows are a few
+        long runs (<= 2^(world-2) by construction, far fewer in practice); with row_order="id" mostly runs of one row."""
+        rp = getattr(self, "_range_plan", None)
+        if rp is None:
+            send, recv, so, ro = [], [], 0, 0
+            lo = [self.offsets[q] for q in range(self.world)]
+            for q in range(self.world):
+                ns, nr = int(self.pull_splits[q]), int(self.halo_splits[q])
+                send.append(self._runs(self.send_idx[so:so + ns]))
+                runs = self._runs(self.halo_global[ro:ro + nr])            # global (new) ids: consecutive ids = consecutive rows of q
+                pos, rq = 0, []
+                for _, n in runs:
+                    rq.append((pos, n)); pos += n
+                recv.append(rq)
+                so += ns; ro += nr
+            rp = self._range_plan = (send, recv)
+        return rp
+
     @classmethod
     def from_edge_slabs(cls, slabs, num_nodes, rank, world, part=None, device=None):
         """The pull plan of one rank built from the edge list handed over SLAB BY SLAB (an iterable of int64 [k, 2] (src, dst)
@@ -392,6 +538,7 @@ class HaloPlan(object):
         cat = lambda parts, i: torch.cat([p_[i] for p_ in parts]) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
         plan = cls.__new__(cls)
         plan.rank, plan.world, plan.num_nodes, plan.offsets, plan.n_own = rank, P, N, offsets, n_own
+        plan.row_order = "id"
         plan.own_global = torch.arange(lo, hi, device=dev) if order is None else order[lo:hi]
         plan.loc_rows, plan.loc_cols = cat(loc, 0), cat(loc, 1)
         hd, hs = cat(inc, 0), cat(inc, 1)
@@ -445,7 +592,7 @@ class HaloPlan(object):
 _PLAN_ARRAYS = ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "halo_global", "send_idx", "in_degree",
                 "out_degree", "edge_global", "recv_rows", "recv_cols", "send_rows", "send_cols", "push")
 _PLAN_META = ("rank", "world", "num_nodes", "n_own", "n_halo", "local_edges", "offsets", "halo_splits", "pull_splits",
-              "recv_splits", "send_splits", "n_recv", "n_send", "pushed_pairs")
+              "recv_splits", "send_splits", "n_recv", "n_send", "pushed_pairs", "row_order")
 
 
 def _plan_dump(plan, path):
@@ -582,7 +729,7 @@ class DistGraph(object):
     # ---- construction ----------------------------------------------------------------------------------------------
     @classmethod
     def from_global(cls, edges, num_nodes, rank, world, method="kway", device=None, part=None, group=None, backend=None,
-                    seed=0, push="never"):
+                    seed=0, push="never", row_order="id"):
         """Every rank holds the same global edge list (synthetic graphs are regenerated from the seed on each rank);
         rank 0 partitions and broadcasts the part vector.
         method: "kway" (default: the engine's own multilevel partitioner, balanced on aggregation work -- in-degree + 1 -- and
@@ -601,7 +748,7 @@ class DistGraph(object):
         best = None
         for m in methods:
             pt = part if given else cls.partition(edges, num_nodes, world, m, rank, group, seed)
-            plan = HaloPlan(edges, num_nodes, pt, rank, world)
+            plan = HaloPlan(edges, num_nodes, pt, rank, world, row_order=row_order)
             xplan = plan
             pull_c = push_c = choice = None
             if world > 1 and (push == "auto" or len(methods) > 1):
@@ -609,7 +756,7 @@ class DistGraph(object):
             if push == "auto" and world > 1:
                 choice = HaloPlan.choose_push(pull_c, push_c)
                 if bool(choice.any()):
-                    xplan = HaloPlan(edges, num_nodes, pt, rank, world, push=choice)
+                    xplan = HaloPlan(edges, num_nodes, pt, rank, world, push=choice, row_order=row_order)
             cost = 0.0
             if len(methods) > 1:
                 # the SAME number on every rank, with or without a process group: rows received by the slowest rank (from the
@@ -783,6 +930,11 @@ class DistGraph(object):
                 rows, cols, nr = xp.recv_cols, xp.recv_rows, xp.n_recv
             elif base == "recv":                                      # out[rows] += recv_buf[cols]   (accumulate mode)
                 rows, cols, nr = xp.recv_rows, xp.recv_cols, p.n_own
+            elif base in ("recvA", "recvB"):                          # the two halves of the row-pipelined exchange (flow "rows2")
+                r2 = self._rows2()
+                pos = r2["rmap"][xp.recv_cols]                        # position in the receive buffer laid out [A halves | B halves]
+                sel = (pos < r2["nA_r"]) if base == "recvA" else (pos >= r2["nA_r"])
+                rows, cols, nr = xp.recv_rows[sel], pos[sel], p.n_own
             elif base == "send_t":                                    # g_own[rows] += returned_buf[cols]   (accumulate mode, backward)
                 rows, cols, nr = xp.send_cols, xp.send_rows, p.n_own
             elif base in ("int", "bnd", "all"):
@@ -991,6 +1143,103 @@ class DistGraph(object):
             self._idx[key] = s
         return s
 
+    # ---- flow "rows2": the exchange in two HALVES OF THE ROWS, optionally without a send buffer (round 5) ------------------------
+    def _rows2(self):
+        """Bookkeeping of the row-pipelined exchange: every pair's block is cut in two halves (ceil(n / 2) rows first -- both ends
+        know n, so both know the cut); the send and receive buffers are laid out [A halves of all peers | B halves of all peers], so
+        that each half is ONE all-to-all-v of contiguous per-peer pieces and each half's edges are one index (xrecvA / xrecvB)."""
+        r = self._idx.get("rows2")
+        if r is None:
+            xp = self.xplan
+            dev = self.plan.loc_rows.device
+            def layout(splits):
+                halves = [(int(c) + 1) // 2 for c in splits]
+                n, nA = int(sum(splits)), int(sum(halves))
+                m = torch.empty(n, dtype=torch.int64)
+                o, a, b = 0, 0, nA
+                for c, h in zip(splits, halves):
+                    c = int(c)
+                    m[o:o + h] = torch.arange(a, a + h)
+                    m[o + h:o + c] = torch.arange(b, b + c - h)
+                    o, a, b = o + c, a + h, b + c - h
+                return halves, nA, m
+            hr, nA_r, rmap = layout(xp.recv_splits)
+            hs, nA_s, smap = layout(xp.send_splits)
+            inv = torch.empty_like(smap)
+            inv[smap] = torch.arange(smap.shape[0])
+            send_cols = xp.send_cols.to(dev)
+            r = self._idx["rows2"] = {
+                "hr": hr, "hs": hs, "nA_r": nA_r, "nA_s": nA_s, "rmap": rmap.to(dev),
+                "rB": [int(c) - h for c, h in zip(xp.recv_splits, hr)], "sB": [int(c) - h for c, h in zip(xp.send_splits, hs)],
+                # pack index of the [A | B] send layout: new position j holds owned row send_cols[inv[j]]
+                "pack32": send_cols[inv.to(dev)].to(torch.int32) if send_cols.is_cuda else send_cols[inv.to(dev)]}
+        return r
+
+    def _rows2_ranges(self):
+        """Zero-copy form: the (first row, rows) ranges of the owned feature matrix each peer pulls, cut at the A / B boundary, and
+        the matching (position, rows) ranges of the [A | B] receive buffer -- from HaloPlan.range_plan()."""
+        rr = self._idx.get("rows2_ranges")
+        if rr is None:
+            p, r2 = self.plan, self._rows2()
+            send, recv = p.range_plan()
+            def cut(runs, h, base_a, base_b, positional):
+                a, b, pos = [], [], 0
+                for first, n in runs:
+                    na = max(0, min(n, h - pos))
+                    if positional:                                     # receive side: `first` IS the position inside the peer's block
+                        if na: a.append((base_a + pos, na))
+                        if n - na: b.append((base_b + pos + na - h, n - na))
+                    else:
+                        if na: a.append((first, na))
+                        if n - na: b.append((first + na, n - na))
+                    pos += n
+                return a, b
+            sa, sb, ra, rb = [], [], [], []
+            oa, ob = 0, r2["nA_r"]
+            for q in range(p.world):
+                a, b = cut(send[q], r2["hs"][q], 0, 0, False); sa.append(a); sb.append(b)
+                a, b = cut(recv[q], r2["hr"][q], oa, ob, True); ra.append(a); rb.append(b)
+                oa += r2["hr"][q]; ob += r2["rB"][q]
+            rr = self._idx["rows2_ranges"] = (sa, sb, ra, rb)
+        return rr
+
+    def _zero_copy(self, x):
+        """True when the rows can travel from the feature matrix itself: a peer-ordered pull plan (few ranges per peer), the rows in
+        their own dtype, contiguous, and the mechanism not switched off (PGLAMD_ZERO_COPY=0)."""
+        return (getattr(self.plan, "row_order", "id") == "peers" and int(self.xplan.pushed_pairs) == 0 and x.is_contiguous()
+                and self._wire(x.dtype) == x.dtype and os.environ.get("PGLAMD_ZERO_COPY", "1") != "0")
+
+    def _start_rows2(self, x):
+        """-> (work A, work B, receive buffer [A halves | B halves]).  Zero-copy when the plan allows it (no pack launch, no send
+        buffer); otherwise ONE gather packs the [A | B] send layout and each half is an all-to-all-v of its slice."""
+        xp, r2 = self.xplan, self._rows2()
+        tail = tuple(x.shape[1:])
+        in_buf = self._buffer("in_rows2", (xp.n_recv,) + tail, x.dtype, x.device)
+        if self._zero_copy(x):
+            sa, sb, ra, rb = self._rows2_ranges()
+            wa = _exchange_ranges(x, sa, in_buf, ra, self.group, tag0=0)
+            wb = _exchange_ranges(x, sb, in_buf, rb, self.group, tag0=1 << 16)
+            self._idx[("ran_pack", "x")] = "zero-copy"
+            return wa, wb, in_buf
+        out_buf = self._buffer("out_rows2", (xp.n_send,) + tail, x.dtype, x.device)
+        if xp.n_send:
+            if x.dtype in (torch.float32, torch.float16, torch.bfloat16):
+                self._b.gather_rows_cast(x, r2["pack32"], x.dtype, out_buf)
+            else:
+                out_buf = self._b.gather_rows(x, r2["pack32"])
+        nA_s, nA_r = r2["nA_s"], r2["nA_r"]
+        wa = _exchange(out_buf[:nA_s], r2["hs"], in_buf[:nA_r], r2["hr"], self.group)
+        wb = _exchange(out_buf[nA_s:], r2["sB"], in_buf[nA_r:], r2["rB"], self.group)
+        self._idx[("ran_pack", "x")] = "pack"
+        return wa, wb, in_buf
+
+    def _rows2_ok(self, kind, transposed, additive, x, emit_in, emit_out):
+        """The row-pipelined flow serves the forward sum / mean of a pull plan with the rows travelling in their own dtype."""
+        forced = _env_flow()
+        want = forced == "rows2" or (forced == "" and _pipe_kind() == "rows")      # PGLAMD_FLOW=pipeline means the column blocks
+        return (want and kind == "x" and not transposed and additive and int(self.xplan.pushed_pairs) == 0
+                and self._wire(x.dtype) == x.dtype and emit_in is None and emit_out is None)
+
     # ---- the overlapped two-phase flow (forward and, with the indices transposed, backward) --------------------------------
     def _flow(self, x, scale, transposed, reduce="sum", kind="x", emit_in=None, emit_out=None):
         """out[v] = scale[v] * REDUCE over ALL in-edges of owned row v (transposed: the gradient of that).  SURVEY 8e steps
@@ -1020,6 +1269,19 @@ class DistGraph(object):
             emit_in = None                                           # (cannot happen for one plan and row width; be safe)
         if wo is not None and bool(emit_out.piped) != bool(piped):
             wo = wo1 = None
+        if piped and self._rows2_ok(kind, transposed, additive, x, emit_in, emit_out):
+            # ROW-PIPELINED (round 5): the rows travel in two halves, each half the full row width -- half A's edges are added while
+            # half B is still on the wire, every launch walks full-width rows (the column blocks below walk ALL received edges twice
+            # at half width), and with a peer-ordered plan neither half is packed: the rows are sent from the feature matrix itself.
+            wa, wb, in_buf = self._start_rows2(x)
+            out = B.aggregate(x, self._index("loc"), reduce, p.n_own, dst_scale=scale_k)
+            for work, name in ((wa, "xrecvA"), (wb, "xrecvB")):
+                work.wait()
+                idx = self._index(name)
+                if idx.num_edges if hasattr(idx, "num_edges") else int(idx[0].shape[0]):
+                    B.aggregate(in_buf, idx, reduce, p.n_own, dst_scale=scale_k, out=out, accumulate=1)
+            self._idx[("ran", kind, transposed)] = "rows2"
+            return out
         if piped:
             # COLUMN-PIPELINED (all ranks agreed on it): the rows travel in two column blocks, one all-to-all-v each.  While block
             # 0 is on the wire block 1 is packed and the local-source edges run; the received rows' edges of block 0 are added
@@ -1141,7 +1403,7 @@ class DistGraph(object):
                 end_a = max(t_a, t_c) + rem
                 est["pipeline"] = max(end_a, t_a + half_x) + rem + rmw
             forced = _env_flow()
-            if forced in est and forced != "pipeline":
+            if forced in est and forced not in ("pipeline", "rows2"):
                 hit = forced
             elif os.environ.get("PGLAMD_FOLD_INTERIOR"):              # (round-3 knob kept for the tests: fold below this interior share)
                 hit = "fold" if e_int < float(os.environ["PGLAMD_FOLD_INTERIOR"]) * max(p.local_edges, 1) else "split"
@@ -1160,7 +1422,7 @@ class DistGraph(object):
             return False
         forced = _env_flow()
         if forced or os.environ.get("PGLAMD_FOLD_INTERIOR"):
-            return forced == "pipeline"
+            return forced in ("pipeline", "rows2")
         key = ("pipelined", kind, transposed, row_bytes)
         hit = self._idx.get(key)
         if hit is None:
@@ -1408,7 +1670,20 @@ class DistGraph(object):
         pack = (lambda: B.gather_rows_cast(x_own, self._send_cols32("x"), wire, send_buf)) if (xp.n_send and int(xp.pushed_pairs) == 0 and
                x_own.dtype in (torch.float32, torch.float16, torch.bfloat16)) else (lambda: B.aggregate(x_own, self._index("xsend"), "sum", xp.n_send)) if xp.n_send else (lambda: None)
         out = torch.empty_like(x_own)
-        if self._pipelined("x", False, True, x_own, row_bytes):
+        piped = self._pipelined("x", False, True, x_own, row_bytes)
+        if piped and self._rows2_ok("x", False, True, x_own, None, None):
+            flow, r2 = "rows2", self._rows2()
+            zero = self._zero_copy(x_own)
+            in2 = self._buffer("in_rows2", (xp.n_recv, d), x_own.dtype, x_own.device)
+            ob2 = self._buffer("out_rows2", (max(xp.n_send, 1), d), x_own.dtype, x_own.device)
+            pack = (lambda: None) if (zero or not xp.n_send) else (lambda: B.gather_rows_cast(x_own, r2["pack32"], x_own.dtype, ob2[:xp.n_send]))
+            before = lambda: B.aggregate(x_own, self._index("loc"), "sum", p.n_own, out=out)
+            after = lambda: (B.aggregate(in2, self._index("xrecvA"), "sum", p.n_own, out=out, accumulate=1),
+                             B.aggregate(in2, self._index("xrecvB"), "sum", p.n_own, out=out, accumulate=1))
+            res = {"flow": flow + ("/zero-copy" if zero else "/pack"), "pack_ms": 0.0 if zero else timed(pack), "before_ms": timed(before),
+                   "after_ms": timed(after)}
+            return res
+        if piped:
             flow, h = "pipeline", (d // 2 + 15) // 16 * 16
             before = lambda: B.aggregate(x_own, self._index("loc"), "sum", p.n_own, out=out)
             b0 = self._buffer("phase_in0", (xp.n_recv, h), x_own.dtype, x_own.device)

@@ -147,8 +147,8 @@ def cmd_rows(args):
         worst, rows, preds, chains = {"compute": 0.0, "pair_mb": 0.0, "ratio": 0.0}, [], [], []
         stack_layers = None
         for r in range(P):
-            plan = HaloPlan(edges, N, part, r, P)
-            xplan = HaloPlan(edges, N, part, r, P, push=choice) if bool(choice.any()) else plan
+            plan = HaloPlan(edges, N, part, r, P, row_order=args.row_order)
+            xplan = HaloPlan(edges, N, part, r, P, push=choice, row_order=args.row_order) if bool(choice.any()) else plan
             dg = DistGraph(plan, device=dev, exchange_plan=xplan)
             if args.wire:
                 dg.wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.wire]
@@ -158,29 +158,34 @@ def cmd_rows(args):
             # mirrored into the send buffer (pglamd_aggregate_wire): no pack launch.  mean (= sum with the fused 1 / degree scale)
             # keeps the values bounded over the timed steps; the unfused mean step is timed beside it
             chain = [x_own]
+            no_chain = getattr(args, "no_chain", False)
             def chained():
                 chain[0] = dg.send_recv(chain[0], "mean", emit=True)
-            ms_mean = _t(lambda: dg.send_recv(x_own, "mean"), it=10, warm=3)
-            k0 = getattr(dg, "_packs_skipped", 0)
-            ms_chain = _t(chained, it=10, warm=3)
-            fused_ok = getattr(dg, "_packs_skipped", 0) - k0 >= 12
-            # a conv-layer stack (3 x GraphSageConv(d, d, mean), inference): the row kernel that finishes a layer writes its rows into
-            # the next layer's send buffer (pglamd_row_epilogue_wire) -- against the same stack with a pack launch per layer
-            if stack_layers is None:
-                torch.manual_seed(0)
-                stack_layers = [pgl.nn.GraphSageConv(d, d, "mean").to(dev) for _ in range(3)]
-            def stack():
-                h = x_own
-                for L in stack_layers:
-                    h = L(dg, h, act="relu")
-                return h
-            with torch.no_grad():
-                dg.emit_outputs = False
-                ms_stack_pack = _t(stack, it=6, warm=2)
-                dg.emit_outputs = True
-                k1 = getattr(dg, "_packs_skipped", 0)
-                ms_stack_fused = _t(stack, it=6, warm=2)
-                stack_ok = getattr(dg, "_packs_skipped", 0) - k1 >= 2 * 8
+            ms_mean = ms_chain = ms_stack_pack = ms_stack_fused = 0.0
+            fused_ok = stack_ok = True
+            if not no_chain:
+                ms_mean = _t(lambda: dg.send_recv(x_own, "mean"), it=10, warm=3)
+                k0 = getattr(dg, "_packs_skipped", 0)
+                ms_chain = _t(chained, it=10, warm=3)
+                fused_ok = getattr(dg, "_packs_skipped", 0) - k0 >= 12
+                # a conv-layer stack (3 x GraphSageConv(d, d, mean), inference): the row kernel that finishes a layer writes its rows
+                # into the next layer's send buffer (pglamd_row_epilogue_wire) -- against the same stack with a pack launch per layer
+                if stack_layers is None:
+                    torch.manual_seed(0)
+                    stack_layers = [pgl.nn.GraphSageConv(d, d, "mean").to(dev) for _ in range(3)]
+                def stack():
+                    h = x_own
+                    for L in stack_layers:
+                        h = L(dg, h, act="relu")
+                    return h
+                with torch.no_grad():
+                    dg.emit_outputs = False
+                    ms_stack_pack = _t(stack, it=6, warm=2)
+                    dg.emit_outputs = True
+                    k1 = getattr(dg, "_packs_skipped", 0)
+                    ms_stack_fused = _t(stack, it=6, warm=2)
+                    stack_ok = getattr(dg, "_packs_skipped", 0) - k1 >= 2 * 8
+                    dg.emit_outputs = False
             torch.cuda.synchronize()
             t_cpu = time.perf_counter()
             for _ in range(20):
@@ -193,7 +198,27 @@ def cmd_rows(args):
             pair_mb = max(xplan.recv_splits) * d * wb / 1e6
             xch = pair_mb / 1e3 / LINK * 1e3
             out = torch.empty_like(x_own)
-            if dg._pipelined("x", False, True, x_own, d * 4):
+            if os.environ.get("PGLAMD_FLOW") == "rows2":
+                # the exchange in two halves of the ROWS (full-width rows in every launch); with --row-order peers the halves are not
+                # packed at all: the rows travel from the feature matrix itself (pglamd_halo_exchange_start_ranges)
+                mode = "rows2/" + ("zero-copy" if dg._zero_copy(x_own) else "pack")
+                r2 = dg._rows2()
+                in2 = dg._buffer("in_rows2", (xplan.n_recv, d), torch.float32, dev)
+                ob2 = dg._buffer("out_rows2", (xplan.n_send, d), torch.float32, dev)
+                pk = 0.0 if dg._zero_copy(x_own) else _t(lambda: B.gather_rows_cast(x_own, r2["pack32"], torch.float32, ob2), it=10, warm=2)
+                pre = _t(lambda: B.aggregate(x_own, dg._index("loc"), "sum", plan.n_own), it=10, warm=2)
+                po0 = _t(lambda: B.aggregate(in2, dg._index("xrecvA"), "sum", plan.n_own, out=out, accumulate=1), it=10, warm=2)
+                po1 = _t(lambda: B.aggregate(in2, dg._index("xrecvB"), "sum", plan.n_own, out=out, accumulate=1), it=10, warm=2)
+                post = po0 + po1
+                e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecvA").num_edges + dg._index("xrecvB").num_edges
+                n_ranges = sum(len(q) for q in plan.range_plan()[0]) if dg._zero_copy(x_own) else 0
+                mode += " (%d ranges)" % n_ranges if n_ranges else ""
+                def predict(x_ms, lat_ms, pk=pk, pre=pre, po0=po0, po1=po1):
+                    t_a = pk + lat_ms + 0.5 * x_ms                       # half A has arrived
+                    end_a = max(t_a, pk + pre) + po0                     # local edges, then A's edges
+                    return max(end_a, t_a + lat_ms + 0.5 * x_ms) + po1   # B follows A on the same links
+                pred = predict(xch, 0.0)
+            elif dg._pipelined("x", False, True, x_own, d * 4):
                 # two column blocks: block 0 arrives at t_a, block 1 follows it on the same links (and cannot start before it is
                 # packed); the compute stream packs both blocks, runs the local edges, then adds block 0's and block 1's edges
                 mode, h = "pipeline", (d // 2 + 15) // 16 * 16
@@ -248,16 +273,18 @@ def cmd_rows(args):
         for r, n_own, le, e_pre, e_post, ns, nr, ms, pk, pre, post, ideal, pmb, enq, mode, pred in rows:
             print("   rank %d: %7d rows %9d edges, flow %-10s (%8d edges before the wait, %9d after) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms (host enqueue %.3f); alone: pack %.3f, before %.3f, after %.3f | ideal %.3f ms -> x%.2f | with the exchange: %.3f ms"
                   % (r, n_own, le, mode, e_pre, e_post, ns, nr, pmb, ms, enq, pk, pre, post, ideal, ms / ideal, pred))
-        print("   layers >= 2 (input = the previous step's output; its rows were mirrored into the send buffer by the launches that "
-              "produced them: no pack):")
-        for r, mm, mc, ideal, ok, sp, sf, sok in chains:
+        if not getattr(args, "no_chain", False):
+            print("   layers >= 2 (input = the previous step's output; its rows were mirrored into the send buffer by the launches that "
+                  "produced them: no pack):")
+        for r, mm, mc, ideal, ok, sp, sf, sok in ([] if getattr(args, "no_chain", False) else chains):
             print("   rank %d: mean step with pack %.3f ms | chained step, aggregation mirrors its rows %.3f ms (%s) | ideal %.3f ms -> x%.2f || "
                   "3 x GraphSageConv forward: pack per layer %.3f ms | row kernel mirrors its rows %.3f ms (%s)"
                   % (r, mm, mc, "pack skipped every step" if ok else "PACK NOT SKIPPED", ideal, mc / ideal, sp, sf,
                      "layers 2, 3 without pack" if sok else "PACK NOT SKIPPED"))
-        wc = max(c[2] for c in chains)
-        print("   slowest rank, layers >= 2: compute %.3f ms (worst compute/ideal x%.2f) -> bound %.2fx of one GPU with the exchange fully hidden"
-              % (wc, max(c[2] / c[3] for c in chains), t1 / wc))
+        if not getattr(args, "no_chain", False):
+            wc = max(c[2] for c in chains)
+            print("   slowest rank, layers >= 2: compute %.3f ms (worst compute/ideal x%.2f) -> bound %.2fx of one GPU with the exchange fully hidden"
+                  % (wc, max(c[2] / c[3] for c in chains), t1 / wc))
         t_link = worst["pair_mb"] / 1e3 / LINK * 1e3
         print("   slowest rank compute %.3f ms (worst compute/ideal x%.2f; ideal = E/P at the 1-GPU rate = %.3f ms) | exchange >= %.3f ms (largest pair block at %.0f GB/s per link)"
               % (worst["compute"], worst["ratio"], t1 / P, t_link, LINK))
@@ -1182,7 +1209,9 @@ def main():
     r.add_argument("--wire", default="", choices=["", "fp16", "bf16"])
     r.add_argument("--graph", default="rmat", choices=["rmat", "community"])
     r.add_argument("--reorder", action="store_true", help="renumber the nodes with Graph.reorder() before partitioning")
-    r.add_argument("--flow", default="", choices=["", "split", "fold", "accumulate", "pipeline"], help="force one flow (PGLAMD_FLOW) instead of the cost model's")
+    r.add_argument("--flow", default="", choices=["", "split", "fold", "accumulate", "pipeline", "rows2"], help="force one flow (PGLAMD_FLOW) instead of the cost model's")
+    r.add_argument("--row-order", default="id", choices=["id", "peers"], help="peers: a rank's rows ordered by the set of peers that pull them (zero-copy exchange)")
+    r.add_argument("--no-chain", action="store_true", help="skip the layers >= 2 / layer-stack measurements")
     sub.add_parser("noreuse")
     sub.add_parser("gcn")
     tr = sub.add_parser("traffic")

@@ -845,3 +845,48 @@ def test_plan_from_edge_slabs_equals_the_plan_from_the_whole_list(given_part):
     assert [int(t.shape[0]) for t in s1] == [3000, 3000, 3000, 1000]
     assert torch.equal(torch.cat(s1) % 1000, torch.cat(s2)) and int(torch.cat(s1).max()) < 1024
     assert torch.equal(list(rmat_slabs(10, 10000, 3000, seed=5))[2], s1[2])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: flow "rows2" -- the exchange in two halves of the rows; with a peer-ordered plan the rows travel from the feature matrix
+# itself (no pack, no send buffer)
+# ------------------------------------------------------------------------------------------------
+def _rows2_worker(rank, world, row_order, method):
+    from pgl_amd.distributed import DistGraph
+    edges, x = _graph(d=32)
+    n = x.shape[0]
+    dg = DistGraph.from_global(torch.from_numpy(edges), n, rank, world, method=method, backend=TorchBackend(), push="never", row_order=row_order)
+    _nan_buffers(dg)
+    x_own = dg.take_owned(torch.from_numpy(x))
+    xg = x_own.clone().requires_grad_(True)
+    out = dg.send_recv(xg, "mean")
+    (out * out).sum().backward()
+    res = {"sum": dg.send_recv(x_own, "sum").numpy(), "mean": out.detach().numpy(), "grad": xg.grad.numpy(),
+           "flow": dg.stats()["flow"], "pack": dg._idx.get(("ran_pack", "x")),
+           "ranges": sum(len(r) for r in dg.plan.range_plan()[0]), "n_send": dg.plan.n_send}
+    return (rank, dg.plan.own_global.numpy(), res)
+
+
+@pytest.mark.parametrize("world,row_order,method", [(2, "id", "random"), (3, "peers", "random"), (4, "peers", "kway"), (2, "peers", "random")])
+def test_gloo_row_pipelined_flow_and_zero_copy(monkeypatch, world, row_order, method):
+    monkeypatch.setenv("PGLAMD_FLOW", "rows2")
+    got = _spawn(_rows2_worker, world, row_order, method)
+    edges, x = _graph(d=32)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    src, dst = torch.from_numpy(edges[:, 0]), torch.from_numpy(edges[:, 1])
+    s = torch.zeros_like(xt).index_add(0, dst, xt[src])
+    m = s / torch.bincount(dst, minlength=x.shape[0]).clamp(min=1).reshape(-1, 1)
+    (m * m).sum().backward()
+    want = {"sum": s.detach().numpy(), "mean": m.detach().numpy(), "grad": xt.grad.numpy()}
+    for key, w in want.items():
+        full = np.full_like(w, np.nan)
+        for _, own, res in got:
+            full[own] = res[key]
+        assert np.isfinite(full).all(), key
+        assert np.abs(full - w).max() <= 2e-5 * np.abs(w).max(), key
+    for _, _, res in got:
+        assert res["flow"] == "rows2"
+        assert res["pack"] == ("zero-copy" if row_order == "peers" else "pack")
+        if row_order == "peers" and world >= 3:
+            assert res["ranges"] <= (1 << (world - 2)) * (world - 1) and res["ranges"] < res["n_send"]   # a few runs per peer, not one per row
+    assert sorted(np.concatenate([own for _, own, _ in got]).tolist()) == list(range(x.shape[0]))

@@ -455,3 +455,48 @@ def test_fused_pack_chains_and_layer_stacks_vs_single_gpu(world, flow):
         if flow:
             assert r["flow"] == flow
     print("input-gradient error of the 3-layer stacks vs one GPU (mirrored rows, pack per layer):", [(r["sage_grad_err"], r["gcn_grad_err"]) for r in got])
+
+
+# ------------------------------------------------------------------------------------------------
+# round 5: flow "rows2" on the HIP kernels -- the exchange in two halves of the rows, with a peer-ordered plan from the feature
+# matrix itself (no pack launch, no send buffer)
+# ------------------------------------------------------------------------------------------------
+def _rows2_worker(rank, world, row_order):
+    import pgl_amd as pgl
+    from pgl_amd.distributed import DistGraph
+    os.environ["PGLAMD_FLOW"] = "rows2"
+    dev = torch.device("cuda:0")
+    scale, e, d = 16, 1_000_000, 128
+    n = 1 << scale
+    from pgl_amd.utils.rmat import rmat_edges
+    edges = rmat_edges(scale, e, seed=42, device=dev)
+    g = pgl.Graph(edges=edges, num_nodes=n)
+    dg = DistGraph.from_global(edges, n, rank, world, method="kway", device=dev, row_order=row_order)
+    own = dg.plan.own_global
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(n, d, generator=gen, device=dev)
+    for dt, tol in ((torch.float32, 2e-5), (torch.float16, 4e-3)):
+        for op in ("sum", "mean"):
+            with torch.no_grad():
+                got = dg.send_recv(dg.take_owned(x.to(dt)), op)
+            _close(got.float(), g.send_recv(x.to(dt), op)[own].float(), tol, "rows2 %s %s" % (op, dt))
+    cot = torch.randn(n, d, generator=gen, device=dev)
+    xf = x.clone().requires_grad_(True)
+    (g.send_recv(xf, "mean") * cot).sum().backward()
+    xo = dg.take_owned(x).requires_grad_(True)
+    (dg.send_recv(xo, "mean") * cot[own]).sum().backward()
+    _close(xo.grad, xf.grad[own], 1e-4, "rows2 gradient")
+    ph = dg.phase_times(dg.take_owned(x), iters=3, warm=1)
+    return {"flow": dg.stats()["flow"], "pack": dg._idx.get(("ran_pack", "x")), "ranges": sum(len(r) for r in dg.plan.range_plan()[0]),
+            "n_send": dg.plan.n_send, "phases": ph}
+
+
+@pytest.mark.parametrize("world,row_order", [(2, "id"), (3, "peers"), (4, "peers")])
+def test_row_pipelined_flow_and_zero_copy_on_rmat16_vs_single_gpu(world, row_order):
+    got = _spawn(_rows2_worker, world, row_order)
+    for r in got:
+        assert r["flow"] == "rows2", r
+        assert r["pack"] == ("zero-copy" if row_order == "peers" else "pack"), r
+        if row_order == "peers":
+            assert r["ranges"] <= (1 << (world - 2)) * (world - 1) and r["ranges"] * 50 < r["n_send"], r
+            assert r["phases"]["pack_ms"] == 0.0, r
