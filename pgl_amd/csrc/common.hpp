@@ -65,6 +65,7 @@ struct Carver {
 // (dispatcher places block b on XCD b % 8; speed only, never correctness).
 // Launch ceil(nb/8)*8 blocks; returns -1 for the padding blocks.
 __device__ __forceinline__ int64_t xcd_swizzle(int64_t b, int64_t nb) {
+    if (nb < 0) return b < -nb ? b : -1;       // -nb blocks, NOT remapped: block b is chunk b, i.e. consecutive chunks go round the XCDs
     int64_t per = (nb + kXcds - 1) / kXcds;
     int64_t lb = (b % kXcds) * per + b / kXcds;
     return lb < nb ? lb : -1;

@@ -1222,13 +1222,16 @@ class DistGraph(object):
             self._idx[("ran_pack", "x")] = "zero-copy"
             return wa, wb, in_buf
         out_buf = self._buffer("out_rows2", (xp.n_send,) + tail, x.dtype, x.device)
-        if xp.n_send:
-            if x.dtype in (torch.float32, torch.float16, torch.bfloat16):
-                self._b.gather_rows_cast(x, r2["pack32"], x.dtype, out_buf)
-            else:
-                out_buf = self._b.gather_rows(x, r2["pack32"])
         nA_s, nA_r = r2["nA_s"], r2["nA_r"]
+        fast = x.dtype in (torch.float32, torch.float16, torch.bfloat16)
+        # half A is packed and on the wire before half B is packed: the exchange starts after HALF a pack
+        if not fast and xp.n_send:
+            out_buf = self._b.gather_rows(x, r2["pack32"])
+        if fast and nA_s:
+            self._b.gather_rows_cast(x, r2["pack32"][:nA_s], x.dtype, out_buf[:nA_s])
         wa = _exchange(out_buf[:nA_s], r2["hs"], in_buf[:nA_r], r2["hr"], self.group)
+        if fast and xp.n_send - nA_s:
+            self._b.gather_rows_cast(x, r2["pack32"][nA_s:], x.dtype, out_buf[nA_s:])
         wb = _exchange(out_buf[nA_s:], r2["sB"], in_buf[nA_r:], r2["rB"], self.group)
         self._idx[("ran_pack", "x")] = "pack"
         return wa, wb, in_buf
@@ -1281,6 +1284,8 @@ class DistGraph(object):
                 if idx.num_edges if hasattr(idx, "num_edges") else int(idx[0].shape[0]):
                     B.aggregate(in_buf, idx, reduce, p.n_own, dst_scale=scale_k, out=out, accumulate=1)
             self._idx[("ran", kind, transposed)] = "rows2"
+            if post is not None:
+                out = out * post
             return out
         if piped:
             # COLUMN-PIPELINED (all ranks agreed on it): the rows travel in two column blocks, one all-to-all-v each.  While block

@@ -214,9 +214,9 @@ def cmd_rows(args):
                 n_ranges = sum(len(q) for q in plan.range_plan()[0]) if dg._zero_copy(x_own) else 0
                 mode += " (%d ranges)" % n_ranges if n_ranges else ""
                 def predict(x_ms, lat_ms, pk=pk, pre=pre, po0=po0, po1=po1):
-                    t_a = pk + lat_ms + 0.5 * x_ms                       # half A has arrived
-                    end_a = max(t_a, pk + pre) + po0                     # local edges, then A's edges
-                    return max(end_a, t_a + lat_ms + 0.5 * x_ms) + po1   # B follows A on the same links
+                    t_a = 0.5 * pk + lat_ms + 0.5 * x_ms                 # half A (packed first) has arrived
+                    end_a = max(t_a, pk + pre) + po0                     # both halves packed, local edges, then A's edges
+                    return max(end_a, max(t_a, pk) + lat_ms + 0.5 * x_ms) + po1   # B follows A on the same links
                 pred = predict(xch, 0.0)
             elif dg._pipelined("x", False, True, x_own, d * 4):
                 # two column blocks: block 0 arrives at t_a, block 1 follows it on the same links (and cannot start before it is
