@@ -68,6 +68,10 @@ extern "C" {
 #define PGLAMD_DIV 3
 
 int32_t pglamd_abi_version(void);
+/* Process-wide launch options.  "xcd_swizzle": 1 (default) = consecutive chunks of the destination-sorted edge stream run on ONE XCD
+ * (they share its L2: partition- / cluster-ordered graphs); 0 = chunks are dealt round the XCDs -- for row orders that correlate with
+ * row length (pgl_amd.distributed.HaloPlan(row_order="peers")), where the blocked mapping unbalances the XCDs. */
+int32_t pglamd_set_option(const char* name, int64_t value);
 const char* pglamd_last_error(void);
 /* name of the device the library sees, e.g. "gfx950..." (host string, valid until next call) */
 const char* pglamd_device_arch(void);

@@ -24,6 +24,7 @@ class WireOut(ctypes.Structure):
 # name -> (restype, argtypes) ; mirrors include/pgl_amd.h one to one
 _SIGNATURES = {
     "pglamd_abi_version": (c_i32, []),
+    "pglamd_set_option": (c_i32, [ctypes.c_char_p, c_i64]),
     "pglamd_last_error": (ctypes.c_char_p, []),
     "pglamd_device_arch": (ctypes.c_char_p, []),
     "pglamd_csr_build_workspace_bytes": (c_sz, [c_i64, c_i64]),

@@ -727,10 +727,11 @@ template <typename T, int VEC, int NT, int RCLS, int YMODE>
 int32_t launch_flat(AggParams p, hipStream_t st) {
     const int64_t nb = ceil_div(p.n_chunks, kWavesPerBlock);
     // consecutive chunks on ONE XCD (shared L2 for partition-ordered graphs) -- unless the caller's rows are ordered by something that
-    // correlates with their LENGTH (HaloPlan(row_order="peers"): few-reader, i.e. low-degree, rows first, hubs last): a blocked
-    // mapping then gives one XCD all the store-heavy short-row chunks.  PGLAMD_XCD_SWIZZLE=0 deals the chunks round the XCDs instead.
-    const char* sw = getenv("PGLAMD_XCD_SWIZZLE");
-    p.n_blocks = (sw && sw[0] == '0') ? -(int)nb : (int)nb;
+    // correlates with their LENGTH (HaloPlan(row_order="peers"): rows grouped by the set of peers that read them, i.e. by degree
+    // class): a blocked mapping then gives one XCD all the store-heavy short-row chunks (measured: 1.11 vs 1.00 ms per rank at
+    // C2' / P = 8).  pglamd_set_option("xcd_swizzle", 0) / PGLAMD_XCD_SWIZZLE=0 deal the chunks round the XCDs instead.
+    static const bool env_off = [] { const char* sw = getenv("PGLAMD_XCD_SWIZZLE"); return sw && sw[0] == '0'; }();
+    p.n_blocks = (env_off || xcd_swizzle_option().load(std::memory_order_relaxed) == 0) ? -(int)nb : (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     const bool fixups = needs_fixups(p);

@@ -1,5 +1,6 @@
 // common.cpp -- error state + version/introspection entry points of libpglamd.
 #include "common.hpp"
+#include <atomic>
 
 namespace pglamd {
 
@@ -18,9 +19,17 @@ int32_t fail(int32_t code, const char* fmt, ...) {
     return code;
 }
 
+std::atomic<int>& xcd_swizzle_option() { static std::atomic<int> v{1}; return v; }
+
 }  // namespace pglamd
 
 extern "C" int32_t pglamd_abi_version(void) { return PGLAMD_ABI_VERSION; }
+
+extern "C" int32_t pglamd_set_option(const char* name, int64_t value) {
+    if (!name) return pglamd::fail(PGLAMD_E_ARG, "set_option: NULL name");
+    if (strcmp(name, "xcd_swizzle") == 0) { pglamd::xcd_swizzle_option().store(value ? 1 : 0, std::memory_order_relaxed); return PGLAMD_OK; }
+    return pglamd::fail(PGLAMD_E_ARG, "set_option: unknown option %s", name);
+}
 
 extern "C" const char* pglamd_last_error(void) { return pglamd::last_error_ref().c_str(); }
 

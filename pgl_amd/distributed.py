@@ -358,8 +358,12 @@ class HaloPlan(object):
             while sh < P:                                                 # position of the mask in the reflected Gray sequence:
                 k ^= k >> sh                                              # neighbouring sets differ in one peer, so a peer's rows
                 sh <<= 1                                                  # form about half as many runs as in binary order
-            order = torch.argsort(part * (1 << P) + k, stable=True)
-            del ps_, pd_, cut_, mask, k
+            # the rows EVERY peer reads -- the hubs, which carry most of the edge mass -- come first: the first half of the
+            # row-pipelined exchange (cut by EDGES, DistGraph._rows2) then is a short transfer with half the work behind it
+            everyone = ((1 << P) - 1) ^ (torch.ones_like(part) << part)
+            k = torch.where(mask == everyone, torch.zeros_like(k), k + 1)
+            order = torch.argsort(part * (2 << P) + k, stable=True)
+            del ps_, pd_, cut_, mask, k, everyone
         elif row_order not in ("id", "peers"):
             raise ValueError("row_order must be 'id' or 'peers'")
         else:
@@ -400,7 +404,7 @@ class HaloPlan(object):
         self.halo_splits = (bounds[1:] - bounds[:-1]).cpu().tolist()
         self.edge_global = torch.cat([eid[loc], eid[inc]])            # original edge id of local edge k
         # rows of mine that each peer pulls: distinct (peer, src) pairs over the outgoing edges, peer-major
-        key = torch.unique(own_d[outg] * N + src[outg], sorted=True)
+        key, self.send_counts = torch.unique(own_d[outg] * N + src[outg], sorted=True, return_counts=True)   # counts: edges of that peer reading the row
         self.send_idx = (key % N) - lo
         self.pull_splits = torch.bincount(key // N, minlength=P).cpu().tolist()
 
@@ -487,8 +491,8 @@ class HaloPlan(object):
         part: int64 [N] part vector, or None = RANGE partition of the node ids as they are (rank p owns ids [p N / P, (p+1) N / P):
         the documented fallback where a partitioner's input does not fit in host memory, pgl/partition.py:94-123 / SURVEY 8e --
         RMAT ids are randomly permuted already, so this is a balanced random partition that needs no [N] array at all).
-        Kept per slab: the slab's edges into owned rows (relabelled), a [world, n_own] bitmap of which peer reads which owned row,
-        and the owned rows' out-degree counts."""
+        Kept per slab: the slab's edges into owned rows (relabelled), a [world, n_own] table of how many edges of each peer read which
+        owned row, and the owned rows' out-degree counts."""
         N, P, rank = int(num_nodes), int(world), int(rank)
         it = iter(slabs)
         first = next(it)
@@ -508,7 +512,7 @@ class HaloPlan(object):
         offsets = off.cpu().tolist()
         lo, hi = offsets[rank], offsets[rank + 1]
         n_own = hi - lo
-        reads = torch.zeros((P, max(n_own, 1)), dtype=torch.bool, device=dev)      # reads[p, r]: peer p has an edge from my row r
+        reads = torch.zeros((P, max(n_own, 1)), dtype=torch.int32, device=dev)     # reads[p, r]: edges of peer p's rows that read my row r
         out_deg = torch.zeros(max(n_own, 1), dtype=torch.int64, device=dev)
         loc, inc = [], []                                                            # per slab: (rows, cols, eid) / (rows, src_new, eid)
         base = 0
@@ -527,7 +531,7 @@ class HaloPlan(object):
                 outg = s_mine & ~d_mine
                 if bool(outg.any()):
                     owner = torch.searchsorted(off, dst[outg], right=True) - 1
-                    reads[owner, src[outg] - lo] = True
+                    reads.view(-1).index_add_(0, owner * max(n_own, 1) + (src[outg] - lo), torch.ones(int(owner.shape[0]), dtype=torch.int32, device=dev))
             eid = torch.arange(base, base + k, device=dev)
             both = d_mine & s_mine
             loc.append((dst[both] - lo, src[both] - lo, eid[both]))
@@ -553,9 +557,10 @@ class HaloPlan(object):
         plan.halo_global = halo_ids
         b = torch.searchsorted(halo_ids, off)
         plan.halo_splits = (b[1:] - b[:-1]).cpu().tolist()
-        reads[rank] = False
+        reads[rank] = 0
         nz = torch.nonzero(reads[:, :n_own]) if n_own else torch.zeros((0, 2), dtype=torch.int64, device=dev)   # peer-major, rows ascending
         plan.send_idx = nz[:, 1].contiguous()
+        plan.send_counts = reads[nz[:, 0], nz[:, 1]].to(torch.int64) if n_own else torch.zeros(0, dtype=torch.int64, device=dev)
         plan.pull_splits = torch.bincount(nz[:, 0], minlength=P).cpu().tolist()
         # exchange plan = the pull plan (no push decisions without the global pair counts)
         plan.push = torch.zeros((P, P), dtype=torch.bool)
@@ -590,7 +595,7 @@ class HaloPlan(object):
 
 
 _PLAN_ARRAYS = ("own_global", "loc_rows", "loc_cols", "hal_rows", "hal_cols", "halo_global", "send_idx", "in_degree",
-                "out_degree", "edge_global", "recv_rows", "recv_cols", "send_rows", "send_cols", "push")
+                "out_degree", "edge_global", "recv_rows", "recv_cols", "send_rows", "send_cols", "push", "send_counts")
 _PLAN_META = ("rank", "world", "num_nodes", "n_own", "n_halo", "local_edges", "offsets", "halo_splits", "pull_splits",
               "recv_splits", "send_splits", "n_recv", "n_send", "pushed_pairs", "row_order")
 
@@ -715,6 +720,10 @@ class DistGraph(object):
         self._inv_deg = None
         self._all_ids = None
         self.method = "given"
+        if getattr(plan, "row_order", "id") == "peers" and backend is None:
+            # rows grouped by reader set are rows grouped by degree class: deal the aggregation's chunks round the XCDs (process-wide
+            # library option; a blocked chunk -> XCD mapping gives one XCD all the short-row chunks: 1.11 vs 1.00 ms per rank)
+            ops.set_option("xcd_swizzle", 0)
         # True: the row kernel that finishes a GraphSageConv / GCNConv layer also writes its rows into the next layer's halo send
         # buffer (wire / mark below), so that layer starts its exchange without a pack launch.  OFF by default: measured at
         # |E| = 100 M, P = 8 (profiles/r05/rows_c2p.txt) it does not beat the pack launch it removes -- the pack's reads are served
@@ -1152,8 +1161,26 @@ class DistGraph(object):
         if r is None:
             xp = self.xplan
             dev = self.plan.loc_rows.device
-            def layout(splits):
-                halves = [(int(c) + 1) // 2 for c in splits]
+            by_edges = int(xp.send_counts.shape[0]) == int(xp.n_send) and int(xp.pushed_pairs) == 0
+            def cut_points(splits, weights):
+                """first half of every pair's block: rows until half of the EDGES that read the block are covered (both ends hold
+                the same per-row counts, so both compute the same cut); plans without counts cut by rows"""
+                if not by_edges:
+                    return [(int(c) + 1) // 2 for c in splits]
+                w = weights.to(torch.float64).cpu()
+                out, o = [], 0
+                for c in splits:
+                    c = int(c)
+                    if c == 0:
+                        out.append(0); continue
+                    cum = torch.cumsum(w[o:o + c], 0)
+                    h = int(torch.searchsorted(cum, cum[-1] * 0.5).item()) + 1
+                    out.append(min(max(h, 1), c))
+                    o += c
+                return out
+            recv_w = torch.bincount(xp.recv_cols, minlength=xp.n_recv) if by_edges else None
+            def layout(splits, weights):
+                halves = cut_points(splits, weights)
                 n, nA = int(sum(splits)), int(sum(halves))
                 m = torch.empty(n, dtype=torch.int64)
                 o, a, b = 0, 0, nA
@@ -1163,8 +1190,8 @@ class DistGraph(object):
                     m[o + h:o + c] = torch.arange(b, b + c - h)
                     o, a, b = o + c, a + h, b + c - h
                 return halves, nA, m
-            hr, nA_r, rmap = layout(xp.recv_splits)
-            hs, nA_s, smap = layout(xp.send_splits)
+            hr, nA_r, rmap = layout(xp.recv_splits, recv_w)
+            hs, nA_s, smap = layout(xp.send_splits, xp.send_counts)
             inv = torch.empty_like(smap)
             inv[smap] = torch.arange(smap.shape[0])
             send_cols = xp.send_cols.to(dev)

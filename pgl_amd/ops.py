@@ -51,6 +51,11 @@ _WS_HOT_TOTAL = 1 << 30                  # bytes held over all entries; the leas
 _WS_HOT_ENTRIES = 16
 
 
+def set_option(name, value):
+    """pglamd_set_option: process-wide launch options of the library ("xcd_swizzle": 1 / 0)."""
+    _ffi.check(_ffi.lib().pglamd_set_option(name.encode(), int(value)), "set_option")
+
+
 def release_workspaces():
     """Drops every cached scratch buffer (they return to torch's caching allocator; torch.cuda.empty_cache() then gives the
     memory back to the device).  Safe at any point: a buffer in use by queued kernels stays alive through the allocator's
