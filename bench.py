@@ -204,7 +204,7 @@ def target_size_leg_dist(pgl, dev, d, rank, world, args, timed, note, steps=10):
     note("target size: generating RMAT scale %d, %d edges" % (scale, E))
     edges = rmat_edges(scale, E, seed=42, device=dev)
     t0 = time.perf_counter()
-    dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push)
+    dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push, row_order=args.row_order)
     t_plan = time.perf_counter() - t0
     note("target size: partition + plan %.1f s" % t_plan)
     del edges
@@ -380,6 +380,10 @@ def main():
                     help="'never' (default) = halo source rows are pulled, every edge is aggregated by its destination's owner (what the "
                          "partitioner balanced); 'auto' = per rank pair the cheaper of pulling source rows and pushing pre-aggregated "
                          "destination rows (fewer bytes, but it moves edge work between ranks)")
+    ap.add_argument("--row-order", default="peers", choices=["peers", "id"],
+                    help="N > 1: how a rank orders its rows.  'peers' (default): rows pulled by the same set of peers lie together, so every "
+                         "peer's rows are a few contiguous ranges of the feature matrix and the row-pipelined exchange (flow 'rows2') sends "
+                         "them from where they are -- no pack launch, no send buffer; 'id': by node id (round 4's layout; the exchange packs)")
     ap.add_argument("--no-alternatives", action="store_true", help="(kept for compatibility: alternatives are off unless --alternatives)")
     ap.add_argument("--alternatives", action="store_true", help="N > 1: also time the other layouts (feature columns) as secondary fields")
     ap.add_argument("--transport", default="auto", choices=["auto", "torch", "abi"],
@@ -471,7 +475,7 @@ def main():
         if mode == "rows":
             # ---- north_star's layout: row partition + one halo all-to-all-v per step ------------------------------------------------
             wd.begin("partition + halo plan", 4 * lim)
-            dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push)
+            dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push, row_order=args.row_order)
             x_own = dg.take_owned(x)
             st0 = dg.stats()
             wd.end()
@@ -481,7 +485,10 @@ def main():
             # exchange, possibly two column blocks in flight); then the same over the library's own RCCL communicator and side
             # stream (pglamd_halo_exchange_*).  Every trial runs under the phase limit; a candidate that raises is dropped on all
             # ranks; one that hangs ends the run with the best candidate measured before it.
-            want = [("fold", "torch"), ("", "torch")] if args.transport in ("auto", "torch") else []
+            # ("pipeline" = round 4's flow: two column blocks, packed; "" = the cost model's choice, which with a peer-ordered plan is
+            #  the zero-copy row-pipelined flow where pipelining pays: over torch.distributed point-to-point, then over the library's
+            #  own communicator -- pglamd_halo_exchange_start_ranges)
+            want = [("fold", "torch"), ("pipeline", "torch"), ("", "torch")] if args.transport in ("auto", "torch") else []
             if args.transport in ("auto", "abi"):
                 want.append(("", "abi"))
             best = None
@@ -499,16 +506,22 @@ def main():
                     print("[bench] candidate %s failed (rank %d: %r)" % (label, rank, err), file=sys.stderr, flush=True)
                     wd.end()
                     continue
-                ms = timed(step, n_trial) / n_trial * 1e3
+                # a candidate's trial IS a full measurement (W warm-up + K steps, barrier + synchronize on both sides, max over ranks:
+                # tens of milliseconds): if a later phase hangs, the line left behind is a complete measurement of the best
+                # candidate that finished, not a 3-step sample
+                for _ in range(args.warmup):
+                    step()
+                ms = timed(step, args.steps) / args.steps * 1e3
                 ran = dg.stats()["flow"]
                 cands.append({"flow": flow or "cost-model", "ran_flow": ran, "transport": transport, "status": "ok", "trial_ms_per_step": ms,
-                              "trial_steps": n_trial})
+                              "trial_steps": args.steps, "packs": dg._idx.get(("ran_pack", "x"), "pack")})
                 wd.end()
                 note("candidate %-22s -> %.3f ms/step (flow that ran: %s)" % (label, ms, ran))
                 if best is None or ms < best[0]:
                     best = (ms, flow, transport, ran)
                     wd.best = (lambda ms=ms, label=label, ran=ran: dict(
-                        base_record(ms, "trial of %d steps of candidate %s (a later phase did not finish)" % (n_trial, label)),
+                        base_record(ms, "%d steps after %d warm-up steps of candidate %s, barrier + synchronize on both sides, max over ranks (a later "
+                                        "phase did not finish)" % (args.steps, args.warmup, label)),
                         config={"workload": "RMAT scale %d |V|=%d |E|=%d d=%d fp32" % (args.scale, N, E, d), "parallelism":
                                 "row partition (%s) x%d + halo all-to-all-v, flow %s" % (st0["partition"], world, ran)},
                         roofline={"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None},

@@ -291,6 +291,11 @@ def _all_reduce_sum(tensor, group=None):
 # methods as a test seam -- the product has only this one and it refuses CPU tensors.)
 # ------------------------------------------------------------------------------------------------------------------
 class _EngineBackend(object):
+    def __init__(self, deal_chunks=False):
+        # deal_chunks: the aggregation's chunks go round the XCDs instead of in blocks (pglamd_set_option "xcd_swizzle" = 0 around
+        # every launch of this backend) -- for plans whose row order correlates with row length (HaloPlan(row_order="peers"))
+        self.deal_chunks = bool(deal_chunks)
+
     def index(self, rows, cols, n_rows, edge_ids=None, n_edge_rows=0):
         """CSR of the (rows, cols) pairs.  edge_ids: the LOCAL edge id of every pair (edge operands of send_ue_recv are in
         local edge order, n_edge_rows of them); None = pair k is edge k.  The longest row rides along (`max_row`: one host read at plan set-up),
@@ -305,8 +310,15 @@ class _EngineBackend(object):
 
     def aggregate(self, x, index, reduce_op, n_rows, y=None, message_op="add", src_scale=None, dst_scale=None, out=None,
                   accumulate=0, x2=None, zero_indptr=None, wire=None):
-        return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
-                             x2=x2, zero_indptr=zero_indptr, wire=wire)
+        if not self.deal_chunks:
+            return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
+                                 x2=x2, zero_indptr=zero_indptr, wire=wire)
+        ops.set_option("xcd_swizzle", 0)
+        try:
+            return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
+                                 x2=x2, zero_indptr=zero_indptr, wire=wire)
+        finally:
+            ops.set_option("xcd_swizzle", 1)
 
     def row_epilogue(self, z, bias, act, normalize, wire=None):
         from . import autograd as ag
@@ -713,17 +725,15 @@ class DistGraph(object):
         self.plan, self.group = plan, group
         self.xplan = exchange_plan if exchange_plan is not None else plan     # pull/push plan of send_recv(sum | mean)
         self.device = device if device is not None else plan.loc_rows.device
-        self._b = backend if backend is not None else _EngineBackend()
+        # (rows grouped by reader set are rows grouped by degree class: a blocked chunk -> XCD mapping gives one XCD all the short-row
+        #  chunks -- 1.11 vs 1.00 ms per rank at C2' / P = 8 -- so such plans deal the chunks round the XCDs)
+        self._b = backend if backend is not None else _EngineBackend(deal_chunks=getattr(plan, "row_order", "id") == "peers")
         self._idx = {}
         self._buf = {}
         self._local_graph = None
         self._inv_deg = None
         self._all_ids = None
         self.method = "given"
-        if getattr(plan, "row_order", "id") == "peers" and backend is None:
-            # rows grouped by reader set are rows grouped by degree class: deal the aggregation's chunks round the XCDs (process-wide
-            # library option; a blocked chunk -> XCD mapping gives one XCD all the short-row chunks: 1.11 vs 1.00 ms per rank)
-            ops.set_option("xcd_swizzle", 0)
         # True: the row kernel that finishes a GraphSageConv / GCNConv layer also writes its rows into the next layer's halo send
         # buffer (wire / mark below), so that layer starts its exchange without a pack launch.  OFF by default: measured at
         # |E| = 100 M, P = 8 (profiles/r05/rows_c2p.txt) it does not beat the pack launch it removes -- the pack's reads are served
@@ -1266,7 +1276,8 @@ class DistGraph(object):
     def _rows2_ok(self, kind, transposed, additive, x, emit_in, emit_out):
         """The row-pipelined flow serves the forward sum / mean of a pull plan with the rows travelling in their own dtype."""
         forced = _env_flow()
-        want = forced == "rows2" or (forced == "" and _pipe_kind() == "rows")      # PGLAMD_FLOW=pipeline means the column blocks
+        # PGLAMD_FLOW=pipeline means the column blocks; unforced, a peer-ordered plan pipelines by rows (that is what it is ordered for)
+        want = forced == "rows2" or (forced == "" and (_pipe_kind() == "rows" or getattr(self.plan, "row_order", "id") == "peers"))
         return (want and kind == "x" and not transposed and additive and int(self.xplan.pushed_pairs) == 0
                 and self._wire(x.dtype) == x.dtype and emit_in is None and emit_out is None)
 

@@ -153,7 +153,7 @@ def cmd_rows(args):
             if args.wire:
                 dg.wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.wire]
             x_own = dg.take_owned(x)
-            ms = _t(lambda: dg.send_recv(x_own, "sum"), it=10, warm=3)
+            ms = min(_t(lambda: dg.send_recv(x_own, "sum"), it=10, warm=3) for _ in range(3))     # (min of three: one in ~20 first measurements catches an allocator hiccup)
             # layers >= 2 of a stack: the step's input is the previous step's output, whose rows the producing launches already
             # mirrored into the send buffer (pglamd_aggregate_wire): no pack launch.  mean (= sum with the fused 1 / degree scale)
             # keeps the values bounded over the timed steps; the unfused mean step is timed beside it
@@ -213,10 +213,13 @@ def cmd_rows(args):
                 e_pre, e_post = dg._index("loc").num_edges, dg._index("xrecvA").num_edges + dg._index("xrecvB").num_edges
                 n_ranges = sum(len(q) for q in plan.range_plan()[0]) if dg._zero_copy(x_own) else 0
                 mode += " (%d ranges)" % n_ranges if n_ranges else ""
-                def predict(x_ms, lat_ms, pk=pk, pre=pre, po0=po0, po1=po1):
-                    t_a = 0.5 * pk + lat_ms + 0.5 * x_ms                 # half A (packed first) has arrived
+                fa = r2["nA_r"] / max(xplan.n_recv, 1)                    # share of the ROWS that travels in half A (the halves are cut by edges)
+                fs = r2["nA_s"] / max(xplan.n_send, 1)
+                mode += ", half A = %.2f of the rows" % fa
+                def predict(x_ms, lat_ms, pk=pk, pre=pre, po0=po0, po1=po1, fa=fa, fs=fs):
+                    t_a = fs * pk + lat_ms + fa * x_ms                   # half A (packed first) has arrived
                     end_a = max(t_a, pk + pre) + po0                     # both halves packed, local edges, then A's edges
-                    return max(end_a, max(t_a, pk) + lat_ms + 0.5 * x_ms) + po1   # B follows A on the same links
+                    return max(end_a, max(t_a, pk) + lat_ms + (1.0 - fa) * x_ms) + po1   # B follows A on the same links
                 pred = predict(xch, 0.0)
             elif dg._pipelined("x", False, True, x_own, d * 4):
                 # two column blocks: block 0 arrives at t_a, block 1 follows it on the same links (and cannot start before it is
