@@ -281,21 +281,21 @@ class PhaseWatchdog(object):
             # only an extra leg hung); a run that ends before it exits 3, and the record it leaves behind for diagnosis says so in
             # its `metric` string, so a driver reading value / n_gpus / rc cannot take a 3-step candidate trial for the headline.
             rc = 3
-            if self.rank == 0 and self.best is not None:
+            if self.best is not None:
                 try:
-                    rec = self.best()
+                    rec = self.best()                                # (the same record on every rank: only rank 0 prints it)
                     rec["aborted"] = {"phase": name, "what": "this phase did not finish within its limit; the line reports the best "
                                                              "measurement completed before it"}
                     full = not str(rec.get("timed", "")).startswith("trial")
                     if not full:
                         rec["metric"] = "ABORTED before the timed region (candidate trial only, not a measurement): " + rec["metric"]
-                    self.emit(rec)
+                    if self.rank == 0:
+                        self.emit(rec)
+                    else:
+                        time.sleep(self.grace)                       # rank 0 prints first
                     rc = 0 if full else 3
                 except Exception as ex:                              # noqa: BLE001
                     print("[bench] could not emit the fallback record: %r" % ex, file=sys.stderr, flush=True)
-            elif self.rank != 0:
-                time.sleep(self.grace)                               # rank 0 prints first
-                rc = 0 if self.timed_done else 3
             os._exit(rc)
 
 
