@@ -1445,6 +1445,16 @@ class DistGraph(object):
                 rem = H * 0.5 * e_rem / R + L
                 end_a = max(t_a, t_c) + rem
                 est["pipeline"] = max(end_a, t_a + half_x) + rem + rmw
+                if not transposed and kind == "x" and getattr(p, "row_order", "id") == "peers" and int(xp.pushed_pairs) == 0 and n_in:
+                    # rows2, zero-copy: no pack; half A (share fa of the rows, half of the received edges) arrives first, half B
+                    # travels under A's edges; full-width rows in every launch
+                    r2 = self._rows2()
+                    fa = r2["nA_r"] / max(n_in, 1)
+                    xrow = xch - self._LAT
+                    ta = fa * xrow + self._LAT
+                    half = 0.5 * e_rem / R + L
+                    enda = max(ta, e_loc / R + L) + half
+                    est["rows2"] = max(enda, ta + (1.0 - fa) * xrow + self._LAT) + half + rmw
             forced = _env_flow()
             if forced in est and forced not in ("pipeline", "rows2"):
                 hit = forced
@@ -1471,7 +1481,7 @@ class DistGraph(object):
         if hit is None:
             self._mode(kind, transposed, additive, row_bytes)
             est = self._idx[("mode_estimates", kind, transposed, additive, row_bytes)]
-            mine = [min(v for k, v in est.items() if k != "pipeline"), est["pipeline"]]
+            mine = [min(v for k, v in est.items() if k not in ("pipeline", "rows2")), min(est["pipeline"], est.get("rows2", float("inf")))]
             if _group_ready(self.group):
                 on_gpu = dist.get_backend(self.group) == "nccl"
                 t = torch.tensor(mine, dtype=torch.float64, device=x.device if on_gpu else "cpu")
