@@ -29,6 +29,26 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 //     the shadow of the row gathers (the kernel is HBM-bound; the MFMA pipe was idle).
 // SS: 0 no per-source scale, 1 src_scale[col] (one random 4-byte read per edge), 2 src_scale[p] by edge POSITION (the scale of every
 //     edge's source laid out along the sorted stream once per graph: 4 sequential bytes per edge)
+// non-temporal gather of one lane's piece of a row (experiments with the L2 replacement policy: PGLAMD_FLAT_NT variant builds)
+template <typename V> __device__ __forceinline__ V load_nt(const V* p) {
+    V out;
+    if constexpr (sizeof(V) == 16) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+        __builtin_memcpy(&out, &v, 16);
+    } else if constexpr (sizeof(V) == 8) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p));
+        __builtin_memcpy(&out, &v, 8);
+    } else if constexpr (sizeof(V) == 4) {
+        const unsigned v = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
+        __builtin_memcpy(&out, &v, 4);
+    } else {
+        out = *p;
+    }
+    return out;
+}
+
 // WIRE: every row this launch stores ALSO goes to its slots of the halo send buffer of the next aggregation (pglamd_aggregate_wire).
 //     A template variant, not a run-time test: the test alone cost the 256-byte-row kernel 16 SGPRs (70 -> 86: one resident workgroup
 //     per CU fewer) although the code sits in the once-per-row store path.
@@ -293,10 +313,30 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         if constexpr (has_ss) sv = sscale_v[cl];
 #pragma unroll
         for (int i = 0; i < U; ++i) {
+#if defined(PGLAMD_FLAT_NT) && PGLAMD_FLAT_NT == 2
+            // experiment (scripts/prof.py hotcold): the sign bit of a column id marks a HOT source row (top out-degrees, ~3 MB of
+            // rows); cold rows are gathered with the non-temporal policy so that they do not push the hot ones out of the XCD's L2
+            const bool hot = cc[i] < 0;
+            const T* xr = src_row(cc[i] & 0x7fffffff);
+            const T* xc = xr;
+            asm volatile("" : "+s"(xc));            // an opaque copy of the base: the two loads must not be merged into one (the merge drops the policy)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (act[t]) {
+                    if (hot) vx[i][t] = *reinterpret_cast<const V*>(xr + j0[t]);
+                    else vx[i][t] = load_nt(reinterpret_cast<const V*>(xc + j0[t]));
+                }
+#elif defined(PGLAMD_FLAT_NT) && PGLAMD_FLAT_NT == 1
+            const T* xr = src_row(cc[i]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (act[t]) vx[i][t] = load_nt(reinterpret_cast<const V*>(xr + j0[t]));
+#else
             const T* xr = src_row(cc[i]);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (act[t]) vx[i][t] = *reinterpret_cast<const V*>(xr + j0[t]);
+#endif
             if constexpr (YMODE == 1) {
                 const T* yr = y + (int64_t)yy[i] * p.ldy;
 #pragma unroll
@@ -427,6 +467,9 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     for (; e < e1; ++e) {   // remainder (< U edges): one at a time
         int r = rowp[e];
         int cc = colp ? colp[e] : e;
+#if defined(PGLAMD_FLAT_NT) && PGLAMD_FLAT_NT == 2
+        cc &= 0x7fffffff;
+#endif
         float s = has_ss ? scale_of(SS == 2 ? e : cc) : 1.f;
         V vx[NT], vy[NT];
         const T* xr = src_row(cc);

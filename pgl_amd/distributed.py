@@ -22,6 +22,12 @@ gradients flow through every one of them -- the mechanism is replaced:
     launch, accumulate mode 2) -- SURVEY 8e lever iii.
   * backward = the same flow over the transposed indices with the send / receive splits swapped
     (`_HaloAggregate`, `_HaloExtend`): multi-GPU layers train.
+  * round 5 -- NO send buffer (flow "rows2"): with HaloPlan(row_order="peers") a rank's rows are ordered by the set of peers that
+    pull them (hubs first, the other sets in Gray-code order), so the rows any peer pulls are a few contiguous ranges of the
+    feature matrix itself and travel from where they lie (pglamd_halo_exchange_start_ranges; torch point-to-point / gloo beside
+    it) -- in two halves of the rows cut by EDGES, half B under half A's edges.  No pack launch, no send-buffer traffic: per-rank
+    compute / ideal 1.29 -> 1.15 at |E| = 100 M, P = 8.  Also here, opt-in and measured not to pay: the
+    producer of a layer's rows mirroring them into the next exchange's send buffer (wire / mark / emit).
 
 Two classes:
   DistGraph      the engine's distributed graph: features are the OWNED rows ([n_own, ...]) -- nothing is replicated;

@@ -25,6 +25,11 @@ for STEP in "$@"; do
     rows_c2p_fp16) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --wire fp16 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_pipe) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow pipeline --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2_pipe)  timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow pipeline --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
+    hotcold)
+      echo "== product library" > $F; timeout 300 python scripts/prof.py hotcold 2>&1 | grep -v amdgpu.ids >> $F
+
+      echo "== cold rows non-temporal, hot rows (sign bit of the column id) cached (PGLAMD_FLAT_NT=2)" >> $F; PGLAMD_HOTCOLD=1 PGLAMD_LIB=$R/pgl_amd/csrc/variants/libpglamd_nt2.so timeout 600 python scripts/prof.py hotcold 2>&1 | grep -v amdgpu.ids >> $F
+      cat $F ;;
     rows_c2p_rows2) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero_nosw)  PGLAMD_XCD_SWIZZLE=0 timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero)  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;

@@ -642,6 +642,40 @@ def cmd_coo(args):
             del edges, src32, dst32, c, a, b
 
 
+def cmd_hotcold(args):
+    """L2 replacement experiment on the headline kernel (C2, d = 128 fp32): gathers of COLD source rows with the non-temporal policy, so
+    that the top out-degree rows (the sign bit of their column ids, set here on a copy of the index) stay in the XCD's L2.  Meaningful
+    with the PGLAMD_FLAT_NT=2 variant library (PGLAMD_LIB); with =1 every gather is non-temporal; the product library ignores the bit...
+    so the flagged run is only made when the library was built for it (PGLAMD_HOTCOLD=1)."""
+    import torch
+    pgl, dev, g = _c2(with_src_index=False)
+    N, E = g.num_nodes, g.num_edges
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, 128, generator=gen, device=dev)
+    c = g.adj_dst_index.csr
+    t0 = _t(lambda: pgl.ops.aggregate(x, c, "sum", N), it=20, warm=5)
+    print("plain index: %.3f ms" % t0, flush=True)
+    if os.environ.get("PGLAMD_HOTCOLD") != "1":
+        return
+    outdeg = torch.bincount(g.edges[:, 0], minlength=N)
+    want = pgl.ops.aggregate(x, c, "sum", N)
+    for hot_rows in (2048, 4096, 6144, 8192, 16384):
+        thr = int(torch.topk(outdeg, hot_rows).values[-1])
+        hot = outdeg >= max(thr, 1)
+        col = c.col32.clone()
+        flag = hot[col.long()]
+        col[flag] = col[flag] | torch.tensor(-2147483648, dtype=torch.int32, device=dev)
+        c2 = pgl.ops.CSR()
+        for k in ("degree", "indptr", "row32", "eid32", "num_nodes", "num_edges"):
+            setattr(c2, k, getattr(c, k))
+        c2.col32 = col
+        c2.sorted_v = c2.sorted_u = c2.sorted_eid = None
+        t1 = _t(lambda: pgl.ops.aggregate(x, c2, "sum", N), it=20, warm=5)
+        ok = torch.equal(pgl.ops.aggregate(x, c2, "sum", N), want)
+        print("hot = top %5d rows by out-degree (degree >= %d, %.1f %% of the edges): %.3f ms (x%.3f), result %s"
+              % (int(hot.sum()), thr, 100.0 * float(flag.float().mean()), t1, t0 / t1, "identical" if ok else "DIFFERS"), flush=True)
+
+
 def cmd_chains(args):
     """the un-fused attention compositions (the reference's own op sequences: send_uv -> element-wise -> edge_softmax
     -> send_ue_recv) at C3 size with their [E, H] tensors kept in the engine's destination-sorted order (EdgeTensor, the default)
@@ -1222,6 +1256,7 @@ def main():
     tr.add_argument("--out", required=True)
     sub.add_parser("csr")
     co = sub.add_parser("coo"); co.add_argument("--dim", type=int, default=128)
+    sub.add_parser("hotcold")
     ch = sub.add_parser("chains"); ch.add_argument("--scale", type=int, default=20); ch.add_argument("--edges", type=int, default=20_000_000)
     o = sub.add_parser("ops"); o.add_argument("--scale", type=int, default=20); o.add_argument("--edges", type=int, default=20_000_000)
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
@@ -1257,6 +1292,8 @@ def main():
         cmd_coo(args)
     elif args.cmd == "chains":
         cmd_chains(args)
+    elif args.cmd == "hotcold":
+        cmd_hotcold(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
     elif args.cmd == "gcn":
