@@ -569,3 +569,31 @@ def test_config5_one_rank_share_streamed_plan_fp16(pgl):
     import os
     os.makedirs("gpurun_out/r05", exist_ok=True)
     open("gpurun_out/r05/config5_one_rank_share.txt", "w").write(msg + "\n")
+
+
+def test_gcnconv_without_the_private_addmm_activation_op(pgl, monkeypatch):
+    """GCNConv's `linear -> + bias -> relu` uses torch._addmm_activation (a private op: bias + relu in the GEMM's
+    epilogue) behind a hasattr guard.  With the op absent the layer takes the row-kernel path: same outputs, same gradients."""
+    rng = np.random.default_rng(4)
+    n, e, d = 5000, 70000, 128
+    edges = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    torch.manual_seed(2)
+    layer = pgl.nn.GCNConv(d, d, activation="relu").cuda()
+    layer.fused_dense = False                                          # (the one-launch aggregate -> dense kernel does not use the op at all)
+    assert hasattr(torch, "_addmm_activation"), "this torch build lost the op: the guard is all that is left -- fine, but say so"
+
+    def run():
+        layer.zero_grad()
+        xt = dev(x).requires_grad_(True)
+        y = layer(g, xt)
+        (y * y).sum().backward()
+        return y.detach(), xt.grad.clone(), [p.grad.clone() for p in layer.parameters()]
+    y1, gx1, gp1 = run()
+    monkeypatch.delattr(torch, "_addmm_activation")
+    y0, gx0, gp0 = run()
+    np.testing.assert_allclose(host(y1), host(y0), rtol=1e-5, atol=1e-5 * float(y0.abs().max()))
+    np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=1e-5 * float(gx0.abs().max()))
+    for a, b in zip(gp1, gp0):
+        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=2e-5 * float(b.abs().max()))
