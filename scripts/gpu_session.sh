@@ -25,6 +25,12 @@ for STEP in "$@"; do
     rows_c2p_fp16) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --wire fp16 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_pipe) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow pipeline --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2_pipe)  timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow pipeline --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
+    distmodel_c2p)
+      # one rank's share (rank 7, the heaviest) of a 2-layer GCN over the 8-way partition of the |E| = 100 M graph: round 4's flow (id order,
+      # column-pipelined, packed) against the peer-ordered plan (forward: zero-copy rows2; backward: column-pipelined as before)
+      echo "== row_order=id (round 4 layout)" > $F; timeout 600 python scripts/prof.py distmodel --scale 22 --edges 100000000 --rank 7 2>&1 | grep -v amdgpu.ids >> $F
+      echo "== row_order=peers (zero-copy row-pipelined forward)" >> $F; timeout 600 python scripts/prof.py distmodel --scale 22 --edges 100000000 --rank 7 --row-order peers 2>&1 | grep -v amdgpu.ids >> $F
+      cat $F ;;
     hotcold)
       echo "== product library" > $F; timeout 300 python scripts/prof.py hotcold 2>&1 | grep -v amdgpu.ids >> $F
 

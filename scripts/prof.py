@@ -1096,7 +1096,7 @@ def cmd_distmodel(args):
     edges = rmat_edges(scale, E, seed=42, device=dev)
     path = os.path.join(ROOT, "scratch", "parts", "rmat%d_e%d_p%d_kway.npy" % (scale, E, P))
     part = torch.from_numpy(np.load(path).astype(np.int64)) if os.path.exists(path) else DistGraph.partition(edges, N, P, "kway", rank=0)
-    dg = DistGraph(HaloPlan(edges, N, part, args.rank, P), device=dev)
+    dg = DistGraph(HaloPlan(edges, N, part, args.rank, P, row_order=getattr(args, "row_order", "id")), device=dev)
     del edges
     gen = torch.Generator(device=dev); gen.manual_seed(7)
     x = torch.randn(dg.plan.n_own, d, generator=gen, device=dev)
@@ -1267,6 +1267,7 @@ def main():
     sub.add_parser("sizes")
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
     dm.add_argument("--rank", type=int, default=0)
+    dm.add_argument("--row-order", default="id", choices=["id", "peers"])
     sub.add_parser("gat"); sub.add_parser("dtypes"); sub.add_parser("gatsplit")
     lo = sub.add_parser("locality"); lo.add_argument("--pmc", action="store_true")
     eo = sub.add_parser("edgeops"); eo.add_argument("--scale", type=int, default=20); eo.add_argument("--edges", type=int, default=20_000_000)
