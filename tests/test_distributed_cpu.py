@@ -890,3 +890,60 @@ def test_gloo_row_pipelined_flow_and_zero_copy(monkeypatch, world, row_order, me
         if row_order == "peers" and world >= 3:
             assert res["ranges"] <= (1 << (world - 2)) * (world - 1) and res["ranges"] < res["n_send"]   # a few runs per peer, not one per row
     assert sorted(np.concatenate([own for _, own, _ in got]).tolist()) == list(range(x.shape[0]))
+
+
+def test_rows2_and_peer_order_on_degenerate_partitions(monkeypatch):
+    """Flow rows2 / row_order="peers" at the edges of the plan: a rank that owns nothing, a pair with an empty block, a graph without
+    cut edges, one rank (no exchange at all), dtype int (the row-pipelined flow serves floats: others fall back) -- in process."""
+    from pgl_amd.distributed import HaloPlan, DistGraph
+    monkeypatch.setenv("PGLAMD_FLOW", "rows2")
+    B = TorchBackend()
+    edges, x = _graph(n=150, e=1200, seed=33, d=32)
+    n = x.shape[0]
+    xt = torch.from_numpy(x)
+    want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "sum")
+    et = torch.from_numpy(edges)
+    # rank 2 of 4 owns nothing; without a process group the exchange is absent, so feed the halves by hand: the in-process check is of
+    # the PLAN (ranges, cuts, remaps) -- every received row must land where the two indices read it
+    part = np.random.default_rng(0).integers(0, 4, n); part[part == 2] = 3
+    for order in ("id", "peers"):
+        dgs = [DistGraph(HaloPlan(et, n, part, r, 4, row_order=order), backend=B) for r in range(4)]
+        xs = [dg.take_owned(xt) for dg in dgs]
+        full = np.full_like(want, np.nan)
+        for r, dg in enumerate(dgs):
+            p, r2 = dg.plan, dg._rows2()
+            assert sum(r2["hr"]) == r2["nA_r"] and all(0 <= h <= c for h, c in zip(r2["hr"], p.recv_splits))
+            in_buf = torch.full((p.n_recv, x.shape[1]), float("nan"))
+            sa, sb, ra, rb = dg._rows2_ranges()
+            for q, dq in enumerate(dgs):
+                if q == r:
+                    continue
+                qa, qb, _, _ = dq._rows2_ranges()
+                for (first, k), (pos, k2) in zip(qa[r] + qb[r], ra[q] + rb[q]):     # sender q's ranges for me <-> my ranges for q
+                    assert k == k2
+                    in_buf[pos:pos + k] = xs[q][first:first + k]
+                assert sum(k for _, k in qa[r] + qb[r]) == p.recv_splits[q]
+            assert p.n_recv == 0 or bool(torch.isfinite(in_buf).all())
+            out = B.aggregate(xs[r], dg._index("loc"), "sum", p.n_own)
+            for name in ("xrecvA", "xrecvB"):
+                idx = dg._index(name)
+                if int(idx[0].shape[0]):
+                    B.aggregate(in_buf, idx, "sum", p.n_own, out=out, accumulate=1)
+            full[p.own_global.numpy()] = out.numpy()
+            if r == 2:
+                assert p.n_own == 0 and p.n_send == 0 and p.n_recv == 0
+        np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5)
+    # one rank: no exchange, any row order
+    p1 = HaloPlan(et, n, np.zeros(n, np.int64), 0, 1, row_order="peers")
+    dg1 = DistGraph(p1, backend=B)
+    np.testing.assert_allclose(dg1.send_recv(dg1.take_owned(xt), "sum").numpy()[np.argsort(p1.own_global.numpy())], want, rtol=1e-5, atol=1e-5)
+    # no cut edges: every block empty
+    half = n // 2
+    e2 = np.concatenate([edges[(edges[:, 0] < half) & (edges[:, 1] < half)], edges[(edges[:, 0] >= half) & (edges[:, 1] >= half)]])
+    part2 = (np.arange(n) >= half).astype(np.int64)
+    want2 = R.c_send_u_recv(x, e2[:, 0], e2[:, 1], "sum")
+    for r in range(2):
+        p = HaloPlan(torch.from_numpy(e2), n, part2, r, 2, row_order="peers")
+        dg = DistGraph(p, backend=B)
+        assert p.range_plan() == ([[], []], [[], []])
+        np.testing.assert_allclose(dg.send_recv(dg.take_owned(xt), "sum").numpy(), want2[p.own_global.numpy()], rtol=1e-5, atol=1e-5)
