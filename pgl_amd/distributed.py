@@ -125,8 +125,15 @@ class AbiTransport(object):
                 ptr.append(len(first))
             mk = lambda v: (ct.c_int64 * max(len(v), 1))(*v)
             return mk(ptr), mk(first), mk(cnt)
-        sp, sf, sc = flat(send_ranges)
-        rp, rf, rc = flat(recv_ranges)
+        # (the range lists of a plan are built once and cached by the caller: their flattened ctypes form is cached here by identity)
+        cache = self.__dict__.setdefault("_range_cache", {})
+        key = (id(send_ranges), id(recv_ranges))
+        hit = cache.get(key)
+        if hit is None or hit[0] is not send_ranges or hit[1] is not recv_ranges:
+            hit = cache[key] = (send_ranges, recv_ranges, flat(send_ranges), flat(recv_ranges))
+            if len(cache) > 16:
+                cache.pop(next(iter(cache)))
+        (sp, sf, sc), (rp, rf, rc) = hit[2], hit[3]
         stream = ct.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         self._ffi.check(L.pglamd_halo_exchange_start_ranges(self.comm, ct.c_void_p(x.data_ptr()), sp, sf, sc, ct.c_void_p(recv_buf.data_ptr()),
                                                             rp, rf, rc, row_bytes, stream), "halo_exchange_start_ranges")
