@@ -177,6 +177,11 @@ class EdgeTensor(object):
     def __truediv__(self, o): return self._binary(torch.div, o)
     def __rtruediv__(self, o): return self._binary(torch.div, o, True)
     def __pow__(self, o): return self._binary(torch.pow, o)
+    def __matmul__(self, o):                          # rows @ W: row-wise when the weight is an ordinary (<= 2-D) tensor
+        if isinstance(o, torch.Tensor) and o.dim() <= 2:
+            return self._wrap(torch.matmul(self._v, o))
+        return torch.matmul(self.materialize(), o.materialize() if isinstance(o, EdgeTensor) else o)
+
     def __neg__(self): return self._wrap(-self._v)
     def __abs__(self): return self._wrap(self._v.abs())
 
@@ -240,6 +245,24 @@ class EdgeTensor(object):
                     return first._wrap(func(first._v, *args[1:], **kwargs))
             if func in (torch.reshape, torch.Tensor.reshape, torch.Tensor.view) and isinstance(args[0], EdgeTensor):
                 return first.reshape(*args[1:])
+            # row-wise ops: every output row depends on the same input row only
+            if func in (torch.matmul, torch.Tensor.matmul, torch.Tensor.__matmul__) and isinstance(args[0], EdgeTensor) and len(ets) == 1 \
+                    and isinstance(args[1], torch.Tensor) and args[1].dim() <= 2:
+                return first._wrap(func(first._v, args[1]))
+            if func is F.linear and isinstance(args[0], EdgeTensor) and len(ets) == 1:
+                return first._wrap(func(first._v, *args[1:], **kwargs))
+            if func in (F.softmax, F.log_softmax, torch.softmax, torch.log_softmax, F.normalize, F.layer_norm) and isinstance(args[0], EdgeTensor) and len(ets) == 1:
+                dim = kwargs.get("dim", args[1] if (len(args) > 1 and isinstance(args[1], int)) else (-1 if func is F.layer_norm else None))
+                if func is F.normalize and dim is None:
+                    dim = 1
+                if dim is not None and (dim if dim >= 0 else dim + first._v.dim()) != 0 and first._v.dim() >= 2:
+                    return first._wrap(func(first._v, *args[1:], **kwargs))
+        if func in (torch.cat, torch.concat) and args and isinstance(args[0], (list, tuple)) and args[0]:
+            parts = list(args[0])
+            dim = kwargs.get("dim", kwargs.get("axis", args[1] if len(args) > 1 else 0))
+            if all(isinstance(t, EdgeTensor) for t in parts) and all(t._view is parts[0]._view and t._v.dim() == parts[0]._v.dim() for t in parts):
+                if (dim if dim >= 0 else dim + parts[0]._v.dim()) != 0:
+                    return parts[0]._wrap(torch.cat([t._v for t in parts], dim=dim))
         # anything else sees ordinary tensors in original edge order
         conv = lambda a: a.materialize() if isinstance(a, EdgeTensor) else a
         return func(*[conv(a) if not isinstance(a, (list, tuple)) else type(a)(conv(x) for x in a) for a in args],

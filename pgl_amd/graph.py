@@ -451,8 +451,14 @@ class Graph(object):
             assert isinstance(edge_feat, dict), "The input edge_feat must be a dict"
             edge_feat_temp.update(edge_feat)
         src32, dst32 = self._edge_cols32()
-        src_reader = _GraphRowReader(src_feat_temp, src32, self._csr_src)
-        dst_reader = _GraphRowReader(dst_feat_temp, dst32, self._csr_dst)
+        view = self.edge_order("dst") if self._lazy_edges(torch.empty(0, device=self._device)) else None
+        # (with the EdgeTensor mechanism on, floating features are gathered straight into the engine's destination-sorted edge order
+        #  and tagged: element-wise message functions keep the tag, and recv(mode="dst") then needs no permutation of the [E, ...]
+        #  messages at all -- the reference permutes every message by eid, pgl/graph.py:821-823)
+        src_reader = _GraphRowReader(src_feat_temp, src32, self._csr_src, view, "src")
+        dst_reader = _GraphRowReader(dst_feat_temp, dst32, self._csr_dst, view, "dst")
+        if view is not None and edge_feat_temp:
+            edge_feat_temp = _EdgeFeatReader(edge_feat_temp, view, self)
         msg = message_func(src_reader, dst_reader, edge_feat_temp)
         if not isinstance(msg, dict):
             raise TypeError("The outputs of the %s function is expected to be a dict, but got %s"
@@ -469,7 +475,7 @@ class Graph(object):
             raise TypeError("reduce_func should be callable")
         src, dst, eid = self.sorted_edges(sort_by=recv_mode)
         csr = self._csr_dst() if recv_mode == "dst" else self._csr_src()
-        msg = op.RowReader(msg, csr.eid32)
+        msg = _SortedAwareReader(msg, csr.eid32, self if recv_mode == "dst" else None)
         uniq_ind, segment_ids = self.get_segment_ids(src, dst, segment_by=recv_mode)
         bucketed_msg = Message(msg, segment_ids, num_segments=int(uniq_ind.shape[0]))
         output = reduce_func(bucketed_msg)
@@ -684,13 +690,61 @@ class _DstOrderedEdges(object):
 
 
 class _GraphRowReader(op.RowReader):
-    """RowReader whose gathers know the CSR keyed by their index, so backward needs no sort."""
+    """RowReader whose gathers know the CSR keyed by their index, so backward needs no sort.  With a destination-order view
+    (EdgeTensor mechanism on) floating features are gathered in the engine's edge order and handed out tagged."""
 
-    def __init__(self, nfeat, index, csr_fn):
+    def __init__(self, nfeat, index, csr_fn, view=None, side="src"):
         super(_GraphRowReader, self).__init__(nfeat, index)
-        self._csr_fn = csr_fn
+        self._csr_fn, self._view, self._side = csr_fn, view, side
 
     def __getitem__(self, key):
         if key not in self.loaded_nfeat:
-            self.loaded_nfeat[key] = ag.gather_rows(self.nfeat[key], self.index, self._csr_fn)
+            feat = self.nfeat[key]
+            v = self._view
+            if v is not None and isinstance(feat, torch.Tensor) and feat.is_cuda and feat.is_floating_point():
+                if self._side == "src":         # position p of the sorted stream reads its source: backward = the src-keyed view
+                    rows = ag.gather_rows(feat, v.src, lambda: v._cs)
+                else:                           # ... its destination: a contiguous run per destination row
+                    rows = ag.gather_rows(feat, v.dst, lambda: v._cd_iota)
+                self.loaded_nfeat[key] = _et.EdgeTensor(rows, v)
+            else:
+                self.loaded_nfeat[key] = ag.gather_rows(feat, self.index, self._csr_fn)
         return self.loaded_nfeat[key]
+
+
+class _EdgeFeatReader(dict):
+    """The edge features a message function sees: floating ones are permuted into the engine's edge order once (lazily, cached)
+    and tagged, so that combining them with gathered node features keeps everything in that order."""
+
+    def __init__(self, feats, view, graph):
+        super(_EdgeFeatReader, self).__init__(feats)
+        self._view, self._graph, self._done = view, graph, {}
+
+    def __getitem__(self, key):
+        if key not in self._done:
+            t = dict.__getitem__(self, key)
+            if isinstance(t, torch.Tensor) and t.is_cuda and t.is_floating_point() and int(t.shape[0]) == self._view.num_edges:
+                t = _et.EdgeTensor(self._view.to_order(t), self._view)
+            self._done[key] = t
+        return self._done[key]
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
+class _SortedAwareReader(op.RowReader):
+    """recv's message reader: a message that is an EdgeTensor of this graph already IS in destination-sorted order -- no gather by
+    eid; anything else is permuted as the reference does (pgl/graph.py:821-823)."""
+
+    def __init__(self, msg, eid, graph):
+        super(_SortedAwareReader, self).__init__(msg, eid)
+        self._graph = graph
+
+    def __getitem__(self, key):
+        if key not in self.loaded_nfeat:
+            val = self.nfeat[key]
+            rows = _et.sorted_rows(val, self._graph) if self._graph is not None else None
+            if rows is not None:
+                self.loaded_nfeat[key] = rows
+                return rows
+        return super(_SortedAwareReader, self).__getitem__(key)

@@ -691,10 +691,18 @@ def cmd_chains(args):
     cases = [("GATConv(fused=False) H=8 D=16   (pgl/nn/conv.py:331-339)", nn_.GATConv(128, 16, feat_drop=0.0, attn_drop=0.0, num_heads=8), True),
              ("FAConv d=128                     (gate = tanh(send_uv) * send_uv)", nn_.FAConv(128, drop=0.0), False),
              ("TransformerConv H=8 D=12 generic (pgl/nn/conv.py:796-834)", nn_.TransformerConv(128, 12, num_heads=8, feat_drop=0.0, attn_drop=0.0), False),
-             ("GATv2Conv H=4 D=12 generic       (pgl/nn/conv.py:421-424)", nn_.GATv2Conv(128, 12, feat_drop=0.0, attn_drop=0.0, num_heads=4), False)]
+             ("GATv2Conv H=4 D=12 generic       (pgl/nn/conv.py:421-424)", nn_.GATv2Conv(128, 12, feat_drop=0.0, attn_drop=0.0, num_heads=4), False),
+             ("UDF send -> recv, [E, 64] messages (pgl/graph.py:694-832)", None, False)]
     print("C3 size: RMAT scale %d, %d edges, 128 input columns; ms per call" % (args.scale, args.edges))
+
+    class UDF(torch.nn.Module):
+        """the reference's general path: Graph.send with a message function, Graph.recv with a reducer (README example shape, d = 64)"""
+        def forward(self, graph, feat):
+            h = feat[:, :64].contiguous()
+            msg = graph.send(lambda s_, d_, e_: {"m": torch.tanh(s_["h"] + d_["h"])}, node_feat={"h": h})
+            return graph.recv(lambda m: m.reduce_sum(m["m"]), msg)
     for name, L, unfuse in cases:
-        L = L.to(dev)
+        L = (UDF() if L is None else L).to(dev)
         if unfuse:
             L.fused = False
         res = {}

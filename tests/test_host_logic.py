@@ -459,3 +459,27 @@ def test_edge_tensor_keeps_the_tag_through_elementwise_work_and_reads_back_in_or
     import pgl_amd
     with pytest.raises(TypeError, match="EdgeTensor"):
         pgl_amd.ops.gather_rows(et, torch.zeros(1, dtype=torch.int64))
+
+
+def test_edge_tensor_row_wise_ops_keep_the_tag():
+    """cat along a trailing dim, matmul / linear with the weight on the right, softmax / normalize over a trailing dim: every output
+    row depends on its own input row only, so they are applied to the sorted rows (the UDF message functions of TransformerConv,
+    PinSage, ... use them)."""
+    import torch
+    import torch.nn.functional as F
+    from pgl_amd.edge_tensor import EdgeTensor
+    rng = np.random.default_rng(1)
+    E, D = 40, 6
+    orig = torch.as_tensor(rng.standard_normal((E, D)).astype(np.float32))
+    view = _FakeView(rng.permutation(E))
+    a, b = EdgeTensor(orig[view.eid], view), EdgeTensor((orig * 2)[view.eid], view)
+    W, bias = torch.as_tensor(rng.standard_normal((D, 4)).astype(np.float32)), torch.as_tensor(rng.standard_normal(4).astype(np.float32))
+    c = torch.cat([a, b], dim=-1)
+    assert isinstance(c, EdgeTensor) and torch.equal(c.materialize(), torch.cat([orig, orig * 2], -1)) and view.calls == 1
+    m = torch.matmul(a, W); l = F.linear(a, W.t(), bias); s = F.softmax(a, dim=-1); nm = F.normalize(a, dim=1)
+    for got, want in ((m, orig @ W), (l, orig @ W + bias), (s, F.softmax(orig, -1)), (nm, F.normalize(orig, dim=1)), (a @ W, orig @ W)):
+        assert isinstance(got, EdgeTensor) and torch.allclose(got.materialize(), want, atol=1e-6)
+    # along the EDGE dimension these are not row-wise: original order first
+    assert not isinstance(torch.cat([a, b], 0), EdgeTensor) and torch.equal(torch.cat([a, b], 0), torch.cat([orig, orig * 2], 0))
+    assert not isinstance(F.softmax(a, dim=0), EdgeTensor) and torch.allclose(F.softmax(a, dim=0), F.softmax(orig, 0))
+    assert not isinstance(torch.matmul(W.t()[:, :D] @ torch.eye(D), a.materialize().t()), EdgeTensor)
