@@ -43,8 +43,8 @@ class BiGraph(Graph):
         self._src_node_feat = {k[4:]: v for k, v in self._node_feat.items() if k.startswith("src:")}
         self._dst_node_feat = {k[4:]: v for k, v in self._node_feat.items() if k.startswith("dst:")}
 
-    def tensor(self, inplace=True, device=None):
-        g = super(BiGraph, self).tensor(inplace, device)
+    def tensor(self, inplace=True, uva=False, device=None):
+        g = super(BiGraph, self).tensor(inplace, uva, device)
         g._split_feats()
         return g
 
@@ -369,7 +369,7 @@ class HeterGraph(object):
             yield nodes[start:start + batch_size]
             start += batch_size
 
-    def tensor(self, inplace=True, device=None):
+    def tensor(self, inplace=True, uva=False, device=None):
         if self._is_tensor:
             return self
         if inplace:

@@ -94,8 +94,14 @@ class Graph(object):
         self._nodes = None
         self._degree_norm_cache = None
 
-    def tensor(self, inplace=True, device=None):
-        """pgl/graph.py:227-267.  Moves edges, features and any already-built index to the GPU."""
+    def tensor(self, inplace=True, uva=False, device=None):
+        """pgl/graph.py:227-267.  Moves edges, features and any already-built index to the GPU.
+        uva: the reference's switch for keeping the graph structure in (pinned) CPU memory while computing on the GPU -- a capacity
+        workaround.  Accepted for signature compatibility (it is the reference's SECOND positional argument); the graph goes to HBM
+        either way: 288 GB hold every graph the reference's UVA mode was written for (ogbn-papers100M's edge list is 26 GB), and
+        the kernels read device memory only.  Like the reference it refuses uva without a GPU."""
+        if uva and not torch.cuda.is_available():
+            raise ValueError("uva tensor graph should be run under gpu environment!")
         if self._is_tensor:
             return self
         if inplace:

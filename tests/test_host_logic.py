@@ -483,3 +483,17 @@ def test_edge_tensor_row_wise_ops_keep_the_tag():
     assert not isinstance(torch.cat([a, b], 0), EdgeTensor) and torch.equal(torch.cat([a, b], 0), torch.cat([orig, orig * 2], 0))
     assert not isinstance(F.softmax(a, dim=0), EdgeTensor) and torch.allclose(F.softmax(a, dim=0), F.softmax(orig, 0))
     assert not isinstance(torch.matmul(W.t()[:, :D] @ torch.eye(D), a.materialize().t()), EdgeTensor)
+
+
+def test_graph_tensor_accepts_the_reference_uva_argument():
+    """pgl/graph.py:227: tensor(self, inplace=True, uva=False) -- uva is the reference's second positional argument."""
+    import inspect
+    import torch
+    import pgl_amd
+    for cls in (pgl_amd.Graph, pgl_amd.BiGraph):
+        params = list(inspect.signature(cls.tensor).parameters)
+        assert params[:3] == ["self", "inplace", "uva"], (cls.__name__, params)
+    g = pgl_amd.Graph(edges=np.array([[0, 1], [1, 2]], np.int64), num_nodes=3)
+    if not torch.cuda.is_available():
+        with pytest.raises(ValueError, match="uva"):
+            g.tensor(True, True)
