@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpglamd.so")
 OBJ = os.path.join(CSRC, "build")
-SOURCES = ["aggregate.hip", "aggregate_f64.hip", "aggregate_more.hip", "aggregate_half.hip", "aggregate_narrow.hip", "csr_build.hip", "edge_ops.hip", "gat_fused.hip", "sampling.hip", "halo_comm.hip", "dense_epilogue.hip", "grad_ops.hip", "common.cpp", "host_ops.cpp", "partition.cpp"]
+SOURCES = ["aggregate.hip", "aggregate_f64.hip", "aggregate_more.hip", "aggregate_half.hip", "aggregate_bf16.hip", "aggregate_narrow.hip", "csr_build.hip", "edge_ops.hip", "gat_fused.hip", "sampling.hip", "halo_comm.hip", "dense_epilogue.hip", "grad_ops.hip", "common.cpp", "host_ops.cpp", "partition.cpp"]
 HEADERS = ["common.hpp", "scan.hpp", "aggregate.hpp", "aggregate_flat.hpp", "aggregate_group.hpp", "aggregate_dense2.hpp", os.path.join("..", "..", "include", "pgl_amd.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
