@@ -70,7 +70,11 @@ extern "C" {
 int32_t pglamd_abi_version(void);
 /* Process-wide launch options.  "xcd_swizzle": 1 (default) = consecutive chunks of the destination-sorted edge stream run on ONE XCD
  * (they share its L2: partition- / cluster-ordered graphs); 0 = chunks are dealt round the XCDs -- for row orders that correlate with
- * row length (pgl_amd.distributed.HaloPlan(row_order="peers")), where the blocked mapping unbalances the XCDs. */
+ * row length (pgl_amd.distributed.HaloPlan(row_order="peers")), where the blocked mapping unbalances the XCDs.
+ * "csr_onesweep": how pglamd_csr_build sorts.  -1 (default) = by size: one-sweep passes (one histogram of all digits, then ONE kernel per
+ * digit with decoupled look-back: 7 launches) for up to 1 M edges, the multi-kernel passes (histogram / scan / scatter per digit: 12
+ * launches, XCD-local tile order) above; 0 = always multi-kernel; g >= 1 = always one-sweep with g consecutive tiles per XCD.  The output
+ * is bit-identical either way. */
 int32_t pglamd_set_option(const char* name, int64_t value);
 const char* pglamd_last_error(void);
 /* name of the device the library sees, e.g. "gfx950..." (host string, valid until next call) */

@@ -133,6 +133,10 @@ struct SortArgs {
     int32_t* range_flag;
     int64_t n, n_rows;
     int shift, nblk;
+    uint32_t* status;      // one-sweep: [tile][bins] look-back words, {flag:2, count:30}
+    uint32_t* ticket;      // one-sweep: the pass's tile counter
+    int group;             // one-sweep: tiles per XCD group (tile_of_ticket)
+    int clear_status;      // one-sweep: the launcher clears this pass's look-back words first (big builds; small ones clear all passes at once)
     int pair;              // FIRST: 0 = separate strided columns; 1 / 2 = u and v are the two columns of ONE [E, 2] int64 array
                            // (u first / v first): both come from a single 16-byte load per edge
 };
@@ -247,7 +251,38 @@ __global__ __launch_bounds__(kBlock) void scan_apply_kernel(uint32_t* __restrict
 // (the hardware serves the lanes of one ds_add_rtn in lane order; an on-device check of ascending edge ids inside every row guarded
 // it) and bought nothing: 0.576 -> 0.561 ms at C2, 2.39 -> 2.49 ms at C2' (profiles/r04/csr_build_variants.txt) -- the kernel is not
 // bound by its vector instructions either.
-template <int BITS, bool FIRST, bool LAST>
+//
+// SWEEP (round 5): the one-sweep form of a pass.  No per-tile histogram kernel and no scan kernels: a pass is this kernel alone, after ONE
+// histogram of all the digits of all the passes (sweep_hist_kernel) whose exclusive scan over the digits (sweep_base_kernel) is a.dbase.
+// A block draws its tile from a ticket counter (so every tile before it is running or done), counts its digits while ranking as before,
+// publishes the counts in status[tile][digit] (flag 1 = this tile's count, flag 2 = count of this and ALL earlier tiles; the flag and the
+// 30-bit count share one 32-bit word, so a relaxed agent-scope store / load is the whole protocol) and every thread walks back over the
+// earlier tiles' words of ITS digit, adding counts until it meets a flag 2 (decoupled look-back), then publishes its own flag 2.
+// position = dbase[digit] + count in earlier tiles + rank inside the tile: the same position the scanned per-tile histogram gives -- the
+// output is bit-identical (tests/test_gpu_round5.py::test_csr_onesweep_*).
+constexpr uint32_t kSweepCountMask = (1u << 30) - 1;
+#ifndef PGLAMD_SWEEP_BATCH
+#define PGLAMD_SWEEP_BATCH 4
+#endif
+#ifndef PGLAMD_SWEEP_AUTO_MAX_EDGES
+#define PGLAMD_SWEEP_AUTO_MAX_EDGES 1000000
+#endif
+constexpr int kSweepOneFillTiles = 1024;        // up to this many tiles the look-back words of all passes are cleared by ONE fill with the digit totals
+constexpr int kSweepBatch = PGLAMD_SWEEP_BATCH;
+
+// ticket -> tile.  Tickets are drawn in dispatch order and dispatch goes round the 8 XCDs, so ticket t runs on XCD t % 8 (a performance
+// assumption only).  `group` consecutive tiles go to one XCD: the short runs neighbouring tiles write to the same digit (4 items = 16 B at
+// 10-bit digits) meet in that XCD's L2 and leave it as whole lines.  Inside a window of 8 * group tickets a tile may wait for a tile whose
+// ticket is up to 8 * group later, so the host keeps 8 * group far below the number of resident blocks (sweep_group); group 1 is plain
+// ticket order.  The tail that does not fill a window is taken in ticket order.
+__device__ __forceinline__ int64_t tile_of_ticket(uint32_t t, int nblk, int group) {
+    const uint32_t win = 8u * (uint32_t)group;
+    if (group <= 1 || t >= ((uint32_t)nblk / win) * win) return t;
+    const uint32_t w = t / win, r = t % win;
+    return (int64_t)w * win + (r % 8u) * (uint32_t)group + r / 8u;
+}
+
+template <int BITS, bool FIRST, bool LAST, bool SWEEP>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) {
     constexpr int BINS = 1 << BITS;
     constexpr int PER = BINS / kSortThreads > 0 ? BINS / kSortThreads : 1;     // digits per thread in the block-level scans
@@ -259,15 +294,22 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
     __shared__ uint32_t wave_tot[kSortWaves];
     int32_t* stage = reinterpret_cast<int32_t*>(lds_pool);                     // one 32-bit stream of the tile at a time ...
     CntT (*cnt)[BINS] = reinterpret_cast<CntT (*)[BINS]>(lds_pool);           // ... over the per-wave digit counters: [kSortWaves][BINS] counts, then prefixes over waves
-    const int64_t tile = sort_tile(a.nblk);
-    if (tile < 0) return;
+    __shared__ int64_t s_tile;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
-    for (int i = tid; i < BINS; i += kSortThreads) gb[i] = a.hist[(int64_t)i * a.nblk + tile];       // (already the global position: flat scan)
+    if constexpr (SWEEP) {
+        if (tid == 0) s_tile = tile_of_ticket(atomicAdd(a.ticket, 1u), a.nblk, a.group);
+    } else {
+        if (tid == 0) s_tile = sort_tile(a.nblk);
+    }
     {
         uint32_t* z = reinterpret_cast<uint32_t*>(&cnt[0][0]);
         for (int i = tid; i < (int)(kCntBytes / 4); i += kSortThreads) z[i] = 0;
     }
     __syncthreads();
+    const int64_t tile = s_tile;
+    if (tile < 0) return;                                  // (block-uniform)
+    for (int i = tid; i < BINS; i += kSortThreads) gb[i] = SWEEP ? 0u : a.hist[(int64_t)i * a.nblk + tile];       // (already the global position: flat scan)
+    if constexpr (SWEEP) __syncthreads();
     const int64_t tbase = tile * kSortTile;
     const int64_t wbase = tbase + (int64_t)w * (kWave * kSortItems);
     int32_t key[kSortItems], col[kSortItems], eid[kSortItems];
@@ -295,6 +337,20 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
         }
     }
     if (FIRST && a.range_flag && __any(bad)) { if (lane == 0) atomicOr(a.range_flag, 1); }
+    if constexpr (SWEEP) {
+        // The tile's digit counts are published BEFORE the ranking (one LDS atomic per item into gb, which is free until the look-back):
+        // ranking is half of a block's life, and a tile cannot finish its look-back before every earlier tile has published its counts --
+        // published after the ranking (version 1) the passes ran in convoys behind the slowest ranker, 1.7 x the multi-kernel scatter.
+#pragma unroll
+        for (int s = 0; s < kSortItems; ++s)
+            if (wbase + s * kWave + lane < a.n) atomicAdd(&gb[(key[s] >> a.shift) & (BINS - 1)], 1u);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int d = tid * PER + j;
+            if (d < BINS) __hip_atomic_store(a.status + tile * BINS + d, ((tile == 0 ? 2u : 1u) << 30) | gb[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     // rank inside the wave, in item order: the lanes of a 64-item step that hold the same digit find each other with BITS
     // ballots; the lowest of them bumps the wave's counter of that digit by the group size
 #pragma unroll
@@ -317,8 +373,9 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
     }
     __syncthreads();
     // counts -> exclusive prefixes over the waves (per digit); block totals -> exclusive scan over the digits
+    uint32_t tot[PER];
     {
-        uint32_t tot[PER], sum = 0;
+        uint32_t sum = 0;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int d = tid * PER + j;
@@ -353,6 +410,43 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
 #pragma unroll
     for (int s = 0; s < kSortItems; ++s)
         if (wbase + s * kWave + lane < a.n) stage[pos[s]] = key[s];
+    if constexpr (SWEEP) {
+        // decoupled look-back, one digit per thread (PER digits at 10 bits): four earlier tiles' words per round trip
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int d = tid * PER + j;
+            if (d >= BINS) continue;
+            uint32_t before = 0;
+            if (tile > 0) {
+                int64_t k = tile - 1;
+                bool done = false;
+                uint32_t spins = 0;
+                while (!done) {
+                    uint32_t sw[kSweepBatch];
+#pragma unroll
+                    for (int i = 0; i < kSweepBatch; ++i)
+                        sw[i] = k - i >= 0 ? __hip_atomic_load(a.status + (k - i) * BINS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (2u << 30);
+                    int adv = 0;
+#pragma unroll
+                    for (int i = 0; i < kSweepBatch; ++i) {
+                        if (done || adv != i) continue;                  // (stopped at a word that is not published yet: re-read from there)
+                        const uint32_t f = sw[i] >> 30;
+                        if (f == 0) continue;
+                        before += sw[i] & kSweepCountMask;
+                        ++adv;
+                        if (f == 2) done = true;
+                    }
+                    k -= adv;
+                    if (!done && adv == 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 26)) __builtin_trap();      // (seconds: a predecessor that never ran -- fail loudly, never hang the device)
+                    }
+                }
+                __hip_atomic_store(a.status + tile * BINS + d, (2u << 30) | (before + tot[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            gb[d] = a.dbase[d] + before;
+        }
+    }
     __syncthreads();
     int32_t dest[kSortItems];
 #pragma unroll
@@ -406,6 +500,88 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
     }
 }
 
+// One-sweep, step 1: the histogram of every pass's digit over ALL keys, in one read of the key column.  At most 1 024 blocks, each over a
+// strided set of tiles with all the passes' bins in LDS (4 passes x 10 bits = 16 KB at most), flushed with one global atomic per non-empty bin.
+struct SweepHistArgs {
+    const int64_t* u; int64_t us;
+    int64_t n, n_rows;
+    int nblk, passes;
+    int shift[4], width[4];
+    uint32_t* ghist;               // [sum of 2^width]: pass p starts at the sum of the earlier passes' bins
+};
+
+__global__ __launch_bounds__(kSortThreads) void sweep_hist_kernel(SweepHistArgs a) {
+    __shared__ uint32_t h[4 << kSortMaxBits];
+    int off[4], total = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { off[p] = total; if (p < a.passes) total += 1 << a.width[p]; }
+    for (int i = threadIdx.x; i < total; i += kSortThreads) h[i] = 0;
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < a.nblk; tile += gridDim.x) {
+        const int64_t base = tile * kSortTile;
+        int64_t k[kSortItems];
+#pragma unroll
+        for (int i = 0; i < kSortItems; ++i) {
+            const int64_t idx = base + (int64_t)i * kSortThreads + threadIdx.x;
+            k[i] = idx < a.n ? a.u[idx * a.us] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < kSortItems; ++i) {
+            if (base + (int64_t)i * kSortThreads + threadIdx.x >= a.n) continue;
+            const uint32_t key = (uint64_t)k[i] >= (uint64_t)a.n_rows ? 0u : (uint32_t)k[i];       // (clamped exactly as the pass clamps it)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (p < a.passes) atomicAdd(&h[off[p] + ((key >> a.shift[p]) & ((1u << a.width[p]) - 1))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += kSortThreads) { const uint32_t c = h[i]; if (c) atomicAdd(a.ghist + i, c); }
+}
+
+// step 2: block p turns pass p's digit totals into the position of every digit's first item (exclusive scan over the digits)
+__global__ __launch_bounds__(kBlock) void sweep_base_kernel(SweepHistArgs a, uint32_t* __restrict__ dbase) {
+    __shared__ uint32_t wave_tot[kBlock / kWave];
+    int off = 0;
+    for (int p = 0; p < (int)blockIdx.x; ++p) off += 1 << a.width[p];
+    const int bins = 1 << a.width[blockIdx.x];
+    uint32_t carry = 0;
+    for (int b = 0; b < bins; b += kBlock) {
+        const int j = b + threadIdx.x;
+        const uint32_t v = j < bins ? a.ghist[off + j] : 0;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan_256(v, wave_tot, total);
+        if (j < bins) dbase[off + j] = carry + ex;
+        carry += total;
+    }
+}
+
+// One-sweep or multi-kernel passes?  Returns the tiles per XCD group of the one-sweep passes (tile_of_ticket), 0 = multi-kernel passes.
+// Option "csr_onesweep" (pglamd_set_option; first value from PGLAMD_CSR_ONESWEEP): -1 (default) by size, 0 never, g >= 1 always, group g
+// -- capped so that a window of 8 * group tickets stays below a sixteenth of the blocks the device holds at two per CU (a tile may wait for
+// a ticket up to one window later).
+// By size = up to 1 M edges (profiles/r05/csr_onesweep.txt): the one-sweep build is 7 launches instead of 12 and wins where launches
+// dominate -- 0.038 against 0.054 ms at Cora's size, 0.041 / 0.060 at 100 k edges, 0.060 / 0.071 at a sampled block of 600 k edges, level
+// at 1 M -- and loses on big graphs: 0.095 / 0.086 ms at 2 M edges, 0.74 / 0.60 at 20 M, 2.8 / 2.4 at 100 M.  Counters say why: tiles in ticket order go round the XCDs, so the 16-byte runs neighbouring tiles write to one
+// digit no longer meet in one L2 -- 12.2 M write requests, half of them 32-byte, 570 MB written, where the multi-kernel scatter (an XCD
+// takes consecutive tiles) issues 4.2 M, 94 % full 64-byte, 256 MB.  Giving an XCD groups of consecutive tiles (group 4 .. 32) restores
+// the merging but makes the first tile of a group wait for tickets drawn later: slower still (0.78 - 0.82 ms).  Publishing the counts
+// before the ranking, wider look-back reads (16 words per round trip) and a path-compressed look-back did not change the picture
+// (profiles/r05/csr_onesweep_v1..v3.txt).
+constexpr int64_t kSweepAutoMaxEdges = PGLAMD_SWEEP_AUTO_MAX_EDGES;
+
+static int sweep_group(int64_t E) {
+    static int cap = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 1; }
+        const int c = prop.multiProcessorCount / 8;
+        return c < 1 ? 1 : c;
+    }();
+    if (E >= ((int64_t)1 << 30)) return 0;                 // (the look-back words carry 30-bit counts)
+    int g = csr_onesweep_option().load(std::memory_order_relaxed);
+    if (g < 0) return E <= kSweepAutoMaxEdges ? 1 : 0;
+    return g > cap ? cap : g;
+}
+
 // Widest digit a pass may take.  Measured (profiles/r03/csr_build.txt): 20-bit keys sort faster in 2 passes of 10 bits (0.64 ms at
 // 20 M edges) than in 3 of 7 (0.69); 22-bit keys faster in 3 passes of 8 / 7 / 7 (3.1 ms at 100 M edges) than in 2 of 11 (4.4):
 // at 11 bits a tile of 8 192 items leaves runs of four items per digit, too short to write whole cache lines.
@@ -427,9 +603,28 @@ static int32_t sort_pass_launch(const SortArgs& a, uint32_t* totals, hipStream_t
     PGLAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)pieces), dim3(kBlock), 0, st, a.hist, n_hist, totals);
     PGLAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL((sort_scatter_kernel<BITS, FIRST, LAST>), dim3(grid), dim3(kSortThreads), 0, st, a);
+    hipLaunchKernelGGL((sort_scatter_kernel<BITS, FIRST, LAST, false>), dim3(grid), dim3(kSortThreads), 0, st, a);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
+}
+
+template <int BITS, bool FIRST, bool LAST>
+static int32_t sweep_pass_launch(const SortArgs& a, hipStream_t st) {
+    if (a.clear_status) PGLAMD_HIP_CHECK(hipMemsetAsync(a.status, 0, (size_t)a.nblk * sizeof(uint32_t) << BITS, st));
+    hipLaunchKernelGGL((sort_scatter_kernel<BITS, FIRST, LAST, true>), dim3((unsigned)a.nblk), dim3(kSortThreads), 0, st, a);
+    PGLAMD_LAUNCH_CHECK();
+    return PGLAMD_OK;
+}
+
+template <bool FIRST, bool LAST>
+static int32_t sweep_pass(int bits, const SortArgs& a, hipStream_t st) {
+    switch (bits) {
+        case 6: return sweep_pass_launch<6, FIRST, LAST>(a, st);
+        case 7: return sweep_pass_launch<7, FIRST, LAST>(a, st);
+        case 8: return sweep_pass_launch<8, FIRST, LAST>(a, st);
+        case 9: return sweep_pass_launch<9, FIRST, LAST>(a, st);
+        default: return sweep_pass_launch<10, FIRST, LAST>(a, st);
+    }
 }
 
 template <bool FIRST, bool LAST>
@@ -459,6 +654,12 @@ static int sort_plan(int bits, int (&width)[8]) {
     return passes;
 }
 
+// small builds (up to kSweepOneFillTiles tiles): the look-back words of ALL passes, cleared by one fill together with the digit totals
+static size_t sweep_small_words(int64_t E) {
+    const size_t n_tiles = (size_t)ceil_div(E > 0 ? E : 1, (int64_t)kSortTile);
+    return n_tiles <= (size_t)kSweepOneFillTiles ? n_tiles * ((size_t)4 << kSortMaxBits) : 0;
+}
+
 static size_t sort_hist_entries(int64_t E) { return ((size_t)1 << kSortMaxBits) * (size_t)ceil_div(E > 0 ? E : 1, (int64_t)kSortTile); }
 
 static unsigned grid_for(int64_t n) {
@@ -477,7 +678,9 @@ extern "C" size_t pglamd_csr_build_workspace_bytes(int64_t num_edges, int64_t nu
     // two (key, neighbour, edge id) int32 ping-pong sets, row32 when the caller does not keep it, block histograms + digit totals / bases
     (void)num_nodes;
     return 7 * align_up((size_t)E * 4, 256) + align_up(sort_hist_entries(E) * 4, 256) +
-           align_up((size_t)(ceil_div((int64_t)sort_hist_entries(E), (int64_t)kScanPiece) + 1) * 4, 256) + align_up(((size_t)1 << kSortMaxBits) * 4, 256) + 1024;
+           align_up((size_t)(ceil_div((int64_t)sort_hist_entries(E), (int64_t)kScanPiece) + 1) * 4, 256) + align_up(((size_t)1 << kSortMaxBits) * 4, 256) + 1024 +
+           2 * align_up(((size_t)4 << kSortMaxBits) * 4 + 64, 256) +               // one-sweep: digit totals of four passes + tickets, digit bases,
+           align_up(sweep_small_words(E) * 4, 256);                                 //            look-back words of all passes of a small build
 }
 
 extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const int64_t* v, int64_t v_stride,
@@ -503,6 +706,9 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
     uint32_t* hist = cv.take<uint32_t>(sort_hist_entries(E));
     uint32_t* totals = cv.take<uint32_t>(ceil_div((int64_t)sort_hist_entries(E), (int64_t)kScanPiece) + 1);
     uint32_t* dbase = cv.take<uint32_t>((size_t)1 << kSortMaxBits);
+    uint32_t* sweep_base = cv.take<uint32_t>(((size_t)4 << kSortMaxBits) + 16);
+    const size_t small_words = sweep_small_words(E);
+    uint32_t* sweep_hist = cv.take<uint32_t>(((size_t)4 << kSortMaxBits) + 16 + small_words);      // [4 passes' bins] + 4 tickets (+ small builds: every pass's look-back words)
     if (!cv.ok()) return fail(PGLAMD_E_WORKSPACE, "csr_build: workspace carve overflow");
     int32_t* rows = row32 ? row32 : row_tmp;
 
@@ -514,14 +720,38 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
         if (u_stride == 2 && v_stride == 2 && v == u + 1 && reinterpret_cast<uintptr_t>(u) % 16 == 0) a.pair = 1;
         else if (u_stride == 2 && v_stride == 2 && u == v + 1 && reinterpret_cast<uintptr_t>(v) % 16 == 0) a.pair = 2;
         a.hist = hist; a.dbase = dbase; a.n = E; a.n_rows = N; a.nblk = (int)ceil_div(E, (int64_t)kSortTile);
+        const int group = passes <= 4 ? sweep_group(E) : 0;
+        int bin0[8] = {0};
+        if (group) {
+            SweepHistArgs h{};
+            h.u = u; h.us = u_stride; h.n = E; h.n_rows = N; h.nblk = a.nblk; h.passes = passes; h.ghist = sweep_hist;
+            int sh = 0, bins = 0;
+            for (int p = 0; p < passes; ++p) { h.shift[p] = sh; h.width[p] = width[p]; sh += width[p]; bin0[p] = bins; bins += 1 << width[p]; }
+            PGLAMD_HIP_CHECK(hipMemsetAsync(sweep_hist, 0, (((size_t)4 << kSortMaxBits) + 16 + (small_words ? (size_t)a.nblk * bins : 0)) * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(sweep_hist_kernel, dim3((unsigned)(a.nblk < 1024 ? a.nblk : 1024)), dim3(kSortThreads), 0, st, h);
+            PGLAMD_LAUNCH_CHECK();
+            hipLaunchKernelGGL(sweep_base_kernel, dim3((unsigned)passes), dim3(kBlock), 0, st, h, sweep_base);
+            PGLAMD_LAUNCH_CHECK();
+            a.status = hist; a.group = group; a.clear_status = small_words ? 0 : 1;
+        }
         int shift = 0;
         for (int p = 0; p < passes; ++p) {
             const bool first = p == 0, last = p == passes - 1;
             a.shift = shift;
+            if (group) {
+                a.dbase = sweep_base + bin0[p]; a.ticket = sweep_hist + ((size_t)4 << kSortMaxBits) + p;
+                if (small_words) a.status = sweep_hist + ((size_t)4 << kSortMaxBits) + 16 + (size_t)a.nblk * bin0[p];
+            }
             a.key_in = (p & 1) ? key_a : key_b; a.col_in = (p & 1) ? col_a : col_b; a.eid_in = (p & 1) ? eid_a : eid_b;      // pass 0 writes A, pass 1 reads A ...
             a.key_out = (p & 1) ? key_b : key_a; a.col_out = (p & 1) ? col_b : col_a; a.eid_out = (p & 1) ? eid_b : eid_a;
             if (last) { a.row32 = rows; a.col32 = col32; a.eid32 = eid32; a.sorted_u = sorted_u; a.sorted_v = sorted_v; a.sorted_eid = sorted_eid; }
             int32_t rc;
+            if (group) {
+                if (first && last) rc = sweep_pass<true, true>(width[p], a, st);
+                else if (first) rc = sweep_pass<true, false>(width[p], a, st);
+                else if (last) rc = sweep_pass<false, true>(width[p], a, st);
+                else rc = sweep_pass<false, false>(width[p], a, st);
+            } else
             if (first && last) rc = sort_pass<true, true>(width[p], a, totals, st);
             else if (first) rc = sort_pass<true, false>(width[p], a, totals, st);
             else if (last) rc = sort_pass<false, true>(width[p], a, totals, st);

@@ -41,7 +41,7 @@ for STEP in "$@"; do
     rows_c2p_zero)  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2_zero)   timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
-    csr|coo|chains|noreuse|gcn|gat|ops|dtypes|gatsplit|model) timeout 900 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
+    csr|csrsweep|coo|chains|noreuse|gcn|gat|ops|dtypes|gatsplit|model) timeout 900 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     edgeops)    timeout 600 python scripts/prof.py edgeops > $F 2>&1; timeout 600 python scripts/prof.py edgeops --sorted >> $F 2>&1; grep -v amdgpu.ids $F ;;
     pmc_edgeops)
       # rows a7 / a8 / a10 in original edge order: fetched / written bytes, L2 hit rate and memory-side request mix per KERNEL

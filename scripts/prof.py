@@ -609,6 +609,37 @@ def cmd_csr(args):
         del edges, c, u_sorted, v_sorted
 
 
+def cmd_csrsweep(args):
+    """CSR build: the one-sweep passes (pglamd_set_option("csr_onesweep", group)) beside the multi-kernel passes (group 0), same inputs,
+    every output array compared bit for bit."""
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    sizes = (("C2", 20, 20_000_000), ("C2'", 22, 100_000_000), ("sampled block", 17, 600_000), ("Cora-sized", 12, 13_264))
+    if args.crossover:
+        sizes = (("Cora-sized", 12, 13_264), ("100 k", 14, 100_000), ("sampled block", 17, 600_000), ("1 M", 18, 1_000_000), ("2 M", 18, 2_000_000),
+                 ("4 M", 19, 4_000_000), ("8 M", 20, 8_000_000), ("C2", 20, 20_000_000))
+    for name, scale, E in sizes:
+        N = 1 << scale
+        edges = rmat_edges(scale, E, seed=42, device=dev)
+        u, v = edges[:, 1], edges[:, 0]
+        want = None
+        for group in args.groups:
+            pgl.ops.set_option("csr_onesweep", group)
+            ms = _t(lambda: pgl.ops.csr_build(u, v, N, want_i64=False, check_range=False), it=10, warm=3)
+            c = pgl.ops.csr_build(u, v, N, want_i64=False, check_range=False)
+            got = (c.indptr, c.row32, c.col32, c.eid32, c.degree)
+            if want is None:
+                want = got
+            same = all(torch.equal(a, b) for a, b in zip(want, got))
+            model = E * 28 + N * 12
+            print("%-14s |E|=%-10d N=2^%-2d csr_onesweep=%-3d csr_build %.3f ms = %6.2f G edges/s, %.3f of the 28 B/edge model at 8 TB/s%s"
+                  % (name, E, scale, group, ms, E / ms / 1e6, model / ms / 1e6 / 8000.0, "" if same else "   OUTPUT DIFFERS"), flush=True)
+        pgl.ops.set_option("csr_onesweep", 0)
+        del edges, c, want, got
+
+
 def cmd_coo(args):
     """K1' (row n1): paddle.geometric.send_u_recv straight from raw COO for a graph used ONCE (pgl/graph.py:859-861) --
     pglamd_scatter_add_coo against the engine's default for the same call: csr_build + aggregate (+ the int32 narrowing of the edge
@@ -1263,6 +1294,7 @@ def main():
     tr.add_argument("--dir", required=True)
     tr.add_argument("--out", required=True)
     sub.add_parser("csr")
+    cs = sub.add_parser("csrsweep"); cs.add_argument("--groups", type=int, nargs="*", default=[0, 1, 4, 16, 32]); cs.add_argument("--crossover", action="store_true")
     co = sub.add_parser("coo"); co.add_argument("--dim", type=int, default=128)
     sub.add_parser("hotcold")
     ch = sub.add_parser("chains"); ch.add_argument("--scale", type=int, default=20); ch.add_argument("--edges", type=int, default=20_000_000)
@@ -1297,6 +1329,8 @@ def main():
          "trace": cmd_trace}[args.cmd](args)
     elif args.cmd == "csr":
         cmd_csr(args)
+    elif args.cmd == "csrsweep":
+        cmd_csrsweep(args)
     elif args.cmd == "coo":
         cmd_coo(args)
     elif args.cmd == "chains":

@@ -654,3 +654,73 @@ def test_edge_tensor_through_the_udf_send_recv_path(pgl):
     msg = g.send(lambda s_, d_, e_: {"h": d_["h"] * 2.0}, node_feat={"h": dev(x)})
     want_src = R.c_send_u_recv(2.0 * x, dst, src, "sum")                         # reduced by source: rows of the SOURCE collect their out-edges' dst features
     np.testing.assert_allclose(host(g.recv(lambda m: m.reduce_sum(m["h"]), msg, recv_mode="src")), want_src, rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# (k) CSR build, one-sweep passes (pgl/graph_kernel.pyx:59-88 is the semantics): one histogram of
+#     all digits + one kernel per pass with decoupled look-back.  The default for builds of up to 1 M edges (where it is faster:
+#     profiles/r05/csr_onesweep.txt), forced on / off with pglamd_set_option("csr_onesweep", group / 0); the output must be
+#     BIT-identical to the multi-kernel passes (both are stable sorts) and to the oracle.
+# ------------------------------------------------------------------------------------------------
+def _csr_fields(c):
+    return [("degree", c.degree), ("indptr", c.indptr), ("row32", c.row32), ("col32", c.col32), ("eid32", c.eid32),
+            ("sorted_u", c.sorted_u), ("sorted_v", c.sorted_v), ("sorted_eid", c.sorted_eid)]
+
+
+def _csr_keys(kind, E, N, gen):
+    if kind == "uniform":
+        return torch.randint(0, N, (E,), generator=gen, device="cuda")
+    if kind == "one-row":
+        return torch.full((E,), N - 1, dtype=torch.int64, device="cuda")
+    if kind == "sorted":
+        return torch.sort(torch.randint(0, N, (E,), generator=gen, device="cuda")).values
+    # skewed: a few hubs take most of the edges (digit bins of very different sizes, long look-back chains on the hot digits)
+    k = (torch.rand(E, generator=gen, device="cuda") ** 6 * N).long().clamp_(max=N - 1)
+    return k
+
+
+@pytest.mark.parametrize("group", [1, 2, 16, -1])
+@pytest.mark.parametrize("E,N,kind", [
+    (1, 5, "uniform"), (4095, 1000, "uniform"), (4096, 1000, "skewed"), (4097, 70000, "uniform"),
+    (300_000, 1 << 22, "uniform"),            # 22-bit keys: three passes (8 / 7 / 7)
+    (300_000, 1 << 20, "skewed"),             # two passes of 10 bits
+    (3_000_000, 1 << 20, "skewed"),           # 733 tiles: five full windows of 8 x 16 tickets + a tail in ticket order
+    (1_048_576 + 17, 300, "one-row"),         # one digit takes everything
+    (2_000_000, 50_000, "sorted"),
+])
+def test_csr_onesweep_equals_the_multi_kernel_passes(pgl, E, N, kind, group):
+    gen = torch.Generator(device="cuda"); gen.manual_seed(E % 9973 + N)
+    u = _csr_keys(kind, E, N, gen)
+    v = torch.randint(0, N, (E,), generator=gen, device="cuda")
+    pairs = torch.stack([v, u], 1).contiguous()          # the [E, 2] layout (one 16-byte load per edge) and two separate columns
+    try:
+        pgl.ops.set_option("csr_onesweep", 0)
+        want = pgl.ops.csr_build(u, v, N)
+        pgl.ops.set_option("csr_onesweep", group)
+        for uu, vv in ((u, v), (pairs[:, 1], pairs[:, 0])):
+            for rep in range(2):                          # (a second build reuses the workspace: the look-back words start from zero again)
+                got = pgl.ops.csr_build(uu, vv, N)
+                for (name, a), (_, b) in zip(_csr_fields(want), _csr_fields(got)):
+                    assert torch.equal(a, b), (name, kind, E, N, group, rep)
+    finally:
+        pgl.ops.set_option("csr_onesweep", -1)           # (the default: one-sweep up to 1 M edges)
+
+
+def test_csr_onesweep_vs_oracle_and_range_flag(pgl):
+    rng = np.random.default_rng(5)
+    E, N = 50_000, 3000
+    u = rng.integers(0, N, E); v = rng.integers(0, N, E)
+    try:
+        pgl.ops.set_option("csr_onesweep", -1)
+        c = pgl.ops.csr_build(dev(u), dev(v), N)
+        degree, sorted_v, sorted_u, sorted_eid, indptr = R.np_build_index(u, v, N)
+        np.testing.assert_array_equal(host(c.indptr), indptr)
+        np.testing.assert_array_equal(host(c.sorted_v), sorted_v)
+        np.testing.assert_array_equal(host(c.sorted_u), sorted_u)
+        np.testing.assert_array_equal(host(c.sorted_eid), sorted_eid)
+        np.testing.assert_array_equal(host(c.degree), degree)
+        bad = u.copy(); bad[123] = N + 7                 # an id out of range is still reported (and clamped, not followed) on this path
+        with pytest.raises(Exception):
+            pgl.ops.csr_build(dev(bad), dev(v), N)
+    finally:
+        pgl.ops.set_option("csr_onesweep", -1)           # (the default: one-sweep up to 1 M edges)
