@@ -39,29 +39,50 @@ __global__ __launch_bounds__(kBlock) void narrow_i64_kernel(const int64_t* __res
 // that found them; a LONG gap -- the rows after the last key of a sampled block, whose index spans the node space of the whole
 // graph while only the batch's destinations have edges: tens of thousands of rows, 0.2 - 0.5 ms when one lane wrote them, 40 % of the
 // GPU time of a mini-batch GraphSAGE step -- is written by the whole wave, 64 rows per store.
+// Round 5: a lane takes kBoundsVec CONSECUTIVE positions (one 16-byte load of int32 keys; the key before them comes from the lane below)
+// instead of one position and two 4-byte loads: the whole build 0.59 -> 0.56 ms at 20 M edges, 2.42 -> 2.30 ms at 100 M, csr_from_sorted
+// 0.178 -> 0.155 / 0.84 -> 0.72 ms (profiles/r05/csr_build.txt against profiles/r04/csr_build.txt).
+constexpr int kBoundsVec = 4;
+
 template <typename K>
 __global__ __launch_bounds__(kBlock) void row_bounds_kernel(const K* __restrict__ key, int64_t n, int64_t n_rows,
                                                             int64_t* __restrict__ indptr) {
     constexpr int64_t kLong = 16;
+    constexpr int V = kBoundsVec;
+    struct alignas(sizeof(K) * V) KV { K k[V]; };
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t step = (int64_t)gridDim.x * kBlock;
-    for (int64_t base = (int64_t)blockIdx.x * kBlock + (threadIdx.x - lane); base <= n; base += step) {     // (wave-uniform trip count)
-        const int64_t p = base + lane;
-        int64_t lo = 0, hi = -1;                                  // rows [lo, hi] get the value p
-        if (p <= n) {
-            lo = p == 0 ? 0 : (int64_t)key[p - 1] + 1;
-            hi = p == n ? n_rows : (int64_t)key[p];
-            if (hi > n_rows) hi = n_rows;
+    const int64_t step = (int64_t)gridDim.x * kBlock * V;
+    const bool aligned = reinterpret_cast<uintptr_t>(key) % sizeof(KV) == 0;
+    for (int64_t base = ((int64_t)blockIdx.x * kBlock + (threadIdx.x - lane)) * V; base <= n; base += step) {     // (wave-uniform trip count)
+        const int64_t p0 = base + (int64_t)lane * V;              // this lane's positions p0 .. p0 + V - 1
+        KV kv;
+        if (aligned && p0 + V <= n) {
+            kv = *reinterpret_cast<const KV*>(key + p0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; ++i) kv.k[i] = p0 + i < n ? key[p0 + i] : (K)0;
         }
-        const bool is_long = hi - lo >= kLong;
-        if (!is_long)
-            for (int64_t r = lo; r <= hi; ++r) indptr[r] = p;
-        unsigned long long m = __ballot(is_long);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const int64_t glo = __shfl(lo, l, kWave), ghi = __shfl(hi, l, kWave), gp = base + l;
-            for (int64_t r = glo + lane; r <= ghi; r += kWave) indptr[r] = gp;
+        K before = (K)__shfl_up((long long)kv.k[V - 1], 1, kWave);           // the key at p0 - 1
+        if (lane == 0) before = p0 > 0 && p0 - 1 < n ? key[p0 - 1] : (K)0;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const int64_t p = p0 + i;
+            int64_t lo = 0, hi = -1;                              // rows [lo, hi] get the value p
+            if (p <= n) {
+                lo = p == 0 ? 0 : (int64_t)(i == 0 ? before : kv.k[i - 1]) + 1;
+                hi = p == n ? n_rows : (int64_t)kv.k[i];
+                if (hi > n_rows) hi = n_rows;
+            }
+            const bool is_long = hi - lo >= kLong;
+            if (!is_long)
+                for (int64_t r = lo; r <= hi; ++r) indptr[r] = p;
+            unsigned long long m = __ballot(is_long);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int64_t glo = __shfl(lo, l, kWave), ghi = __shfl(hi, l, kWave), gp = base + (int64_t)l * V + i;
+                for (int64_t r = glo + lane; r <= ghi; r += kWave) indptr[r] = gp;
+            }
         }
     }
 }
@@ -760,7 +781,7 @@ extern "C" int32_t pglamd_csr_build(const int64_t* u, int64_t u_stride, const in
             shift += width[p];
         }
     }
-    hipLaunchKernelGGL(row_bounds_kernel<int32_t>, dim3(grid_for(E + 1)), dim3(kBlock), 0, st, rows, E, N, indptr);
+    hipLaunchKernelGGL(row_bounds_kernel<int32_t>, dim3(grid_for(ceil_div(E + 1, (int64_t)kBoundsVec))), dim3(kBlock), 0, st, rows, E, N, indptr);
     PGLAMD_LAUNCH_CHECK();
     if (N > 0) {
         hipLaunchKernelGGL(degree_kernel, dim3(grid_for(N)), dim3(kBlock), 0, st, indptr, N, degree);
@@ -822,10 +843,10 @@ extern "C" int32_t pglamd_seg_ptr_from_ids(const void* ids, int32_t ids_i64, int
     if (!seg_ptr || (num_rows > 0 && !ids) || num_rows < 0 || n_seg < 0) return fail(PGLAMD_E_ARG, "seg_ptr_from_ids: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (ids_i64)
-        hipLaunchKernelGGL(row_bounds_kernel<int64_t>, dim3(grid_for(num_rows + 1)), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL(row_bounds_kernel<int64_t>, dim3(grid_for(ceil_div(num_rows + 1, (int64_t)kBoundsVec))), dim3(kBlock), 0, st,
                            static_cast<const int64_t*>(ids), num_rows, n_seg, seg_ptr);
     else
-        hipLaunchKernelGGL(row_bounds_kernel<int32_t>, dim3(grid_for(num_rows + 1)), dim3(kBlock), 0, st,
+        hipLaunchKernelGGL(row_bounds_kernel<int32_t>, dim3(grid_for(ceil_div(num_rows + 1, (int64_t)kBoundsVec))), dim3(kBlock), 0, st,
                            static_cast<const int32_t*>(ids), num_rows, n_seg, seg_ptr);
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
