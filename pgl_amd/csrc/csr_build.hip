@@ -134,6 +134,9 @@ __global__ __launch_bounds__(kBlock) void seg_ids_kernel(const int64_t* __restri
 #ifndef PGLAMD_SORT_THREADS          // (variant builds: scripts/prof.py variant NAME PGLAMD_SORT_THREADS=512 ...)
 #define PGLAMD_SORT_THREADS 512
 #endif
+#ifndef PGLAMD_SORT_ABLATE           // timing experiments of the scatter kernel (variant builds; the results are WRONG by construction):
+#define PGLAMD_SORT_ABLATE 0          // 2 = no global stores, 4 = the loads alone -- profiles/r05/csr_scatter_ablation.txt
+#endif
 #ifndef PGLAMD_SORT_ITEMS
 #define PGLAMD_SORT_ITEMS 8
 #endif
@@ -326,6 +329,14 @@ __device__ __forceinline__ int64_t tile_of_ticket(uint32_t t, int nblk, int grou
     return (int64_t)w * win + (r % 8u) * (uint32_t)group + r / 8u;
 }
 
+// Round 5, what bounds this kernel (profiles/r05/csr_scatter_ablation.txt; pass 0 / pass 1 at 20 M edges): the tile's loads alone 73 / 54 us
+// (4.4 TB/s: sequential reads), loads + ranking + LDS staging 120 / 91 us, everything 208 / 156 us -- the store phase adds 88 / 65 us for 240 MB =
+// 2.7 TB/s.  A PERSISTENT form (two blocks per CU walking their XCD's tiles, the next tile's 24 loads + histogram row prefetched into a second
+// register set before the current tile is ranked; bit-exact) was built to overlap the three: 221 / 159 us, and 867 against 640 us on the first
+// pass at 100 M edges -- slower.  Its loads-only time is the same 79 us and its stores still add 65 us: reads and writes share the HBM, and
+// 3 072 concurrent write streams (1 024 digit runs x 3 arrays, 16-byte pieces merged to 64-byte requests in L2) drain at 2.7 TB/s whatever
+// else is in flight.  The sort is bound by the scatter's DRAM locality, not by the phases between a tile's loads and stores; it stays one
+// tile per block.
 template <int BITS, bool FIRST, bool LAST, bool SWEEP>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) {
     constexpr int BINS = 1 << BITS;
@@ -381,6 +392,12 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
         }
     }
     if (FIRST && a.range_flag && __any(bad)) { if (lane == 0) atomicOr(a.range_flag, 1); }
+#if PGLAMD_SORT_ABLATE == 4      // (timing experiment, wrong results: the tile's loads alone)
+    { int acc = 0;
+#pragma unroll
+      for (int s = 0; s < kSortItems; ++s) acc ^= key[s] ^ col[s] ^ eid[s];
+      if (acc != 0x7ffffff1) return; }
+#endif
     if constexpr (SWEEP) {
         // The tile's digit counts are published BEFORE the ranking (one LDS atomic per item into gb, which is free until the look-back):
         // ranking is half of a block's life, and a tile cannot finish its look-back before every earlier tile has published its counts --
@@ -501,6 +518,9 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) 
         const int32_t k = stage[i];
         const int d = (k >> a.shift) & (BINS - 1);
         dest[s] = (int32_t)(gb[d] + (uint32_t)(i - (int)dstart[d]));
+#if PGLAMD_SORT_ABLATE == 2      // (timing experiment, wrong results: everything but the global stores)
+        if (dest[s] != 0x7ffffff0) { dest[s] = -1; continue; }
+#endif
         if constexpr (LAST) {
             if (a.row32) a.row32[dest[s]] = k;
             if (a.sorted_u) a.sorted_u[dest[s]] = k;
