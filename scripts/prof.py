@@ -1191,8 +1191,15 @@ def cmd_gat(args):
         (g.send_ue_recv(f, al, "mul", "sum") * w).sum().backward()
     with torch.no_grad():
         print("fused forward only          %.3f ms" % _t(lambda: g.gat_aggregate(f, a_s, a_d, 0.2), 10, 2))
-    print("fused fwd+bwd               %.3f ms" % _t(lambda: fused(0.0), 10, 2))
+    print("fused fwd+bwd               %.3f ms   (loss = (out * w).sum(): the product, the reduction and their backward are torch kernels inside this time)" % _t(lambda: fused(0.0), 10, 2))
     print("fused fwd+bwd, dropout 0.6  %.3f ms" % _t(lambda: fused(0.6), 10, 2))
+
+    def handed(p=0.0):                      # the layer's own forward + backward: the output gradient is handed in, no loss kernels
+        for t_ in (f, a_s, a_d):
+            t_.grad = None
+        g.gat_aggregate(f, a_s, a_d, 0.2, p, 17).backward(w)
+    print("fused fwd+bwd, output gradient handed in (out.backward(w))              %.3f ms" % _t(lambda: handed(0.0), 10, 2))
+    print("fused fwd+bwd, output gradient handed in (out.backward(w)), dropout 0.6 %.3f ms" % _t(lambda: handed(0.6), 10, 2))
     print("unfused fwd+bwd (reference-style composition on the same engine) %.3f ms" % _t(unfused, 3, 1))
 
 
