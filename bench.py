@@ -372,7 +372,7 @@ def main():
                          "balanced on in-degree + 1 and on rows), 'random' = balanced random, 'auto' = kway vs random, "
                          "keep the plan whose slowest rank receives fewer rows")
     ap.add_argument("--parallel", default="rows", choices=["rows", "cols", "grid", "auto"],
-                    help="N > 1 headline layout: 'rows' (default, north_star) = METIS row partition + one RCCL halo all-to-all-v "
+                    help="N > 1 headline layout: 'rows' (default, north_star) = row partition by the engine's own partitioner (where north_star says METIS) + one RCCL halo all-to-all-v "
                          "per step overlapped with the local edges (DistGraph); 'cols' = graph replicated, feature columns split, "
                          "no data-path collective (FeatureShardedGraph); 'grid' = 2 row parts x N/2 column slices; 'auto' = time "
                          "all three and report the fastest.  With 'rows' the others are still timed and reported as secondary fields")
