@@ -335,8 +335,10 @@ __device__ __forceinline__ int64_t tile_of_ticket(uint32_t t, int nblk, int grou
 // register set before the current tile is ranked; bit-exact) was built to overlap the three: 221 / 159 us, and 867 against 640 us on the first
 // pass at 100 M edges -- slower.  Its loads-only time is the same 79 us and its stores still add 65 us: reads and writes share the HBM, and
 // 3 072 concurrent write streams (1 024 digit runs x 3 arrays, 16-byte pieces merged to 64-byte requests in L2) drain at 2.7 TB/s whatever
-// else is in flight.  The sort is bound by the scatter's DRAM locality, not by the phases between a tile's loads and stores; it stays one
-// tile per block.
+// else is in flight.  A second persistent form (reads split around the ranking: neighbour / edge ids before it, the next tile's keys after it)
+// took 0.645 / 2.89 ms for the whole build against 0.553 / 2.30.  The sort is bound by what the memory system gives this mix of sequential
+// reads and scattered writes, not by the phases between a tile's loads and stores; it stays one tile per block
+// (csrc/variants/csr_build_persistent_scatter*.patch).
 template <int BITS, bool FIRST, bool LAST, bool SWEEP>
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(SortArgs a) {
     constexpr int BINS = 1 << BITS;
