@@ -1,5 +1,7 @@
+"""Ten CSR builds (multi-kernel passes) at 20 M and 100 M edges: run under rocprofv3 --kernel-trace against variant libraries built with
+-DPGLAMD_SORT_ABLATE=2|4 (PGLAMD_LIB=...) to split the scatter kernel's time -- profiles/r05/csr_scatter_ablation.txt."""
 import os, sys, torch
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pgl_amd as pgl
 from pgl_amd.utils.rmat import rmat_edges
 dev = torch.device("cuda:0")
