@@ -122,7 +122,37 @@ def compile_examples(force=False):
     return out
 
 
+REF_TESTS = ("testsuite.py", "test_graph.py", "test_math.py", "test_graph_op.py", "test_conv.py", "test_bigraph.py", "test_pool.py",
+             "test_hetergraph.py", "test_dist_graph.py", "test_transform.py", "test_partition.py")
+
+
+def tests_dir():
+    return os.path.join(OUT, "tests")
+
+
+def compile_tests(force=False):
+    """Byte-compiles the reference's own UNIT-TEST files (tests/test_graph.py ... + their helper testsuite.py) from the
+    sources where they lie into oracle/_ref/tests/<name>.pyc -- build outputs like the examples above (git-ignored, never
+    source; they travel to the GPU box).  tests/test_reference_unit_tests.py runs them UNMODIFIED with `pgl` / `paddle`
+    resolved to pgl_amd/compat, i.e. the reference's assertions are made against the ENGINE (HIP kernels through the
+    C ABI), not against the oracle's stand-in (oracle/run_reference_tests.py does that).  Returns the directory or None."""
+    import py_compile
+    root = os.path.join(REF, "tests")
+    out = tests_dir()
+    if not os.path.isdir(root):
+        return out if os.path.isdir(out) else None
+    os.makedirs(out, exist_ok=True)
+    for rel in REF_TESTS:
+        src, dst = os.path.join(root, rel), os.path.join(out, rel[:-3] + ".pyc")
+        if not os.path.exists(src):
+            continue
+        if force or not os.path.exists(dst) or os.path.getmtime(dst) < os.path.getmtime(src):
+            py_compile.compile(src, cfile=dst, dfile="<reference>/tests/" + rel, doraise=True)
+    return out
+
+
 if __name__ == "__main__":
     compile_examples(force="--force" in sys.argv)
+    compile_tests(force="--force" in sys.argv)
     p = build(force="--force" in sys.argv)
     print(p if p else "reference not present and no prebuilt module")

@@ -43,10 +43,30 @@ class BiGraph(Graph):
         self._src_node_feat = {k[4:]: v for k, v in self._node_feat.items() if k.startswith("src:")}
         self._dst_node_feat = {k[4:]: v for k, v in self._node_feat.items() if k.startswith("dst:")}
 
+    def _rebuild(self, **kw):
+        # Graph.tensor / numpy (inplace=False) copy through Graph's constructor arguments: hand them on in BiGraph's own form
+        nf = kw.pop("node_feat", {})
+        kw.pop("num_nodes", None)
+        return self.__class__(src_num_nodes=self._src_num_nodes, dst_num_nodes=self._dst_num_nodes,
+                              src_node_feat={k[4:]: v for k, v in nf.items() if k.startswith("src:")},
+                              dst_node_feat={k[4:]: v for k, v in nf.items() if k.startswith("dst:")}, **kw)
+
     def tensor(self, inplace=True, uva=False, device=None):
         g = super(BiGraph, self).tensor(inplace, uva, device)
         g._split_feats()
         return g
+
+    def node_batch_iter(self, batch_size, shuffle=True, mode="src_node"):
+        """pgl/bigraph.py:1472-1500: batches of source ("src_node") or destination node ids."""
+        n = self._src_num_nodes if mode == "src_node" else self._dst_num_nodes
+        if self._is_tensor:
+            perm = torch.randperm(n, device=self._edges.device) if shuffle else torch.arange(n, device=self._edges.device)
+        else:
+            perm = np.arange(n)
+            if shuffle:
+                np.random.shuffle(perm)
+        for start in range(0, n, batch_size):
+            yield perm[start:start + batch_size]
 
     def numpy(self, inplace=True):
         g = super(BiGraph, self).numpy(inplace)
@@ -304,7 +324,11 @@ class HeterGraph(object):
 
     @property
     def num_nodes(self):
-        return self._graphs[self._edge_types[0]].num_nodes if self._edge_types else self._num_nodes
+        """pgl/heter_graph.py:147-152.  In tensor mode the reference hands back a Tensor (its Graph keeps num_nodes as one,
+        pgl/graph.py:244) and its tests assert that; a 0-dim int64 tensor on the host: int(), range(), indexing and arithmetic
+        accept it and no use of it costs a device synchronisation."""
+        n = self._graphs[self._edge_types[0]].num_nodes if self._edge_types else self._num_nodes
+        return torch.tensor(int(n), dtype=torch.int64) if self._is_tensor else n
 
     @property
     def num_edges(self):

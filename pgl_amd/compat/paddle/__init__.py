@@ -112,6 +112,23 @@ def arange(start=0, end=None, step=1, dtype=None):
     return _t.arange(start, end, step, dtype=_dtype(dtype or "int64"), device=_device())
 
 
+def randn(shape, dtype=None, name=None):
+    return _t.randn([int(v) for v in shape], dtype=_dtype(dtype or _default_dtype[0]), device=_device())
+
+
+def scatter(x, index, updates, overwrite=True, name=None):
+    """paddle.scatter: rows `index` of a COPY of x replaced by (overwrite) or, after zeroing them, summed with `updates`."""
+    out = x.clone()
+    idx = _index(index)
+    upd = updates.to(out.dtype)
+    if overwrite:
+        out[idx] = upd
+    else:
+        out[idx] = 0
+        out.index_add_(0, idx, upd)
+    return out
+
+
 def seed(s):
     _t.manual_seed(int(s))
     return s
@@ -147,6 +164,46 @@ def _numpy(self, *a, **k):
 
 
 _t.Tensor.numpy = _numpy
+
+# Tensor.shape is a LIST in Paddle and the reference's code and tests compare it with lists (tests/test_graph.py:222): hand out a
+# tuple that also equals the LIST of the same numbers (torch.Size cannot be subclassed; it is itself a tuple, and everything torch
+# does with a shape -- sizes of factory calls, slicing, unpacking, numel() -- works on this one too).
+class _Shape(tuple):
+    def __eq__(self, other):
+        return tuple.__eq__(self, tuple(other)) if isinstance(other, (list, tuple)) else NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    __hash__ = tuple.__hash__
+
+    def numel(self):
+        n = 1
+        for v in self:
+            n *= int(v)
+        return n
+
+    def __repr__(self):
+        return "paddle.shape(%s)" % list(self)
+
+
+_torch_shape = _t.Tensor.shape
+_t.Tensor.shape = property(lambda self: _Shape(_torch_shape.__get__(self)))
+
+# Tensor.transpose(perm) takes the whole permutation in Paddle (tests/test_pool.py:125); torch's takes two axes
+_torch_transpose = _t.Tensor.transpose
+
+
+def _transpose(self, *a, **k):
+    if len(a) == 1 and isinstance(a[0], (list, tuple)):
+        return self.permute(*[int(v) for v in a[0]])
+    if "perm" in k:
+        return self.permute(*[int(v) for v in k["perm"]])
+    return _torch_transpose(self, *a, **k)
+
+
+_t.Tensor.transpose = _transpose
 _t.Tensor.astype = lambda self, d: self.to(_dtype(d))
 _t.Tensor.clear_gradient = lambda self: setattr(self, "grad", None)
 _t.Tensor.stop_gradient = property(lambda self: not self.requires_grad,

@@ -107,7 +107,7 @@ class Graph(object):
         if inplace:
             self._to_tensor_inplace(device)
             return self
-        g = self.__class__(edges=self._edges.copy(), num_nodes=self._num_nodes, node_feat=dict(self._node_feat),
+        g = self._rebuild(edges=self._edges.copy(), num_nodes=self._num_nodes, node_feat=dict(self._node_feat),
                            edge_feat=dict(self._edge_feat),
                            adj_src_index=None if self._adj_src_index is None else self._adj_src_index.tensor(False, device),
                            adj_dst_index=None if self._adj_dst_index is None else self._adj_dst_index.tensor(False, device),
@@ -116,6 +116,10 @@ class Graph(object):
         if not g._is_tensor:
             g._to_tensor_inplace(device)
         return g
+
+    def _rebuild(self, **kw):
+        """The copy tensor(inplace=False) / numpy(inplace=False) return: Graph's own constructor arguments (BiGraph translates them)."""
+        return self.__class__(**kw)
 
     def numpy(self, inplace=True):
         """pgl/graph.py:269-300."""
@@ -136,7 +140,7 @@ class Graph(object):
             self._csr_views = None
             self._degree_norm_cache = None           # (device tensors of the graph that was: ADVICE r4)
             return self
-        return self.__class__(edges=edges, num_nodes=self._num_nodes, node_feat=nf, edge_feat=ef,
+        return self._rebuild(edges=edges, num_nodes=self._num_nodes, node_feat=nf, edge_feat=ef,
                               adj_src_index=None if self._adj_src_index is None else self._adj_src_index.numpy(False),
                               adj_dst_index=None if self._adj_dst_index is None else self._adj_dst_index.numpy(False),
                               _num_graph=self._num_graph, _graph_node_index=self._graph_node_index,

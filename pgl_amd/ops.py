@@ -855,6 +855,8 @@ def sddmm_supported(H, D):
 def gather_rows(x, index):
     """paddle.gather(x, index, axis=0) (pgl/utils/op.py:45, pgl/message.py:157, pgl/graph.py:822)."""
     _need_cuda(x, index)
+    if index.dim() == 0:                       # a scalar id (paddle.to_tensor(5) is a one-element tensor in Paddle 2.4): one row
+        index = index.reshape(1)
     x = x.contiguous(); index = index.contiguous()
     if index.dtype not in (torch.int32, torch.int64):
         raise TypeError("index must be int32 or int64")

@@ -707,6 +707,72 @@ def cmd_hotcold(args):
               % (int(hot.sum()), thr, 100.0 * float(flag.float().mean()), t1, t0 / t1, "identical" if ok else "DIFFERS"), flush=True)
 
 
+def cmd_hub(args):
+    """VERDICT r5 item 3b on the headline kernel (C2 / C2', d = 128 fp32): do contiguous HUB rows cut the L2 misses / translation misses?
+      (i)  hub table: the top-K out-degree source rows packed into x2, their column ids remapped once per graph, through the
+           existing two-table path (pglamd_aggregate_ext); the result is bit-identical (same edge order, same values);
+      (ii) sources relabelled by out-degree (an upper bound for (i): EVERY source row is laid out by degree; costs a pass over x
+           per call unless the caller keeps x in that order), destinations untouched -- output rows in the original order;
+      (iii) whole graph relabelled by out-degree (Graph.reorder(by="out_degree") form: output rows permuted too).
+    Prints ms per launch; `--pmc` runs three launches of each form for a counter pass (FETCH_SIZE, TCC_HIT/MISS, UTCL1)."""
+    import torch
+    pgl, dev, g = _c2(with_src_index=False, scale=args.scale, E=args.edges)
+    N, E = g.num_nodes, g.num_edges
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, 128, generator=gen, device=dev)
+    c = g.adj_dst_index.csr
+    it, warm = (3, 0) if args.pmc else (20, 5)
+    want = pgl.ops.aggregate(x, c, "sum", N)
+    t0 = _t(lambda: pgl.ops.aggregate(x, c, "sum", N), it=it, warm=warm)
+    print("RMAT-%d |E| = %d d = 128 fp32; plain index: %.3f ms" % (args.scale, E, t0), flush=True)
+    outdeg = torch.bincount(g.edges[:, 0], minlength=N)
+    order = torch.argsort(outdeg, descending=True, stable=True)           # order[k] = id of the k-th largest source
+    rank = torch.empty_like(order); rank[order] = torch.arange(N, device=dev)
+
+    def clone_index(col):
+        c2 = pgl.ops.CSR()
+        for k in ("degree", "indptr", "row32", "eid32", "num_nodes", "num_edges"):
+            setattr(c2, k, getattr(c, k))
+        c2.col32 = col.to(torch.int32).contiguous()
+        c2.sorted_v = c2.sorted_u = c2.sorted_eid = None
+        return c2
+    col = c.col32.long()
+    for K in args.hub_rows:
+        hub = rank[col] < K
+        colh = torch.where(hub, N + rank[col], col)
+        ch = clone_index(colh)
+        ids = order[:K].contiguous()
+        x2 = x[ids].contiguous()
+        t1 = _t(lambda: pgl.ops.aggregate(x, ch, "sum", N, x2=x2), it=it, warm=warm)
+        tg = _t(lambda: pgl.ops.gather_rows(x, ids), it=it, warm=warm)
+        ok = torch.equal(pgl.ops.aggregate(x, ch, "sum", N, x2=x2), want)
+        print("(i)  hub table K = %6d rows (%5.1f MB, %4.1f %% of the edges): %.3f ms (x%.3f) + gather of the table %.4f ms per call; result %s"
+              % (K, K * 512 / 1e6, 100.0 * float(hub.float().mean()), t1, t0 / t1, tg, "identical" if ok else "DIFFERS"), flush=True)
+    cr = clone_index(rank[col])
+    xr = x[order].contiguous()
+    t2 = _t(lambda: pgl.ops.aggregate(xr, cr, "sum", N), it=it, warm=warm)
+    tp = _t(lambda: pgl.ops.gather_rows(x, order), it=it, warm=warm)
+    ok = torch.equal(pgl.ops.aggregate(xr, cr, "sum", N), want)
+    print("(ii) sources laid out by out-degree (destinations untouched): %.3f ms (x%.3f) + the pass over x %.3f ms per call; result %s"
+          % (t2, t0 / t2, tp, "identical" if ok else "DIFFERS"), flush=True)
+    e2 = rank[g.edges]
+    g2 = pgl.Graph(edges=e2, num_nodes=N)
+    c3 = g2.adj_dst_index.csr
+    t3 = _t(lambda: pgl.ops.aggregate(xr, c3, "sum", N), it=it, warm=warm)
+    got = pgl.ops.aggregate(xr, c3, "sum", N)
+    err = float((got[rank] - want).abs().max() / want.abs().max())
+    print("(iii) whole graph relabelled by out-degree (rows permuted too): %.3f ms (x%.3f); max |diff| / max |want| after un-permuting %.2e"
+          % (t3, t0 / t3, err), flush=True)
+    indeg = torch.bincount(g.edges[:, 1], minlength=N)
+    order_in = torch.argsort(indeg + outdeg, descending=True, stable=True)
+    rank2 = torch.empty_like(order_in); rank2[order_in] = torch.arange(N, device=dev)
+    g4 = pgl.Graph(edges=rank2[g.edges], num_nodes=N)
+    c4 = g4.adj_dst_index.csr
+    x4 = x[order_in].contiguous()
+    t4 = _t(lambda: pgl.ops.aggregate(x4, c4, "sum", N), it=it, warm=warm)
+    print("(iv) whole graph relabelled by total degree: %.3f ms (x%.3f)" % (t4, t0 / t4), flush=True)
+
+
 def cmd_chains(args):
     """the un-fused attention compositions (the reference's own op sequences: send_uv -> element-wise -> edge_softmax
     -> send_ue_recv) at C3 size with their [E, H] tensors kept in the engine's destination-sorted order (EdgeTensor, the default)
@@ -1304,6 +1370,8 @@ def main():
     cs = sub.add_parser("csrsweep"); cs.add_argument("--groups", type=int, nargs="*", default=[0, 1, 4, 16, 32]); cs.add_argument("--crossover", action="store_true")
     co = sub.add_parser("coo"); co.add_argument("--dim", type=int, default=128)
     sub.add_parser("hotcold")
+    hb = sub.add_parser("hub"); hb.add_argument("--scale", type=int, default=20); hb.add_argument("--edges", type=int, default=20_000_000)
+    hb.add_argument("--hub-rows", type=int, nargs="*", default=[2048, 8192, 32768, 131072]); hb.add_argument("--pmc", action="store_true")
     ch = sub.add_parser("chains"); ch.add_argument("--scale", type=int, default=20); ch.add_argument("--edges", type=int, default=20_000_000)
     o = sub.add_parser("ops"); o.add_argument("--scale", type=int, default=20); o.add_argument("--edges", type=int, default=20_000_000)
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
@@ -1344,6 +1412,8 @@ def main():
         cmd_chains(args)
     elif args.cmd == "hotcold":
         cmd_hotcold(args)
+    elif args.cmd == "hub":
+        cmd_hub(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
     elif args.cmd == "gcn":
