@@ -11,7 +11,7 @@ feature matrix already resident in HBM.  Workload (config.workload): BASELINE.js
 N = 1, one JSON line with the driver's contract fields plus
   roofline      PHYSICAL: achieved / frac come from the same kernel (agg_flat_kernel, d = 128 fp32 sum) on a graph whose gathered
                 bytes are KNOWN (uniform in-degree-19 graph over 8.6 GB of features: <= 3.5 % of the gathers can hit any cache),
-                timed with HIP events in this run; `traffic` = PMC bytes of that leg from profiles/r04/traffic.json, replayed only
+                timed with HIP events in this run; `traffic` = PMC bytes of that leg from profiles/r06/traffic.json, replayed only
                 when the file's stamp (kernel symbol + sha256 of the kernel sources) matches this tree, else null.  The headline
                 workload's own figures -- section 8(d) model bytes / kernel time, which is NOT a bandwidth on RMAT (hub rows live
                 in L2 / Infinity Cache) -- ride along under roofline.headline_workload, labelled; no ratio above 1 is printed.
@@ -29,8 +29,7 @@ along; target_size = the |E| = 100 M graph through the same flow.  The run is se
 on stderr, candidates tried from the most conservative flow / transport up (halo.candidates: fold over torch.distributed, the cost
 model's flow over torch.distributed, the same over the library's own RCCL communicator -- --transport), the timed region on the
 fastest; a phase that exceeds its limit ends the run with the best COMPLETED measurement instead of hanging, and a failure of
-the target-size leg cannot lose the headline.  --alternatives also times the feature-column layout; --parallel cols / grid make
-another layout the headline.
+the target-size leg cannot lose the headline.
 """
 import os
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver (set before HIP initialises)
@@ -52,7 +51,7 @@ def algorithmic_bytes(E, N, d, s):
     return E * (d * s + 4) + N * (d * s + 8)
 
 
-TRAFFIC_FILES = ("profiles/r05/traffic.json", "profiles/r04/traffic.json",)
+TRAFFIC_FILES = ("profiles/r05/traffic.json", "profiles/r06/traffic.json",)
 KERNEL_SOURCES = ("pgl_amd/csrc/aggregate_flat.hpp", "pgl_amd/csrc/aggregate.hpp", "pgl_amd/csrc/aggregate.hip", "pgl_amd/csrc/common.hpp")
 
 
@@ -371,11 +370,10 @@ def main():
                     help="row partition for N > 1: 'kway' (default) = the engine's own multilevel partitioner (pglamd_partition_edges, "
                          "balanced on in-degree + 1 and on rows), 'random' = balanced random, 'auto' = kway vs random, "
                          "keep the plan whose slowest rank receives fewer rows")
-    ap.add_argument("--parallel", default="rows", choices=["rows", "cols", "grid", "auto"],
-                    help="N > 1 headline layout: 'rows' (default, north_star) = row partition by the engine's own partitioner (where north_star says METIS) + one RCCL halo all-to-all-v "
-                         "per step overlapped with the local edges (DistGraph); 'cols' = graph replicated, feature columns split, "
-                         "no data-path collective (FeatureShardedGraph); 'grid' = 2 row parts x N/2 column slices; 'auto' = time "
-                         "all three and report the fastest.  With 'rows' the others are still timed and reported as secondary fields")
+    ap.add_argument("--parallel", default="rows", choices=["rows"],
+                    help="N > 1 layout: row partition by the engine's own partitioner (where north_star says METIS) + one RCCL halo "
+                         "all-to-all-v per step overlapped with the local edges (DistGraph) -- north_star's layout, the only one in the product "
+                         "(rounds 3-5 also carried a feature-column and a grid layout: removed in round 6)")
     ap.add_argument("--push", default="never", choices=["never", "auto"],
                     help="'never' (default) = halo source rows are pulled, every edge is aggregated by its destination's owner (what the "
                          "partitioner balanced); 'auto' = per rank pair the cheaper of pulling source rows and pushing pre-aggregated "
@@ -384,8 +382,6 @@ def main():
                     help="N > 1: how a rank orders its rows.  'peers' (default): rows pulled by the same set of peers lie together, so every "
                          "peer's rows are a few contiguous ranges of the feature matrix and the row-pipelined exchange (flow 'rows2') sends "
                          "them from where they are -- no pack launch, no send buffer; 'id': by node id (round 4's layout; the exchange packs)")
-    ap.add_argument("--no-alternatives", action="store_true", help="(kept for compatibility: alternatives are off unless --alternatives)")
-    ap.add_argument("--alternatives", action="store_true", help="N > 1: also time the other layouts (feature columns) as secondary fields")
     ap.add_argument("--transport", default="auto", choices=["auto", "torch", "abi"],
                     help="N > 1 halo transport: 'torch' = torch.distributed all_to_all_single (RCCL), 'abi' = the library's own RCCL "
                          "communicator on its side stream (pglamd_halo_exchange_*, SURVEY 8b), 'auto' = time both, report both, run the "
@@ -438,7 +434,7 @@ def main():
     else:
         import torch.distributed as dist
         import pgl_amd.distributed as pd
-        from pgl_amd.distributed import DistGraph, FeatureShardedGraph, GridShardedGraph
+        from pgl_amd.distributed import DistGraph
         sync = lambda: torch.cuda.synchronize()
         barrier = lambda: dist.barrier()
 
@@ -469,10 +465,10 @@ def main():
         lim = args.phase_limit
         n_trial = max(args.warmup, 3)
         trial, cands, built = {}, [], {}
-        mode = "rows" if args.parallel in ("rows", "auto") else args.parallel
+        mode = "rows"
         extra = None
 
-        if mode == "rows":
+        if True:
             # ---- north_star's layout: row partition + one halo all-to-all-v per step ------------------------------------------------
             wd.begin("partition + halo plan", 4 * lim)
             dg = DistGraph.from_global(edges, N, rank, world, method=args.partition, device=dev, push=args.push, row_order=args.row_order)
@@ -559,38 +555,6 @@ def main():
                 print("[bench] per-rank phases failed on rank %d: %r" % (rank, ex), file=sys.stderr, flush=True)
                 dist.all_reduce(torch.zeros((world, 3), dtype=torch.float64, device=dev))
             wd.end()
-            if args.alternatives:                                    # the feature-column layout as a secondary field (not by default:
-                wd.begin("alternative layout: feature columns", 2 * lim)   # the first hardware run spends its minutes on rows + target size)
-                try:
-                    g2 = pgl.Graph(edges=edges, num_nodes=N); g2.adj_dst_index
-                    fs = FeatureShardedGraph(g2, rank, world)
-                    x_cols = fs.take_cols(x)
-                    fn = lambda: fs.send_recv(x_cols, "sum")
-                    fn(); fn()
-                    trial["cols"] = timed(fn, n_trial) / n_trial * 1e3
-                    del g2, fs, x_cols
-                except Exception as ex:                              # noqa: BLE001
-                    print("[bench] alternative layout failed (rank %d: %r)" % (rank, ex), file=sys.stderr, flush=True)
-                wd.end()
-            halo["alternatives_ms_per_step"] = trial
-        else:
-            # ---- the other layouts as the headline, on request (--parallel cols | grid) ---------------------------------------------
-            wd.begin("layout %r" % mode, 4 * lim)
-            if mode == "cols":
-                g2 = pgl.Graph(edges=edges, num_nodes=N); g2.adj_dst_index
-                fs = FeatureShardedGraph(g2, rank, world)
-                x_cols = fs.take_cols(x)
-                step, halo, (d_loc, n_loc, e_loc) = (lambda: fs.send_recv(x_cols, "sum")), fs.stats(), (int(x_cols.shape[1]), N, E)
-            else:
-                pr = 2 if world % 2 == 0 else 1                      # grid: 2 row parts x world/2 column slices
-                gg = GridShardedGraph(edges, N, rank, world, grid=(pr, world // pr), method=args.partition, device=dev, push=args.push)
-                blk = gg.take(x)
-                st = gg.stats()
-                step, halo, (d_loc, n_loc, e_loc) = (lambda: gg.send_recv(blk, "sum")), st, (int(blk.shape[1]), st["local_rows"], st["local_edges"])
-            step(); step()
-            trial[mode] = timed(step, n_trial) / n_trial * 1e3
-            halo = dict(halo, mode=mode, alternatives_ms_per_step=trial)
-            wd.end()
         del x
 
     if world > 1:
@@ -661,10 +625,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else
                        ("row partition (%s) x%d + RCCL halo all-to-all-v (pull/push per pair: %d pairs push), interior rows "
                         "overlap the exchange, boundary rows read [owned | received]"
-                        % (halo["partition"], world, halo.get("pushed_pairs", 0)) if halo["mode"] == "rows" else
-                        "grid %s: row partition (%s) x column slices, halo all-to-all-v inside each column group"
-                        % (halo.get("grid"), halo["partition"]) if halo["mode"] == "grid" else
-                        "feature columns x%d (graph replicated, %d of %d columns per GPU, no data-path collective)" % (world, d_loc, d))},
+                        % (halo["partition"], world, halo.get("pushed_pairs", 0)))},
         }
         # roofline.  The section 8(d) byte model assumes NO cache reuse; on RMAT the hub rows are served from L2 / Infinity Cache, so
         # model bytes / kernel time is not a bandwidth and can exceed the peak.  roofline.achieved / frac are therefore

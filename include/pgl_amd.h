@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PGLAMD_ABI_VERSION 3
+#define PGLAMD_ABI_VERSION 4
 
 /* status codes */
 #define PGLAMD_OK 0
@@ -68,9 +68,8 @@ extern "C" {
 #define PGLAMD_DIV 3
 
 int32_t pglamd_abi_version(void);
-/* Process-wide launch options.  "xcd_swizzle": 1 (default) = consecutive chunks of the destination-sorted edge stream run on ONE XCD
- * (they share its L2: partition- / cluster-ordered graphs); 0 = chunks are dealt round the XCDs -- for row orders that correlate with
- * row length (pgl_amd.distributed.HaloPlan(row_order="peers")), where the blocked mapping unbalances the XCDs.
+/* Process-wide TUNING option (tests and experiments; every hot-path choice a caller makes is a per-call argument -- see
+ * PGLAMD_AGG_DEAL_CHUNKS -- and the entry points are re-entrant).
  * "csr_onesweep": how pglamd_csr_build sorts.  -1 (default) = by size: one-sweep passes (one histogram of all digits, then ONE kernel per
  * digit with decoupled look-back: 7 launches) for up to 1 M edges, the multi-kernel passes (histogram / scan / scatter per digit: 12
  * launches, XCD-local tile order) above; 0 = always multi-kernel; g >= 1 = always one-sweep with g consecutive tiles per XCD.  The output
@@ -181,53 +180,20 @@ int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t
  *                   the full row length as the stride.  The column-pipelined halo exchange aggregates columns [0, d/2) of the
  *                   received rows while columns [d/2, d) are still on the wire.  (With accumulate 0 a strided output needs
  *                   num_edges > 0: the stand-alone zero-fill of an edgeless index is dense.)
+ *   flags           per-call launch choices (ABI 4; replaces the process-wide "xcd_swizzle" option of ABI <= 3, which two threads
+ *                   with different plans raced on).  PGLAMD_AGG_DEAL_CHUNKS: the chunks of the destination-sorted edge stream are
+ *                   dealt round the 8 XCDs instead of running in contiguous blocks per XCD (the default: neighbouring chunks share
+ *                   an L2, which partition- / cluster-ordered graphs use) -- for row orders that correlate with row LENGTH
+ *                   (pgl_amd.distributed.HaloPlan(row_order="peers")), where the blocked mapping gives one XCD all the short rows.
  * ---------------------------------------------------------------------------------------------- */
+#define PGLAMD_AGG_DEAL_CHUNKS 1
 int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx,
                              int64_t ldx, const void* y, int64_t dy, const int32_t* eid, const int32_t* row,
                              const int32_t* col, const int64_t* indptr, const int64_t* zero_indptr,
                              int64_t max_row_edges, int64_t num_edges, int64_t n_csr_rows,
                              int64_t out_rows, int64_t dout, int64_t ldout, int32_t message_op, int32_t reduce_op,
                              const float* dst_scale, int32_t accumulate, void* out, void* workspace,
-                             size_t workspace_bytes, void* stream);
-
-/* K1w  pglamd_aggregate_ext whose finished rows ALSO land in the halo send buffer of the NEXT aggregation (ABI 3).
- * A row-partitioned layer stack (pgl_amd/distributed.py; the reference's DistGPUGraph, pgl/graph.py:1509-1553, all-reduces
- * [N, d] instead) starts every aggregation by packing the owned rows its peers pull into a contiguous send buffer -- a gather
- * that re-reads rows the previous layer has just written (0.18 of 1.15 ms per rank at |E| = 100 M, P = 8).  With a wire
- * descriptor the producing launch writes each finished row to `out` and, in the same store, to its slots of that buffer
- * (a row pulled by k peers has k slots), so layer L+1's exchange starts with no pack launch at all.
- *   slot_desc [out_rows][4], slot_more   where row r goes: slot_desc[r] = {count, p0, p1, p2} (int32 x 4, 16-byte aligned) --
- *                      count <= 3: the wire rows are p0 .. p(count-1); count > 3: p0, p1 and slot_more[p2 .. p2 + count - 2).
- *                      One 16-byte scalar load per stored row, issued before the row's last arithmetic, instead of a dependent
- *                      chain through a CSR (which cost more than the pack launch it replaced: profiles/r05)
- *   wire, ldw          the send buffer [n_wire_rows, ldw] in the SAME dtype as out (ldw elements per row, 0 = row length);
- *                      for a column-block launch pass the address of the block's first column, as for out
- *   scale              optional fp32 [out_rows]: the wire copy is scale[r] * row -- GCN's source-side degree norm of the next
- *                      layer (pgl/nn/conv.py:242) applied while the row is in registers       } pglamd_row_epilogue_wire only:
- *   scaled_out, ld_scaled   optional dense [out_rows, ld_scaled] copy of scale[r] * row: what  } pglamd_aggregate_wire refuses them
- *                      the next layer's LOCAL edges read                                       } (its store paths are short of SGPRs)
- *   wire2, ldw2, split      optional: columns [split, d) of every row go to a second buffer (at column j - split)
- * The mirror follows every store to `out`: with accumulate 0 all rows the launch writes (zero-filled ones included, as
- * zeros), with accumulate 1 / 2 the rows that receive edges -- a sequence of launches that together finalise `out` (interior
- * + boundary, or local edges + received edges) finalises the wire when each carries the descriptor.  SUM / MEAN, no edge
- * operand; the launch takes the flat kernel whatever the row width (the lane-per-edge kernels have no mirror).  Deterministic. */
-typedef struct pglamd_wire_out {
-    const int32_t* slot_desc;
-    const int32_t* slot_more;
-    void* wire;
-    int64_t ldw;
-    const float* scale;
-    void* scaled_out;
-    int64_t ld_scaled;
-    void* wire2;          /* optional second buffer: columns >= split of a row go to wire2 at column (j - split) -- the column- */
-    int64_t ldw2;         /* pipelined exchange sends the rows as two contiguous column blocks, one all-to-all-v each          */
-    int64_t split;        /* 0 = one buffer; otherwise a multiple of 16 elements                                              */
-} pglamd_wire_out;
-int32_t pglamd_aggregate_wire(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx, int64_t ldx,
-                              const int32_t* row, const int32_t* col, const int64_t* indptr, const int64_t* zero_indptr,
-                              int64_t max_row_edges, int64_t num_edges, int64_t n_csr_rows, int64_t out_rows,
-                              int64_t ldout, int32_t reduce_op, const float* dst_scale, int32_t accumulate, void* out,
-                              const pglamd_wire_out* wire, void* workspace, size_t workspace_bytes, void* stream);
+                             size_t workspace_bytes, int32_t flags, void* stream);
 
 /* K1d  aggregation feeding a dense layer inside ONE kernel (row f1: "SpMM -> GEMM epilogue"; GCNConv's
  * send_recv(sum) -> linear -> + bias -> activation, pgl/nn/conv.py:242-254, when input_size <= output_size):
@@ -502,12 +468,6 @@ int32_t pglamd_reindex(const int64_t* nodes, int64_t num_nodes, const int64_t* n
 int64_t pglamd_row_epilogue_partials(int64_t n_rows);
 int32_t pglamd_row_epilogue(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act,
                             int32_t normalize, float eps, float* y, float* inv_norm, void* stream);
-/* the same with a wire descriptor (see pglamd_aggregate_wire): a conv layer's OUTPUT row is the next layer's input, so the row
- * kernel that finishes it also writes it -- times wire->scale[r] if given -- into the halo send buffer slots of the peers
- * that pull it and, optionally, into a dense scaled copy (GraphSageConv: wire = y; GCNConv: wire = norm * y). */
-int32_t pglamd_row_epilogue_wire(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act,
-                                 int32_t normalize, float eps, float* y, float* inv_norm,
-                                 const pglamd_wire_out* wire, void* stream);
 int32_t pglamd_row_epilogue_backward(const float* dy, const float* y, const float* inv_norm,
                                      int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
                                      float* dz, float* col_partials, void* stream);

@@ -8,18 +8,11 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# PGLAMD_LIB: load another build of the same ABI (kernel experiments: scripts/build_variant.py)
+# PGLAMD_LIB: load another build of the same ABI (kernel experiments: scripts/prof.py variant)
 LIB_PATH = os.environ.get("PGLAMD_LIB") or os.path.join(_HERE, "csrc", "libpglamd.so")
 _lib = None
 
 c_i32, c_i64, c_sz, c_vp, c_u64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint64
-
-class WireOut(ctypes.Structure):
-    """struct pglamd_wire_out (include/pgl_amd.h): where a producing launch mirrors its finished rows -- the halo send buffer of the
-    next aggregation (slot CSR + buffer), an optional per-row scale and an optional dense scaled copy."""
-    _fields_ = [("slot_desc", c_vp), ("slot_more", c_vp), ("wire", c_vp), ("ldw", c_i64), ("scale", c_vp), ("scaled_out", c_vp),
-                ("ld_scaled", c_i64), ("wire2", c_vp), ("ldw2", c_i64), ("split", c_i64)]
-
 
 # name -> (restype, argtypes) ; mirrors include/pgl_amd.h one to one
 _SIGNATURES = {
@@ -39,9 +32,7 @@ _SIGNATURES = {
     "pglamd_aggregate": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64,
                                   c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "pglamd_aggregate_ext": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64,
-                                      c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz, c_vp]),
-    "pglamd_aggregate_wire": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i64,
-                                       c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+                                      c_i64, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_sz, c_i32, c_vp]),
     "pglamd_aggregate_dense_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "pglamd_aggregate_dense": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64,
                                         c_vp, c_vp, c_vp, c_sz, c_vp]),
@@ -87,7 +78,6 @@ _SIGNATURES = {
                                         c_u64, c_i32, c_vp, c_vp]),
     "pglamd_row_epilogue_partials": (c_i64, [c_i64]),
     "pglamd_row_epilogue": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.c_float, c_vp, c_vp, c_vp]),
-    "pglamd_row_epilogue_wire": (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, ctypes.c_float, c_vp, c_vp, c_vp, c_vp]),
     "pglamd_row_epilogue_backward": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "pglamd_comm_unique_id": (c_i32, [c_vp]),
     "pglamd_comm_init": (c_i32, [c_i32, c_i32, c_vp, c_vp]),
@@ -99,7 +89,7 @@ _SIGNATURES = {
     "pglamd_halo_plan_fill": (c_i32, [c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32] + [c_vp] * 13),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _ERRORS = {-1: ValueError, -2: TypeError, -3: OverflowError, -4: RuntimeError, -5: RuntimeError, -6: ValueError, -7: RuntimeError, -8: RuntimeError}
 
 

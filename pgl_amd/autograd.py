@@ -406,8 +406,8 @@ class _RowEpilogue(torch.autograd.Function):
     """y = normalize_L2(act(z + bias)): one kernel forward, one backward (which also yields the bias gradient)."""
 
     @staticmethod
-    def forward(ctx, z, bias, act, normalize, wire=None):
-        y, inv = ops.row_epilogue(z, bias, act, normalize, wire=wire)
+    def forward(ctx, z, bias, act, normalize):
+        y, inv = ops.row_epilogue(z, bias, act, normalize)
         ctx.act, ctx.normalize, ctx.has_bias = act, normalize, bias is not None
         ctx.save_for_backward(y, inv if inv is not None else y.new_zeros(0))
         return y
@@ -417,15 +417,13 @@ class _RowEpilogue(torch.autograd.Function):
         y, inv = ctx.saved_tensors
         want_b = ctx.has_bias and ctx.needs_input_grad[1]
         dz, db = ops.row_epilogue_backward(dy, y, inv if ctx.normalize else None, ctx.act, ctx.normalize, want_b)
-        return dz, db, None, None, None
+        return dz, db, None, None
 
 
-def row_epilogue(z, bias=None, act=None, normalize=False, wire=None):
-    """wire (ops.Wire, forward only -- it carries no gradient): the finished rows also go to the halo send buffer of the next
-    aggregation on a row-partitioned graph (DistGraph.wire / DistGraph.emitted)."""
+def row_epilogue(z, bias=None, act=None, normalize=False):
     if torch.is_grad_enabled() and (z.requires_grad or (bias is not None and bias.requires_grad)):
-        return _RowEpilogue.apply(z, bias, act, normalize, wire)
-    return ops.row_epilogue(z, bias, act, normalize, wire=wire)[0]
+        return _RowEpilogue.apply(z, bias, act, normalize)
+    return ops.row_epilogue(z, bias, act, normalize)[0]
 
 
 def column_sum(g):

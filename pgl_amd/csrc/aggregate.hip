@@ -206,26 +206,13 @@ extern "C" int32_t pglamd_aggregate_ext(const void* x, const void* x2, int64_t x
                                         const int64_t* indptr, const int64_t* zero_indptr, int64_t max_row_edges,
                                         int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, int64_t dout, int64_t ldout,
                                         int32_t message_op, int32_t reduce_op, const float* dst_scale, int32_t accumulate,
-                                        void* out, void* workspace, size_t workspace_bytes, void* stream) {
+                                        void* out, void* workspace, size_t workspace_bytes, int32_t flags, void* stream) {
     if (ldx < 0 || ldout < 0) return fail(PGLAMD_E_ARG, "aggregate_ext: negative row stride");
+    if (flags & ~PGLAMD_AGG_DEAL_CHUNKS) return fail(PGLAMD_E_ARG, "aggregate_ext: unknown flag bits 0x%x", (unsigned)flags);
     AggExtra ex;
     ex.x2 = x2; ex.x_split = x_split; ex.zero_indptr = zero_indptr; ex.max_row_edges = max_row_edges; ex.ldx = ldx; ex.ldo = ldout;
+    ex.flags = flags;
     return aggregate_entry(x, dtype, dx, y, dy, eid, row, col, indptr, num_edges, n_csr_rows, out_rows, dout, message_op, reduce_op,
-                           nullptr, dst_scale, accumulate, out, workspace, workspace_bytes, ex, stream);
-}
-
-extern "C" int32_t pglamd_aggregate_wire(const void* x, const void* x2, int64_t x_split, int32_t dtype, int64_t dx, int64_t ldx,
-                                         const int32_t* row, const int32_t* col, const int64_t* indptr, const int64_t* zero_indptr,
-                                         int64_t max_row_edges, int64_t num_edges, int64_t n_csr_rows, int64_t out_rows, int64_t ldout,
-                                         int32_t reduce_op, const float* dst_scale, int32_t accumulate, void* out,
-                                         const pglamd_wire_out* wire, void* workspace, size_t workspace_bytes, void* stream) {
-    if (ldx < 0 || ldout < 0) return fail(PGLAMD_E_ARG, "aggregate_wire: negative row stride");
-    if (reduce_op != PGLAMD_SUM && reduce_op != PGLAMD_MEAN) return fail(PGLAMD_E_ARG, "aggregate_wire: sum or mean");
-    if (wire && (wire->ldw < 0 || wire->ld_scaled < 0 || wire->ldw2 < 0)) return fail(PGLAMD_E_ARG, "aggregate_wire: negative wire stride");
-    AggExtra ex;
-    ex.x2 = x2; ex.x_split = x_split; ex.zero_indptr = zero_indptr; ex.max_row_edges = max_row_edges; ex.ldx = ldx; ex.ldo = ldout;
-    ex.wire = wire;
-    return aggregate_entry(x, dtype, dx, nullptr, 0, nullptr, row, col, indptr, num_edges, n_csr_rows, out_rows, dx, 0, reduce_op,
                            nullptr, dst_scale, accumulate, out, workspace, workspace_bytes, ex, stream);
 }
 

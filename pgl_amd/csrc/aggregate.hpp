@@ -36,6 +36,7 @@ struct AggParams {
     int align;                            // 1: never split rows of <= chunk edges (chunk_cut)
     int narrow_vec;                       // aggregate_narrow: rows may be moved with (<=16-byte) vector loads / stores
     int x_split;                          // INT32_MAX when there is no second table
+    int deal_chunks;                      // 1: logical chunk blocks are dealt round the XCDs (launch_flat) instead of in contiguous runs
     // ---- SINK = 1 (aggregate_flat.hpp): the aggregated rows feed a dense layer without leaving the chip -------------------------
     const float* w;                       // [d_in, dout2] row-major weight (split-row fix-up: one matrix-vector product per hub row)
     const float* wp;                      // the same weight packed in MFMA B-operand order: wp[(ct * (d_in / 4) + kk) * 64 + lane]
@@ -44,12 +45,6 @@ struct AggParams {
     int dout2, act;                       // act: 0 none, 1 relu
     int max_row_edges;                    // host-side hint: longest row of the index (0 = unknown).  Rows of <= chunk edges are never
                                           // split (chunk_cut), so when it is <= chunk no partial exists and the fix-up launches are skipped
-    // ---- wire out (pglamd_aggregate_wire): every row this launch stores to `out` ALSO goes to its slots of the halo send buffer ----
-    const int* wdesc;                     // [out_rows][4] or NULL: {count, p0, p1, p2} -- the wire rows of output row r (count <= 3), or
-    const int* wmore;                     //   p0, p1 and wmore[p2 .. p2 + count - 2) (count > 3)
-    void* wire;                           // [n_wire_rows, ldw], same element type as out, ALREADY offset to this launch's column block
-    int64_t ldw;
-    void* wire2; int64_t ldw2; int wsplit;   // columns >= wsplit (of the whole row) go to wire2 at column (j - wsplit); wsplit 0 = one buffer
 };
 
 // true when this launch can leave split-row partials behind (=> the counter reset and the two fix-up launches are needed)
@@ -70,35 +65,6 @@ template <typename T> __device__ __forceinline__ T from_acc(typename AccT<T>::ty
 template <> __device__ __forceinline__ __half from_acc<__half>(float v) { return __float2half(v); }
 template <> __device__ __forceinline__ __hip_bfloat16 from_acc<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 
-// The wire slots of one output row, fetched with ONE 16-byte scalar load (wave-uniform row) at the top of a store path.
-struct WDesc { int n, p0, p1, p2; };
-__device__ __forceinline__ WDesc wire_desc(const int* wdesc, int64_t r) {
-    typedef int i4 __attribute__((ext_vector_type(4)));
-    const i4 v = *reinterpret_cast<const i4 __attribute__((address_space(4)))*>((unsigned long long)(wdesc + 4 * r));
-    return WDesc{v.x, v.y, v.z, v.w};
-}
-// Mirrors one finished piece of output row r (columns j .. j+VEC-1 of the whole row, already converted to T) into the row's wire
-// slots and, if asked for, into the scaled dense copy.  Called from the store paths only (once per row and tile).
-// Q: a pointer to the launch parameters (generic or constant address space).
-template <typename T, int VEC, typename Q, typename VT>
-__device__ __forceinline__ void wire_mirror(Q q, const WDesc& dsc, int64_t r, int j, const VT& w) {
-    // (no scale / scaled dense copy here: the aggregation kernels' store paths are short of SGPRs -- every pointer this touches is
-    //  re-read from the kernarg segment at the store and still counts towards the kernel's allocation; the row kernel that ends a
-    //  conv layer, pglamd_row_epilogue_wire, has both)
-    if (dsc.n <= 0) return;
-    const int split = q->wsplit;
-    const bool second = split > 0 && j >= split;          // column-pipelined exchange: columns >= split live in the second buffer
-    T* base = static_cast<T*>(second ? q->wire2 : q->wire) + (second ? j - split : j);
-    const int64_t ld = second ? q->ldw2 : q->ldw;
-    *reinterpret_cast<VT*>(base + (int64_t)dsc.p0 * ld) = w;
-    if (dsc.n > 1) *reinterpret_cast<VT*>(base + (int64_t)dsc.p1 * ld) = w;
-    if (dsc.n == 3) *reinterpret_cast<VT*>(base + (int64_t)dsc.p2 * ld) = w;
-    else if (dsc.n > 3) {
-        const int* more = q->wmore + dsc.p2;
-        for (int i = 0; i < dsc.n - 2; ++i) *reinterpret_cast<VT*>(base + (int64_t)more[i] * ld) = w;
-    }
-}
-
 template <typename T> struct Limits;
 template <> struct Limits<float> { static __device__ float lo() { return -INFINITY; } static __device__ float hi() { return INFINITY; } };
 template <> struct Limits<double> { static __device__ double lo() { return -INFINITY; } static __device__ double hi() { return INFINITY; } };
@@ -117,7 +83,7 @@ template <typename T> __device__ __forceinline__ T apply_mop(T a, T b, int mop) 
 // Zero-fills the columns [j_base, j_base+tile_cols) of output rows that receive no edge: rows
 // r < n_csr_rows with indptr[r]==indptr[r+1], and rows in [n_csr_rows, out_rows).  One wave
 // inspects 64 rows (coalesced indptr read) and clears the empty ones, lanes across the columns.
-template <typename T, bool WIRE = false>
+template <typename T>
 __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t zb, int lane) {
     const int64_t w = zb * kWavesPerBlock + (threadIdx.x >> 6);
     const int64_t r0 = w * kWave;
@@ -137,12 +103,6 @@ __device__ __forceinline__ void zero_empty_rows_role(const AggParams& p, int64_t
             for (int j = lane * 2; j < p.tile_cols; j += kWave * 2) *reinterpret_cast<VecT<T, 2>*>(dst + j) = VecT<T, 2>{};
         } else {
             for (int j = lane; j < p.tile_cols; j += kWave) dst[j] = from_acc<T>(typename AccT<T>::type(0));
-        }
-        if constexpr (WIRE) {                   // an empty row travels as zeros
-            const VecT<T, 1> z{{from_acc<T>(typename AccT<T>::type(0))}};
-            const WDesc dsc = wire_desc(p.wdesc, r0 + l);
-            for (int j = lane; j < p.tile_cols; j += kWave)
-                wire_mirror<T, 1>(&p, dsc, r0 + l, p.j_base + j, z);
         }
     }
 }

@@ -29,32 +29,10 @@ int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_r
 //     the shadow of the row gathers (the kernel is HBM-bound; the MFMA pipe was idle).
 // SS: 0 no per-source scale, 1 src_scale[col] (one random 4-byte read per edge), 2 src_scale[p] by edge POSITION (the scale of every
 //     edge's source laid out along the sorted stream once per graph: 4 sequential bytes per edge)
-// non-temporal gather of one lane's piece of a row (experiments with the L2 replacement policy: PGLAMD_FLAT_NT variant builds)
-template <typename V> __device__ __forceinline__ V load_nt(const V* p) {
-    V out;
-    if constexpr (sizeof(V) == 16) {
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
-        __builtin_memcpy(&out, &v, 16);
-    } else if constexpr (sizeof(V) == 8) {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
-        const u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p));
-        __builtin_memcpy(&out, &v, 8);
-    } else if constexpr (sizeof(V) == 4) {
-        const unsigned v = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
-        __builtin_memcpy(&out, &v, 4);
-    } else {
-        out = *p;
-    }
-    return out;
-}
-
-// WIRE: every row this launch stores ALSO goes to its slots of the halo send buffer of the next aggregation (pglamd_aggregate_wire).
 //     A template variant, not a run-time test: the test alone cost the 256-byte-row kernel 16 SGPRs (70 -> 86: one resident workgroup
 //     per CU fewer) although the code sits in the once-per-row store path.
-template <typename T, int VEC, int NT, int RCLS, int YMODE, int SS = 0, bool PIPE3 = true, int UB = 0, int SINK = 0, bool TWO = false, bool WIRE = false>
+template <typename T, int VEC, int NT, int RCLS, int YMODE, int SS = 0, bool PIPE3 = true, int UB = 0, int SINK = 0, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
-    static_assert(!WIRE || (RCLS == 0 && YMODE == 0 && SS == 0 && SINK == 0), "the wire mirror rides with plain sum / mean rows");
     constexpr int U = 8;
     constexpr int kTileRows = 16;                      // rows per MFMA tile (v_mfma_f32_16x16x4_f32)
     constexpr int kTileStride = kWave * VEC + 4;       // floats per parked row: +4 keeps the A-operand reads bank-conflict free
@@ -70,7 +48,7 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
             if (p.out) zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
             dense_empty_rows_role(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
         } else {
-            zero_empty_rows_role<T, WIRE>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
+            zero_empty_rows_role<T>(p, (int64_t)blockIdx.x - p.n_grid_chunks, lane);
         }
         return;
     }
@@ -121,12 +99,6 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                 acc[t][k] = RCLS == 0 ? A(0) : Limits<A>::lo();
     };
     reset();
-#ifdef PGLAMD_FLAT_EXTRA_LDS            // occupancy experiment (scripts/prof.py variant): the same kernel with fewer resident workgroups
-    {
-        __shared__ float occupancy_pad[PGLAMD_FLAT_EXTRA_LDS / 4];
-        if (p.E == -12345) { occupancy_pad[threadIdx.x] = (float)lane; __syncthreads(); acc[0][0] += (A)occupancy_pad[threadIdx.x ^ 1]; }
-    }
-#endif
     // min / max: one v_max per element over order-reversed values for min (aggregate_group.hpp: order_flip), turned back at every store
     const bool neg = RCLS == 1 && !is_max;
 
@@ -212,8 +184,6 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         const cptr<AggParams> q = cold();
         if (r >= q->out_rows) return;
         T* dst = static_cast<T*>(q->out) + (int64_t)r * q->ldo;
-        WDesc wdsc{};
-        if constexpr (WIRE) wdsc = wire_desc(q->wdesc, r);       // issued first: its latency hides behind the row's scale / old-value loads
         const float* dsp = q->dst_scale;
         const bool is_mean = q->is_mean != 0, accumulate = q->accumulate == 1;
         float ds = 1.f;
@@ -256,8 +226,6 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                     if (q->out) *reinterpret_cast<V*>(dst + j0[t]) = o;
                 } else {
                     *reinterpret_cast<V*>(dst + j0[t]) = o;
-                    if constexpr (WIRE)          // halo send buffer of the NEXT aggregation: the finished row goes there in the same store
-                        wire_mirror<T, VEC>(q, wdsc, r, j0[t], o);
                 }
             }
         if constexpr (SINK == 1) {
@@ -313,30 +281,10 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
         if constexpr (has_ss) sv = sscale_v[cl];
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-#if defined(PGLAMD_FLAT_NT) && PGLAMD_FLAT_NT == 2
-            // experiment (scripts/prof.py hotcold): the sign bit of a column id marks a HOT source row (top out-degrees, ~3 MB of
-            // rows); cold rows are gathered with the non-temporal policy so that they do not push the hot ones out of the XCD's L2
-            const bool hot = cc[i] < 0;
-            const T* xr = src_row(cc[i] & 0x7fffffff);
-            const T* xc = xr;
-            asm volatile("" : "+s"(xc));            // an opaque copy of the base: the two loads must not be merged into one (the merge drops the policy)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (act[t]) {
-                    if (hot) vx[i][t] = *reinterpret_cast<const V*>(xr + j0[t]);
-                    else vx[i][t] = load_nt(reinterpret_cast<const V*>(xc + j0[t]));
-                }
-#elif defined(PGLAMD_FLAT_NT) && PGLAMD_FLAT_NT == 1
-            const T* xr = src_row(cc[i]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (act[t]) vx[i][t] = load_nt(reinterpret_cast<const V*>(xr + j0[t]));
-#else
             const T* xr = src_row(cc[i]);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
                 if (act[t]) vx[i][t] = *reinterpret_cast<const V*>(xr + j0[t]);
-#endif
             if constexpr (YMODE == 1) {
                 const T* yr = y + (int64_t)yy[i] * p.ldy;
 #pragma unroll
@@ -467,9 +415,6 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
     for (; e < e1; ++e) {   // remainder (< U edges): one at a time
         int r = rowp[e];
         int cc = colp ? colp[e] : e;
-#if defined(PGLAMD_FLAT_NT) && PGLAMD_FLAT_NT == 2
-        cc &= 0x7fffffff;
-#endif
         float s = has_ss ? scale_of(SS == 2 ? e : cc) : 1.f;
         V vx[NT], vy[NT];
         const T* xr = src_row(cc);
@@ -514,7 +459,7 @@ constexpr int kFixWaves = 16;
 constexpr int kFixGridShort = 2048;
 constexpr int kFixGridLong = 512;
 
-template <typename T, int VEC, int NT, int RCLS, bool LONG, bool WIRE = false>
+template <typename T, int VEC, int NT, int RCLS, bool LONG>
 __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_kernel(AggParams p) {
     using A = typename AccT<T>::type;
     using V = VecT<A, VEC>;     // partials are stored in the accumulator type
@@ -638,8 +583,6 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
                 }
         }
         if (r >= p.out_rows) continue;
-        WDesc wdsc{};
-        if constexpr (WIRE) wdsc = wire_desc(p.wdesc, r);
         T* dst = static_cast<T*>(p.out) + (int64_t)r * p.ldo + p.j_base;
         float ds = 1.f;
         if constexpr (RCLS == 0) { if (p.dst_scale) ds = p.dst_scale[r]; }
@@ -683,8 +626,6 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = from_acc<T>(ov[k]);
                 *reinterpret_cast<VO*>(dst + j0[t]) = o;
-                if constexpr (WIRE)
-                    wire_mirror<T, VEC>(&p, wdsc, r, p.j_base + j0[t], o);
             }
     }
 }
@@ -772,9 +713,10 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     // consecutive chunks on ONE XCD (shared L2 for partition-ordered graphs) -- unless the caller's rows are ordered by something that
     // correlates with their LENGTH (HaloPlan(row_order="peers"): rows grouped by the set of peers that read them, i.e. by degree
     // class): a blocked mapping then gives one XCD all the store-heavy short-row chunks (measured: 1.11 vs 1.00 ms per rank at
-    // C2' / P = 8).  pglamd_set_option("xcd_swizzle", 0) / PGLAMD_XCD_SWIZZLE=0 deal the chunks round the XCDs instead.
+    // C2' / P = 8).  The caller says so PER CALL (pglamd_aggregate_ext flags & PGLAMD_AGG_DEAL_CHUNKS; PGLAMD_XCD_SWIZZLE=0 forces it
+    // for experiments): the chunks are then dealt round the XCDs.  No process-wide state is involved.
     static const bool env_off = [] { const char* sw = getenv("PGLAMD_XCD_SWIZZLE"); return sw && sw[0] == '0'; }();
-    p.n_blocks = (env_off || xcd_swizzle_option().load(std::memory_order_relaxed) == 0) ? -(int)nb : (int)nb;
+    p.n_blocks = (env_off || p.deal_chunks) ? -(int)nb : (int)nb;
     p.n_grid_chunks = (int)xcd_grid(nb);
     const int64_t zb = p.accumulate ? 0 : ceil_div(ceil_div(p.out_rows, kWave), kWavesPerBlock);
     const bool fixups = needs_fixups(p);
@@ -792,24 +734,11 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
     // workgroups/CU) measured 4 % faster there; everywhere else the three-deep one wins (up to 20 % on [E,8]).
     const size_t row_bytes = (size_t)p.tile_cols * sizeof(T);
     const bool two = p.x_split != INT32_MAX;
-    constexpr bool can_wire = RCLS == 0 && YMODE == 0 && (std::is_same_v<T, float> || sizeof(T) == 2);
-    const bool wire = p.wdesc != nullptr;
-    if (wire && (!can_wire || p.src_scale)) return fail(PGLAMD_E_ARG, "aggregate_wire: fp32 / fp16 / bf16 rows, sum or mean, no source scale");
 #define PGLAMD_LAUNCH_FLAT(...)                                                                                                          \
     do {                                                                                                                                 \
         const dim3 grid_((unsigned)(p.n_grid_chunks + zb));                                                                              \
-        bool done_ = false;                                                                                                              \
-        if constexpr (can_wire) {                                                                                                        \
-            if (wire) {                                                                                                                  \
-                if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, true, true>), grid_, dim3(kBlock), 0, st, p);   \
-                else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, false, true>), grid_, dim3(kBlock), 0, st, p);      \
-                done_ = true;                                                                                                            \
-            }                                                                                                                            \
-        }                                                                                                                                \
-        if (!done_) {                                                                                                                    \
-            if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, true>), grid_, dim3(kBlock), 0, st, p);  \
-            else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, false>), grid_, dim3(kBlock), 0, st, p);     \
-        }                                                                                                                                \
+        if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, true>), grid_, dim3(kBlock), 0, st, p);      \
+        else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, __VA_ARGS__, 0, false>), grid_, dim3(kBlock), 0, st, p);         \
         PGLAMD_LAUNCH_CHECK();                                                                                                           \
     } while (0)
     if constexpr (NT == 1 && YMODE == 0) {
@@ -849,20 +778,9 @@ launched:
     }
     if (fixups) {
         const dim3 gs((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), gl((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks));
-        bool done = false;
-        if constexpr (can_wire) {
-            if (wire) {
-                hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false, true>), gs, dim3(kBlock), 0, st, p);
-                PGLAMD_LAUNCH_CHECK();
-                hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true, true>), gl, dim3(kFixWaves * kWave), 0, st, p);
-                done = true;
-            }
-        }
-        if (!done) {
-            hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), gs, dim3(kBlock), 0, st, p);
-            PGLAMD_LAUNCH_CHECK();
-            hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), gl, dim3(kFixWaves * kWave), 0, st, p);
-        }
+        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), gs, dim3(kBlock), 0, st, p);
+        PGLAMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), gl, dim3(kFixWaves * kWave), 0, st, p);
     }
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;
@@ -950,7 +868,7 @@ template <typename T> int max_tiles(int vec) { return (sizeof(T) == 2 && vec == 
 struct AggExtra {
     const void* x2 = nullptr; int64_t x_split = 0; const int64_t* zero_indptr = nullptr; int64_t max_row_edges = 0;
     int64_t ldx = 0, ldo = 0;
-    const pglamd_wire_out* wire = nullptr;       // pglamd_aggregate_wire: mirror every stored row into the halo send buffer
+    int32_t flags = 0;                           // PGLAMD_AGG_DEAL_CHUNKS: chunks dealt round the XCDs instead of in blocks (per call)
 };
 
 // argument list of aggregate_typed<T> for the explicit instantiations (aggregate*.hip)
@@ -971,30 +889,14 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     const int64_t ldx = ex.ldx ? ex.ldx : dx, ldo = ex.ldo ? ex.ldo : dout;
     if (ldx < dx || ldo < dout) return fail(PGLAMD_E_SHAPE, "aggregate_ext: row stride shorter than the row (ldx %lld < %lld or ldout %lld < %lld)",
                                             (long long)ldx, (long long)dx, (long long)ldo, (long long)dout);
-    const pglamd_wire_out* wo = ex.wire && ex.wire->slot_desc ? ex.wire : nullptr;
-    if (wo) {
-        if (!wo->wire || reinterpret_cast<uintptr_t>(wo->slot_desc) % 16 != 0) return fail(PGLAMD_E_ARG, "aggregate_wire: wire missing or slot_desc not 16-byte aligned");
-        if (dout != dx || y) return fail(PGLAMD_E_ARG, "aggregate_wire: plain send_u_recv rows only (no edge operand, no source-side broadcast)");
-        if (wo->scale || wo->scaled_out)
-            return fail(PGLAMD_E_ARG, "aggregate_wire: scale / scaled_out belong to pglamd_row_epilogue_wire (the aggregation mirrors rows as they are)");
-    }
     if (E == 0) {
         if (accumulate) return PGLAMD_OK;
-        if (wo) return fail(PGLAMD_E_ARG, "aggregate_wire: an index without edges (the stand-alone zero-fill has no wire mirror)");
         if (ldo != dout) return fail(PGLAMD_E_ARG, "aggregate_ext: an index without edges cannot zero-fill a strided output");
         return zero_empty_rows(zip, n_csr_rows, out_rows, out, (size_t)dout * sizeof(T), st);
     }
 
     AggParams p{};
-    if (wo) {
-        p.wdesc = wo->slot_desc; p.wmore = wo->slot_more; p.wire = wo->wire; p.ldw = wo->ldw ? wo->ldw : dout;
-        if (wo->split) {
-            if (wo->split < 0 || wo->split >= dout || wo->split % 16 != 0 || !wo->wire2 || wo->ldw2 < 0)
-                return fail(PGLAMD_E_ARG, "aggregate_wire: split must be a multiple of 16 inside the row, with a second buffer");
-            p.wire2 = wo->wire2; p.wsplit = (int)wo->split; p.ldw2 = wo->ldw2 ? wo->ldw2 : dout - wo->split;
-            if (!wo->ldw) p.ldw = wo->split;
-        }
-    }
+    p.deal_chunks = (ex.flags & PGLAMD_AGG_DEAL_CHUNKS) ? 1 : 0;
     // A one-value edge operand given IN THE ORDER OF THE SORTED STREAM (eid NULL) and multiplied into fp32 rows that are summed
     // is a per-edge scale read sequentially: it rides in the flat kernel's scale slot (SS = 2: one coalesced 4-byte load per
     // edge) instead of the general edge-operand path.  This is how GCN's source-side degree norm is applied (pgl/nn/conv.py:242):
@@ -1030,9 +932,8 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     int vmax = max_vec<T>();
     const uintptr_t align_bits = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) |
                                  (y && gy == 1 ? reinterpret_cast<uintptr_t>(y) : 0) |
-                                 reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(p.wire) | reinterpret_cast<uintptr_t>(p.wire2);
-    while (vmax > 1 && (dout % vmax != 0 || ldx % vmax != 0 || ldo % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0 ||
-                        (p.wire && p.ldw % vmax != 0) || (p.wire2 && p.ldw2 % vmax != 0))) vmax >>= 1;
+                                 reinterpret_cast<uintptr_t>(ws);
+    while (vmax > 1 && (dout % vmax != 0 || ldx % vmax != 0 || ldo % vmax != 0 || align_bits % (vmax * sizeof(T)) != 0)) vmax >>= 1;
     int ymode = 0;
     if (y) {
         if (gy == 1) ymode = 2;
@@ -1078,7 +979,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
             const int64_t rb = (int64_t)((size_t)dout * sizeof(T));
             const bool narrow_ok = dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u;
             const int64_t gmin = (rcls == 1 || !narrow_ok) ? std::min<int64_t>(32, group_min_bytes()) : group_min_bytes();
-            if (ymode == 0 && !src_scale && !p.wdesc && rb > gmin && rb <= group_row_bytes()) {
+            if (ymode == 0 && !src_scale && rb > gmin && rb <= group_row_bytes()) {
                 AggParams q = p;
                 q.j_base = 0; q.tile_cols = (int)dout;
                 bool handled = false;
@@ -1088,7 +989,7 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         }
         // measured at C2 sizes: the lane-per-edge kernel wins up to 32 B of accumulator per row for every reduce op
         // (2.6-3.4x at d <= 8 fp32) and up to 64 B for sum / mean (1.3x at d = 16 fp32)
-        if (!p.wdesc && dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {   // (the wire mirror lives in the flat kernel's stores)
+        if (dout <= narrow_max() && (size_t)dout * sizeof(typename AccT<T>::type) <= 64u) {
             AggParams q = p;
             const int nk = std::max(K, narrow_chunk_edges());                   // fewer, longer chunks: the carved arrays still fit
             q.chunk = nk; q.n_chunks = (int)ceil_div(E, nk);
@@ -1112,7 +1013,6 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
         if (fast) return PGLAMD_OK;
     }
     // generic fallback: rewrites every row < out_rows (rows without edges get 0)
-    if (p.wdesc) return fail(PGLAMD_E_SHAPE, "aggregate_wire: this shape takes the generic kernel, which has no wire mirror");
     p.tile_cols = (int)dout; p.j_base = 0;
     p.is_max = rop == PGLAMD_MAX ? 1 : rop == PGLAMD_MIN ? 2 : 0;
     if (src_scale || dst_scale) return fail(PGLAMD_E_SHAPE, "scales unsupported with this broadcast pattern");

@@ -19,7 +19,6 @@ int32_t fail(int32_t code, const char* fmt, ...) {
     return code;
 }
 
-std::atomic<int>& xcd_swizzle_option() { static std::atomic<int> v{1}; return v; }
 std::atomic<int>& csr_onesweep_option() {
     static std::atomic<int> v{[] { const char* e = getenv("PGLAMD_CSR_ONESWEEP"); return e ? atoi(e) : -1; }()};
     return v;
@@ -31,7 +30,6 @@ extern "C" int32_t pglamd_abi_version(void) { return PGLAMD_ABI_VERSION; }
 
 extern "C" int32_t pglamd_set_option(const char* name, int64_t value) {
     if (!name) return pglamd::fail(PGLAMD_E_ARG, "set_option: NULL name");
-    if (strcmp(name, "xcd_swizzle") == 0) { pglamd::xcd_swizzle_option().store(value ? 1 : 0, std::memory_order_relaxed); return PGLAMD_OK; }
     if (strcmp(name, "csr_onesweep") == 0) { pglamd::csr_onesweep_option().store(value < -1 ? -1 : value > 64 ? 64 : (int)value, std::memory_order_relaxed); return PGLAMD_OK; }
     return pglamd::fail(PGLAMD_E_ARG, "set_option: unknown option %s", name);
 }

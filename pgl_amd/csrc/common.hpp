@@ -73,7 +73,6 @@ __device__ __forceinline__ int64_t xcd_swizzle(int64_t b, int64_t nb) {
 }
 inline int64_t xcd_grid(int64_t nb) { return ceil_div(nb, kXcds) * kXcds; }
 std::atomic<int>& csr_onesweep_option();       // common.cpp: csr_build.hip sweep_group (pglamd_set_option "csr_onesweep")
-std::atomic<int>& xcd_swizzle_option();        // common.cpp: 1 (default) = consecutive chunks on one XCD, 0 = dealt round the XCDs (pglamd_set_option)
 
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

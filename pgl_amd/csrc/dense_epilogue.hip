@@ -24,7 +24,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int VEC, int NT>
 __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(const float* __restrict__ z, const float* __restrict__ bias,
                                                               int64_t n_rows, int d, int act, int normalize, float eps,
-                                                              float* __restrict__ y, float* __restrict__ inv_norm, pglamd_wire_out wo) {
+                                                              float* __restrict__ y, float* __restrict__ inv_norm) {
     using V = RV<VEC>;
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -39,8 +39,6 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(const float* __res
     for (int64_t r = wave; r < n_rows; r += n_waves) {
         V v[NT];
         float ss = 0.f;
-        int4 dsc = {0, 0, 0, 0};
-        if (wo.slot_desc) dsc = *reinterpret_cast<const int4*>(wo.slot_desc + 4 * r);   // {count, p0, p1, p2}: issued with the row's own loads
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int j = (t * kWave + lane) * VEC;
@@ -70,26 +68,6 @@ __global__ __launch_bounds__(kBlock) void row_epilogue_kernel(const float* __res
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) o.v[k] = v[t].v[k] * inv;
                 *reinterpret_cast<V*>(y + r * d + j) = o;
-                if (wo.slot_desc) {
-                    // the finished row is the next aggregation's input: its (scaled) copy goes straight into the halo send buffer
-                    // (one store per peer that pulls the row) and, if asked for, into the dense scaled matrix the local edges read
-                    if (wo.scale) {
-                        const float sc = wo.scale[r];
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) o.v[k] *= sc;
-                    }
-                    if (wo.scaled_out) *reinterpret_cast<V*>(static_cast<float*>(wo.scaled_out) + r * wo.ld_scaled + j) = o;
-                    if (dsc.x > 0) {
-                        const bool second = wo.split > 0 && j >= wo.split;          // (the column-pipelined exchange: two contiguous blocks)
-                        float* wb = static_cast<float*>(second ? wo.wire2 : wo.wire) + (second ? j - (int)wo.split : j);
-                        const int64_t wl = second ? wo.ldw2 : wo.ldw;
-                        *reinterpret_cast<V*>(wb + (int64_t)dsc.y * wl) = o;
-                        if (dsc.x > 1) *reinterpret_cast<V*>(wb + (int64_t)dsc.z * wl) = o;
-                        if (dsc.x == 3) *reinterpret_cast<V*>(wb + (int64_t)dsc.w * wl) = o;
-                        else if (dsc.x > 3)
-                            for (int i = 0; i < dsc.x - 2; ++i) *reinterpret_cast<V*>(wb + (int64_t)wo.slot_more[dsc.w + i] * wl) = o;
-                    }
-                }
             }
         }
     }
@@ -174,46 +152,18 @@ using namespace pglamd;
 
 extern "C" int64_t pglamd_row_epilogue_partials(int64_t n_rows) { return (int64_t)grid_blocks(n_rows) * kWavesPerBlock; }
 
-static int32_t row_epilogue_entry(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
-                                  float eps, float* y, float* inv_norm, const pglamd_wire_out* wire, void* stream) {
+extern "C" int32_t pglamd_row_epilogue(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
+                                       float eps, float* y, float* inv_norm, void* stream) {
     if (n_rows < 0 || d <= 0 || !z || !y || (normalize && !inv_norm) || act < 0 || act > 1)
         return fail(PGLAMD_E_ARG, "row_epilogue: bad argument");
-    pglamd_wire_out wo{};
-    if (wire && wire->slot_desc) {
-        wo = *wire;
-        if (!wo.wire || reinterpret_cast<uintptr_t>(wo.slot_desc) % 16 != 0 || wo.ldw < 0 || wo.ld_scaled < 0 || (wo.scaled_out && !wo.scale))
-            return fail(PGLAMD_E_ARG, "row_epilogue_wire: incomplete wire descriptor");
-        if (wo.split) {
-            if (wo.split < 0 || wo.split >= d || wo.split % 16 != 0 || !wo.wire2 || wo.ldw2 < 0)
-                return fail(PGLAMD_E_ARG, "row_epilogue_wire: split must be a multiple of 16 inside the row, with a second buffer");
-            if (!wo.ldw) wo.ldw = wo.split;
-            if (!wo.ldw2) wo.ldw2 = d - wo.split;
-        }
-        if (!wo.ldw) wo.ldw = d;
-        if (!wo.ld_scaled) wo.ld_scaled = d;
-        const int vec = d % 4 == 0 ? 4 : d % 2 == 0 ? 2 : 1;         // the kernel moves rows in vectors of this many floats
-        if (wo.ldw % vec != 0 || wo.ld_scaled % vec != 0 || (wo.split && wo.ldw2 % vec != 0) ||
-            (reinterpret_cast<uintptr_t>(wo.wire) | reinterpret_cast<uintptr_t>(wo.scaled_out) | reinterpret_cast<uintptr_t>(wo.wire2)) % (4 * vec) != 0)
-            return fail(PGLAMD_E_ARG, "row_epilogue_wire: wire / scaled_out not aligned to the %d-float vectors rows of %lld floats move in", vec, (long long)d);
-    }
     if (n_rows == 0) return PGLAMD_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return dispatch((int)d, [&](auto V, auto T) -> int32_t {
         hipLaunchKernelGGL((row_epilogue_kernel<decltype(V)::value, decltype(T)::value>), dim3(grid_blocks(n_rows)), dim3(kBlock), 0, st,
-                           z, bias, n_rows, (int)d, act, normalize, eps, y, inv_norm, wo);
+                           z, bias, n_rows, (int)d, act, normalize, eps, y, inv_norm);
         PGLAMD_LAUNCH_CHECK();
         return PGLAMD_OK;
     });
-}
-
-extern "C" int32_t pglamd_row_epilogue(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
-                                       float eps, float* y, float* inv_norm, void* stream) {
-    return row_epilogue_entry(z, bias, n_rows, d, act, normalize, eps, y, inv_norm, nullptr, stream);
-}
-
-extern "C" int32_t pglamd_row_epilogue_wire(const float* z, const float* bias, int64_t n_rows, int64_t d, int32_t act, int32_t normalize,
-                                            float eps, float* y, float* inv_norm, const pglamd_wire_out* wire, void* stream) {
-    return row_epilogue_entry(z, bias, n_rows, d, act, normalize, eps, y, inv_norm, wire, stream);
 }
 
 extern "C" int32_t pglamd_row_epilogue_backward(const float* dy, const float* y, const float* inv_norm, int64_t n_rows, int64_t d,

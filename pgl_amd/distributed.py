@@ -26,8 +26,9 @@ gradients flow through every one of them -- the mechanism is replaced:
     pull them (hubs first, the other sets in Gray-code order), so the rows any peer pulls are a few contiguous ranges of the
     feature matrix itself and travel from where they lie (pglamd_halo_exchange_start_ranges; torch point-to-point / gloo beside
     it) -- in two halves of the rows cut by EDGES, half B under half A's edges.  No pack launch, no send-buffer traffic: per-rank
-    compute / ideal 1.29 -> 1.15 at |E| = 100 M, P = 8.  Also here, opt-in and measured not to pay: the
-    producer of a layer's rows mirroring them into the next exchange's send buffer (wire / mark / emit).
+    compute / ideal 1.29 -> 1.15 at |E| = 100 M, P = 8.  (Round 5 also built the producer of a layer's rows
+    mirroring them into the next exchange's send buffer -- measured slower than the pack launch it removed, profiles/r05/rows_c2p.txt
+    -- and two alternative layouts, feature sharding and a rows x columns grid; round 6 removed all three from the product.)
 
 Two classes:
   DistGraph      the engine's distributed graph: features are the OWNED rows ([n_own, ...]) -- nothing is replicated;
@@ -67,16 +68,28 @@ class AbiTransport(object):
     is handed out through the already initialised torch process group."""
     _by_group = {}
 
-    def __init__(self, group=None):
+    @staticmethod
+    def unique_id():
+        """-> the 128-byte id one rank creates (pglamd_comm_unique_id) and hands to every rank of the communicator."""
+        import ctypes
+        from . import _ffi
+        ident = torch.zeros(128, dtype=torch.uint8)
+        _ffi.check(_ffi.lib().pglamd_comm_unique_id(ctypes.c_void_p(ident.data_ptr())), "comm_unique_id")
+        return ident
+
+    def __init__(self, group=None, rank=None, world=None, unique_id=None):
+        """group: the torch process group the id travels through.  rank / world / unique_id given explicitly: no torch.distributed
+        involved at all -- a caller that hands the id round by its own means (MPI, a file, one process driving several ranks)."""
         import ctypes
         from . import _ffi
         self._ffi, self._ct = _ffi, ctypes
         L = _ffi.lib()
-        ready = _group_ready(group)
-        self.rank = dist.get_rank(group) if ready else 0
-        self.world = dist.get_world_size(group) if ready else 1
-        ident = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
+        explicit = unique_id is not None
+        ready = _group_ready(group) and not explicit
+        self.rank = int(rank) if explicit else (dist.get_rank(group) if ready else 0)
+        self.world = int(world) if explicit else (dist.get_world_size(group) if ready else 1)
+        ident = unique_id.clone() if explicit else torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0 and not explicit:
             _ffi.check(L.pglamd_comm_unique_id(ctypes.c_void_p(ident.data_ptr())), "comm_unique_id")
         if ready:
             buf = ident.cuda() if dist.get_backend(group) == "nccl" else ident
@@ -187,8 +200,11 @@ def set_flow(flow=None, transport=None, graphs=(), pipe=None):
             del g._idx[k]
 
 
-def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
-    """all-to-all-v of rows.  Returns an object with .wait()."""
+def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None, transport=None):
+    """all-to-all-v of rows.  Returns an object with .wait().  transport: an AbiTransport handed to the DistGraph explicitly (the
+    library's own communicator, no torch process group involved) takes precedence over the group's backend."""
+    if transport is not None:
+        return transport.exchange(send_buf, send_splits, recv_buf, recv_splits)
     if not _group_ready(group):
         return _Done()
     backend = dist.get_backend(group)
@@ -225,12 +241,14 @@ def _exchange(send_buf, send_splits, recv_buf, recv_splits, group=None):
     return _W()
 
 
-def _exchange_ranges(x, send_ranges, recv_buf, recv_ranges, group=None, tag0=0):
+def _exchange_ranges(x, send_ranges, recv_buf, recv_ranges, group=None, tag0=0, transport=None):
     """The halo exchange WITHOUT a send buffer: for every peer q the rows x[first : first + n] of each (first, n) in send_ranges[q]
     travel from where they lie (x = the owner's feature matrix, rows contiguous) into recv_buf[pos : pos + n] for the matching
     (pos, n) of the peer's recv_ranges -- range k of a pair has the same length on both ends (HaloPlan.range_plan).  Returns an
     object with .wait().  Transports: the library's own RCCL communicator (pglamd_halo_exchange_start_ranges: grouped ncclSend /
     ncclRecv per range on its side stream), torch.distributed point-to-point on RCCL, or gloo (tests; staged through the host)."""
+    if transport is not None:
+        return transport.exchange_ranges(x, send_ranges, recv_buf, recv_ranges)
     if not _group_ready(group):
         return _Done()
     backend = dist.get_backend(group)
@@ -257,6 +275,8 @@ def _exchange_ranges(x, send_ranges, recv_buf, recv_ranges, group=None, tag0=0):
     staged = x.is_cuda
     dst = torch.empty(recv_buf.shape, dtype=recv_buf.dtype) if staged else recv_buf
     reqs, keep = [], []
+    if max([len(r) for r in send_ranges] + [len(r) for r in recv_ranges] + [0]) >= (1 << 16):
+        raise ValueError("_exchange_ranges (gloo): a peer has 65536 or more ranges -- the tags of the two halves (tag0 = 0 / 1 << 16) would collide")
     for q in range(world):
         if q == rank:
             continue
@@ -305,7 +325,7 @@ def _all_reduce_sum(tensor, group=None):
 # ------------------------------------------------------------------------------------------------------------------
 class _EngineBackend(object):
     def __init__(self, deal_chunks=False):
-        # deal_chunks: the aggregation's chunks go round the XCDs instead of in blocks (pglamd_set_option "xcd_swizzle" = 0 around
+        # deal_chunks: the aggregation's chunks go round the XCDs instead of in blocks (the per-call flag PGLAMD_AGG_DEAL_CHUNKS of
         # every launch of this backend) -- for plans whose row order correlates with row length (HaloPlan(row_order="peers"))
         self.deal_chunks = bool(deal_chunks)
 
@@ -322,20 +342,14 @@ class _EngineBackend(object):
         return c
 
     def aggregate(self, x, index, reduce_op, n_rows, y=None, message_op="add", src_scale=None, dst_scale=None, out=None,
-                  accumulate=0, x2=None, zero_indptr=None, wire=None):
-        if not self.deal_chunks:
-            return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
-                                 x2=x2, zero_indptr=zero_indptr, wire=wire)
-        ops.set_option("xcd_swizzle", 0)
-        try:
-            return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
-                                 x2=x2, zero_indptr=zero_indptr, wire=wire)
-        finally:
-            ops.set_option("xcd_swizzle", 1)
+                  accumulate=0, x2=None, zero_indptr=None):
+        # (per call: PGLAMD_AGG_DEAL_CHUNKS of pglamd_aggregate_ext -- no process-wide option to race on)
+        return ops.aggregate(x, index, reduce_op, int(n_rows), y, message_op, src_scale, dst_scale, out, accumulate,
+                             x2=x2, zero_indptr=zero_indptr, deal_chunks=self.deal_chunks)
 
-    def row_epilogue(self, z, bias, act, normalize, wire=None):
+    def row_epilogue(self, z, bias, act, normalize):
         from . import autograd as ag
-        return ag.row_epilogue(z, bias, act, normalize, wire=wire)
+        return ag.row_epilogue(z, bias, act, normalize)
 
     def gather_rows(self, x, idx):
         return ops.gather_rows(x, idx)
@@ -644,8 +658,14 @@ def _plan_load(path, rank, device=None, mmap_mode=None):
     plan = HaloPlan.__new__(HaloPlan)
     for k, v in json.load(open(os.path.join(d, "meta.json"))).items():
         setattr(plan, k, v)
+    if not hasattr(plan, "row_order"):                 # dumps written before round 5 carry neither: id order, cuts by rows
+        plan.row_order = "id"
     for k in _PLAN_ARRAYS:
-        t = torch.from_numpy(np.array(np.load(os.path.join(d, k + ".npy"), mmap_mode=mmap_mode)))
+        f = os.path.join(d, k + ".npy")
+        if k == "send_counts" and not os.path.exists(f):
+            t = torch.zeros(0, dtype=torch.int64)      # (absent counts: DistGraph._rows2 cuts the halves by rows)
+        else:
+            t = torch.from_numpy(np.array(np.load(f, mmap_mode=mmap_mode)))
         setattr(plan, k, t.to(device) if (device is not None and k != "push") else t)
     return plan
 
@@ -658,13 +678,13 @@ class _HaloAggregate(torch.autograd.Function):
     Backward: the transposed indices, splits swapped: gx = A_loc^T g' + S^T (exchange^T (R^T g')), g' = dst_scale * g."""
 
     @staticmethod
-    def forward(ctx, x_own, dg, scale, emit_in=None, emit_out=None):
+    def forward(ctx, x_own, dg, scale):
         ctx.dg, ctx.scale = dg, scale
-        return dg._flow(x_own, scale, transposed=False, emit_in=emit_in, emit_out=emit_out)
+        return dg._flow(x_own, scale, transposed=False)
 
     @staticmethod
     def backward(ctx, grad):
-        return ctx.dg._flow(grad.contiguous(), ctx.scale, transposed=True), None, None, None, None
+        return ctx.dg._flow(grad.contiguous(), ctx.scale, transposed=True), None, None
 
 
 class _HaloExtend(torch.autograd.Function):
@@ -700,31 +720,6 @@ class _AllGatherRows(torch.autograd.Function):
         return g[dg.plan.own_global.to(g.device)].contiguous(), None
 
 
-class Emission(object):
-    """One fused pack: the ops.Wire a producing launch mirrors its rows into, and what identifies the tensor it produced."""
-    __slots__ = ("graph", "kind", "wire", "wire_first", "epoch", "scale", "piped", "d", "dtype", "version", "shape")
-
-    def __init__(self, graph, kind, wire, epoch, scale, piped, d, dtype):
-        self.graph, self.kind, self.wire, self.epoch, self.scale, self.piped, self.d, self.dtype = graph, kind, wire, epoch, scale, piped, d, dtype
-        self.version, self.shape, self.wire_first = None, None, wire
-
-
-def _version_of(t):
-    """Version counter of a tensor; -1 for tensors made under torch.inference_mode() (they track none: taken as unmodified)."""
-    v = ops.tensor_version(t)
-    if v is None:
-        try:
-            return -1 if t.is_inference() else None
-        except Exception:                                            # noqa: BLE001
-            return None
-    return v
-
-
-def _wk(wire):
-    """keyword of a backend.aggregate call that mirrors its rows (nothing when there is no wire: other backends need not know it)."""
-    return {} if wire is None else {"wire": wire}
-
-
 # ------------------------------------------------------------------------------------------------------------------
 # the distributed graph
 # ------------------------------------------------------------------------------------------------------------------
@@ -734,8 +729,9 @@ class DistGraph(object):
     `gather_global`).  Mirrors the method set of the reference's DistGPUGraph (pgl/graph.py:1509-1553) plus the engine
     extensions pgl_amd.nn layers use (send_recv_scaled, gat_aggregate, send_uv, send / recv)."""
 
-    def __init__(self, plan, device=None, group=None, backend=None, exchange_plan=None):
+    def __init__(self, plan, device=None, group=None, backend=None, exchange_plan=None, transport=None):
         self.plan, self.group = plan, group
+        self.transport = transport                   # an explicit AbiTransport (see _exchange); None = the process group's backend
         self.xplan = exchange_plan if exchange_plan is not None else plan     # pull/push plan of send_recv(sum | mean)
         self.device = device if device is not None else plan.loc_rows.device
         # (rows grouped by reader set are rows grouped by degree class: a blocked chunk -> XCD mapping gives one XCD all the short-row
@@ -747,12 +743,6 @@ class DistGraph(object):
         self._inv_deg = None
         self._all_ids = None
         self.method = "given"
-        # True: the row kernel that finishes a GraphSageConv / GCNConv layer also writes its rows into the next layer's halo send
-        # buffer (wire / mark below), so that layer starts its exchange without a pack launch.  OFF by default: measured at
-        # |E| = 100 M, P = 8 (profiles/r05/rows_c2p.txt) it does not beat the pack launch it removes -- the pack's reads are served
-        # by the Infinity Cache (the rows were written by the launch before it), what it costs is the 0.5 GB of send-buffer
-        # writes, and the mirror pays those too
-        self.emit_outputs = False
         # halo rows of fp32 features travel as fp16 / bf16 when set (half the xGMI bytes; ~1e-3 relative error on the
         # remote contributions, so OFF by default: north_star's 1e-5 parity holds only with the features' own dtype);
         # PGLAMD_WIRE=fp16|bf16 sets the default
@@ -761,7 +751,7 @@ class DistGraph(object):
     # ---- construction ----------------------------------------------------------------------------------------------
     @classmethod
     def from_global(cls, edges, num_nodes, rank, world, method="kway", device=None, part=None, group=None, backend=None,
-                    seed=0, push="never", row_order="id"):
+                    seed=0, push="never", row_order="id", transport=None):
         """Every rank holds the same global edge list (synthetic graphs are regenerated from the seed on each rank);
         rank 0 partitions and broadcasts the part vector.
         method: "kway" (default: the engine's own multilevel partitioner, balanced on aggregation work -- in-degree + 1 -- and
@@ -799,7 +789,7 @@ class DistGraph(object):
                 cost = float((rows_in + edges_in / 16.0).max())
             if best is None or float(cost) < best[0]:
                 best = (float(cost), m, plan, xplan)
-        dg = cls(best[2], device=edges.device, group=group, backend=backend, exchange_plan=best[3])
+        dg = cls(best[2], device=edges.device, group=group, backend=backend, exchange_plan=best[3], transport=transport)
         dg.method = "given" if given else ("kway" if best[1] == "metis" else best[1])   # say what actually ran
         return dg
 
@@ -1031,91 +1021,8 @@ class DistGraph(object):
         w = self.wire_dtype
         return w if (w is not None and dtype == torch.float32 and w in (torch.float16, torch.bfloat16)) else dtype
 
-    # ---- fused pack: the producer of a layer's output rows writes them into the NEXT aggregation's send buffer ----------------
-    def wire(self, like, scale=None, scaled=False, kind="x"):
-        """-> an Emission for rows shaped / typed like `like` ([n_own, d]), or None when this graph cannot take one.
-        Hand `emission.wire` to the launch that produces a layer's output (ops.aggregate / ag.row_epilogue / DistGraph.send_recv(...,
-        emit=True)): every finished row is then ALSO written into the halo send buffer of the next aggregation, in the slots of
-        the peers that pull it -- so that aggregation starts its exchange with no pack launch (the pack re-read
-        rows the previous layer had just written, 0.18 of 1.15 ms per rank at |E| = 100 M / P = 8).  `mark(y, emission)` then tags
-        the produced tensor; send_recv / send_recv_scaled recognise the tag.
-        scale: optional fp32 [n_own] -- the wire copy is scale[r] * row (GCN's source-side norm of the NEXT layer);
-        scaled: also keep a dense [n_own, d] copy of the scaled rows (what the next layer's local edges read).
-        Eligible: world > 1, pull plan (every send row is one owned row), the rows travel in their own dtype (no 16-bit wire cast),
-        fp32 / fp16 / bf16, 2-D.  Two send buffers alternate, so the emission of step k+1 never writes what exchange k+1 still sends."""
-        p = self.plan
-        xp = self.xplan if kind == "x" else p
-        if p.world == 1 or int(xp.pushed_pairs) != 0 or like.dim() != 2 or not xp.n_send:
-            return None
-        if like.dtype not in (torch.float32, torch.float16, torch.bfloat16) or self._wire(like.dtype) != like.dtype:
-            return None
-        if scale is not None and (scale.dtype != torch.float32 or scale.numel() != p.n_own):
-            return None
-        if int(like.shape[0]) != p.n_own:
-            return None
-        d, dev = int(like.shape[1]), like.device
-        key = "wslots" + kind
-        slots = self._idx.get(key)
-        if slots is None:
-            # per owned row: its positions in the send buffer ({count, p0, p1, p2} records, ops.wire_slots).  Two sets: `all`, and
-            # `first` with the rows that also receive remote edges emptied -- in the two-launch flows that store such a row twice
-            # (accumulate, pipeline) only the second store is the final value, so only that launch mirrors it
-            cols = xp.send_cols.to(dev)
-            d_all, more = ops.wire_slots(cols, p.n_own)
-            d_first, _ = ops.wire_slots(cols, p.n_own, drop_rows=torch.unique(xp.recv_rows.to(dev)))
-            slots = self._idx[key] = (d_all, d_first, more)
-        row_bytes = d * like.element_size()
-        piped = self._pipelined(kind, False, True, like, row_bytes)
-        self._emit_epoch = getattr(self, "_emit_epoch", 0) + 1
-        par = self._emit_epoch & 1
-        if piped:
-            h = (d // 2 + 15) // 16 * 16
-            b0 = self._buffer("emit%s%d_0" % (kind, par), (xp.n_send, h), like.dtype, dev)
-            b1 = self._buffer("emit%s%d_1" % (kind, par), (xp.n_send, d - h), like.dtype, dev)
-            bufs, split = (b0, b1), h
-        else:
-            bufs, split = (self._buffer("emit%s%d" % (kind, par), (xp.n_send, d), like.dtype, dev), None), 0
-        sc = None if scale is None else scale.reshape(-1).contiguous()
-        so = self._buffer("emits%s%d" % (kind, par), (p.n_own, d), like.dtype, dev) if (scaled and sc is not None) else None
-        w = ops.Wire(slots[0], slots[2], bufs[0], sc, so, bufs[1], split)
-        em = Emission(self, kind, w, self._emit_epoch, scale, piped, d, like.dtype)
-        em.wire_first = w.with_desc(slots[1])
-        return em
-
-    def can_wire(self, d, dtype, kind="x"):
-        """True when wire() would hand out an emission for [n_own, d] rows of `dtype` (no side effects)."""
-        xp = self.xplan if kind == "x" else self.plan
-        return bool(self.plan.world > 1 and int(xp.pushed_pairs) == 0 and xp.n_send and
-                    dtype in (torch.float32, torch.float16, torch.bfloat16) and self._wire(dtype) == dtype)
-
-    def mark(self, tensor, emission):
-        """Tags `tensor` as the rows `emission` mirrored into the send buffer (valid until the tensor is written to or a newer
-        emission of the same kind is produced two steps later)."""
-        if emission is not None:
-            emission.version = _version_of(tensor)
-            emission.shape = tuple(tensor.shape)
-            try:
-                tensor._pglamd_emission = emission
-            except Exception:                                        # noqa: BLE001 -- a tensor type that takes no attributes
-                pass
-        return tensor
-
-    def _emission_of(self, x, kind, scale=None):
-        """The valid emission carried by x for this graph / plan / scale, else None."""
-        em = getattr(x, "_pglamd_emission", None)
-        if em is None or em.graph is not self or em.kind != kind:
-            return None
-        if em.version is None or _version_of(x) != em.version or tuple(x.shape) != em.shape or x.dtype != em.dtype:
-            return None
-        if getattr(self, "_emit_epoch", 0) - em.epoch > 1:            # its buffer has been handed to a newer emission
-            return None
-        if (scale is None) != (em.scale is None) or (scale is not None and scale is not em.scale and
-                                                     not (scale.data_ptr() == em.scale.data_ptr() and scale.numel() == em.scale.numel())):
-            return None
-        return em
-
     # ---- the exchange: pack -> all-to-all-v (asynchronous) ------------------------------------------------------------
-    def _start_exchange(self, x, kind, transposed, cols=None, emit=None):
+    def _start_exchange(self, x, kind, transposed, cols=None):
         """-> (work, in_buf, unpack) or None when this plan moves nothing.  Pack = ONE launch: a row gather straight into
         the wire buffer (in the wire dtype) when every send row is a single owned row, otherwise the aggregation kernel over
         the send index (pushed partial rows; the transposed flow's pre-summed gradients) followed by the wire cast.
@@ -1136,17 +1043,8 @@ class DistGraph(object):
         tail = tuple(x.shape[1:])
         wire = self._wire(x.dtype)
         tag = "%s%d%s" % (kind, transposed, blk)
-        out_buf = None
-        if emit is not None and not transposed:
-            # the producer of x already wrote these rows into the send buffer (DistGraph.wire): no pack launch
-            w = emit.wire
-            out_buf = w.buf if (cols is None or cols[0] == 0) else w.buf2
-            if cols is None and w.split:
-                raise RuntimeError("DistGraph: a column-split emission met a single-block exchange")
-            self._packs_skipped = getattr(self, "_packs_skipped", 0) + 1
-        if out_buf is None:
-            out_buf = self._buffer("out" + tag, (n_out,) + tail, wire, x.device)
-        if n_out and not (emit is not None and not transposed):
+        out_buf = self._buffer("out" + tag, (n_out,) + tail, wire, x.device)
+        if n_out:
             plain = (not transposed) and int(xp.pushed_pairs) == 0
             if plain and x.dtype in (torch.float32, torch.float16, torch.bfloat16):
                 B.gather_rows_cast(x, self._send_cols32(kind), wire, out_buf)    # (same-dtype "casts" too: the persistent wire buffer is written in place)
@@ -1160,7 +1058,7 @@ class DistGraph(object):
         # the receive buffer persists across steps; its reuse is ordered by the stream (the previous step's boundary launch
         # is queued before this exchange)
         in_wire = self._buffer("in" + tag, (n_in,) + tail, wire, x.device)
-        work = _exchange(out_buf, out_splits, in_wire, in_splits, self.group)
+        work = _exchange(out_buf, out_splits, in_wire, in_splits, self.group, self.transport)
         if wire == x.dtype:
             return work, in_wire, None
         in_buf = self._buffer("inw" + tag, (n_in,) + tail, x.dtype, x.device)
@@ -1267,8 +1165,8 @@ class DistGraph(object):
         in_buf = self._buffer("in_rows2", (xp.n_recv,) + tail, x.dtype, x.device)
         if self._zero_copy(x):
             sa, sb, ra, rb = self._rows2_ranges()
-            wa = _exchange_ranges(x, sa, in_buf, ra, self.group, tag0=0)
-            wb = _exchange_ranges(x, sb, in_buf, rb, self.group, tag0=1 << 16)
+            wa = _exchange_ranges(x, sa, in_buf, ra, self.group, tag0=0, transport=self.transport)
+            wb = _exchange_ranges(x, sb, in_buf, rb, self.group, tag0=1 << 16, transport=self.transport)
             self._idx[("ran_pack", "x")] = "zero-copy"
             return wa, wb, in_buf
         out_buf = self._buffer("out_rows2", (xp.n_send,) + tail, x.dtype, x.device)
@@ -1279,23 +1177,24 @@ class DistGraph(object):
             out_buf = self._b.gather_rows(x, r2["pack32"])
         if fast and nA_s:
             self._b.gather_rows_cast(x, r2["pack32"][:nA_s], x.dtype, out_buf[:nA_s])
-        wa = _exchange(out_buf[:nA_s], r2["hs"], in_buf[:nA_r], r2["hr"], self.group)
+        wa = _exchange(out_buf[:nA_s], r2["hs"], in_buf[:nA_r], r2["hr"], self.group, self.transport)
         if fast and xp.n_send - nA_s:
             self._b.gather_rows_cast(x, r2["pack32"][nA_s:], x.dtype, out_buf[nA_s:])
-        wb = _exchange(out_buf[nA_s:], r2["sB"], in_buf[nA_r:], r2["rB"], self.group)
+        wb = _exchange(out_buf[nA_s:], r2["sB"], in_buf[nA_r:], r2["rB"], self.group, self.transport)
         self._idx[("ran_pack", "x")] = "pack"
         return wa, wb, in_buf
 
-    def _rows2_ok(self, kind, transposed, additive, x, emit_in, emit_out):
-        """The row-pipelined flow serves the forward sum / mean of a pull plan with the rows travelling in their own dtype."""
+    def _rows2_ok(self, kind, transposed, additive, x):
+        """The row-pipelined flow serves the forward sum / mean of a pull plan with the rows travelling in their own dtype.
+        Decided from rank-invariant inputs only (the plan kind, the forced flow, the dtype): every rank takes the same branch."""
         forced = _env_flow()
         # PGLAMD_FLOW=pipeline means the column blocks; unforced, a peer-ordered plan pipelines by rows (that is what it is ordered for)
         want = forced == "rows2" or (forced == "" and (_pipe_kind() == "rows" or getattr(self.plan, "row_order", "id") == "peers"))
         return (want and kind == "x" and not transposed and additive and int(self.xplan.pushed_pairs) == 0
-                and self._wire(x.dtype) == x.dtype and emit_in is None and emit_out is None)
+                and self._wire(x.dtype) == x.dtype)
 
     # ---- the overlapped two-phase flow (forward and, with the indices transposed, backward) --------------------------------
-    def _flow(self, x, scale, transposed, reduce="sum", kind="x", emit_in=None, emit_out=None):
+    def _flow(self, x, scale, transposed, reduce="sum", kind="x"):
         """out[v] = scale[v] * REDUCE over ALL in-edges of owned row v (transposed: the gradient of that).  SURVEY 8e steps
         1-4: pack -> all-to-all-v on the side stream -> work that needs no received row while the rows travel -> wait -> the rest.
         WHAT runs under the exchange is chosen per plan (`_mode`, `_pipelined`): "split" -- INTERIOR rows (every source local)
@@ -1314,16 +1213,8 @@ class DistGraph(object):
         sfx = "_t" if transposed else ""
         additive = reduce in ("sum", "mean")
         row_bytes = max(1, x.element_size() * int(np.prod(tail)) if tail else x.element_size())
-        if transposed or post is not None or not additive:
-            emit_in = emit_out = None
-        wo = None if emit_out is None else emit_out.wire             # every launch that stores output rows mirrors them ...
-        wo1 = None if emit_out is None else emit_out.wire_first      # ... but a row two launches store is mirrored by the second only
         piped = p.world > 1 and self._pipelined(kind, transposed, additive, x, row_bytes)
-        if emit_in is not None and bool(emit_in.piped) != bool(piped):
-            emit_in = None                                           # (cannot happen for one plan and row width; be safe)
-        if wo is not None and bool(emit_out.piped) != bool(piped):
-            wo = wo1 = None
-        if piped and self._rows2_ok(kind, transposed, additive, x, emit_in, emit_out):
+        if piped and self._rows2_ok(kind, transposed, additive, x):
             # ROW-PIPELINED (round 5): the rows travel in two halves, each half the full row width -- half A's edges are added while
             # half B is still on the wire, every launch walks full-width rows (the column blocks below walk ALL received edges twice
             # at half width), and with a peer-ordered plan neither half is packed: the rows are sent from the feature matrix itself.
@@ -1346,8 +1237,8 @@ class DistGraph(object):
             d = int(x.shape[1])
             h = (d // 2 + 15) // 16 * 16
             blocks = [(0, h), (h, d)]
-            started = [self._start_exchange(x, kind, transposed, cols=c, emit=emit_in) for c in blocks]
-            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo1))
+            started = [self._start_exchange(x, kind, transposed, cols=c) for c in blocks]
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k)
             recv = kind + ("send_t" if transposed else "recv")
             for st, (c0, c1) in zip(started, blocks):
                 if st is None:
@@ -1357,15 +1248,12 @@ class DistGraph(object):
                 if (xp.n_send if transposed else xp.n_recv):
                     if unpack is not None:
                         unpack()
-                    B.aggregate(in_buf, self._index(recv), reduce, p.n_own, dst_scale=scale_k, out=out[:, c0:c1], accumulate=1,
-                                **_wk(None if wo is None else wo.block(c0, c1)))
+                    B.aggregate(in_buf, self._index(recv), reduce, p.n_own, dst_scale=scale_k, out=out[:, c0:c1], accumulate=1)
             self._idx[("ran", kind, transposed)] = "pipeline"
             if post is not None:
                 out = out * post
-            if wo is not None:
-                self.mark(out, emit_out)
             return out
-        started = self._start_exchange(x, kind, transposed, emit=emit_in)
+        started = self._start_exchange(x, kind, transposed)
         n_in = (xp.n_send if transposed else xp.n_recv) if started is not None else 0
         mode = self._mode(kind, transposed, additive=additive, row_bytes=row_bytes) if n_in else "split"
         self._idx[("ran", kind, transposed)] = mode
@@ -1376,20 +1264,20 @@ class DistGraph(object):
             work.wait()
             if unpack is not None:
                 unpack()
-            out = B.aggregate(x, self._index(kind + "all" + sfx), reduce, p.n_own, dst_scale=scale_k, x2=in_buf, **_wk(wo))
+            out = B.aggregate(x, self._index(kind + "all" + sfx), reduce, p.n_own, dst_scale=scale_k, x2=in_buf)
         elif mode == "accumulate":
             # most edges are local, most rows have a few remote sources: ALL local-source edges run under the exchange, the
             # received rows' edges are added on top afterwards (their rows are read-modify-written)
-            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k, **_wk(wo1))
+            out = B.aggregate(x, self._index("loc" + sfx), reduce, p.n_own, dst_scale=scale_k)
             work, in_buf, unpack = started
             work.wait()
             if unpack is not None:
                 unpack()
             B.aggregate(in_buf, self._index(kind + ("send_t" if transposed else "recv")), reduce, p.n_own, dst_scale=scale_k, out=out,
-                        accumulate=1, **_wk(wo))
+                        accumulate=1)
         else:
             out = B.aggregate(x, self._index(kind + "int" + sfx), reduce, p.n_own, dst_scale=scale_k,
-                              zero_indptr=self._zero_indptr(transposed) if n_in else None, **_wk(wo))    # overlaps the exchange
+                              zero_indptr=self._zero_indptr(transposed) if n_in else None)    # overlaps the exchange
             if started is not None:
                 work, in_buf, unpack = started
                 work.wait()
@@ -1397,11 +1285,9 @@ class DistGraph(object):
                     if unpack is not None:
                         unpack()
                     B.aggregate(x, self._index(kind + "bnd" + sfx), reduce, p.n_own, dst_scale=scale_k, out=out, accumulate=2,
-                                x2=in_buf, **_wk(wo))
+                                x2=in_buf)
         if post is not None:
             out = out * post
-        if wo is not None:
-            self.mark(out, emit_out)
         return out
 
     # edges / s of the aggregation kernel on a rank-sized problem, fixed cost of one aggregation launch (counter reset, kernel ramp
@@ -1504,20 +1390,14 @@ class DistGraph(object):
             self._idx[key] = hit
         return hit
 
-    def _sum_like(self, x_own, reduce_func, extra_dst_scale=None, emit_in=None, emit=False):
-        """emit_in: the valid Emission of x_own (its rows already sit in the send buffer: no pack).  emit: mirror the OUTPUT rows
-        into the send buffer of the next aggregation and tag the result."""
+    def _sum_like(self, x_own, reduce_func, extra_dst_scale=None):
         scale = self._scale(reduce_func)
         if extra_dst_scale is not None:
             scale = extra_dst_scale if scale is None else scale * extra_dst_scale
         x_own = x_own.contiguous()
-        emit_out = self.wire(x_own) if emit else None
         if torch.is_grad_enabled() and x_own.requires_grad:
-            out = _HaloAggregate.apply(x_own, self, scale, emit_in, emit_out)
-            if emit_out is not None and emit_out.version is not None:
-                self.mark(out, emit_out)                               # (the Function returned a fresh tensor object)
-            return out
-        return self._flow(x_own, scale, transposed=False, emit_in=emit_in, emit_out=emit_out)
+            return _HaloAggregate.apply(x_own, self, scale)
+        return self._flow(x_own, scale, transposed=False)
 
     # ---- halo extension (pull), differentiable ------------------------------------------------------------------------
     def _extend(self, x_own, work_out=None):
@@ -1528,7 +1408,7 @@ class DistGraph(object):
         work = None
         if p.world > 1 and (p.n_halo or p.send_idx.shape[0]):
             send_buf = B.gather_rows(x_own, self._send_idx32())
-            work = _exchange(send_buf, p.pull_splits, x_ext[p.n_own:], p.halo_splits, self.group)
+            work = _exchange(send_buf, p.pull_splits, x_ext[p.n_own:], p.halo_splits, self.group, self.transport)
         x_ext[:p.n_own].copy_(x_own)                                   # overlaps the exchange
         if work_out is not None:
             work_out.append(work)
@@ -1543,7 +1423,7 @@ class DistGraph(object):
         n_send = int(p.send_idx.shape[0])
         if p.world > 1 and (p.n_halo or n_send):
             g_send = self._buffer("gsend", (n_send,) + tail, g_ext.dtype, g_ext.device)
-            work = _exchange(g_ext[p.n_own:].contiguous(), p.halo_splits, g_send, p.pull_splits, self.group)
+            work = _exchange(g_ext[p.n_own:].contiguous(), p.halo_splits, g_send, p.pull_splits, self.group, self.transport)
             work.wait()
             if n_send:
                 B.aggregate(g_send, self._index("pull_t"), "sum", p.n_own, out=gx, accumulate=1)
@@ -1585,23 +1465,21 @@ class DistGraph(object):
         return self.local_graph._edge_cols32()
 
     # ---- the reference's method set (pgl/graph.py:1509-1553), on owned rows -----------------------------------------------
-    def send_recv(self, feature, reduce_func="sum", out_size=None, emit=False):
-        """pgl/graph.py:1534-1538 role; Graph.send_recv semantics (pgl/graph.py:834-861).  feature: [n_own, ...].
-        emit=True (sum / mean): the result's rows are also written into the send buffer of the NEXT aggregation on this graph
-        (a propagation chain h <- A h: every step after the first starts its exchange without a pack launch)."""
+    def send_recv(self, feature, reduce_func="sum", out_size=None):
+        """pgl/graph.py:1534-1538 role; Graph.send_recv semantics (pgl/graph.py:834-861).  feature: [n_own, ...]."""
         assert reduce_func in ("sum", "mean", "max", "min"), \
             "Only support 'sum', 'mean', 'max', 'min' built-in reduce functions."
         if out_size is not None and int(out_size) not in (0, self.plan.n_own):
             raise ValueError("DistGraph: out_size must equal the number of owned rows (%d)" % self.plan.n_own)
         if reduce_func in ("sum", "mean"):
-            return self._sum_like(feature, reduce_func, emit_in=self._emission_of(feature, "x"), emit=emit)
+            return self._sum_like(feature, reduce_func)
         if torch.is_grad_enabled() and feature.requires_grad:
             return self.local_graph.send_recv(self.halo_extend(feature), reduce_func)[:self.plan.n_own]
         return self._minmax(feature.contiguous(), reduce_func)
 
-    def send_u_recv(self, feature, reduce_op="sum", out_size=None, emit=False):
+    def send_u_recv(self, feature, reduce_op="sum", out_size=None):
         """pgl/graph.py:1540-1544."""
-        return self.send_recv(feature, reduce_op, out_size, emit=emit)
+        return self.send_recv(feature, reduce_op, out_size)
 
     def _minmax(self, x_own, reduce_func):
         """Interior rows while the halo is in flight, boundary rows afterwards from [owned | received] (pull plan: max / min
@@ -1665,23 +1543,13 @@ class DistGraph(object):
         return self.local_graph.recv(reduce_func, msg, recv_mode)[:self.plan.n_own]
 
     # ---- engine extensions the pgl_amd.nn layers look for ---------------------------------------------------------------
-    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None, emit=False):
+    def send_recv_scaled(self, feature, src_scale=None, dst_scale=None):
         """out[v] = dst_scale[v] * sum_{u->v} src_scale[u] * feature[u] (GCN's symmetric norm, pgl/nn/conv.py:242-250): the
-        source scale is applied to the owned rows before they travel, the destination scale inside the kernels.
-        A `feature` that carries an emission made with THIS src_scale (DistGraph.wire(..., scale=src_scale, scaled=True): the row
-        kernel that finished the previous layer wrote scale * row into the send buffer and into a dense scaled copy) needs neither
-        the scaling pass nor the pack.  emit: mirror the result's rows AS THEY ARE for the next aggregation (a propagation chain
-        h <- norm * A (norm * h) runs as g <- norm^2 * A g on g = norm * h: no source scale, so every step can feed the next)."""
-        em = self._emission_of(feature, "x", src_scale) if src_scale is not None else self._emission_of(feature, "x")
+        source scale is applied to the owned rows before they travel, the destination scale inside the kernels."""
         if src_scale is not None:
-            if em is not None and em.wire.scaled_out is not None and not (torch.is_grad_enabled() and feature.requires_grad):
-                feature = em.wire.scaled_out                          # scale * row, written by the producer: no scaling pass either
-            else:
-                # (training: the product stays an autograd op; the send buffer already holds the same values, so the pack is
-                #  skipped all the same)
-                feature = feature * src_scale.reshape((-1,) + (1,) * (feature.dim() - 1)).to(feature.dtype)
+            feature = feature * src_scale.reshape((-1,) + (1,) * (feature.dim() - 1)).to(feature.dtype)
         ds = None if dst_scale is None else dst_scale.reshape(-1).to(torch.float32).contiguous()
-        return self._sum_like(feature, "sum", extra_dst_scale=ds, emit_in=em, emit=emit)
+        return self._sum_like(feature, "sum", extra_dst_scale=ds)
 
     def gat_aggregate(self, feature, attn_src, attn_dst, negative_slope=0.2, attn_drop=0.0, seed=0):
         """The fused GAT attention of Graph.gat_aggregate over the partitioned graph: a_src rides with the halo feature
@@ -1855,151 +1723,6 @@ class DistGPUGraph(object):
     def send_ue_recv(self, feature, edge_feature, message_op="add", reduce_op="sum", out_size=None):
         dg = self.dist
         return self._out(dg.send_ue_recv(dg.take_owned(feature), dg.take_edges(edge_feature), message_op, reduce_op))
-
-
-# ------------------------------------------------------------------------------------------------------------------
-# feature sharding and the rows x columns grid
-# ------------------------------------------------------------------------------------------------------------------
-def _balanced_ranges(n, world):
-    """[lo, hi) of every rank for n items split as evenly as possible (the first n % world ranks get one more)."""
-    base, extra = divmod(int(n), int(world))
-    out, lo = [], 0
-    for r in range(world):
-        hi = lo + base + (1 if r < extra else 0)
-        out.append((lo, hi))
-        lo = hi
-    return out
-
-
-class FeatureShardedGraph(object):
-    """The other way to spread message passing over the GPUs of a node: every rank holds the WHOLE graph (an index of
-    20 M edges is 0.3 GB; MI355X has 288 GB) and a slice of the feature COLUMNS.  Aggregation is column-wise independent,
-    so  out[:, cols_r] = A x[:, cols_r]  needs no communication at all, for every reduce op; the ranks only exchange data
-    where a dense layer mixes columns (rows_to_cols / cols_to_rows: one balanced all-to-all of N*d*(P-1)/P^2 elements
-    per rank -- 56 MB at C2, P = 8, against 128 MB of halo rows for the row partition of the same RMAT graph, and
-    independent of the graph's locality).  Power-law graphs without communities (RMAT: 82 % of the edges cut by any
-    8-way partition) are the case for it; graphs with locality keep DistGraph's row partition + halo exchange.
-    The two layout changes are each other's backward (`_LayoutChange`), so layers between them train."""
-
-    def __init__(self, graph, rank, world, group=None):
-        self.graph, self.rank, self.world, self.group = graph, int(rank), int(world), group
-        self.num_nodes = graph.num_nodes
-
-    def col_range(self, d):
-        return _balanced_ranges(d, self.world)[self.rank]
-
-    def row_range(self):
-        return _balanced_ranges(self.num_nodes, self.world)[self.rank]
-
-    def take_cols(self, x_global):
-        lo, hi = self.col_range(int(x_global.shape[1]))
-        return x_global[:, lo:hi].contiguous()
-
-    def send_recv(self, x_cols, reduce_func="sum"):
-        """Graph.send_recv on this rank's columns: [N, d_r] -> [N, d_r]; no collective."""
-        return self.graph.send_recv(x_cols, reduce_func)
-
-    def send_ue_recv(self, x_cols, edge_feature, message_op="add", reduce_op="sum"):
-        return self.graph.send_ue_recv(x_cols, edge_feature, message_op, reduce_op)
-
-    # ---- layout changes around dense layers ----------------------------------------------------------------------------
-    def _cols_to_rows(self, x_cols, d):
-        rows, cols = _balanced_ranges(self.num_nodes, self.world), _balanced_ranges(d, self.world)
-        (r0, r1), me = rows[self.rank], self.rank
-        w = cols[me][1] - cols[me][0]
-        send = x_cols.contiguous().reshape(-1)            # peer q's rows of my columns are a contiguous block already
-        send_splits = [(b - a) * w for a, b in rows]
-        recv_splits = [(r1 - r0) * (c1 - c0) for c0, c1 in cols]
-        recv = torch.empty(sum(recv_splits), dtype=x_cols.dtype, device=x_cols.device)
-        _exchange(send, send_splits, recv, recv_splits, self.group).wait()
-        out = torch.empty((r1 - r0, d), dtype=x_cols.dtype, device=x_cols.device)
-        off = 0
-        for (c0, c1), n in zip(cols, recv_splits):
-            out[:, c0:c1] = recv[off:off + n].reshape(r1 - r0, c1 - c0)
-            off += n
-        return out
-
-    def _rows_to_cols(self, x_rows):
-        d = int(x_rows.shape[1])
-        rows, cols = _balanced_ranges(self.num_nodes, self.world), _balanced_ranges(d, self.world)
-        (c0, c1), me = cols[self.rank], self.rank
-        n_me = rows[me][1] - rows[me][0]
-        send = torch.empty(n_me * d, dtype=x_rows.dtype, device=x_rows.device)
-        off = 0
-        for a, b in cols:                                 # peer q gets its columns of my rows: strided copies into one buffer
-            send[off:off + n_me * (b - a)].view(n_me, b - a).copy_(x_rows[:, a:b])
-            off += n_me * (b - a)
-        send_splits = [n_me * (b - a) for a, b in cols]
-        recv_splits = [(b - a) * (c1 - c0) for a, b in rows]
-        recv = torch.empty(sum(recv_splits), dtype=x_rows.dtype, device=x_rows.device)
-        _exchange(send, send_splits, recv, recv_splits, self.group).wait()
-        return recv.reshape(self.num_nodes, c1 - c0)      # peers' row blocks arrive in rank order
-
-    def cols_to_rows(self, x_cols, d):
-        """[N, d_r] (all rows, my columns) -> [n_r, d] (my rows, all columns).  Differentiable."""
-        if self.world == 1:
-            return x_cols
-        if torch.is_grad_enabled() and x_cols.requires_grad:
-            return _LayoutChange.apply(x_cols, self, True, int(d))
-        return self._cols_to_rows(x_cols, int(d))
-
-    def rows_to_cols(self, x_rows):
-        """[n_r, d] (my rows, all columns) -> [N, d_r] (all rows, my columns).  Differentiable."""
-        if self.world == 1:
-            return x_rows
-        if torch.is_grad_enabled() and x_rows.requires_grad:
-            return _LayoutChange.apply(x_rows, self, False, int(x_rows.shape[1]))
-        return self._rows_to_cols(x_rows)
-
-    def stats(self):
-        return {"partition": "feature columns (graph replicated)", "local_rows": int(self.num_nodes),
-                "local_edges": int(self.graph.num_edges), "halo_rows": 0, "recv_rows": 0}
-
-
-class _LayoutChange(torch.autograd.Function):
-    """cols_to_rows and rows_to_cols are permutations of the same elements across ranks: each is the other's backward."""
-
-    @staticmethod
-    def forward(ctx, x, fs, to_rows, d):
-        ctx.fs, ctx.to_rows, ctx.d = fs, to_rows, d
-        return fs._cols_to_rows(x, d) if to_rows else fs._rows_to_cols(x)
-
-    @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous()
-        return (ctx.fs._rows_to_cols(g) if ctx.to_rows else ctx.fs._cols_to_rows(g, ctx.d)), None, None, None
-
-
-class GridShardedGraph(object):
-    """Hybrid of the two layouts (third candidate): world = Pr x Pc ranks; the graph is row-partitioned Pr ways
-    and the feature columns are split Pc ways.  Rank (i, c) owns row part i and column slice c; halo rows travel only
-    between the Pr ranks that share a column slice, and are d / Pc wide -- Pc times fewer bytes per link than the pure
-    row partition, Pr times more columns per rank than pure feature sharding (whose narrow rows are line-rate bound)."""
-
-    def __init__(self, edges, num_nodes, rank, world, grid, method="kway", device=None, seed=0, push="auto", backend=None):
-        pr, pc = int(grid[0]), int(grid[1])
-        assert pr * pc == int(world), "grid %r does not tile %d ranks" % (grid, world)
-        self.grid, self.rank, self.world = (pr, pc), int(rank), int(world)
-        self.row_rank, self.col_rank = self.rank // pc, self.rank % pc
-        group = None
-        if _group_ready():
-            for c in range(pc):                                       # every rank creates every group, in the same order
-                g = dist.new_group([i * pc + c for i in range(pr)])
-                if c == self.col_rank:
-                    group = g
-        self.row_graph = DistGraph.from_global(edges, num_nodes, self.row_rank, pr, method=method, device=device, group=group,
-                                               seed=seed, push=push, backend=backend)
-
-    def take(self, x_global):
-        """[N, d] replicated -> this rank's [n_own, d / Pc] block."""
-        lo, hi = _balanced_ranges(int(x_global.shape[1]), self.grid[1])[self.col_rank]
-        return self.row_graph.take_owned(x_global)[:, lo:hi].contiguous()
-
-    def send_recv(self, x_block, reduce_func="sum"):
-        return self.row_graph.send_recv(x_block, reduce_func)
-
-    def stats(self):
-        return dict(self.row_graph.stats(), grid="%dx%d" % self.grid)
 
 
 def init_parallel_env(backend=None):

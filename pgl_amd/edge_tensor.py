@@ -41,6 +41,15 @@ _BINARY = {torch.add, torch.sub, torch.mul, torch.div, torch.true_divide, torch.
 _REDUCE_TRAILING = {torch.sum, torch.mean, torch.amax, torch.amin, torch.Tensor.sum, torch.Tensor.mean, torch.Tensor.amax, torch.Tensor.amin}
 
 
+def _extras_safe(extra_args, kwargs, ref):
+    """True when every tensor among the EXTRA operands of an element-wise call (torch.clamp(t, min=<tensor>), alpha=..., ...) can be
+    combined with the sorted rows `ref` without knowing the edge order (an [E, ...] tensor in original order cannot)."""
+    for v in list(extra_args) + list(kwargs.values()):
+        if isinstance(v, EdgeTensor) or (isinstance(v, torch.Tensor) and not _rows_safe(v, ref)):
+            return False
+    return "out" not in kwargs
+
+
 def _rows_safe(other, ref):
     """True when `other` can be combined element-wise with rows `ref` ([E, ...]) without knowing the edge order: a Python scalar,
     or a tensor that broadcasts over the edge dimension (fewer dims, or size 1 there)."""
@@ -190,11 +199,22 @@ class EdgeTensor(object):
     def sigmoid(self): return self._wrap(self._v.sigmoid())
     def relu(self): return self._wrap(self._v.relu())
     def abs(self): return self._wrap(self._v.abs())
-    def clamp(self, *a, **k): return self._wrap(self._v.clamp(*a, **k))
+    def clamp(self, *a, **k):
+        return self._wrap(self._v.clamp(*a, **k)) if _extras_safe(a, k, self._v) else self.materialize().clamp(*[materialize(x) for x in a], **{n: materialize(v) for n, v in k.items()})
 
     # ---- everything else: original order first ------------------------------------------------------------------------------------
     def __getitem__(self, idx):
         return self.materialize()[idx]
+
+    # ---- writes: they land in the original-order copy, and the sorted rows FOLLOW it ---------------------------------
+    def _resync(self):
+        """The original-order copy was written to in place: the destination-sorted rows are rebuilt from it (one gather), so that
+        edge_softmax / send_ue_recv / recv never consume values the caller has since overwritten."""
+        self._v = self._view.to_order(self._orig)
+
+    def __setitem__(self, idx, value):
+        self.materialize()[materialize(idx)] = materialize(value)
+        self._resync()
 
     def __iter__(self):
         return iter(self.materialize())
@@ -216,7 +236,14 @@ class EdgeTensor(object):
     def __getattr__(self, name):                      # any Tensor method / attribute not handled above
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
-        return getattr(self.materialize(), name)
+        attr = getattr(self.materialize(), name)
+        if name.endswith("_") and callable(attr):     # an in-place Tensor method (mul_, clamp_, masked_fill_, zero_, copy_, ...)
+            def inplace(*a, **k):
+                attr(*[materialize(x) for x in a], **{n: materialize(v) for n, v in k.items()})
+                self._resync()
+                return self
+            return inplace
+        return attr
 
     def __array__(self, *a, **k):
         return self.materialize().detach().cpu().numpy().__array__(*a, **k)
@@ -227,9 +254,9 @@ class EdgeTensor(object):
         ets = [a for a in args if isinstance(a, EdgeTensor)]
         first = ets[0] if ets else None
         if first is not None and not any(isinstance(v, EdgeTensor) for v in kwargs.values()):
-            if func in _UNARY and isinstance(args[0], EdgeTensor) and len(ets) == 1:
+            if func in _UNARY and isinstance(args[0], EdgeTensor) and len(ets) == 1 and _extras_safe(args[1:], kwargs, first._v):
                 return first._wrap(func(first._v, *args[1:], **kwargs))
-            if func in _BINARY and len(args) >= 2:
+            if func in _BINARY and len(args) >= 2 and _extras_safe(args[2:], kwargs, first._v):
                 a, b = args[0], args[1]
                 if isinstance(a, EdgeTensor) and isinstance(b, EdgeTensor):
                     if a._view is b._view and a._v.dim() == b._v.dim():
@@ -265,8 +292,17 @@ class EdgeTensor(object):
                     return parts[0]._wrap(torch.cat([t._v for t in parts], dim=dim))
         # anything else sees ordinary tensors in original edge order
         conv = lambda a: a.materialize() if isinstance(a, EdgeTensor) else a
-        return func(*[conv(a) if not isinstance(a, (list, tuple)) else type(a)(conv(x) for x in a) for a in args],
-                    **{k: conv(v) for k, v in kwargs.items()})
+        res = func(*[conv(a) if not isinstance(a, (list, tuple)) else type(a)(conv(x) for x in a) for a in args],
+                   **{k: conv(v) for k, v in kwargs.items()})
+        out = kwargs.get("out")
+        if isinstance(out, EdgeTensor):               # func wrote into the original-order copy: the sorted rows follow
+            out._resync()
+            return out
+        name = getattr(func, "__name__", "")
+        if name.endswith("_") and not name.endswith("__") and args and isinstance(args[0], EdgeTensor):   # torch.Tensor.mul_(et, ...) and friends
+            args[0]._resync()
+            return args[0]
+        return res
 
 
 def _known_prod(shape):

@@ -138,6 +138,8 @@ class Graph(object):
             self._src32 = self._dst32 = None
             self._seg_cache = {}
             self._csr_views = None
+            self._csr_dview = None                   # (index views of the device the graph was on: ADVICE r5)
+            self._edge_order_view = None
             self._degree_norm_cache = None           # (device tensors of the graph that was: ADVICE r4)
             return self
         return self._rebuild(edges=edges, num_nodes=self._num_nodes, node_feat=nf, edge_feat=ef,

@@ -134,11 +134,7 @@ class GraphSageConv(nn.Module):
             # self_linear(x) + neigh_linear(agg) -> act -> F.normalize as two GEMMs (the second accumulating into the first)
             # and ONE row kernel (both biases, the activation and the L2 normalisation); backward likewise one row kernel
             z = ag.dual_linear(feature[1].contiguous(), neigh_feature, self.self_linear.weight, self.neigh_linear.weight)
-            # on a row-partitioned graph the finished rows are the next layer's send_recv input: the row kernel also writes them into
-            # that aggregation's halo send buffer (DistGraph.wire), which then starts its exchange without a pack launch
-            em = graph.wire(z) if (hasattr(graph, "can_wire") and getattr(graph, "emit_outputs", False)) else None
-            y = ag.row_epilogue(z, self.self_linear.bias + self.neigh_linear.bias, act, self.normalize, wire=None if em is None else em.wire)
-            return y if em is None else graph.mark(y, em)
+            return ag.row_epilogue(z, self.self_linear.bias + self.neigh_linear.bias, act, self.normalize)
         neigh_feature = self.neigh_linear(neigh_feature)
         self_feature = self.self_linear(feature[1])
         output = self_feature + neigh_feature
@@ -191,23 +187,6 @@ class GCNConv(nn.Module):
             output = graph.send_recv_scaled(feature, norm, norm)
             if self.input_size <= self.output_size:
                 tall = output.shape[0] >= 65536 and torch.is_grad_enabled()
-                em = None
-                if hasattr(graph, "can_wire") and getattr(graph, "emit_outputs", False) and self.activation in (None, F.relu) \
-                        and ops.row_epilogue_supported(output, self.output_size) and self.linear.weight.dtype == torch.float32 \
-                        and output.dtype == torch.float32 and graph.can_wire(self.output_size, torch.float32):
-                    # row-partitioned graph: finish the layer with the row kernel, which also writes norm * row into the next layer's
-                    # halo send buffer and into the dense scaled copy its local edges read (DistGraph.wire): the next GCNConv then
-                    # needs neither its `feature * norm` pass nor its pack launch
-                    z = _TallLinearFn.apply(output, self.linear.weight, None) if tall else F.linear(output, self.linear.weight)
-                    em = graph.wire(z, scale=norm, scaled=True)
-                    if em is not None:
-                        y = ag.row_epilogue(z, self.bias, "relu" if self.activation is F.relu else None, False, wire=em.wire)
-                        return graph.mark(y, em)
-                    output_z = z
-                else:
-                    output_z = None
-                if output_z is not None:
-                    return ag.row_epilogue(output_z, self.bias, "relu" if self.activation is F.relu else None, False)
                 if self.activation is F.relu and self.linear.weight.dtype == output.dtype and hasattr(torch, "_addmm_activation") \
                         and output.dim() == 2 and self.bias.dtype == output.dtype:
                     # bias + relu in the GEMM's own epilogue: no pass over [N, d] after the GEMM at all (round 3; round 2 ran

@@ -52,7 +52,8 @@ _WS_HOT_ENTRIES = 16
 
 
 def set_option(name, value):
-    """pglamd_set_option: process-wide launch options of the library ("xcd_swizzle": 1 / 0)."""
+    """pglamd_set_option: process-wide TUNING options of the library ("csr_onesweep": tests / experiments).  Launch choices a
+    caller makes per graph are per-call arguments (aggregate(deal_chunks=...))."""
     _ffi.check(_ffi.lib().pglamd_set_option(name.encode(), int(value)), "set_option")
 
 
@@ -280,83 +281,8 @@ def _row_strided(t):
     return t.dim() == 2 and t.shape[1] > 0 and t.stride(1) == 1 and t.stride(0) > t.shape[1] and not t.is_contiguous()
 
 
-def wire_slots(row_of_pos, n_rows, drop_rows=None):
-    """Slot descriptors of pglamd_wire_out from `row_of_pos` (send-buffer position i holds output row row_of_pos[i]):
-    -> (desc int32 [n_rows, 4] = {count, p0, p1, p2}, more int32 [*]): count <= 3 -> the positions themselves; count > 3 -> p0, p1 and
-    more[p2 : p2 + count - 2].  drop_rows: rows whose descriptor is emptied (count 0) -- rows a LATER launch of the same flow
-    stores again, so that only their last store is mirrored."""
-    dev = row_of_pos.device
-    cols = row_of_pos.long()
-    order = torch.argsort(cols, stable=True)
-    cnt = torch.bincount(cols, minlength=n_rows)
-    start = torch.cumsum(cnt, 0) - cnt
-    desc = torch.zeros((n_rows, 4), dtype=torch.int64, device=dev)
-    desc[:, 0] = cnt
-    n_pos = int(order.shape[0])
-    pad = torch.cat([order, order.new_zeros(3)]) if n_pos else order.new_zeros(3)
-    for k in range(3):
-        desc[:, 1 + k] = torch.where(cnt > k, pad[(start + k).clamp(max=n_pos + 2)], torch.zeros_like(cnt))
-    big = cnt > 3
-    more = torch.zeros(1, dtype=torch.int32, device=dev)
-    if bool(big.any()):
-        extra = (cnt - 2) * big
-        off = torch.cumsum(extra, 0) - extra
-        desc[:, 3] = torch.where(big, off, desc[:, 3])
-        rows_big = torch.nonzero(big).reshape(-1)
-        rep = torch.repeat_interleave(rows_big, extra[rows_big])
-        within = torch.arange(int(rep.shape[0]), device=dev) - off[rep]
-        more = order[start[rep] + 2 + within].to(torch.int32).contiguous()
-    if drop_rows is not None:
-        desc[drop_rows.long(), 0] = 0
-    return desc.to(torch.int32).contiguous(), more
-
-
-class Wire(object):
-    """Where a producing launch mirrors its finished rows (struct pglamd_wire_out): `buf` = the halo send buffer of the NEXT
-    aggregation ([n_send, d]; or, for the column-pipelined exchange, `buf` = columns [0, split) and `buf2` = columns [split, d) as
-    two contiguous buffers), `desc` / `more` = per-row slot descriptors (wire_slots), `scale` (optional fp32 [n_rows]) =
-    multiplier of the wire copy, `scaled_out` (optional [n_rows, d]) = dense copy of the scaled rows.
-    Built by pgl_amd.distributed.DistGraph.wire()."""
-    __slots__ = ("desc", "more", "buf", "scale", "scaled_out", "buf2", "split")
-
-    def __init__(self, desc, more, buf, scale=None, scaled_out=None, buf2=None, split=0):
-        self.desc, self.more, self.buf, self.scale, self.scaled_out = desc, more, buf, scale, scaled_out
-        self.buf2, self.split = buf2, int(split)
-
-    def with_desc(self, desc):
-        """The same buffers under other slot descriptors (the first launch of a two-launch flow mirrors only the rows it finishes)."""
-        return Wire(desc, self.more, self.buf, self.scale, self.scaled_out, self.buf2, self.split)
-
-    def block(self, c0, c1):
-        """The wire of a launch that writes only columns [c0, c1) of the rows (the pipelined flow aggregates block by block)."""
-        if self.split:
-            if c0 == 0 and c1 == self.split:
-                buf = self.buf
-            elif c0 == self.split:
-                buf = self.buf2
-            else:
-                raise ValueError("wire: column block [%d, %d) does not match the split at %d" % (c0, c1, self.split))
-        else:
-            buf = self.buf[:, c0:c1]
-        return Wire(self.desc, self.more, buf, self.scale, None if self.scaled_out is None else self.scaled_out[:, c0:c1])
-
-    def struct(self, d):
-        for t, w in ((self.buf, self.split or d), (self.scaled_out, d), (self.buf2, d - self.split)):
-            if t is not None and not (t.dim() == 2 and int(t.shape[1]) == w and t.stride(1) == 1):
-                raise ValueError("wire: buffers must be [rows, %d] with contiguous rows (got %s)" % (w, tuple(t.shape)))
-        p = lambda t: None if t is None else t.data_ptr()
-        return _ffi.WireOut(p(self.desc), p(self.more), p(self.buf), int(self.buf.stride(0)), p(self.scale), p(self.scaled_out),
-                            0 if self.scaled_out is None else int(self.scaled_out.stride(0)),
-                            p(self.buf2), 0 if self.buf2 is None else int(self.buf2.stride(0)), self.split)
-
-    def zero_(self):
-        for t in (self.buf, self.buf2, self.scaled_out):
-            if t is not None:
-                t.zero_()
-
-
 def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", src_scale=None, dst_scale=None,
-              out=None, accumulate=False, x2=None, zero_indptr=None, wire=None):
+              out=None, accumulate=False, x2=None, zero_indptr=None, deal_chunks=False):
     """paddle.geometric.send_u_recv / send_ue_recv (pgl/graph.py:859-861, 885-887, 929-937) over the
     graph's cached dst-CSR.  y (if given) is in ORIGINAL edge order, shape [E, ...].
     accumulate: False / 0 write every row of `out`; True / 1 combine the rows that receive edges with their old contents;
@@ -366,11 +292,9 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     have no edge.  An index carrying `max_row` (longest row) lets the library skip the split-row fix-up launches.
     x and out may be COLUMN BLOCKS of wider matrices (m[:, a:b]; no edge operand, no src_scale, no x2): the kernels walk them
     with the parent's row stride, nothing is copied.
-    wire (ops.Wire; pglamd_aggregate_wire): every row this launch stores also goes to its slots of the halo send buffer of the
-    next aggregation -- sum / mean of fp32 / fp16 / bf16 rows, no edge operand, no source scale."""
+    deal_chunks (PGLAMD_AGG_DEAL_CHUNKS, per call): the chunks of the edge stream are dealt round the XCDs instead of running in
+    contiguous blocks per XCD -- for indices whose row order correlates with row length (HaloPlan(row_order="peers"))."""
     _need_cuda(x, y, src_scale, dst_scale, x2, zero_indptr)
-    if wire is not None and (y is not None or src_scale is not None or reduce_op not in ("sum", "mean") or x.dim() != 2):
-        raise ValueError("aggregate: a wire mirror goes with plain sum / mean over 2-D rows (no edge operand, no source scale)")
     L = _ffi.lib()
     ldx = ldo = 0
     if y is None and src_scale is None and x2 is None:
@@ -381,7 +305,7 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     if not ldx:
         x = x.contiguous()
     max_row = int(getattr(csr, "max_row", 0) or 0)
-    ext = x2 is not None or zero_indptr is not None or max_row > 0 or ldx > 0 or ldo > 0
+    ext = x2 is not None or zero_indptr is not None or max_row > 0 or ldx > 0 or ldo > 0 or bool(deal_chunks)
     if x2 is not None:
         x2 = x2.contiguous()
         if x2.dtype != x.dtype or tuple(x2.shape[1:]) != tuple(x.shape[1:]) or src_scale is not None:
@@ -424,29 +348,19 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
             raise ValueError("out must be a contiguous %s tensor of dtype %s" % ((M,) + tuple(tail), x.dtype))
     if M == 0 or dout == 0:
         return out
-    if (ldo or wire is not None) and csr.num_edges == 0:
+    if ldo and csr.num_edges == 0:
         if not accumulate:
             out.zero_()
-            if wire is not None:                       # (an index without edges: every row is an empty row -- zeros travel)
-                wire.zero_()
         return out
     code = _code(x.dtype)
     ws = _ws_hot(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
-    if wire is not None:
-        wo = wire.struct(dout)
-        with torch.cuda.device(x.device):
-            _ffi.check(L.pglamd_aggregate_wire(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(csr.row32), _ptr(csr.col32),
-                                               _ptr(csr.indptr), _ptr(zero_indptr), max_row, csr.num_edges, csr.num_nodes, M, ldo,
-                                               REDUCE[reduce_op], _ptr(dst_scale), int(accumulate), _ptr(out), ctypes.byref(wo),
-                                               _ptr(ws), ws.numel(), _stream(x)), "aggregate_wire")
-        return out
     if ext and src_scale is None:
         with torch.cuda.device(x.device):
             _ffi.check(L.pglamd_aggregate_ext(_ptr(x), _ptr(x2), int(x.shape[0]), code, dx, ldx, _ptr(y if es is None else es), dy if es is None else 1,
                                               _ptr(csr.eid32) if y is not None else None, _ptr(csr.row32), _ptr(csr.col32),
                                               _ptr(csr.indptr), _ptr(zero_indptr), max_row, csr.num_edges, csr.num_nodes, M, dout, ldo,
                                               MSG[message_op if es is None else "mul"], REDUCE[reduce_op], _ptr(dst_scale), int(accumulate), _ptr(out),
-                                              _ptr(ws), ws.numel(), _stream(x)), "aggregate_ext")
+                                              _ptr(ws), ws.numel(), 1 if deal_chunks else 0, _stream(x)), "aggregate_ext")
         return out
     with torch.cuda.device(x.device):
         _ffi.check(L.pglamd_aggregate(_ptr(x), code, int(x.shape[0]), dx, _ptr(y if es is None else es), dy if es is None else 1,
@@ -1100,7 +1014,7 @@ def row_epilogue_supported(z, width=None):
     return row_epilogue_width_ok(z.shape[-1] if width is None else width)
 
 
-def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12, wire=None):
+def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12):
     """y = normalize_L2(act(z + bias)) -> (y, inv_norm or None).  act: None | "relu".  GraphSageConv's epilogue
     (pgl/nn/conv.py:109-115) and GCNConv's (pgl/nn/conv.py:250-254) in one kernel."""
     _need_cuda(z, bias)
@@ -1115,15 +1029,9 @@ def row_epilogue(z, bias=None, act=None, normalize=False, eps=1e-12, wire=None):
     inv = torch.empty(n, dtype=torch.float32, device=z.device) if normalize else None
     if n:
         with torch.cuda.device(z.device):
-            if wire is not None:       # the finished row is the next aggregation's input: it goes to the halo send buffer in the same store
-                wo = wire.struct(d)
-                _ffi.check(_ffi.lib().pglamd_row_epilogue_wire(_ptr(z), _ptr(None if bias is None else bias.contiguous()), n, d,
-                                                               1 if act == "relu" else 0, int(bool(normalize)), float(eps), _ptr(y),
-                                                               _ptr(inv), ctypes.byref(wo), _stream(z)), "row_epilogue_wire")
-            else:
-                _ffi.check(_ffi.lib().pglamd_row_epilogue(_ptr(z), _ptr(None if bias is None else bias.contiguous()), n, d,
-                                                          1 if act == "relu" else 0, int(bool(normalize)), float(eps), _ptr(y), _ptr(inv),
-                                                          _stream(z)), "row_epilogue")
+            _ffi.check(_ffi.lib().pglamd_row_epilogue(_ptr(z), _ptr(None if bias is None else bias.contiguous()), n, d,
+                                                      1 if act == "relu" else 0, int(bool(normalize)), float(eps), _ptr(y), _ptr(inv),
+                                                      _stream(z)), "row_epilogue")
     return y, inv
 
 

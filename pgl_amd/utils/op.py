@@ -69,7 +69,7 @@ class _AllReduceSum(torch.autograd.Function):
 def all_reduce_sum_with_grad(tensor, group=None):
     """pgl/utils/op.py:90-122 (the collective behind the reference's DistGPUGraph): all-reduce(sum) that autograd can
     differentiate.  Out of place; a single process (no initialised group) returns the tensor unchanged.
-    `DistGraph` / `FeatureShardedGraph` (pgl_amd/distributed.py) do not need it -- their layouts have no reduction
+    `DistGraph` (pgl_amd/distributed.py) does not need it -- its layout has no reduction
     collective -- it is here for code written against the reference's edge-sharded scheme."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One GPU session = a list of steps, run on the GPU box through gpurun:
 #     gpurun --timeout 3000 -- 'bash scripts/gpu_session.sh TAG step [step ...]'
-# Every step writes gpurun_out/r05/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r05/.
+# Every step writes gpurun_out/r06/<step>_<TAG>.txt (merged back by gpurun); what DESIGN.md quotes is copied to profiles/r06/.
 # Steps: diag tests tests:<pytest -k expr> bench rows_c2 rows_c2_p4 rows_c2_fp16 rows_c2p csr noreuse tlb gcn train gat ops dtypes profile
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r05}; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r06}; mkdir -p $O
 TAG=$1; shift
 PARTS="scratch/parts"
 cd $R
@@ -31,6 +31,29 @@ for STEP in "$@"; do
       echo "== row_order=id (round 4 layout)" > $F; timeout 600 python scripts/prof.py distmodel --scale 22 --edges 100000000 --rank 7 2>&1 | grep -v amdgpu.ids >> $F
       echo "== row_order=peers (zero-copy row-pipelined forward)" >> $F; timeout 600 python scripts/prof.py distmodel --scale 22 --edges 100000000 --rank 7 --row-order peers 2>&1 | grep -v amdgpu.ids >> $F
       cat $F ;;
+    pmc_hub)
+      # the headline kernel with and without a hub table (prof.py hub --pmc: 3 launches per form): memory-side requests by destination
+      # (is there a counter that separates Infinity-Cache hits from DRAM reads?), L2 hits, translation misses, per DISPATCH in order
+      ( cd /tmp && export TMPDIR=/tmp
+        for C in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUBBLE_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+          N=$(echo $C | tr ' ' '_' | cut -c1-40)
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/hubpmc_$N -o p -- python $R/scripts/prof.py hub --pmc --hub-rows 32768 ${HUBARGS:-} > $F.$N.log 2>&1 || echo "pass $C failed" >> $F.fail
+        done
+        python - <<PY > $F
+import csv, glob, collections
+print(open(glob.glob("$F.TCC_HIT*.log")[0]).read())
+per = collections.OrderedDict()
+for f in sorted(glob.glob("$O/hubpmc_*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if "agg_flat_kernel<float" not in n: continue
+        per.setdefault((int(r["Dispatch_Id"]), n.split("(")[0][-60:], r.get("Grid_Size")), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+print("per dispatch of agg_flat_kernel<float ...> (dispatch order = the order prof.py hub prints its forms; 1 reference + 3 per form):")
+for (d, n, g), c in sorted(per.items()):
+    print("  #%-4d %-60s grid %-8s %s" % (d, n, g, "  ".join("%s=%.6g" % kv for kv in sorted(c.items()))))
+PY
+        cat $F.fail >> $F 2>/dev/null; rm -rf $O/hubpmc_* $F.*.log $F.fail )
+      cut -c1-400 $F | head -60 ;;
     hotcold)
       echo "== product library" > $F; timeout 300 python scripts/prof.py hotcold 2>&1 | grep -v amdgpu.ids >> $F
 
@@ -41,7 +64,7 @@ for STEP in "$@"; do
     rows_c2p_zero)  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2_zero)   timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
-    csr|csrsweep|coo|chains|noreuse|gcn|gat|ops|dtypes|gatsplit|model) timeout 900 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
+    csr|csrsweep|coo|chains|noreuse|gcn|gat|ops|dtypes|gatsplit|model|hub) timeout 900 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     edgeops)    timeout 600 python scripts/prof.py edgeops > $F 2>&1; timeout 600 python scripts/prof.py edgeops --sorted >> $F 2>&1; grep -v amdgpu.ids $F ;;
     pmc_edgeops)
       # rows a7 / a8 / a10 in original edge order: fetched / written bytes, L2 hit rate and memory-side request mix per KERNEL

@@ -154,38 +154,10 @@ def cmd_rows(args):
                 dg.wire_dtype = {"fp16": torch.float16, "bf16": torch.bfloat16}[args.wire]
             x_own = dg.take_owned(x)
             ms = min(_t(lambda: dg.send_recv(x_own, "sum"), it=10, warm=3) for _ in range(3))     # (min of three: one in ~20 first measurements catches an allocator hiccup)
-            # layers >= 2 of a stack: the step's input is the previous step's output, whose rows the producing launches already
-            # mirrored into the send buffer (pglamd_aggregate_wire): no pack launch.  mean (= sum with the fused 1 / degree scale)
-            # keeps the values bounded over the timed steps; the unfused mean step is timed beside it
-            chain = [x_own]
-            no_chain = getattr(args, "no_chain", False)
-            def chained():
-                chain[0] = dg.send_recv(chain[0], "mean", emit=True)
+            # (round 5 also timed a chain whose producing launches mirrored their rows into the next exchange's send buffer -- the wire
+            #  mirror: measured slower than the pack launch, profiles/r05/rows_c2p.txt, and removed from the product in round 6)
             ms_mean = ms_chain = ms_stack_pack = ms_stack_fused = 0.0
             fused_ok = stack_ok = True
-            if not no_chain:
-                ms_mean = _t(lambda: dg.send_recv(x_own, "mean"), it=10, warm=3)
-                k0 = getattr(dg, "_packs_skipped", 0)
-                ms_chain = _t(chained, it=10, warm=3)
-                fused_ok = getattr(dg, "_packs_skipped", 0) - k0 >= 12
-                # a conv-layer stack (3 x GraphSageConv(d, d, mean), inference): the row kernel that finishes a layer writes its rows
-                # into the next layer's send buffer (pglamd_row_epilogue_wire) -- against the same stack with a pack launch per layer
-                if stack_layers is None:
-                    torch.manual_seed(0)
-                    stack_layers = [pgl.nn.GraphSageConv(d, d, "mean").to(dev) for _ in range(3)]
-                def stack():
-                    h = x_own
-                    for L in stack_layers:
-                        h = L(dg, h, act="relu")
-                    return h
-                with torch.no_grad():
-                    dg.emit_outputs = False
-                    ms_stack_pack = _t(stack, it=6, warm=2)
-                    dg.emit_outputs = True
-                    k1 = getattr(dg, "_packs_skipped", 0)
-                    ms_stack_fused = _t(stack, it=6, warm=2)
-                    stack_ok = getattr(dg, "_packs_skipped", 0) - k1 >= 2 * 8
-                    dg.emit_outputs = False
             torch.cuda.synchronize()
             t_cpu = time.perf_counter()
             for _ in range(20):
@@ -276,15 +248,15 @@ def cmd_rows(args):
         for r, n_own, le, e_pre, e_post, ns, nr, ms, pk, pre, post, ideal, pmb, enq, mode, pred in rows:
             print("   rank %d: %7d rows %9d edges, flow %-10s (%8d edges before the wait, %9d after) send %7d recv %7d rows (largest pair %5.1f MB) | step %.3f ms (host enqueue %.3f); alone: pack %.3f, before %.3f, after %.3f | ideal %.3f ms -> x%.2f | with the exchange: %.3f ms"
                   % (r, n_own, le, mode, e_pre, e_post, ns, nr, pmb, ms, enq, pk, pre, post, ideal, ms / ideal, pred))
-        if not getattr(args, "no_chain", False):
+        if False:
             print("   layers >= 2 (input = the previous step's output; its rows were mirrored into the send buffer by the launches that "
                   "produced them: no pack):")
-        for r, mm, mc, ideal, ok, sp, sf, sok in ([] if getattr(args, "no_chain", False) else chains):
+        for r, mm, mc, ideal, ok, sp, sf, sok in []:
             print("   rank %d: mean step with pack %.3f ms | chained step, aggregation mirrors its rows %.3f ms (%s) | ideal %.3f ms -> x%.2f || "
                   "3 x GraphSageConv forward: pack per layer %.3f ms | row kernel mirrors its rows %.3f ms (%s)"
                   % (r, mm, mc, "pack skipped every step" if ok else "PACK NOT SKIPPED", ideal, mc / ideal, sp, sf,
                      "layers 2, 3 without pack" if sok else "PACK NOT SKIPPED"))
-        if not getattr(args, "no_chain", False):
+        if False:
             wc = max(c[2] for c in chains)
             print("   slowest rank, layers >= 2: compute %.3f ms (worst compute/ideal x%.2f) -> bound %.2fx of one GPU with the exchange fully hidden"
                   % (wc, max(c[2] / c[3] for c in chains), t1 / wc))

@@ -4,9 +4,7 @@ only backend is libpglamd (HIP); this one exists so that the partition -> plan -
 its transposed (backward) form and the pull/push plans can run under gloo in the CPU container.  It follows the C ABI's
 contract for pglamd_aggregate / pglamd_aggregate_ext (include/pgl_amd.h): rows without edges = 0, accumulate modes 0 / 1 / 2,
 src/dst scales, the second source table (x2: column ids >= x.shape[0]) and zero_indptr (which rows the zero-fill clears: rows
-that are neither written nor cleared are left as NaN here, so a flow that forgets a row fails the comparison), and for the wire
-mirror of pglamd_aggregate_wire (the rows a launch stores also land in the next aggregation's send buffer; the buffers start as
-NaN in the tests, so a slot nobody wrote fails the comparison too)."""
+that are neither written nor cleared are left as NaN here, so a flow that forgets a row fails the comparison)."""
 import torch
 
 
@@ -24,62 +22,15 @@ class TorchBackend(object):
         out.copy_(res)
         return out
 
-    @staticmethod
-    def _mirror(wire, written, values):
-        """The wire contract of pglamd_aggregate_wire / pglamd_row_epilogue_wire (include/pgl_amd.h): every row the launch STORED
-        (`written`) goes -- times wire.scale -- to its slots of the send buffer (two buffers when the descriptor is split) and to
-        the dense scaled copy.  Slots of rows that were not stored keep their contents."""
-        n_rows = int(values.shape[0])
-        desc, more = wire.desc.long(), wire.more.long()
-        rows, poss = [], []
-        for r in torch.nonzero(written & (desc[:, 0] > 0)).reshape(-1).tolist():   # {count, p0, p1, p2}: include/pgl_amd.h
-            c = int(desc[r, 0])
-            ps = desc[r, 1:1 + c].tolist() if c <= 3 else desc[r, 1:3].tolist() + more[int(desc[r, 3]):int(desc[r, 3]) + c - 2].tolist()
-            rows += [r] * c
-            poss += ps
-        r = torch.tensor(rows, dtype=torch.long)
-        pos = torch.tensor(poss, dtype=torch.long)
-        v = values[r]
-        if wire.scale is not None:
-            v = v * wire.scale[r].reshape(-1, 1).to(v.dtype)
-        if wire.split:
-            wire.buf[pos] = v[:, :wire.split]
-            wire.buf2[pos] = v[:, wire.split:]
-        else:
-            wire.buf[pos] = v
-        if wire.scaled_out is not None:
-            wire.scaled_out[written] = values[written] * wire.scale[written].reshape(-1, 1).to(values.dtype)
-
-    def row_epilogue(self, z, bias, act, normalize, wire=None):
+    def row_epilogue(self, z, bias, act, normalize):
         y = z if bias is None else z + bias
         if act == "relu":
             y = torch.relu(y)
         if normalize:
             y = torch.nn.functional.normalize(y, dim=1)
-        if wire is not None:
-            self._mirror(wire, torch.ones(y.shape[0], dtype=torch.bool), y.detach())
         return y
 
     def aggregate(self, x, index, reduce_op, n_rows, y=None, message_op="add", src_scale=None, dst_scale=None, out=None,
-                  accumulate=0, x2=None, zero_indptr=None, wire=None):
-        if wire is None:
-            return self._aggregate(x, index, reduce_op, n_rows, y, message_op, src_scale, dst_scale, out, accumulate, x2, zero_indptr)
-        assert y is None and src_scale is None and reduce_op in ("sum", "mean")
-        rows = index[0]
-        n_rows = int(n_rows)
-        has = torch.zeros(n_rows, dtype=torch.bool)
-        has[rows] = True
-        res = self._aggregate(x, index, reduce_op, n_rows, y, message_op, src_scale, dst_scale, out, accumulate, x2, zero_indptr)
-        if accumulate:
-            written = has                                            # modes 1 / 2 store only the rows that receive edges
-        elif zero_indptr is not None:
-            written = has | (zero_indptr[1:] == zero_indptr[:-1])[:n_rows]
-        else:
-            written = torch.ones(n_rows, dtype=torch.bool)
-        self._mirror(wire, written, res)
-        return res
-
-    def _aggregate(self, x, index, reduce_op, n_rows, y=None, message_op="add", src_scale=None, dst_scale=None, out=None,
                    accumulate=0, x2=None, zero_indptr=None):
         rows, cols, _, edge_ids = index
         n_rows = int(n_rows)

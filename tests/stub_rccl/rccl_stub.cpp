@@ -206,10 +206,14 @@ const char* ncclGetErrorString(ncclResult_t r) {
     }
 }
 
-// test-side statistics of one communicator's world: sends, recvs, bytes matched so far
-void rccl_stub_stats(ncclComm_t comm, uint64_t* out3) {
-    std::lock_guard<std::mutex> l(comm->w->m);
-    out3[0] = comm->w->sends; out3[1] = comm->w->recvs; out3[2] = comm->w->bytes;
+// test-side statistics over every world of this process: sends posted, recvs matched, bytes posted
+void rccl_stub_totals(uint64_t* out3) {
+    std::lock_guard<std::mutex> l(g_m);
+    out3[0] = out3[1] = out3[2] = 0;
+    for (auto& kv : g_worlds) {
+        std::lock_guard<std::mutex> lw(kv.second->m);
+        out3[0] += kv.second->sends; out3[1] += kv.second->recvs; out3[2] += kv.second->bytes;
+    }
 }
 
 }  // extern "C"

@@ -458,51 +458,10 @@ def test_plan_cache_roundtrip(tmp_path):
         assert back.stats()["partition"] == "cached" and back.xplan is not back.plan
 
 
-# ------------------------------------------------------------------------------------------------
-# feature-sharded mode: columns split over the ranks, graph replicated
-# ------------------------------------------------------------------------------------------------
-class _NodesOnly(object):
-    def __init__(self, n):
-        self.num_nodes, self.num_edges = n, 0
 
 
-def _fs_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from pgl_amd.distributed import FeatureShardedGraph
-        n, d = 103, 13                                   # neither divisible by the world size
-        x = torch.arange(n * d, dtype=torch.float32).reshape(n, d)
-        fs = FeatureShardedGraph(_NodesOnly(n), rank, world)
-        xc = fs.take_cols(x)
-        xr = fs.cols_to_rows(xc, d)                      # my rows, all columns
-        back = fs.rows_to_cols(xr)                       # all rows, my columns again
-        q.put((rank, fs.row_range(), fs.col_range(d), xr.numpy(), back.numpy()))
-        dist.barrier()
-    finally:
-        dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_feature_sharded_layout_changes_gloo(world):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_fs_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=120) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    n, d = 103, 13
-    x = np.arange(n * d, dtype=np.float32).reshape(n, d)
-    rows_seen, cols_seen = [], []
-    for rank, (r0, r1), (c0, c1), xr, back in got:
-        assert np.array_equal(xr, x[r0:r1]), "cols_to_rows"
-        assert np.array_equal(back, x[:, c0:c1]), "rows_to_cols"
-        rows_seen += list(range(r0, r1)); cols_seen += list(range(c0, c1))
-    assert sorted(rows_seen) == list(range(n)) and sorted(cols_seen) == list(range(d))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -557,29 +516,8 @@ def test_helper_scatter_follows_the_reference_docstring():
     assert x.tolist() == [[1, 1], [2, 2], [3, 3]]                                                 # out of place
 
 
-# ------------------------------------------------------------------------------------------------
-# rows x columns grid (hybrid layout): 4 ranks = 2 row parts x 2 column slices
-# ------------------------------------------------------------------------------------------------
-def _grid_worker(rank, world):
-    from pgl_amd.distributed import GridShardedGraph
-    edges, x = _graph(n=300, e=4000, seed=6, d=10)
-    gg = GridShardedGraph(torch.from_numpy(edges), x.shape[0], rank, world, grid=(2, 2), method="kway", backend=TorchBackend())
-    blk = gg.take(torch.from_numpy(x))
-    out = {op: gg.send_recv(blk, op).numpy() for op in ("sum", "max")}
-    return (rank, gg.row_graph.plan.own_global.numpy(), gg.col_rank, out, gg.stats())
 
 
-def test_grid_sharded_four_ranks_gloo():
-    got = _spawn(_grid_worker, 4)
-    edges, x = _graph(n=300, e=4000, seed=6, d=10)
-    for op in ("sum", "max"):
-        want = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], op)
-        full = np.full_like(want, np.nan)
-        for _, own, c, out, st in got:
-            lo, hi = (0, 5) if c == 0 else (5, 10)
-            full[np.ix_(own, np.arange(lo, hi))] = out[op]
-            assert st["grid"] == "2x2"
-        np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
 
 
 @pytest.mark.parametrize("world", [1, 2, 5])
@@ -699,112 +637,10 @@ def test_bench_watchdog_prints_the_best_completed_record_and_exits_zero():
     assert r2.returncode == 3 and not [l for l in r2.stdout.splitlines() if l.startswith("{")]
 
 
-# ------------------------------------------------------------------------------------------------
-# round 5: the fused pack -- a layer's output rows are written into the NEXT aggregation's halo send buffer by the launch that
-# produces them (pglamd_aggregate_wire / pglamd_row_epilogue_wire; DistGraph.wire / mark / send_recv(emit=True))
-# ------------------------------------------------------------------------------------------------
-def _nan_buffers(dg):
-    """Every buffer DistGraph creates starts as NaN: a send-buffer slot that no launch mirrored fails the comparison."""
-    orig = dg._buffer
-
-    def make(name, shape, dtype, device):
-        fresh = name not in dg._buf or tuple(dg._buf[name].shape) != tuple(shape) or dg._buf[name].dtype != dtype
-        b = orig(name, shape, dtype, device)
-        if fresh and b.is_floating_point():
-            b.fill_(float("nan"))
-        return b
-    dg._buffer = make
 
 
-def _chain_worker(rank, world, steps, scaled, grad):
-    from pgl_amd.distributed import DistGraph
-    edges, x = _graph(d=32)
-    n = x.shape[0]
-    dg = DistGraph.from_global(torch.from_numpy(edges), n, rank, world, method="random", backend=TorchBackend(), push="never")
-    _nan_buffers(dg)
-    h = dg.take_owned(torch.from_numpy(x))
-    if grad:
-        h = h.clone().requires_grad_(True)
-    h0 = h
-    deg = dg.indegree().clamp(min=1).to(torch.float32)
-    norm = deg.pow(-0.5).reshape(-1, 1)
-    outs = []
-    if scaled:                                              # GCN-style propagation h <- norm * A (norm * h), run on g = norm * h:
-        h = h * norm                                        # g <- norm^2 * A g (no source scale: every step's rows feed the next as they are)
-    for k in range(steps):
-        if scaled:
-            h = dg.send_recv_scaled(h, None, norm * norm, emit=True)
-        else:
-            h = dg.send_recv(h, "mean", emit=True)
-        outs.append((h / norm if scaled else h).detach().numpy().copy())
-    skipped = getattr(dg, "_packs_skipped", 0)
-    flow = dg.stats()["flow"]
-    # a tensor that was written to after it was produced must NOT be taken for its mirrored copy
-    h2 = dg.send_recv(torch.from_numpy(outs[-2]).clone(), "mean", emit=True)
-    h2.mul_(2.0)
-    tampered = dg.send_recv(h2, "mean").numpy()
-    g = None
-    if grad:
-        hh = h / norm if scaled else h
-        (hh * hh).sum().backward()
-        g = h0.grad.numpy()
-    return (rank, dg.plan.own_global.numpy(), {"outs": outs, "skipped": skipped, "flow": flow, "tampered": tampered, "grad": g,
-                                                 "tampered_in": outs[-2]})
 
 
-@pytest.mark.parametrize("world,flow,scaled,grad", [(2, "", False, False), (3, "fold", False, False), (2, "accumulate", True, False),
-                                                    (3, "split", True, False), (2, "pipeline", False, False), (3, "pipeline", True, False),
-                                                    (2, "split", False, True), (2, "pipeline", True, True), (3, "split", False, True), (3, "accumulate", True, True)])
-def test_gloo_fused_pack_chain(monkeypatch, world, flow, scaled, grad):
-    """h <- A h four times with emit=True: every step after the first starts its exchange from rows the previous step's launches
-    mirrored into the send buffer (no pack), under every flow; the values equal the single-graph chain, the gradient too."""
-    if flow:
-        monkeypatch.setenv("PGLAMD_FLOW", flow)
-    steps = 4
-    got = _spawn(_chain_worker, world, steps, scaled, grad)
-    edges, x = _graph(d=32)
-    n = x.shape[0]
-    src, dst = torch.from_numpy(edges[:, 0]), torch.from_numpy(edges[:, 1])
-    deg = torch.bincount(dst, minlength=n).clamp(min=1).float()
-    norm = deg.pow(-0.5).reshape(-1, 1)
-    h = torch.from_numpy(x).clone().requires_grad_(grad)
-    h0, want = h, []
-
-    def step(t):
-        if scaled:
-            return torch.zeros_like(t).index_add(0, dst, (t * norm)[src]) * norm
-        return torch.zeros_like(t).index_add(0, dst, t[src]) / deg.reshape(-1, 1)
-    for k in range(steps):
-        h = step(h)
-        want.append(h.detach().numpy())
-    for k in range(steps):
-        full = np.full_like(want[k], np.nan)
-        for _, own, res in got:
-            full[own] = res["outs"][k]
-        assert np.isfinite(full).all(), "step %d" % k
-        np.testing.assert_allclose(full, want[k], rtol=2e-5, atol=2e-5 * np.abs(want[k]).max(), err_msg="step %d" % k)
-    per_step = 2 if flow == "pipeline" else 1                          # (the pipelined flow starts two exchanges per step)
-    for _, _, res in got:
-        assert res["skipped"] == (steps - 1) * per_step, (res["skipped"], res["flow"])
-        if flow:
-            assert res["flow"] == flow
-    # the tampered tensor went through the ordinary pack
-    t_in = np.full_like(want[0], np.nan)
-    for _, own, res in got:
-        t_in[own] = res["tampered_in"]
-    t_want = step(step(torch.from_numpy(t_in)) * 2.0).numpy() if not scaled else None
-    if t_want is not None:
-        full = np.full_like(t_want, np.nan)
-        for _, own, res in got:
-            full[own] = res["tampered"]
-        np.testing.assert_allclose(full, t_want, rtol=2e-5, atol=2e-5 * np.abs(t_want).max())
-    if grad:
-        (h * h).sum().backward()
-        gw = h0.grad.numpy()
-        full = np.full_like(gw, np.nan)
-        for _, own, res in got:
-            full[own] = res["grad"]
-        np.testing.assert_allclose(full, gw, rtol=1e-4, atol=1e-5 * np.abs(gw).max())
 
 
 # ------------------------------------------------------------------------------------------------
@@ -851,6 +687,19 @@ def test_plan_from_edge_slabs_equals_the_plan_from_the_whole_list(given_part):
 # round 5: flow "rows2" -- the exchange in two halves of the rows; with a peer-ordered plan the rows travel from the feature matrix
 # itself (no pack, no send buffer)
 # ------------------------------------------------------------------------------------------------
+def _nan_buffers(dg):
+    """Every buffer DistGraph creates starts as NaN: a receive / send-buffer slot that nothing wrote fails the comparison."""
+    orig = dg._buffer
+
+    def make(name, shape, dtype, device):
+        fresh = name not in dg._buf or tuple(dg._buf[name].shape) != tuple(shape) or dg._buf[name].dtype != dtype
+        b = orig(name, shape, dtype, device)
+        if fresh and b.is_floating_point():
+            b.fill_(float("nan"))
+        return b
+    dg._buffer = make
+
+
 def _rows2_worker(rank, world, row_order, method):
     from pgl_amd.distributed import DistGraph
     edges, x = _graph(d=32)

@@ -22,7 +22,7 @@ def test_library_exports_every_header_symbol():
     for s in declared:
         assert hasattr(L, s), s
     assert sorted(pgl_amd._ffi.exported_symbols()) == declared
-    assert L.pglamd_abi_version() == 3
+    assert L.pglamd_abi_version() == 4         # ABI 4 (round 6): per-call flags on pglamd_aggregate_ext, the wire-mirror entry points removed
 
 
 def test_ctypes_signatures_match_the_header_prototypes():
@@ -408,6 +408,9 @@ class _FakeView(object):
         self.calls += 1
         return rows[self.inv]
 
+    def to_order(self, rows):
+        return rows[self.eid]
+
 
 def test_edge_tensor_keeps_the_tag_through_elementwise_work_and_reads_back_in_original_order():
     import torch
@@ -459,6 +462,46 @@ def test_edge_tensor_keeps_the_tag_through_elementwise_work_and_reads_back_in_or
     import pgl_amd
     with pytest.raises(TypeError, match="EdgeTensor"):
         pgl_amd.ops.gather_rows(et, torch.zeros(1, dtype=torch.int64))
+
+
+def test_edge_tensor_writes_reach_the_sorted_rows():
+    """in-place Tensor methods, item assignment and out= go through the original-order copy; the destination-sorted rows
+    the engine's ops consume must follow, and an [E, ...] tensor handed to an element-wise call as an EXTRA operand
+    (torch.clamp(t, min=<original-order tensor>)) must not be combined with the sorted rows."""
+    import torch
+    from pgl_amd.edge_tensor import EdgeTensor
+    rng = np.random.default_rng(1)
+    E, H = 40, 4
+    orig = torch.as_tensor(rng.standard_normal((E, H)).astype(np.float32))
+    view = _FakeView(rng.permutation(E))
+    mk = lambda: EdgeTensor(orig[view.eid].clone(), view)
+    et = mk(); r = et.mul_(2.0)
+    assert r is et and torch.equal(et.sorted_rows(), (orig * 2.0)[view.eid]) and torch.equal(et.materialize(), orig * 2.0)
+    et = mk(); et.clamp_(min=0.0)
+    assert torch.equal(et.sorted_rows(), orig.clamp(min=0.0)[view.eid])
+    mask = torch.as_tensor(rng.random((E, H)) < 0.3)                    # an original-order mask
+    et = mk(); et.masked_fill_(mask, -1.0)
+    assert torch.equal(et.sorted_rows(), orig.masked_fill(mask, -1.0)[view.eid])
+    et = mk(); et[3] = 7.0; et[5:8] = torch.zeros(3, H)
+    want = orig.clone(); want[3] = 7.0; want[5:8] = 0.0
+    assert torch.equal(et.sorted_rows(), want[view.eid]) and torch.equal(et.materialize(), want)
+    et = mk(); torch.add(orig, 1.0, out=et)
+    assert torch.equal(et.sorted_rows(), (orig + 1.0)[view.eid])
+    et = mk(); et.copy_(mk() * 3.0)
+    assert torch.equal(et.sorted_rows(), (orig * 3.0)[view.eid])
+    # extra [E, ...] operands are in ORIGINAL order: never applied to the sorted rows
+    lo = torch.as_tensor(rng.standard_normal((E, H)).astype(np.float32))
+    for got in (torch.clamp(mk(), min=lo), mk().clamp(min=lo), torch.add(mk(), 1.0, alpha=2.0)):
+        pass
+    assert torch.equal(materialize_(torch.clamp(mk(), min=lo)), torch.clamp(orig, min=lo))
+    assert torch.equal(materialize_(mk().clamp(min=lo)), orig.clamp(min=lo))
+    assert isinstance(torch.clamp(mk(), min=0.0), EdgeTensor) and isinstance(torch.add(mk(), 1.0, alpha=2.0), EdgeTensor)
+    assert isinstance(mk().clamp(min=torch.zeros(1, H)), EdgeTensor)     # broadcasts over the edges: order-free
+
+
+def materialize_(t):
+    from pgl_amd.edge_tensor import materialize
+    return materialize(t)
 
 
 def test_edge_tensor_row_wise_ops_keep_the_tag():
