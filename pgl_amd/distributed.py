@@ -1605,7 +1605,7 @@ class DistGraph(object):
                x_own.dtype in (torch.float32, torch.float16, torch.bfloat16)) else (lambda: B.aggregate(x_own, self._index("xsend"), "sum", xp.n_send)) if xp.n_send else (lambda: None)
         out = torch.empty_like(x_own)
         piped = self._pipelined("x", False, True, x_own, row_bytes)
-        if piped and self._rows2_ok("x", False, True, x_own, None, None):
+        if piped and self._rows2_ok("x", False, True, x_own):
             flow, r2 = "rows2", self._rows2()
             zero = self._zero_copy(x_own)
             in2 = self._buffer("in_rows2", (xp.n_recv, d), x_own.dtype, x_own.device)

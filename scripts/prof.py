@@ -689,6 +689,7 @@ def cmd_hub(args):
     Prints ms per launch; `--pmc` runs three launches of each form for a counter pass (FETCH_SIZE, TCC_HIT/MISS, UTCL1)."""
     import torch
     pgl, dev, g = _c2(with_src_index=False, scale=args.scale, E=args.edges)
+    pgl.ops._HUB_TABLE = False                       # (the product's own hub table off: this command times the forms by hand)
     N, E = g.num_nodes, g.num_edges
     gen = torch.Generator(device=dev); gen.manual_seed(7)
     x = torch.randn(N, 128, generator=gen, device=dev)
@@ -743,6 +744,12 @@ def cmd_hub(args):
     x4 = x[order_in].contiguous()
     t4 = _t(lambda: pgl.ops.aggregate(x4, c4, "sum", N), it=it, warm=warm)
     print("(iv) whole graph relabelled by total degree: %.3f ms (x%.3f)" % (t4, t0 / t4), flush=True)
+    pgl.ops._HUB_TABLE = True
+    pgl.ops._HUB_MIN_EDGES = 0
+    t5 = _t(lambda: g.send_recv(x, "sum"), it=it, warm=warm)
+    ok = torch.equal(g.send_recv(x, "sum"), want)
+    print("(v)  the product path, Graph.send_recv with the hub table on (plan cached on the index, table gathered per call): %.3f ms (x%.3f); result %s"
+          % (t5, t0 / t5, "identical" if ok else "DIFFERS"), flush=True)
 
 
 def cmd_chains(args):

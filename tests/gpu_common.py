@@ -32,8 +32,107 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-def close(got, want, scale=1.0, rtol=RTOL):
-    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * scale)
+EPS = {np.dtype(np.float32): float(np.finfo(np.float32).eps), np.dtype(np.float64): float(np.finfo(np.float64).eps),
+       np.dtype(np.float16): float(np.finfo(np.float32).eps)}      # 16-bit STORAGE accumulates in fp32 (the output rounding is added separately)
+
+
+def reassociation_bound(abs_terms, n_terms, slack=4.0, eps=None):
+    """n * eps * sum|t_i|, per output element (Higham 4.4, first order); `slack` covers the rounding of the terms themselves
+    (a product, a division by the degree, a scale)."""
+    eps = EPS[np.dtype(np.float32)] if eps is None else eps
+    return slack * np.maximum(np.asarray(n_terms, np.float64), 1.0) * eps * np.asarray(abs_terms, np.float64) + float(np.finfo(np.float32).tiny)
+
+
+def _assert_elementwise(err, bound, want, what):
+    bad = err > bound
+    if bad.any():
+        i = np.unravel_index(np.argmax(np.where(bad, err / np.maximum(bound, 1e-300), 0.0)), err.shape)
+        raise AssertionError("%s: element %s: |err| %.3e > bound %.3e (want %.6e); %d of %d elements out of bound"
+                             % (what or "parity", i, err[i], bound[i], np.asarray(want, np.float64)[i], int(bad.sum()), bad.size))
+
+
+def close_terms(got, want, abs_terms, n_terms, slack=4.0, eps=None, what=""):
+    """`got` against ANOTHER finite-precision evaluation `want` of the same sums (the oracle's serial fp32 loop, a torch op, the
+    engine's own other path): each lies within the re-association bound of the exact result, so they differ by at most twice it --
+    per element, scaled by that element's own terms (no max|want| anywhere)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    bound = 2.0 * np.broadcast_to(reassociation_bound(abs_terms, n_terms, slack, eps), got.shape)
+    _assert_elementwise(np.abs(got - want), bound, want, what)
+
+
+def close_rel(got, want, rtol, what=""):
+    """Purely relative, per element (element-wise maps: one or two roundings each -- send_uv, degree_norm, a cast)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    _assert_elementwise(np.abs(got - want), rtol * np.abs(want) + float(np.finfo(np.float32).tiny), want, what)
+
+
+def close_rows(got, want, rtol=RTOL, atol_row=None, what=""):
+    """For COMPOSITE results (a layer's output, a gradient through an attention chain) whose per-element term magnitudes are not at
+    hand: |got - want| <= rtol * |want| + atol_row * (largest |want| of the SAME ROW).  The absolute part is tied to the row the element
+    lives in -- one node's (or edge's) own feature vector -- never to the largest value of the whole tensor: a row 100x smaller than the
+    largest row is held to an error 100x smaller.  (Aggregations, segment ops, send_uv / softmax are held per ELEMENT: check_aggregate,
+    close_terms, close_rel.)"""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (got.shape, want.shape)
+    atol_row = rtol if atol_row is None else atol_row
+    w2 = np.abs(want).reshape(want.shape[0], -1) if want.ndim >= 2 else np.abs(want).reshape(-1, 1)
+    row = w2.max(1).reshape((want.shape[0],) + (1,) * (want.ndim - 1)) if want.ndim >= 1 and want.size else 0.0
+    _assert_elementwise(np.abs(got - want), rtol * np.abs(want) + atol_row * row + float(np.finfo(np.float32).tiny), want, what)
+
+
+def fp64_terms(x, src, dst, op="sum", out_size=None, y=None, mop="add"):
+    """The fp64 evaluation of send_u_recv / send_ue_recv (the oracle's numpy restatement run in float64: oracle/ref_ops.py
+    np_send_u_recv / np_send_ue_recv) together with what bounds a finite-precision evaluation of it, per output
+    element: abs_terms = the sum (mean: the mean) of |message| over the element's in-edges, n_terms = how many there are
+    (+ 1 per extra rounding: the message op, the division of a mean).  -> (want64, abs_terms64, n_terms)"""
+    x64 = np.asarray(x, np.float64)
+    src, dst = np.asarray(src, np.int64), np.asarray(dst, np.int64)
+    m = int(out_size) if (out_size is not None and int(out_size) > 0) else x64.shape[0]
+    red = op if op in ("sum", "mean") else "sum"
+    if y is None:
+        want = R.np_send_u_recv(x64, src, dst, op, out_size)
+        absx = R.np_send_u_recv(np.abs(x64), src, dst, red, out_size)
+    else:
+        y64 = np.asarray(y, np.float64)
+        want = R.np_send_ue_recv(x64, y64, src, dst, mop, op, out_size)
+        absx = R.np_send_ue_recv(np.abs(x64), np.abs(y64), src, dst, mop if mop in ("mul", "div") else "add", red, out_size)
+    deg = np.bincount(dst, minlength=m)[:m].astype(np.float64).reshape((m,) + (1,) * (want.ndim - 1))
+    n_terms = deg + (1.0 if op == "mean" else 0.0) + (1.0 if y is not None else 0.0)
+    return want, absx, np.broadcast_to(n_terms, want.shape)
+
+
+_OUT_ROUND = {"fp16": 2.0 ** -11, "bf16": 2.0 ** -8}
+
+
+def check_aggregate(got, x, src, dst, op="sum", out_size=None, y=None, mop="add", want=None, slack=4.0, storage=None, what=""):
+    """One aggregation result against (1) the fp64 evaluation, per element inside the re-association bound of ITS OWN terms, and
+    (2) the oracle's result `want` (the C port of the Paddle CPU kernel: serial COO loop in the storage type), per element inside
+    twice that bound.  max / min involve no rounding: exact.  Integer features: exact.  storage "fp16" / "bf16": the features are
+    stored in 16 bits, summed in fp32 and the result rounded to 16 bits once (+ half an ulp of the output); float64 features are
+    held to the fp64 epsilon."""
+    got_a = np.asarray(got)
+    if np.issubdtype(np.asarray(x).dtype, np.integer) and op != "mean":
+        exact = R.np_send_u_recv(np.asarray(x), src, dst, op, out_size) if y is None else R.np_send_ue_recv(np.asarray(x), np.asarray(y), src, dst, mop, op, out_size)
+        assert np.array_equal(got_a, exact), what or "integer aggregation must be exact"
+        return
+    want64, absx, n_terms = fp64_terms(x, src, dst, op, out_size, y, mop)
+    eps = EPS[np.dtype(np.float64)] if np.asarray(x).dtype == np.float64 else EPS[np.dtype(np.float32)]
+    if op in ("max", "min") and y is None:
+        assert np.array_equal(got_a.astype(np.float64), want64), what or ("%s of stored values involves no rounding: exact" % op)
+        if want is not None:
+            assert np.array_equal(got_a, np.asarray(want))
+        return
+    if op in ("max", "min"):                                   # (the message op rounds once)
+        bound = 2.0 * eps * np.abs(want64) + float(np.finfo(np.float32).tiny)
+    else:
+        bound = reassociation_bound(absx, n_terms, slack, eps)
+    if storage in _OUT_ROUND:
+        bound = bound + _OUT_ROUND[storage] * np.abs(want64) * 1.01
+    _assert_elementwise(np.abs(got_a.astype(np.float64) - want64), bound, want64, (what + " vs fp64").strip())
+    if want is not None:
+        _assert_elementwise(np.abs(got_a.astype(np.float64) - np.asarray(want, np.float64)), 2.0 * bound, want, (what + " vs the oracle").strip())
 
 
 def rand_graph(n, e, seed, hub=None):
@@ -81,11 +180,8 @@ def assert_within_fp32_reassociation(got, want64, abs_terms64, n_terms, slack=4.
     any order of summing n fp32 terms t_i is within  n_terms * eps32 * sum|t_i|  of the exact sum (first-order bound,
     Higham 4.4); `slack` covers the rounding of the terms themselves.  Unlike an atol tied to max|want| this bound
     scales with each output element's own term magnitudes, so small outputs are held to a small absolute error."""
-    eps = np.finfo(np.float32).eps
-    bound = slack * np.maximum(n_terms, 1) * eps * abs_terms64 + np.finfo(np.float32).tiny
-    err = np.abs(got.astype(np.float64) - want64)
-    worst = np.unravel_index(np.argmax(err - bound), err.shape)
-    assert (err <= bound).all(), "element %s: |err| %.3e > bound %.3e (want %.6e)" % (worst, err[worst], bound[worst], want64[worst])
+    bound = np.broadcast_to(reassociation_bound(abs_terms64, n_terms, slack), np.shape(want64))
+    _assert_elementwise(np.abs(np.asarray(got, np.float64) - np.asarray(want64, np.float64)), bound, want64, "vs fp64")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -34,20 +34,20 @@ def test_gcn_gat_sage_layers(pgl):
             layer.bias.normal_()
             got = host(layer(g, xt))
         want = R.np_gcn_conv(edges, n, x, host(layer.linear.weight).T, host(layer.bias))
-        close(got, want, scale=np.abs(want).max(), rtol=5e-5)
+        close_rows(got, want, rtol=5e-5)
     gat = pgl.nn.GATConv(32, 8, feat_drop=0.0, attn_drop=0.0, num_heads=4).cuda()
     with torch.no_grad():
         got = host(gat(g, xt))
     want = R.np_gat_conv(edges, n, x, host(gat.linear.weight).T, host(gat.linear.bias), host(gat.weight_src),
                          host(gat.weight_dst), 4, 8)
-    close(got, want, scale=np.abs(want).max(), rtol=5e-5)
+    close_rows(got, want, rtol=5e-5)
     sage = pgl.nn.GraphSageConv(32, 16, aggr_func="mean").cuda()
     with torch.no_grad():
         got = host(sage(g, xt))
     nb = R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "mean")
     o = x @ host(sage.self_linear.weight).T + host(sage.self_linear.bias) + nb @ host(sage.neigh_linear.weight).T + host(sage.neigh_linear.bias)
     want = o / np.maximum(np.linalg.norm(o, axis=1, keepdims=True), 1e-12)
-    close(got, want, scale=1.0, rtol=5e-5)
+    close_rows(got, want, rtol=5e-5)
 
 
 @pytest.mark.parametrize("din,dout", [(32, 16), (16, 32)])
@@ -69,10 +69,10 @@ def test_gcn_layer_fused_norm_forward_backward_vs_dense(pgl, din, dout):
     W = layer.linear.weight.detach().double().T
     yd = An @ (xd @ W) + layer.bias.detach().double()
     (yd * w.double()).sum().backward()
-    close(host(layer(g, x).detach()), host(yd.detach().float()), scale=float(yd.abs().max()), rtol=5e-5)
-    close(host(x.grad), host(xd.grad.float()), scale=float(xd.grad.abs().max()), rtol=5e-5)
+    close_rows(host(layer(g, x).detach()), host(yd.detach().float()), rtol=5e-5)
+    close_rows(host(x.grad), host(xd.grad.float()), rtol=5e-5)
     gw = (An @ xd.detach()).T @ w.double()
-    close(host(layer.linear.weight.grad.T), host(gw.float()), scale=float(gw.abs().max()), rtol=5e-5)
+    close_rows(host(layer.linear.weight.grad.T), host(gw.float()), rtol=5e-5)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -94,17 +94,17 @@ def test_gat_fused_matches_unfused_and_oracle(pgl, H, D):
     logits = alpha.copy()
     alpha = R.np_edge_softmax(edges, n, alpha).reshape(-1, H, 1)
     want = R.np_send_ue_recv(f, alpha, edges[:, 0], edges[:, 1], "mul", "sum")
-    close(host(out), want, scale=np.abs(want).max())
+    close_rows(host(out), want)
     # positive-part statistics (what the backward turns into d a_dst): the same sums restricted to edges with pre > 0
     pos = (R.np_send_uv(a_s, a_d, edges[:, 0], edges[:, 1], "add") > 0).astype(np.float32).reshape(-1, H, 1)
-    close(host(out_pos), R.np_send_ue_recv(f, alpha * pos, edges[:, 0], edges[:, 1], "mul", "sum"), scale=np.abs(want).max())
+    close_rows(host(out_pos), R.np_send_ue_recv(f, alpha * pos, edges[:, 0], edges[:, 1], "mul", "sum"))
     want_sp = R.np_send_ue_recv(np.ones((n, H, 1), np.float32), alpha * pos, edges[:, 0], edges[:, 1], "mul", "sum").reshape(n, H)
-    close(host(s_pos), want_sp, scale=1.0)
+    close_rows(host(s_pos), want_sp)
     # unfused engine path
     al = torch.nn.functional.leaky_relu(g.send_uv(dev(a_s), dev(a_d), "add"), 0.2)
     al = pgl.nn.functional.edge_softmax(g, al).reshape(-1, H, 1)
     unf = g.send_ue_recv(dev(f), al, "mul", "sum")
-    close(host(out), host(unf), scale=float(unf.abs().max()))
+    close_rows(host(out), host(unf))
     # statistics: row max of the logits, and rows without in-edges are exactly zero
     has = np.bincount(edges[:, 1], minlength=n) > 0
     want_max = R.np_segment(logits[np.argsort(edges[:, 1], kind="stable")], np.sort(edges[:, 1]), "max")
@@ -116,7 +116,7 @@ def test_gat_fused_matches_unfused_and_oracle(pgl, H, D):
     assert torch.equal(inf1, pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2))
     again = pgl.ops.gat_aggregate(dev(f), dev(a_s), dev(a_d), g.adj_dst_index.csr, 0.2, return_stats=True)
     assert all(torch.equal(a, b) for a, b in zip((out, mx, sm, out_pos, s_pos), again))
-    close(host(inf1), host(out), scale=float(out.abs().max()), rtol=1e-6)
+    close_rows(host(inf1), host(out), rtol=1e-6)
 
 
 def test_gatconv_eval_uses_fused_path_and_matches_training_path(pgl):
@@ -130,7 +130,7 @@ def test_gatconv_eval_uses_fused_path_and_matches_training_path(pgl):
         fused = gat(g, x)
     gat.fused = False
     unfused = gat(g, x.clone().requires_grad_(True))            # the reference's four-op composition
-    close(host(fused), host(unfused.detach()), scale=float(unfused.abs().max()))
+    close_rows(host(fused), host(unfused.detach()))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -169,7 +169,7 @@ def test_gat_fused_backward_matches_unfused_autograd(pgl, H, D):
         (out * w).sum().backward()
         grads.append([host(out.detach())] + [host(t.grad) for t in (f, a_s, a_d)])
     for a, b, name in zip(grads[0], grads[1], ("out", "d_feature", "d_attn_src", "d_attn_dst")):
-        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(b).max()), err_msg=name)
+        close_rows(a, b, rtol=2e-4, atol_row=2e-5, what=name)
 
 
 def test_gat_fused_dropout_is_consistent_between_forward_and_backward(pgl):
@@ -217,16 +217,16 @@ def test_more_conv_layers_vs_dense_formulas(pgl):
     An = nrm[:, None] * A * nrm[None, :]
     xd = x.double()
     with torch.no_grad():
-        close(host(pgl.nn.LightGCNConv()(g, x)), host((An @ xd).float()), scale=3.0)
+        close_rows(host(pgl.nn.LightGCNConv()(g, x)), host((An @ xd).float()))
         h = xd
         for _ in range(3):
             h = 0.8 * (An @ h) + 0.2 * xd
-        close(host(pgl.nn.APPNP(alpha=0.2, k_hop=3)(g, x)), host(h.float()), scale=3.0)
+        close_rows(host(pgl.nn.APPNP(alpha=0.2, k_hop=3)(g, x)), host(h.float()))
         sgc = pgl.nn.SGCConv(d, 7, k_hop=2).cuda()
-        close(host(sgc(g, x)), host(((An @ (An @ xd)) @ sgc.linear.weight.double().T).float()), scale=3.0, rtol=5e-5)
+        close_rows(host(sgc(g, x)), host(((An @ (An @ xd)) @ sgc.linear.weight.double().T).float()), rtol=5e-5)
         gin = pgl.nn.GINConv(d, 9, activation="relu", init_eps=0.3).cuda()
         z = gin.linear2(torch.relu(gin.layer_norm(gin.linear1((A @ xd + 1.3 * xd).float()))))
-        close(host(gin(g, x)), host(z), scale=float(z.abs().max()), rtol=5e-5)
+        close_rows(host(gin(g, x)), host(z), rtol=5e-5)
         g2 = pgl.nn.GCNII(d, k_hop=2, dropout=0.0).cuda().eval()
         assert torch.isfinite(g2(g, x)).all()
 
@@ -252,7 +252,7 @@ def test_gatv2_and_transformer_conv_udf_path(pgl):
     logits = torch.einsum("vhd,uhd->vuh", q, k).masked_fill(~mask[:, :, None], float("-inf"))
     att = torch.nan_to_num(torch.softmax(logits, dim=1), nan=0.0)
     want = torch.einsum("vuh,uhd->vhd", att, v).reshape(n, H * D)
-    close(host(out.detach()), host(want.float()), scale=float(want.abs().max()), rtol=5e-5)
+    close_rows(host(out.detach()), host(want.float()), rtol=5e-5)
     out.square().sum().backward()
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
     # --- GATv2
@@ -264,7 +264,7 @@ def test_gatv2_and_transformer_conv_udf_path(pgl):
     logits = (pair * gv.attn.double()).sum(-1).masked_fill(~mask[:, :, None], float("-inf"))
     att = torch.nan_to_num(torch.softmax(logits, dim=1), nan=0.0)
     want = torch.einsum("vuh,uhd->vhd", att, f).reshape(n, H * D)
-    close(host(out.detach()), host(want.float()), scale=float(want.abs().max()), rtol=5e-5)
+    close_rows(host(out.detach()), host(want.float()), rtol=5e-5)
     out.square().sum().backward()
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().sum()) > 0
 
@@ -294,9 +294,9 @@ def test_tall_linear_split_reduction_gradient(pgl):
         x2 = x.detach().clone().requires_grad_(True)
         ct = torch.randn(n, 10, device="cuda")
         (lin(x) * ct).sum().backward(); (ref(x2) * ct).sum().backward()
-        close(host(x.grad), host(x2.grad), scale=float(x2.grad.abs().max()))
-        close(host(lin.weight.grad), host(ref.weight.grad), scale=float(ref.weight.grad.abs().max()), rtol=1e-4)
-        close(host(lin.bias.grad), host(ref.bias.grad), scale=float(ref.bias.grad.abs().max()), rtol=1e-4)
+        close_rows(host(x.grad), host(x2.grad))
+        close_rows(host(lin.weight.grad), host(ref.weight.grad), rtol=1e-4)
+        close_rows(host(lin.bias.grad), host(ref.bias.grad), rtol=1e-4)
 
 
 def test_gat_backward_variants_agree(pgl):
@@ -320,7 +320,7 @@ def test_gat_backward_variants_agree(pgl):
         pgl.ops._GAT_BWD_EDGE_BUFFER, pgl.ops._GAT_POS_STATS = keep
     for other in grads[1:]:
         for a, b in zip(grads[0], other):
-            close(a, b, scale=np.abs(b).max(), rtol=2e-5)
+            close_rows(a, b, rtol=2e-5)
 
 
 def test_transformer_conv_fused_path_equals_udf_path(pgl):
@@ -344,9 +344,9 @@ def test_transformer_conv_fused_path_equals_udf_path(pgl):
             return getattr(self._g, name)
     out2 = layer(_NoSddmm(g), x)
     out2.sum().backward()
-    close(host(out), host(out2), scale=float(out2.abs().max()), rtol=2e-5)
-    close(host(gx), host(x.grad), scale=float(x.grad.abs().max()), rtol=1e-4)
-    close(host(gw), host(layer.k.weight.grad), scale=float(layer.k.weight.grad.abs().max()), rtol=1e-4)
+    close_rows(host(out), host(out2), rtol=2e-5)
+    close_rows(host(gx), host(x.grad), rtol=1e-4)
+    close_rows(host(gw), host(layer.k.weight.grad), rtol=1e-4)
 
 
 def test_c3_fused_gat_forward_vs_oracle_and_fp64(pgl, c3):
@@ -369,7 +369,7 @@ def test_c3_fused_gat_forward_vs_oracle_and_fp64(pgl, c3):
     alpha = R.np_edge_softmax(sub, n, logit).reshape(-1, H, 1)
     want = R.np_send_ue_recv(fa, alpha, sub[:, 0], sub[:, 1], "mul", "sum")
     got = host(out)
-    np.testing.assert_allclose(got[rows], want[rows], rtol=1e-5, atol=1e-5 * np.abs(want[rows]).max())
+    close_rows(got[rows], want[rows], rtol=1e-5, atol_row=1e-5)
     # (2) every row against the fp64 edge-by-edge formula, with a PER-ELEMENT reassociation bound
     o64, al64 = _dense_gat_fp64(g.edges, f.double(), a_s.double(), a_d.double())
     absterms = torch.zeros_like(o64).index_add(0, g.edges[:, 1], al64[:, :, None] * f.double()[g.edges[:, 0]].abs())
@@ -377,7 +377,7 @@ def test_c3_fused_gat_forward_vs_oracle_and_fp64(pgl, c3):
     assert_within_fp32_reassociation(got, host(o64), host(absterms), host(nterm))
     assert float((out[torch.as_tensor(indeg == 0, device="cuda")]).abs().max()) == 0.0
     # (3) the relative bar of north_star on the bulk: 1e-5 of the data scale
-    np.testing.assert_allclose(got, host(o64), rtol=1e-5, atol=1e-5 * float(o64.abs().max()))
+    close_rows(got, host(o64), rtol=1e-5, atol_row=1e-5)
 
 
 def test_c3_fused_gat_backward_vs_fp64_autograd(pgl, c3):
@@ -428,8 +428,8 @@ def test_row_epilogue_forward_backward_vs_torch(pgl, d, act, normalize):
         t = torch.nn.functional.normalize(t, dim=1)
     (t * dev(w).double()).sum().backward()
     np.testing.assert_allclose(host(y), host(t), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(host(zt.grad), host(z64.grad), rtol=2e-5, atol=2e-5 * float(z64.grad.abs().max()))
-    np.testing.assert_allclose(host(bt.grad), host(b64.grad), rtol=1e-4, atol=1e-4 * float(b64.grad.abs().max()) + 1e-6)
+    close_rows(host(zt.grad), host(z64.grad), rtol=2e-5, atol_row=2e-5)
+    close_rows(host(bt.grad), host(b64.grad), rtol=1e-4, atol_row=1e-4)
     with torch.no_grad():
         assert torch.equal(ag.row_epilogue(zt, bt, act, normalize), y)
 
@@ -454,9 +454,9 @@ def test_graphsage_fused_epilogue_equals_the_reference_composition(pgl):
             res.append((out.detach(), xs.grad, [p.grad.clone() for p in layer.parameters()]))
         (o1, gx1, gp1), (o0, gx0, gp0) = res
         np.testing.assert_allclose(host(o1), host(o0), rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=1e-4 * float(gx0.abs().max()))
+        close_rows(host(gx1), host(gx0), rtol=1e-4, atol_row=1e-4)
         for a, b in zip(gp1, gp0):
-            np.testing.assert_allclose(host(a), host(b), rtol=2e-4, atol=2e-4 * float(b.abs().max()))
+            close_rows(host(a), host(b), rtol=2e-4, atol_row=2e-4)
 
 
 def test_khop_layers_with_caller_norm_zero_or_trainable_take_the_safe_path(pgl):
@@ -778,7 +778,7 @@ def test_gcnconv_without_the_private_addmm_activation_op(pgl, monkeypatch):
     y1, gx1, gp1 = run()
     monkeypatch.delattr(torch, "_addmm_activation")
     y0, gx0, gp0 = run()
-    np.testing.assert_allclose(host(y1), host(y0), rtol=1e-5, atol=1e-5 * float(y0.abs().max()))
-    np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=1e-5 * float(gx0.abs().max()))
+    close_rows(host(y1), host(y0), rtol=1e-5, atol_row=1e-5)
+    close_rows(host(gx1), host(gx0), rtol=1e-4, atol_row=1e-5)
     for a, b in zip(gp1, gp0):
-        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+        close_rows(host(a), host(b), rtol=1e-4, atol_row=2e-5)

@@ -43,7 +43,7 @@ def test_distgraph_compute_path_matches_single_gpu(pgl, world, op):
         recv = torch.cat(recv, 0)
         assert recv.shape[0] == dg.plan.n_halo
         full[dg.plan.own_global] = dg.aggregate_with_halo(dg.take_owned(x), recv, op)
-    close(host(full), host(want), scale=float(want.abs().max()))
+    close_rows(host(full), host(want))
 
 
 def test_distgraph_world1_is_plain_graph(pgl):
@@ -73,7 +73,7 @@ def test_eight_way_partition_in_process_rmat(pgl):
     for r, dg in enumerate(dgs):
         recv = torch.cat([packs[q][sum(dq.plan.send_splits[:r]):sum(dq.plan.send_splits[:r + 1])] for q, dq in enumerate(dgs)], 0)
         full[dg.plan.own_global] = dg.aggregate_with_halo(dg.take_owned(x), recv, "mean")
-    close(host(full), host(want), scale=float(want.abs().max()))
+    close_rows(host(full), host(want))
     assert sum(dg.plan.local_edges for dg in dgs) == E
 
 
@@ -87,18 +87,17 @@ def test_bench_multi_rank_code_path_dry_run():
     env = dict(os.environ, PGLAMD_BENCH_DRYRUN="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29731", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--scale", "16", "--edges", "1000000", "--target-scale", "15", "--target-edges", "400000", "--alternatives"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
+                        "--scale", "16", "--edges", "1000000", "--target-scale", "15", "--target-edges", "400000"], env=env, capture_output=True, text=True, cwd=root, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["scaling"] == "strong"
     assert rec["halo"]["local_edges"] > 0 and "roofline" in rec
     # the headline layout is north_star's: row partition + halo exchange, partitioned by the ENGINE'S OWN partitioner (no code built
-    # from the reference on the default path); the other layouts are secondary fields
+    # from the reference on the default path)
     assert rec["config"]["parallelism"].startswith("row partition (kway)") and rec["halo"]["mode"] == "rows"
     # the |E| = 100 M leg of an N > 1 run (here at a size a shared GPU finishes in seconds)
     assert rec["target_size"]["value"] > 0 and len(rec["target_size"]["recv_bytes_per_rank"]) == 2
-    assert set(rec["halo"]["alternatives_ms_per_step"]) >= {"rows", "cols"}
     assert rec["halo"]["exchange_only_ms"] > 0 and len(rec["halo"]["recv_bytes_per_rank"]) == 2
     flows = ("split", "fold", "accumulate", "pipeline", "rows2")
     assert rec["halo"]["flow"] in flows and rec["target_size"]["flow"] in flows
@@ -171,7 +170,7 @@ def test_distgraph_degenerate_partitions_on_the_engine(pgl):
             assert out.shape[0] == dg.plan.n_own
             if r == 1:
                 want = g.send_recv(x, op)[dg.plan.own_global]
-                np.testing.assert_allclose(host(out), host(want), rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+                close_rows(host(out), host(want), rtol=1e-5, atol_row=1e-5)
         xr = xo.clone().requires_grad_(True)
         dg.send_recv(xr, "sum").sum().backward()
         assert xr.grad.shape == xo.shape
@@ -211,7 +210,7 @@ def test_single_write_partitioned_flow_on_one_gpu(pgl):
         if op in ("max", "min"):
             assert np.array_equal(full, want), op
         else:
-            np.testing.assert_allclose(full, want, rtol=1e-5, atol=1e-5 * np.abs(want).max(), err_msg=op)
+            close_rows(full, want, rtol=1e-5, atol_row=1e-5, what=op)
 
 
 def test_config4_eight_way_engine_partition_vs_oracle(pgl, config4):

@@ -58,9 +58,9 @@ def test_recv_udf_reducers(pgl):
 
     got = host(g.recv(centred, msg))
     want = R.np_recv(np_centred, {"h": x[edges[:, 0]]}, edges, n)
-    close(got, want, scale=np.abs(want).max())
+    close_rows(got, want)
     got = host(g.recv(lambda m: m.reduce_mean(m["h"]), msg))
-    close(got, R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "mean"), scale=3.0)
+    close_rows(got, R.c_send_u_recv(x, edges[:, 0], edges[:, 1], "mean"))
     sm = host(g.recv(lambda m: m.reduce_sum(m.reduce_softmax(m["h"])), msg))
     has = np.bincount(edges[:, 1], minlength=n) > 0
     np.testing.assert_allclose(sm[has], 1.0, rtol=1e-5)
@@ -93,11 +93,11 @@ def test_edge_order_dst_view_matches_the_original_order_api(pgl):
         (out * w).sum().backward()
         outs.append((out.detach(), alpha.detach(), [t.grad for t in xs]))
     (o0, al0, g0), (o1, al1, g1) = outs
-    np.testing.assert_allclose(host(o1), host(o0), rtol=1e-5, atol=1e-5 * float(o0.abs().max()))
+    close_rows(host(o1), host(o0), rtol=1e-5, atol_row=1e-5)
     np.testing.assert_allclose(host(view.from_order(al1)), host(al0), rtol=1e-5, atol=1e-7)
     assert torch.equal(view.to_order(al0), al0[view.eid.long()])
     for a, b in zip(g1, g0):
-        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+        close_rows(host(a), host(b), rtol=1e-4, atol_row=2e-5)
     # endpoints of the view's positions, and the dot-product score
     ed = host(g.edges)
     assert np.array_equal(host(view.src), ed[host(view.eid), 0]) and np.array_equal(host(view.dst), ed[host(view.eid), 1])
@@ -153,7 +153,7 @@ def test_edge_tensor_send_uv_softmax_chain_vs_oracle(pgl):
     x = rng.standard_normal((n, H, 16)).astype(np.float32)
     out = g.send_ue_recv(dev(x), alpha.reshape(-1, H, 1), "mul", "sum")
     want = R.c_send_ue_recv(x, want_alpha.reshape(-1, H, 1).astype(np.float32), edges[:, 0], edges[:, 1], "mul", "sum")
-    np.testing.assert_allclose(host(out), want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+    close_rows(host(out), want, rtol=1e-5, atol_row=1e-5)
     # the same chain with the mechanism off gives the same numbers
     g.lazy_edge_order = False
     s0 = g.send_uv(dev(a), dev(b), "add")
@@ -161,7 +161,7 @@ def test_edge_tensor_send_uv_softmax_chain_vs_oracle(pgl):
     a0 = pgl.nn.functional.edge_softmax(g, torch.nn.functional.leaky_relu(s0, 0.2))
     out0 = g.send_ue_recv(dev(x), a0.reshape(-1, H, 1), "mul", "sum")
     np.testing.assert_allclose(host(alpha), host(a0), rtol=1e-6, atol=1e-8)
-    np.testing.assert_allclose(host(out), host(out0), rtol=1e-5, atol=1e-6 * np.abs(want).max())
+    close_rows(host(out), host(out0), rtol=1e-5, atol_row=1e-6)
     g.lazy_edge_order = True
     # segment ops / user reducers handed an EdgeTensor read it in original order
     ids = dev(np.sort(rng.integers(0, 40, len(edges))).astype(np.int64))
@@ -196,10 +196,10 @@ def test_edge_tensor_layers_equal_original_order_composition(pgl, layer):
         outs.append((y.detach(), xt.grad.clone(), [p.grad.clone() for p in L.parameters()]))
     g.lazy_edge_order = True
     (y1, gx1, gp1), (y0, gx0, gp0) = outs
-    np.testing.assert_allclose(host(y1), host(y0), rtol=2e-5, atol=2e-6 * float(y0.abs().max()))
-    np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=2e-5 * float(gx0.abs().max()))
+    close_rows(host(y1), host(y0), rtol=2e-5, atol_row=2e-6)
+    close_rows(host(gx1), host(gx0), rtol=1e-4, atol_row=2e-5)
     for a, b in zip(gp1, gp0):
-        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=5e-5 * float(b.abs().max()))
+        close_rows(host(a), host(b), rtol=1e-4, atol_row=5e-5)
 
 
 def test_edge_tensor_through_the_udf_send_recv_path(pgl):
@@ -239,9 +239,9 @@ def test_edge_tensor_through_the_udf_send_recv_path(pgl):
         outs.append((out.detach(), xt.grad.clone(), wt.grad.clone()))
     g.lazy_edge_order = True
     (o1, gx1, gw1), (o0, gx0, gw0) = outs
-    np.testing.assert_allclose(host(o1), host(o0), rtol=2e-5, atol=2e-6 * float(o0.abs().max()))
-    np.testing.assert_allclose(host(gx1), host(gx0), rtol=1e-4, atol=2e-5 * float(gx0.abs().max()))
-    np.testing.assert_allclose(host(gw1), host(gw0), rtol=1e-4, atol=2e-5 * float(gw0.abs().max()))
+    close_rows(host(o1), host(o0), rtol=2e-5, atol_row=2e-6)
+    close_rows(host(gx1), host(gx0), rtol=1e-4, atol_row=2e-5)
+    close_rows(host(gw1), host(gw0), rtol=1e-4, atol_row=2e-5)
     # the oracle: the same message / reduce functions on numpy rows in destination-sorted order
     src, dst = edges[:, 0], edges[:, 1]
     mrow = np.tanh(np.concatenate([x[src] * w, x[dst]], -1) @ host(W))
@@ -250,7 +250,7 @@ def test_edge_tensor_through_the_udf_send_recv_path(pgl):
     order = np.argsort(dst, kind="stable")
     want = np.zeros((n, d), np.float32)
     np.add.at(want, dst[order], (mrow[order] * alpha).astype(np.float32))
-    np.testing.assert_allclose(host(o1), want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
+    close_rows(host(o1), want, rtol=2e-4, atol_row=2e-5)
     # messages returned as the reader itself (the reference's tests/test_dist_graph.py send_func1) and recv by SOURCE keep working
     msg = g.send(lambda s_, d_, e_: s_, src_feat={"h": dev(x)})
     np.testing.assert_allclose(host(g.recv(lambda m: m.reduce_sum(m["h"]), msg)), R.c_send_u_recv(x, src, dst, "sum"), rtol=1e-5, atol=1e-4)

@@ -55,7 +55,7 @@ def test_send_ue_recv(pgl, mop, rop, shape):
     want = R.c_send_ue_recv(x, y, edges[:, 0], edges[:, 1], mop, rop)
     got = host(pgl.Graph(edges=edges, num_nodes=n).tensor().send_ue_recv(dev(x), dev(y), mop, rop))
     assert got.shape == want.shape
-    close(got, want, scale=np.abs(want).max())
+    check_aggregate(got, x, edges[:, 0], edges[:, 1], rop, y=y, mop=mop, want=want)
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -74,8 +74,7 @@ def test_send_ue_recv_operand_layouts_and_widths(pgl, dtype):
             want = R.c_send_ue_recv(x, y, edges[:, 0], edges[:, 1], mop, rop)
             got = host(g.send_ue_recv(dev(x), dev(y), mop, rop))
             assert got.shape == want.shape
-            np.testing.assert_allclose(got, want, rtol=RTOL if dtype == np.float32 else 1e-12,
-                                       atol=(1e-5 if dtype == np.float32 else 1e-10) * np.abs(want).max(), err_msg="%s %s %s %s" % (xs, ys, mop, rop))
+            check_aggregate(got, x, edges[:, 0], edges[:, 1], rop, y=y, mop=mop, want=want, what="%s %s %s %s" % (xs, ys, mop, rop))
 
 
 @pytest.mark.parametrize("mop", ["add", "sub", "mul", "div"])
@@ -134,8 +133,8 @@ def test_full_size_gat_path_properties(pgl, rmat20):
     rows = np.unique(e[::400000, 1])[:40]
     sel = np.isin(e[:, 1], rows)
     sub = e[sel]
-    want = R.np_send_ue_recv(host(x).reshape(-1, h, 16), host(alpha)[sel].reshape(-1, h, 1), sub[:, 0], sub[:, 1], "mul", "sum")
-    close(host(out)[rows], want[rows], scale=np.abs(want[rows]).max(), rtol=1e-5)     # north_star's stated bar (round 2 had 5e-5 here)
+    w64, a64, nt = fp64_terms(host(x).reshape(-1, h, 16), sub[:, 0], sub[:, 1], "sum", y=host(alpha)[sel].reshape(-1, h, 1), mop="mul")
+    assert_within_fp32_reassociation(host(out)[rows], w64[rows], a64[rows], nt[rows])     # per element: the row's own alpha * |f| terms
 
 
 @pytest.mark.parametrize("H,D", [(8, 16), (4, 4), (1, 32), (3, 8)])
@@ -147,17 +146,16 @@ def test_sddmm_and_send_ue_recv_edge_gradient(pgl, H, D):
     y = dev(rng.standard_normal((n, H, D)).astype(np.float32))
     got = host(pgl.ops.sddmm(x, y, g.adj_dst_index.csr))
     want = (host(x)[edges[:, 0]] * host(y)[edges[:, 1]]).sum(-1)
-    close(got, want, scale=np.abs(want).max())
+    close_terms(got, want, (np.abs(host(x))[edges[:, 0]] * np.abs(host(y))[edges[:, 1]]).sum(-1), D + 1)      # a dot product of D terms per (edge, head)
     # gradient of send_ue_recv(mul, sum) w.r.t. the edge operand [E,H,1] and the node features
     ef = dev(rng.standard_normal((e, H, 1)).astype(np.float32)).requires_grad_(True)
     xf = x.clone().requires_grad_(True)
     w = dev(rng.standard_normal((n, H, D)).astype(np.float32))
     (g.send_ue_recv(xf, ef, "mul", "sum") * w).sum().backward()
     want_e = (host(x)[edges[:, 0]] * host(w)[edges[:, 1]]).sum(-1, keepdims=True)
-    close(host(ef.grad), want_e, scale=np.abs(want_e).max())
-    want_x = np.zeros((n, H, D), np.float32)
-    np.add.at(want_x, edges[:, 0], host(w)[edges[:, 1]] * host(ef.detach()))
-    close(host(xf.grad), want_x, scale=np.abs(want_x).max())
+    close_terms(host(ef.grad), want_e, (np.abs(host(x))[edges[:, 0]] * np.abs(host(w))[edges[:, 1]]).sum(-1, keepdims=True), D + 1)
+    # d/dx[u] = sum over u's out-edges of w[v] * ef[e]: the aggregation over the REVERSED edges with the same edge operand
+    check_aggregate(host(xf.grad), host(w), edges[:, 1], edges[:, 0], "sum", y=host(ef.detach()), mop="mul")
 
 
 @pytest.mark.parametrize("mop", ["add", "sub", "mul", "div"])
@@ -171,7 +169,7 @@ def test_narrow_rows_send_ue_recv(pgl, mop, rop, dx, dy):
     want = R.c_send_ue_recv(x, y, edges[:, 0], edges[:, 1], mop, rop)
     g = pgl.Graph(edges=edges, num_nodes=n).tensor()
     got = host(g.send_ue_recv(dev(x), dev(y), mop, rop))
-    close(got, want, scale=np.abs(want).max())
+    check_aggregate(got, x, edges[:, 0], edges[:, 1], rop, y=y, mop=mop, want=want)
 
 
 @pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 16])
@@ -213,10 +211,10 @@ def test_graph_sddmm_and_gradients(pgl, H, D):
     src, dst = torch.as_tensor(edges[:, 0]).cuda(), torch.as_tensor(edges[:, 1]).cuda()
     x2, y2 = x.detach().clone().requires_grad_(True), y.detach().clone().requires_grad_(True)
     ref = (x2[src] * y2[dst]).sum(-1)
-    close(host(out), host(ref), scale=float(ref.abs().max()))
+    close_rows(host(out), host(ref))
     (out * ct).sum().backward(); (ref * ct).sum().backward()
-    close(host(x.grad), host(x2.grad), scale=float(x2.grad.abs().max()), rtol=2e-5)
-    close(host(y.grad), host(y2.grad), scale=float(y2.grad.abs().max()), rtol=2e-5)
+    close_rows(host(x.grad), host(x2.grad), rtol=2e-5)
+    close_rows(host(y.grad), host(y2.grad), rtol=2e-5)
 
 
 @pytest.mark.parametrize("H,D", [(4, 8), (8, 16), (1, 64), (3, 4)])
@@ -239,11 +237,11 @@ def test_additive_score_and_gradients(pgl, H, D, order):
     out = ag.add_score(x, y, w, cd, lambda: cs, 0.2)
     x2, y2, w2 = (t.detach().clone().requires_grad_(True) for t in (x, y, w))
     ref = (torch.nn.functional.leaky_relu(x2[src] + y2[dst], 0.2) * w2).sum(-1)
-    close(host(out), host(ref), scale=float(ref.abs().max()), rtol=2e-5)
+    close_rows(host(out), host(ref), rtol=2e-5)
     ct = dev(rng.standard_normal((e, H)).astype(np.float32))
     (out * ct).sum().backward(); (ref * ct).sum().backward()
     for a, b, name in ((x, x2, "x"), (y, y2, "y"), (w, w2, "w")):
-        close(host(a.grad), host(b.grad), scale=float(b.grad.abs().max()), rtol=1e-4)
+        close_rows(host(a.grad), host(b.grad), rtol=1e-4)
 
 
 def test_c3_send_ue_recv_mul_sum_per_element(pgl):
@@ -388,11 +386,11 @@ def test_abi_edge_operand_e1_mul_reroute_equals_the_general_path(pgl, accumulate
         return host(out)
 
     a, b = call(None), call(ident)
-    np.testing.assert_allclose(a, b, rtol=2e-6, atol=2e-6 * np.abs(b).max())
+    close_rows(a, b, rtol=2e-6, atol_row=2e-6)
     want = R.c_send_ue_recv(x, y, src, dst, "mul", "sum", out_size=rows)
     has = np.bincount(dst, minlength=rows) > 0
     if accumulate == 1:
         want = want + before                                             # rows without edges: 0 + their old contents
     elif accumulate == 2:
         want = np.where(has[:, None], want, before)
-    np.testing.assert_allclose(a, want, rtol=1e-5, atol=1e-5 * np.abs(want).max())
+    close_rows(a, want, rtol=1e-5, atol_row=1e-5)

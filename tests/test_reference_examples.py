@@ -227,4 +227,5 @@ def test_example_models_and_train_step_reproduce_the_reference_trajectory(tag, p
         with paddle.no_grad():
             logits = model(g, g.node_feat["words"]).cpu().numpy()
     np.testing.assert_allclose(losses, z["losses"], rtol=2e-4)
-    np.testing.assert_allclose(logits, z["final_logits"], rtol=2e-3, atol=2e-3 * float(np.abs(z["final_logits"]).max()))
+    from gpu_common import close_rows
+    close_rows(logits, z["final_logits"], rtol=2e-3, atol_row=2e-3)
