@@ -1563,6 +1563,30 @@ class DistGraph(object):
         ad_ext = torch.cat([attn_dst, attn_dst.new_zeros((p.n_halo, H))], 0)
         return self.local_graph.gat_aggregate(f_ext, as_ext, ad_ext, negative_slope, attn_drop, seed)[:p.n_own]
 
+    def model_estimates(self, d, element_size=4, transposed=False):
+        """What the cost model predicts for this rank, per flow, in ms (forward send_recv(sum | mean) of [n_own, d] rows): bench.py prints
+        the maximum over the ranks next to every candidate it measures, so ONE multi-GPU run shows how far the constants (_RATE, _LAUNCH,
+        _LINK, _LAT, _RMW; calibrate_link below refits the two wire constants from measured exchanges) are from the machine."""
+        row_bytes = max(1, int(d) * int(element_size))
+        self._mode("x", transposed, True, row_bytes)
+        est = self._idx[("mode_estimates", "x", transposed, True, row_bytes)]
+        return {k: float(v) * 1e3 for k, v in est.items()}
+
+    @staticmethod
+    def calibrate_link(points):
+        """points: [(bytes of the largest pair block, seconds of the all-to-all-v alone), ...] from at least two sizes ->
+        {"link_GBs", "lat_us"} by least squares of t = bytes / link + lat (None when the points do not determine a line)."""
+        pts = [(float(b), float(t)) for b, t in points if b > 0 and t > 0]
+        if len(pts) < 2 or max(b for b, _ in pts) == min(b for b, _ in pts):
+            return None
+        n = len(pts)
+        mb, mt = sum(b for b, _ in pts) / n, sum(t for _, t in pts) / n
+        sxx = sum((b - mb) ** 2 for b, _ in pts)
+        slope = sum((b - mb) * (t - mt) for b, t in pts) / sxx
+        if slope <= 0:
+            return None
+        return {"link_GBs": 1.0 / slope / 1e9, "lat_us": max(mt - slope * mb, 0.0) * 1e6, "points": pts}
+
     def exchange_only(self, x_own):
         """Measurement hook (bench.py): the pack kernel, the all-to-all-v, the wait and the wire unpack of send_recv(sum),
         without the aggregations -- the time the overlap has to hide."""

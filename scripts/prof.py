@@ -393,7 +393,7 @@ def cmd_noreuse(args):
 # ------------------------------------------------------------------------------------------------------------------
 def cmd_traffic(args):
     """Builds traffic.json -- the PMC record bench.py replays as roofline.traffic -- from one profiling session of the DEFAULT
-    bench command (scripts/gpu_r03_profile.sh): a --kernel-trace pass (per-grid average durations + the bench line of that very
+    bench command (scripts/gpu_session.sh TAG profile): a --kernel-trace pass (per-grid average durations + the bench line of that very
     run, which says which duration belongs to which leg) and separate --pmc FETCH_SIZE / WRITE_SIZE passes (per-grid averages).
     Calibration as MI355X_MICROARCH.md prescribes ("calibrate on a known byte count in your own access pattern"): the
     permutation leg reads and writes every byte exactly once, so fetch_factor = known read bytes / FETCH_SIZE there (the guide's
@@ -436,9 +436,11 @@ def cmd_traffic(args):
     ff = known_r / (avg(gp, "FETCH_SIZE") * 1024.0)
     wf = known_w / (avg(gp, "WRITE_SIZE") * 1024.0)
     out = {"_comment": "HBM-side traffic per launch of the dominant kernel from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and "
-                       "--pmc WRITE_SIZE runs of the default bench command, scripts/gpu_r03_profile.sh), calibrated on the permutation "
+                       "--pmc WRITE_SIZE runs of the default bench command, scripts/gpu_session.sh TAG profile), calibrated on the permutation "
                        "leg (every byte read and written exactly once).  Counters include Infinity-Cache hits (MI355X_MICROARCH.md, HBM "
-                       "section), so traffic_bytes is an upper bound on HBM bytes.",
+                       "section), so traffic_bytes is an upper bound on HBM bytes.  No counter of this rocprofv3 separates the two: every one of "
+                       "its 688 counters sits on the compute side of the fabric (no UMC / MALL / DF block) and TCC_EA0_RDREQ_DRAM counts by "
+                       "destination class -- it equals TCC_EA0_RDREQ on this kernel (profiles/r06/pmc_hub.txt).",
            "stamp": {"kernel": kname, "source_sha256": bench.kernel_source_hash(), "sources": list(bench.KERNEL_SOURCES)},
            "calibration": {"fetch_factor": ff, "write_factor": wf, "known_read_bytes": known_r, "known_write_bytes": known_w,
                            "FETCH_SIZE_KB": avg(gp, "FETCH_SIZE"), "WRITE_SIZE_KB": avg(gp, "WRITE_SIZE"), "grid": gp},

@@ -68,18 +68,23 @@ def close_rel(got, want, rtol, what=""):
     _assert_elementwise(np.abs(got - want), rtol * np.abs(want) + float(np.finfo(np.float32).tiny), want, what)
 
 
-def close_rows(got, want, rtol=RTOL, atol_row=None, what=""):
+def close_rows(got, want, rtol=RTOL, atol_row=None, what="", cancel=None):
     """For COMPOSITE results (a layer's output, a gradient through an attention chain) whose per-element term magnitudes are not at
     hand: |got - want| <= rtol * |want| + atol_row * (largest |want| of the SAME ROW).  The absolute part is tied to the row the element
     lives in -- one node's (or edge's) own feature vector -- never to the largest value of the whole tensor: a row 100x smaller than the
     largest row is held to an error 100x smaller.  (Aggregations, segment ops, send_uv / softmax are held per ELEMENT: check_aggregate,
-    close_terms, close_rel.)"""
+    close_terms, close_rel.)
+    cancel: for results that are sums of CANCELLING terms -- the gradient of a softmax score sums to zero over a destination's edges, a
+    key bias has an analytically zero gradient, a bias gradient is a column sum over a million rows -- the error scales with the
+    magnitude of the terms, not of the (possibly zero) result: the caller passes that magnitude (a float or an array broadcastable to
+    the result) and atol_row * cancel is added to the bound.  Every call site says what it passes."""
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     assert got.shape == want.shape, (got.shape, want.shape)
     atol_row = rtol if atol_row is None else atol_row
     w2 = np.abs(want).reshape(want.shape[0], -1) if want.ndim >= 2 else np.abs(want).reshape(-1, 1)
     row = w2.max(1).reshape((want.shape[0],) + (1,) * (want.ndim - 1)) if want.ndim >= 1 and want.size else 0.0
-    _assert_elementwise(np.abs(got - want), rtol * np.abs(want) + atol_row * row + float(np.finfo(np.float32).tiny), want, what)
+    extra = 0.0 if cancel is None else atol_row * np.broadcast_to(np.asarray(cancel, np.float64), want.shape)
+    _assert_elementwise(np.abs(got - want), rtol * np.abs(want) + atol_row * row + extra + float(np.finfo(np.float32).tiny), want, what)
 
 
 def fp64_terms(x, src, dst, op="sum", out_size=None, y=None, mop="add"):

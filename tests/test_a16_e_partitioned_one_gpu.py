@@ -107,6 +107,12 @@ def test_bench_multi_rank_code_path_dry_run():
     assert [(k["flow"], k["transport"]) for k in c] == [("fold", "torch"), ("pipeline", "torch"), ("cost-model", "torch"), ("cost-model", "abi")]
     assert all(k["status"] == "ok" and k["trial_ms_per_step"] > 0 and k["trial_steps"] == 3 for k in c) and c[0]["ran_flow"] == "fold"
     assert c[1]["ran_flow"] == "pipeline"
+    # round 6: what the cost model predicted rides next to every measured candidate and the target-size leg; one run refits the model's
+    # wire constants (halo.calibration); the bf16 wire is timed as a labelled SECONDARY
+    assert all(k["model_predicted_ms"] > 0 for k in c) and rec["target_size"]["model_predicted_ms"] > 0
+    cal = rec["halo"]["calibration"]
+    assert cal["model_constants_used"]["link_GBs"] == 150.0 and "fit" in cal
+    assert rec["halo"]["wire_bf16_secondary"]["ms_per_step"] > 0 and "NOT the headline" in rec["halo"]["wire_bf16_secondary"]["note"]
     # round 5: per-rank phase times ride along (pack / before the wait / after the wait, each alone on its rank)
     ph = rec["halo"]["phases_ms_per_rank"]
     assert len(ph["pack"]) == 2 and len(ph["after_the_wait"]) == 2 and all(v >= 0 for v in ph["before_the_wait"])
