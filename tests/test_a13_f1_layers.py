@@ -378,7 +378,10 @@ def test_c3_fused_gat_forward_vs_oracle_and_fp64(pgl, c3):
     alpha = R.np_edge_softmax(sub, n, logit).reshape(-1, H, 1)
     want = R.np_send_ue_recv(fa, alpha, sub[:, 0], sub[:, 1], "mul", "sum")
     got = host(out)
-    close_rows(got[rows], want[rows], rtol=1e-5, atol_row=1e-5)
+    # per element against the oracle's fp32 evaluation: twice the re-association bound of the element's own terms alpha_e * |f[u]|
+    # (a hub row of 10^4+ edges averages to a SMALL value out of terms of size one: its error scales with the terms, not the result)
+    aterms = R.np_send_ue_recv(np.abs(fa).astype(np.float64), alpha.astype(np.float64), sub[:, 0], sub[:, 1], "mul", "sum")
+    close_terms(got[rows], want[rows], aterms[rows], indeg[rows][:, None, None] + 16.0)
     # (2) every row against the fp64 edge-by-edge formula, with a PER-ELEMENT reassociation bound
     o64, al64 = _dense_gat_fp64(g.edges, f.double(), a_s.double(), a_d.double())
     absterms = torch.zeros_like(o64).index_add(0, g.edges[:, 1], al64[:, :, None] * f.double()[g.edges[:, 0]].abs())
