@@ -31,6 +31,49 @@ for STEP in "$@"; do
       echo "== row_order=id (round 4 layout)" > $F; timeout 600 python scripts/prof.py distmodel --scale 22 --edges 100000000 --rank 7 2>&1 | grep -v amdgpu.ids >> $F
       echo "== row_order=peers (zero-copy row-pipelined forward)" >> $F; timeout 600 python scripts/prof.py distmodel --scale 22 --edges 100000000 --rank 7 --row-order peers 2>&1 | grep -v amdgpu.ids >> $F
       cat $F ;;
+    modelsteps)
+      # the three example models' TRAINING STEPS at C2, each under rocprofv3 --kernel-trace: per step, the time in aggregation kernels,
+      # GEMMs, the engine's row kernels, torch's elementwise / reduction kernels, copies -- and what is left (launch gaps)
+      echo "example models at C2 (RMAT-20, 20 M edges, 2 layers, hidden 128, 41 classes, cross-entropy at every node, Adam): one TRAINING STEP, per kernel class" > $F
+      for M in gcn sage gat; do
+        ( cd /tmp && export TMPDIR=/tmp
+          rocprofv3 --kernel-trace --output-format csv -d $O/ms_tmp_$M -o t -- python $R/scripts/prof.py model $M --engine-only --train-steps 10 > $F.$M.run 2>&1
+          python - <<PY >> $F
+import csv, glob, collections, re
+run = open("$F.$M.run").read()
+wall = float(re.search(r"training step wall ([0-9.]+) ms", run).group(1))
+rows = []
+for f in glob.glob("$O/ms_tmp_$M/**/*kernel_trace.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the last 10 steps: cut at the optimizer's kernels -- take the final 10/13 of the launches after set-up (3 warm-up + 10 timed steps are identical)
+def cls(n):
+    if any(k in n for k in ("agg_", "gat_", "dense_hub", "scatter_add_coo", "sddmm")): return "aggregation (engine)"
+    if n.startswith("Cijk") or "gemm" in n.lower(): return "GEMM (hipBLASLt / rocBLAS)"
+    if "pglamd::" in n: return "row / gather / loss kernels (engine)"
+    if "multi_tensor" in n: return "Adam (torch multi-tensor)"
+    if "rocclr" in n or "copy" in n.lower() or "fill" in n.lower(): return "copies / fills"
+    return "elementwise / reductions (torch)"
+names = [r["Kernel_Name"] for r in rows]
+# find the step period: launches between consecutive first-Adam kernels
+adam = [i for i, n in enumerate(names) if "multi_tensor" in n]
+starts = [adam[i] for i in range(len(adam)) if i == 0 or adam[i] - adam[i - 1] > 3]
+last = starts[-11:]                                                      # 10 whole steps between the last 11 Adam groups
+seg = rows[last[0]:last[-1]]
+tot = collections.OrderedDict(); per = collections.defaultdict(lambda: [0.0, 0])
+for r in seg:
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    c = cls(r["Kernel_Name"]); tot[c] = tot.get(c, 0.0) + us
+    k = re.sub(r"\(.*", "", r["Kernel_Name"].replace("void ", ""))[:88]; per[k][0] += us; per[k][1] += 1
+nst = len(last) - 1
+ksum = sum(tot.values()) / nst / 1e3
+print("\n== $M: wall %.3f ms per training step; kernels %.3f ms; not in any kernel (launch gaps, host) %.3f ms; %d launches per step" % (wall, ksum, wall - ksum, len(seg) // nst))
+for c, us in sorted(tot.items(), key=lambda kv: -kv[1]): print("   %-42s %7.3f ms  %5.1f %%" % (c, us / nst / 1e3, 100 * us / nst / 1e3 / wall))
+for k, (us, n) in sorted(per.items(), key=lambda kv: -kv[1][0])[:14]: print("      %-88s %6.1f us x %4.1f per step" % (k, us / n, n / nst))
+PY
+          rm -rf $O/ms_tmp_$M $F.$M.run )
+      done
+      cat $F | cut -c1-170 ;;
     pmc_hub)
       # the headline kernel with and without a hub table (prof.py hub --pmc: 3 launches per form): memory-side requests by destination
       # (is there a counter that separates Infinity-Cache hits from DRAM reads?), L2 hits, translation misses, per DISPATCH in order

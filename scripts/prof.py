@@ -1143,6 +1143,8 @@ def cmd_model(args):
                                  ("torch.nn.Linear + torch cross_entropy", torch.nn.Linear, F.cross_entropy)):
             if which == "gat" and lin is torch.nn.Linear:
                 continue                                              # (no classifier head in that model)
+            if getattr(args, "engine_only", False) and lin is torch.nn.Linear:
+                continue                                              # (rocprofv3 target: the product's own head only)
             head["Linear"], head["loss"] = lin, lossf
             model = {"gcn": GCN, "sage": SAGE, "gat": GAT}[which]().to(dev)
             opt = torch.optim.Adam(model.parameters(), lr=0.01)
@@ -1158,6 +1160,14 @@ def cmd_model(args):
                         model(g, x)
                 torch.cuda.synchronize()
                 break
+            if getattr(args, "train_steps", 0):                      # rocprofv3 target: N training steps alone, their wall time printed
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                print("MARK kernels before this line belong to set-up and warm-up", flush=True)
+                print("%-5s training step wall %.3f ms over %d steps (events on the stream; the kernel table of the same steps follows)"
+                      % (which, _t(step, args.train_steps, 0), args.train_steps), flush=True)
+                continue
             with torch.no_grad():
                 inf = _t(lambda: model(g, x), 5, 2)
             print("%-5s 2 layers, hidden 128, 41 classes at C2, head = %s: inference %.3f ms, training step (loss + backward + Adam) %.3f ms"
@@ -1359,6 +1369,7 @@ def main():
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
     mo = sub.add_parser("model"); mo.add_argument("which", nargs="*"); mo.add_argument("--infer-only", action="store_true")
+    mo.add_argument("--engine-only", action="store_true"); mo.add_argument("--train-steps", type=int, default=0)
     sub.add_parser("dense")
     sub.add_parser("sizes")
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)

@@ -132,7 +132,7 @@ def _check_grads(layer, x, out, z, tag=""):
     # a PARAMETER gradient is a sum over every node / edge of the graph, and some of them cancel completely (the key bias of a softmax
     # attention has an analytically ZERO gradient): its error scales with the magnitude of the terms, for which the largest parameter
     # gradient of the same layer stands in (close_rows `cancel`)
-    cancel = max(float(np.abs(z["gparam::" + k]).max()) for k, _ in layer.named_parameters())
+    cancel = max([float(np.abs(z["gparam::" + k]).max()) for k, _ in layer.named_parameters()], default=0.0)
     for k, prm in layer.named_parameters():
         want = z["gparam::" + k]
         if k.endswith(".weight") and want.ndim == 2:
