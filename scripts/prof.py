@@ -746,6 +746,28 @@ def cmd_hub(args):
     x4 = x[order_in].contiguous()
     t4 = _t(lambda: pgl.ops.aggregate(x4, c4, "sum", N), it=it, warm=warm)
     print("(iv) whole graph relabelled by total degree: %.3f ms (x%.3f)" % (t4, t0 / t4), flush=True)
+    # (vi) SOURCE-BLOCKED passes: the edges split by source range into B indices, pass b gathers only rows of block b (512 MB / B: B = 2
+    #      fits the 256 MiB Infinity Cache), passes 2.. accumulate into the output.  The fabric traffic GROWS (the output is re-read and
+    #      re-written per extra pass, the L2 misses of the gathers stay) while the DRAM traffic of the gathers shrinks to ~compulsory: if
+    #      the launch were DRAM-bound this would win; if it is bound by what the L2s pull through the fabric it loses by the extra bytes.
+    src_all, dst_all = g.edges[:, 0], g.edges[:, 1]
+    for B in (2, 4):
+        parts = []
+        for b in range(B):
+            lo, hi = b * N // B, (b + 1) * N // B
+            m = (src_all >= lo) & (src_all < hi)
+            parts.append(pgl.ops.csr_build(dst_all[m].contiguous(), src_all[m].contiguous(), N, want_i64=False))
+        outb = torch.empty_like(want)
+        def blocked():
+            pgl.ops.aggregate(x, parts[0], "sum", N, out=outb)
+            for cb in parts[1:]:
+                pgl.ops.aggregate(x, cb, "sum", N, out=outb, accumulate=1)
+            return outb
+        tb = _t(blocked, it=it, warm=warm)
+        err = float((blocked() - want).abs().max() / want.abs().max())
+        print("(vi) %d source blocks of %d MB (one launch each, accumulate): %.3f ms (x%.3f); max |diff| / max |want| %.1e"
+              % (B, N // B * 512 >> 20, tb, t0 / tb, err), flush=True)
+        del parts, outb
     pgl.ops._HUB_TABLE = True
     pgl.ops._HUB_MIN_EDGES = 0
     t5 = _t(lambda: g.send_recv(x, "sum"), it=it, warm=warm)
