@@ -1182,6 +1182,27 @@ def cmd_model(args):
                         model(g, x)
                 torch.cuda.synchronize()
                 break
+            if getattr(args, "capture", False):
+                # the same step captured ONCE into a HIP graph and replayed (every engine op is plain launches on the current stream
+                # with caller-owned buffers and no host sync): what the step costs without the launch gaps of the eager loop
+                opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+                def cstep():
+                    loss = head["loss"](model(g, x), y)
+                    opt.zero_grad(set_to_none=False)
+                    loss.backward()
+                    opt.step()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        cstep()
+                torch.cuda.current_stream().wait_stream(side)
+                eager = _t(cstep, 10, 2)
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    cstep()
+                print("%-5s training step: eager %.3f ms, captured in a HIP graph and replayed %.3f ms" % (which, eager, _t(gr.replay, 20, 3)), flush=True)
+                continue
             if getattr(args, "train_steps", 0):                      # rocprofv3 target: N training steps alone, their wall time printed
                 for _ in range(3):
                     step()
@@ -1391,7 +1412,7 @@ def main():
     ly.add_argument("mode", nargs="?", default="infer", choices=["infer", "train"])
     tn = sub.add_parser("train"); tn.add_argument("which", nargs="*")
     mo = sub.add_parser("model"); mo.add_argument("which", nargs="*"); mo.add_argument("--infer-only", action="store_true")
-    mo.add_argument("--engine-only", action="store_true"); mo.add_argument("--train-steps", type=int, default=0)
+    mo.add_argument("--engine-only", action="store_true"); mo.add_argument("--train-steps", type=int, default=0); mo.add_argument("--capture", action="store_true")
     sub.add_parser("dense")
     sub.add_parser("sizes")
     dm = sub.add_parser("distmodel"); dm.add_argument("--scale", type=int, default=20); dm.add_argument("--edges", type=int, default=20_000_000)
