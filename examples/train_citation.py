@@ -79,7 +79,7 @@ def main(argv=None):
     yt = torch.from_numpy(y).to(dev)
     tr, va, te = (torch.from_numpy(i).to(dev) for i in (tr, va, te))
     net = Net(args.model, x.shape[1], args.hidden, 7).to(dev)
-    opt = torch.optim.Adam(net.parameters(), lr=args.lr, weight_decay=5e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=args.lr, weight_decay=5e-4, capturable=torch.cuda.is_available())   # step counter on the device: no host bookkeeping per step
     hist = []
     for ep in range(args.epochs):
         t0 = time.time()

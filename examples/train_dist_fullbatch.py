@@ -86,7 +86,7 @@ def main():
 
     torch.manual_seed(0)                                                                  # same initial parameters on every rank
     model = Net(args.model, args.dim, args.hidden, args.classes).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=torch.cuda.is_available())
     n_train = torch.tensor([float(train.sum())], device=dev)
     if world > 1:
         buf = n_train.cpu() if dry else n_train

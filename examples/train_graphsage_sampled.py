@@ -107,7 +107,7 @@ def main():
     sampler = pgl.sampling.NeighborSampler(graph_dev, args.samples[::-1], seed=1) if graph_dev is not None else None
     feature, labels = torch.as_tensor(x).to(dev), torch.as_tensor(y).to(dev)
     model = GraphSage(x.shape[1], int(y.max()) + 1, len(args.samples), args.hidden_size).to(dev)
-    optim = torch.optim.Adam(model.parameters(), lr=args.lr)
+    optim = torch.optim.Adam(model.parameters(), lr=args.lr, capturable=torch.cuda.is_available())
     rng = np.random.default_rng(1)
     for epoch in range(args.epochs):
         t0 = time.time()

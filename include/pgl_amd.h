@@ -134,7 +134,7 @@ int32_t pglamd_narrow_i64(const int64_t* in, int64_t in_stride, int64_t n, int32
  *              with the flat kernel's per-position scale slot (the `edge_scale` of pglamd_aggregate_dense: 4 sequential
  *              bytes per edge) instead of the general edge-operand path.  Same result up to the order of one multiplication
  *              (x * y summed, both ways); every accumulate mode and out_rows < n_csr_rows behave as documented below
- *              (tests/test_gpu_round5.py::test_abi_edge_operand_e1_mul_reroute_equals_the_general_path).
+ *              (tests/test_a7_a9_attention_ops.py::test_abi_edge_operand_e1_mul_reroute_equals_the_general_path).
  *   dx, dy, dout   trailing sizes.  Broadcast rule supported on the fast path: trailing-dim
  *              broadcast only, xj = j / (dout/dx), yj = j / (dout/dy)  (covers [H,D]x[H,1],
  *              [H,D]x[H,D], [D]x[1]); other numpy patterns must be expanded by the caller.

@@ -283,7 +283,7 @@ PY
       # every experimental build under pgl_amd/csrc/variants (scripts/prof.py variant ...): CSR parity + CSR timing through PGLAMD_LIB
       for L in pgl_amd/csrc/variants/libpglamd_*.so; do
         echo "== $L" >> $F
-        PGLAMD_LIB=$R/$L timeout 600 python -m pytest tests/test_gpu_round3.py -m gpu -q -x -k "csr_sort" 2>&1 | tail -2 >> $F
+        PGLAMD_LIB=$R/$L timeout 600 python -m pytest tests/test_a1_a3_index.py -m gpu -q -x -k "csr_sort" 2>&1 | tail -2 >> $F
         PGLAMD_LIB=$R/$L timeout 300 python scripts/prof.py csr 2>&1 | grep "csr_build" | grep "dst-keyed" >> $F
       done
       cat $F ;;

@@ -1202,6 +1202,15 @@ def cmd_model(args):
                 with torch.cuda.graph(gr):
                     cstep()
                 print("%-5s training step: eager %.3f ms, captured in a HIP graph and replayed %.3f ms" % (which, eager, _t(gr.replay, 20, 3)), flush=True)
+                # which of the two optimizer settings of that harness closes the gap to the default loop (torch's Adam defaults, grads set to None)?
+                for cap in (False, True):
+                    for to_none in (True, False):
+                        o2 = torch.optim.Adam(model.parameters(), lr=0.01, capturable=cap)
+                        def s2():
+                            o2.zero_grad(set_to_none=to_none)
+                            head["loss"](model(g, x), y).backward()
+                            o2.step()
+                        print("        eager, Adam(capturable=%s), zero_grad(set_to_none=%s): %.3f ms" % (cap, to_none, _t(s2, 10, 3)), flush=True)
                 continue
             if getattr(args, "train_steps", 0):                      # rocprofv3 target: N training steps alone, their wall time printed
                 for _ in range(3):

@@ -318,7 +318,7 @@ def _check_full_output(got, c, what):
     # (1) north_star's bar against the EXACT result
     np.testing.assert_allclose(got, w, rtol=1e-5, atol=1e-5 * scale, err_msg=what + " vs fp64")
     # (2) against the reference's serial fp32 loop: 1e-5, plus what that loop itself is away from the exact result on rows with
-    #     10^5+ in-edges (tests/test_gpu_round4.py::test_c2prime_gcn_spmm_vs_oracle explains the term)
+    #     10^5+ in-edges (tests/test_a6_baseline_sizes.py::test_c2prime_gcn_spmm_vs_oracle explains the term)
     own = np.abs(want.astype(np.float64) - w)
     tol = 1e-5 * np.abs(want) + 1e-5 * scale + own
     err = np.abs(got.astype(np.float64) - want)
