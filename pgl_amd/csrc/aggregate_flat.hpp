@@ -758,7 +758,8 @@ int32_t launch_flat(AggParams p, hipStream_t st) {
             if constexpr (std::is_same_v<T, float> && YMODE == 0) {
                 if (p.ss_by_pos) {
                     by_pos = true;
-                    hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, 2>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+                    if (two) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, 2, true, 0, 0, true>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
+                    else hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, 2>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
                 }
             }
             if (!by_pos) hipLaunchKernelGGL((agg_flat_kernel<T, VEC, NT, RCLS, YMODE, 1>), dim3((unsigned)(p.n_grid_chunks + zb)), dim3(kBlock), 0, st, p);
@@ -902,8 +903,8 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     // edge) instead of the general edge-operand path.  This is how GCN's source-side degree norm is applied (pgl/nn/conv.py:242):
     // norm[col[p]] laid out once per graph, rather than a pass over [N, d] per layer or a random 4-byte read per edge.
     if constexpr (std::is_same_v<T, float>) {
-        if (y && dy == 1 && !eid && mop == PGLAMD_MUL && (rop == PGLAMD_SUM || rop == PGLAMD_MEAN) && !src_scale && !ex.x2 && dout == dx &&
-            (size_t)dout * sizeof(T) > 128) {
+        if (y && dy == 1 && !eid && mop == PGLAMD_MUL && (rop == PGLAMD_SUM || rop == PGLAMD_MEAN) && !src_scale && dout == dx &&
+            (size_t)dout * sizeof(T) > 128) {        // (with or without a second source table: the scale rides by edge POSITION, not by column id)
             src_scale = static_cast<const float*>(y);
             p.ss_by_pos = 1;
             y = nullptr; dy = 0;
@@ -915,8 +916,8 @@ int32_t aggregate_typed(const void* x, int64_t dx, const void* y, int64_t dy, co
     p.x2 = ex.x2 ? static_cast<const char*>(ex.x2) - ex.x_split * ldx * (int64_t)sizeof(T) : x;
     p.x_split = ex.x2 ? (int)ex.x_split : INT32_MAX;
     p.max_row_edges = (int)std::min<int64_t>(ex.max_row_edges, INT32_MAX);
-    if (ex.x2 && (src_scale || dout != dx))
-        return fail(PGLAMD_E_ARG, "aggregate_ext: a second source table excludes src_scale and source-side broadcasting");
+    if (ex.x2 && ((src_scale && !p.ss_by_pos) || dout != dx))
+        return fail(PGLAMD_E_ARG, "aggregate_ext: a second source table excludes a per-NODE src_scale and source-side broadcasting");
     p.src_scale = src_scale; p.dst_scale = dst_scale;
     p.ldx = ldx; p.ldy = dy; p.ldo = ldo; p.out_rows = out_rows; p.n_csr_rows = n_csr_rows; p.E = (int)E;
     p.mop = mop; p.is_mean = rop == PGLAMD_MEAN; p.is_max = rop == PGLAMD_MAX; p.accumulate = accumulate;

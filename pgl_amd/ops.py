@@ -398,7 +398,7 @@ def aggregate(x, csr, reduce_op="sum", out_size=None, y=None, message_op="add", 
     code = _code(x.dtype)
     ws = _ws_hot(L.pglamd_aggregate_workspace_bytes(csr.num_edges, dout, code), x.device)
     col32 = csr.col32
-    if _HUB_TABLE and x2 is None and y is None and es is None and src_scale is None and not ldx and not ldo and x.dim() == 2 \
+    if _HUB_TABLE and x2 is None and y is None and src_scale is None and not ldx and not ldo and x.dim() == 2 \
             and x.dtype == torch.float32 and dx * 4 >= 384 and csr.num_edges >= _HUB_MIN_EDGES and int(x.shape[0]) < (1 << 30):
         hub = hub_plan(csr, int(x.shape[0]), dx * 4)
         if hub is not None:

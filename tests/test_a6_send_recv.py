@@ -565,6 +565,7 @@ def test_hub_table_is_bit_identical_and_on_only_where_it_pays(pgl, monkeypatch, 
     monkeypatch.setattr(ops, "_HUB_TABLE", False)
     plain = {op: ops.aggregate(x, c, op, n) for op in ("sum", "mean", "max", "min")}
     plain_scaled = ops.aggregate(x, c, "sum", n, dst_scale=ds)
+    plain_gcn = g.send_recv_scaled(x, ds, ds)                                        # GCN's two norms: the source one rides by edge position
     assert getattr(c, "_hub", None) is None                                          # below the edge threshold / switched off: no plan
     monkeypatch.setattr(ops, "_HUB_TABLE", True)
     monkeypatch.setattr(ops, "_HUB_MIN_EDGES", 0)
@@ -573,6 +574,7 @@ def test_hub_table_is_bit_identical_and_on_only_where_it_pays(pgl, monkeypatch, 
     plan = next(iter(c._hub.values()))
     assert plan is not None and plan[2] > 0.5 and int((plan[1] >= n).sum()) == round(plan[2] * E)   # RMAT: the top rows carry most edges
     assert torch.equal(ops.aggregate(x, c, "sum", n, dst_scale=ds), plain_scaled)
+    assert torch.equal(g.send_recv_scaled(x, ds, ds), plain_gcn)                     # the table and the per-position scale in one launch
     assert torch.equal(ops.aggregate(x, c, "sum", n + 100)[:n], plain["sum"])        # out_size beyond the index's rows
     acc = torch.ones(n, d, device="cuda")
     ops.aggregate(x, c, "sum", n, out=acc, accumulate=1)                             # (accumulate takes the same path: against the plain library)
