@@ -102,6 +102,14 @@ PY
 
       echo "== cold rows non-temporal, hot rows (sign bit of the column id) cached (PGLAMD_FLAT_NT=2)" >> $F; PGLAMD_HOTCOLD=1 PGLAMD_LIB=$R/pgl_amd/csrc/variants/libpglamd_nt2.so timeout 600 python scripts/prof.py hotcold 2>&1 | grep -v amdgpu.ids >> $F
       cat $F ;;
+    cold)
+      # cold rows past the L2 but not past the Infinity Cache: by allocation type (product library) and by instruction bits (variant builds
+      # of csrc/variants/aggregate_flat_cold_row_cache_policy.patch: aux 0 = default policy through the same buffer loads, 1 = sc0, 16 = sc1, 17 = sc0 sc1, 18 = nt sc1)
+      echo "== product library, x by allocation type" > $F; timeout 600 python scripts/prof.py cold ${COLDARGS:-} 2>&1 | grep -v amdgpu.ids >> $F
+      for L in pgl_amd/csrc/variants/libpglamd_coldaux*.so; do
+        echo "== $L" >> $F; PGLAMD_LIB=$R/$L timeout 300 python scripts/prof.py cold --variant ${COLDARGS:-} 2>&1 | grep -v amdgpu.ids >> $F
+      done
+      cat $F ;;
     rows_c2p_rows2) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero_nosw)  PGLAMD_XCD_SWIZZLE=0 timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero)  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;

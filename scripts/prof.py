@@ -681,6 +681,77 @@ def cmd_hotcold(args):
               % (int(hot.sum()), thr, 100.0 * float(flag.float().mean()), t1, t0 / t1, "identical" if ok else "DIFFERS"), flush=True)
 
 
+def _ext_tensor(like, flags):
+    """A device tensor shaped like `like` whose memory comes from hipExtMallocWithFlags(flags) -- 1 = fine-grained (coherent), 3 = uncached
+    -- filled with a copy of `like`.  The memory type of the ALLOCATION decides how the XCD's L2 treats the lines; no kernel change."""
+    import ctypes, torch
+    hip = ctypes.CDLL("libamdhip64.so")
+    ptr = ctypes.c_void_p()
+    nbytes = like.numel() * like.element_size()
+    rc = hip.hipExtMallocWithFlags(ctypes.byref(ptr), ctypes.c_size_t(nbytes), ctypes.c_uint(flags))
+    if rc != 0 or not ptr.value:
+        raise RuntimeError("hipExtMallocWithFlags(flags=%d) rc=%d" % (flags, rc))
+
+    class Holder:
+        pass
+    h = Holder()
+    h.__cuda_array_interface__ = {"shape": tuple(like.shape), "typestr": "<f4", "data": (ptr.value, False), "version": 2}
+    t = torch.as_tensor(h, device=like.device)
+    t.copy_(like)
+    return t
+
+
+def cmd_cold(args):
+    """Round 6, the question hotcold left open: keep the hub rows in the 4 MiB L2s by making the COLD rows bypass the L2 **without** taking
+    them out of the Infinity Cache (round 5's non-temporal loads bypass both: 1.25 .. 2.03 ms).
+      (a) by ALLOCATION: the node-feature table x lives in fine-grained / uncached device memory (hipExtMallocWithFlags), the hub table x2
+          in ordinary memory; the product kernel unchanged (two-table path);
+      (b) by INSTRUCTION: a variant library (PGLAMD_LIB, built with -DPGLAMD_COLD_AUX=<aux bits>) loads rows of x with the given
+          sc0 / sc1 / nt bits and rows of x2 with the default policy -- run with --variant to time only the ordinary allocation.
+    Prints ms per launch for plain index / hub tables of K rows; results must be bit-identical."""
+    import torch
+    pgl, dev, g = _c2(with_src_index=False, scale=args.scale, E=args.edges)
+    pgl.ops._HUB_TABLE = False
+    N, E = g.num_nodes, g.num_edges
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    x = torch.randn(N, 128, generator=gen, device=dev)
+    c = g.adj_dst_index.csr
+    it, warm = (3, 0) if args.pmc else (20, 5)
+    want = pgl.ops.aggregate(x, c, "sum", N)
+    outdeg = torch.bincount(g.edges[:, 0], minlength=N)
+    order = torch.argsort(outdeg, descending=True, stable=True)
+    rank = torch.empty_like(order); rank[order] = torch.arange(N, device=dev)
+    col = c.col32.long()
+
+    def clone_index(colx):
+        c2 = pgl.ops.CSR()
+        for k in ("degree", "indptr", "row32", "eid32", "num_nodes", "num_edges"):
+            setattr(c2, k, getattr(c, k))
+        c2.col32 = colx.to(torch.int32).contiguous()
+        c2.sorted_v = c2.sorted_u = c2.sorted_eid = None
+        return c2
+    plans = []
+    for K in args.hub_rows:
+        hub = rank[col] < K
+        plans.append((K, clone_index(torch.where(hub, N + rank[col], col)), order[:K].contiguous(), 100.0 * float(hub.float().mean())))
+    allocs = [("ordinary (torch allocator)", None)] if args.variant else [("ordinary (torch allocator)", None), ("fine-grained (hipDeviceMallocFinegrained)", 1), ("uncached (hipDeviceMallocUncached)", 3)]
+    print("RMAT-%d |E| = %d d = 128 fp32, library %s" % (args.scale, E, os.environ.get("PGLAMD_LIB", "product")), flush=True)
+    for name, flags in allocs:
+        try:
+            xa = x if flags is None else _ext_tensor(x, flags)
+        except Exception as ex:                                      # noqa: BLE001
+            print("x in %s memory: %r" % (name, ex), flush=True); continue
+        t0 = _t(lambda: pgl.ops.aggregate(xa, c, "sum", N), it=it, warm=warm)
+        ok = torch.equal(pgl.ops.aggregate(xa, c, "sum", N), want)
+        print("x in %s memory; plain index: %.3f ms, result %s" % (name, t0, "identical" if ok else "DIFFERS"), flush=True)
+        for K, ch, ids, share in plans:
+            x2 = x[ids].contiguous()
+            t1 = _t(lambda: pgl.ops.aggregate(xa, ch, "sum", N, x2=x2), it=it, warm=warm)
+            ok = torch.equal(pgl.ops.aggregate(xa, ch, "sum", N, x2=x2), want)
+            print("   hub table K = %6d rows (%5.1f MB, %4.1f %% of the edges) in ordinary memory: %.3f ms, result %s"
+                  % (K, K * 512 / 1e6, share, t1, "identical" if ok else "DIFFERS"), flush=True)
+
+
 def cmd_hub(args):
     """VERDICT r5 item 3b on the headline kernel (C2 / C2', d = 128 fp32): do contiguous HUB rows cut the L2 misses / translation misses?
       (i)  hub table: the top-K out-degree source rows packed into x2, their column ids remapped once per graph, through the
@@ -1415,6 +1486,9 @@ def main():
     sub.add_parser("hotcold")
     hb = sub.add_parser("hub"); hb.add_argument("--scale", type=int, default=20); hb.add_argument("--edges", type=int, default=20_000_000)
     hb.add_argument("--hub-rows", type=int, nargs="*", default=[2048, 8192, 32768, 131072]); hb.add_argument("--pmc", action="store_true")
+    cd = sub.add_parser("cold"); cd.add_argument("--scale", type=int, default=20); cd.add_argument("--edges", type=int, default=20_000_000)
+    cd.add_argument("--hub-rows", type=int, nargs="*", default=[2048, 4096, 8192, 16384, 32768]); cd.add_argument("--pmc", action="store_true")
+    cd.add_argument("--variant", action="store_true")
     ch = sub.add_parser("chains"); ch.add_argument("--scale", type=int, default=20); ch.add_argument("--edges", type=int, default=20_000_000)
     o = sub.add_parser("ops"); o.add_argument("--scale", type=int, default=20); o.add_argument("--edges", type=int, default=20_000_000)
     ly = sub.add_parser("layers"); ly.add_argument("which", choices=["gcn", "gcn_relu", "sage", "gat", "transformer"])
@@ -1458,6 +1532,8 @@ def main():
         cmd_hotcold(args)
     elif args.cmd == "hub":
         cmd_hub(args)
+    elif args.cmd == "cold":
+        cmd_cold(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
     elif args.cmd == "gcn":
