@@ -16,6 +16,14 @@ namespace pglamd {
 int narrow_max();
 int32_t zero_empty_rows(const int64_t* indptr, int64_t n_csr_rows, int64_t out_rows, void* out, size_t row_bytes, hipStream_t st);
 
+// fix-up geometry (the kernels are further down; the flat kernel classifies its tasks with kFixShort)
+constexpr int kFixShort = 16;        // rows with at most this many further pieces are finished by one wave
+constexpr int kFixWaves = 16;
+constexpr int kFixGridShort = 2048;
+constexpr int kFixGridLong = 512;
+constexpr int kFixGridMergedShort = 1024;  // merged launch: blocks of kFixWaves waves, every wave of a short-role block takes its own tasks
+                                           // (C2: 15 035 split rows, 211 of them hub rows -- one task per wave, no second trip round the list)
+
 
 // RCLS: 0 = additive (sum / mean), 1 = min / max.   YMODE: 0 none, 1 one y per VEC group, 2 y vector,
 // 3 = as 1 for NT == 1 and y rows of <= 8 elements (attention weights [E,H,1]): the 8 x ypad operand values of a batch come
@@ -176,7 +184,17 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
                 for (int k = 0; k < VEC; ++k) o.v[k] = RCLS == 1 ? order_flip(acc[t][k], neg) : acc[t][k];
                 *reinterpret_cast<VA*>(dst + (j0[t] - jb)) = o;
             }
-        if (!head && lane == 0) q->long_list[atomicAdd(q->long_count, 1)] = c;   // this chunk owns the row's fix-up
+        if (!head && lane == 0) {                           // this chunk owns the row's fix-up
+            if constexpr (SINK == 0) {
+                // the producer files the task under its class -- rows of <= kFixShort further pieces / hub rows -- so that both fix-up
+                // roles run in ONE launch after this one (agg_fixup_merged_kernel) instead of a short pass that defers to a long pass
+                const int b = (int)((as_const(q->indptr)[cur + 1] - 1) / q->chunk);
+                const bool lng = b - c > kFixShort;
+                (lng ? q->long_list2 : q->long_list)[atomicAdd(q->long_count + (lng ? 1 : 0), 1)] = c;
+            } else {
+                q->long_list[atomicAdd(q->long_count, 1)] = c;
+            }
+        }
     };
     // (a row stored here lies wholly inside the chunk, so the count a mean needs is the row's degree: read from indptr at
     //  the store instead of being carried -- and branched on -- at every edge: d = 64 fp32 sum 0.63 -> 0.54 ms)
@@ -454,18 +472,14 @@ __global__ __launch_bounds__(kBlock) void agg_flat_kernel(AggParams p) {
 //          a 10^5-edge hub is not one serial dependent chain.
 // List order is arbitrary; every row's own combination order is fixed => bit-reproducible.
 // ------------------------------------------------------------------------------------------------
-constexpr int kFixShort = 16;
-constexpr int kFixWaves = 16;
-constexpr int kFixGridShort = 2048;
-constexpr int kFixGridLong = 512;
-
-template <typename T, int VEC, int NT, int RCLS, bool LONG>
-__global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_kernel(AggParams p) {
+// CLASSIFIED: the producer filed every task under its class already (agg_flat_kernel, SINK == 0): the short role never defers.
+// `first` / `stride`: the tasks this wave (short role) or block (long role) takes.
+template <typename T, int VEC, int NT, int RCLS, bool LONG, bool CLASSIFIED, typename RED>
+__device__ __forceinline__ void fixup_tasks(const AggParams& p, const int first, const int stride, RED& red) {
     using A = typename AccT<T>::type;
     using V = VecT<A, VEC>;     // partials are stored in the accumulator type
     using VO = VecT<T, VEC>;
     constexpr int NW = LONG ? kFixWaves : 1;
-    __shared__ A red[LONG ? kFixWaves : 1][LONG ? NT * kWave * VEC : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = wave_uniform(threadIdx.x >> 6);
     const cptr<int> rowp = as_const(p.row);
@@ -483,15 +497,13 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
 
     const int* list = LONG ? p.long_list2 : p.long_list;
     const int n_tasks = LONG ? p.long_count[1] : p.long_count[0];
-    const int first = LONG ? (int)blockIdx.x : (int)blockIdx.x * kWavesPerBlock + wib;
-    const int stride = LONG ? (int)gridDim.x : (int)gridDim.x * kWavesPerBlock;
     for (int t_id = first; t_id < n_tasks; t_id += stride) {
         const int a = wave_uniform(list[t_id]);
         const int e1 = (a + 1) * p.chunk;
         const int r = rowp[e1 - 1];
         const int64_t rs = ip[r], re = ip[r + 1];
         const int b = (int)((re - 1) / p.chunk);        // last chunk holding a piece of row r
-        if constexpr (!LONG) {
+        if constexpr (!LONG && !CLASSIFIED) {
             if (b - a > kFixShort) {                    // hub row: defer to the block-parallel pass
                 if (lane == 0) p.long_list2[atomicAdd(p.long_count + 1, 1)] = a;
                 continue;
@@ -628,6 +640,28 @@ __global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_k
                 *reinterpret_cast<VO*>(dst + j0[t]) = o;
             }
     }
+}
+
+// the two-launch form (producers that put every task on list 1: the dense sink, the grouped and the generic kernels)
+template <typename T, int VEC, int NT, int RCLS, bool LONG>
+__global__ __launch_bounds__(LONG ? kFixWaves * kWave : kBlock) void agg_fixup_kernel(AggParams p) {
+    using A = typename AccT<T>::type;
+    __shared__ A red[LONG ? kFixWaves : 1][LONG ? NT * kWave * VEC : 1];
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    fixup_tasks<T, VEC, NT, RCLS, LONG, false>(p, LONG ? (int)blockIdx.x : (int)blockIdx.x * kWavesPerBlock + wib,
+                                               LONG ? (int)gridDim.x : (int)gridDim.x * kWavesPerBlock, red);
+}
+
+// ONE launch for both classes (the flat kernel files its tasks by class): blocks [0, gl) take the hub rows (the block's 16 waves split
+// one row's partial list), blocks [gl, gridDim) the short rows (every wave its own task).  The two launches cost 22 + 13 us per call at
+// C2 one after the other -- the second waited for the first only because the first handed it its list.
+template <typename T, int VEC, int NT, int RCLS>
+__global__ __launch_bounds__(kFixWaves * kWave) void agg_fixup_merged_kernel(AggParams p, int gl) {
+    using A = typename AccT<T>::type;
+    __shared__ A red[kFixWaves][NT * kWave * VEC];
+    const int wib = wave_uniform(threadIdx.x >> 6);
+    if ((int)blockIdx.x < gl) fixup_tasks<T, VEC, NT, RCLS, true, true>(p, (int)blockIdx.x, gl, red);
+    else fixup_tasks<T, VEC, NT, RCLS, false, true>(p, ((int)blockIdx.x - gl) * kFixWaves + wib, ((int)gridDim.x - gl) * kFixWaves, red);
 }
 
 // Zero-fills output rows that receive no edge: rows r < n_csr_rows with indptr[r]==indptr[r+1],
@@ -778,10 +812,8 @@ launched:
         prof().ev.emplace_back(e0, e1);
     }
     if (fixups) {
-        const dim3 gs((unsigned)std::min<int64_t>(kFixGridShort, ceil_div(p.n_chunks, kWavesPerBlock))), gl((unsigned)std::min<int64_t>(kFixGridLong, p.n_chunks));
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, false>), gs, dim3(kBlock), 0, st, p);
-        PGLAMD_LAUNCH_CHECK();
-        hipLaunchKernelGGL((agg_fixup_kernel<T, VEC, NT, RCLS, true>), gl, dim3(kFixWaves * kWave), 0, st, p);
+        const int gl = (int)std::min<int64_t>(kFixGridLong, p.n_chunks), gs = (int)std::min<int64_t>(kFixGridMergedShort, ceil_div(p.n_chunks, kFixWaves));
+        hipLaunchKernelGGL((agg_fixup_merged_kernel<T, VEC, NT, RCLS>), dim3((unsigned)(gl + gs)), dim3(kFixWaves * kWave), 0, st, p, gl);
     }
     PGLAMD_LAUNCH_CHECK();
     return PGLAMD_OK;

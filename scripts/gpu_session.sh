@@ -58,6 +58,7 @@ names = [r["Kernel_Name"] for r in rows]
 # find the step period: launches between consecutive first-Adam kernels
 adam = [i for i, n in enumerate(names) if "multi_tensor" in n]
 starts = [adam[i] for i in range(len(adam)) if i == 0 or adam[i] - adam[i - 1] > 20]    # (a step's Adam launches come in two groups a few elementwise kernels apart)
+if len(starts) % 13 == 0 and len(starts) > 13: starts = starts[::len(starts) // 13]     # 3 warm-up + 10 timed steps; a model whose optimizer launches in several far-apart groups per step (GraphSage) has a multiple of 13
 last = starts[-11:]                                                      # 10 whole steps between the last 11 Adam groups
 seg = rows[last[0]:last[-1]]
 tot = collections.OrderedDict(); per = collections.defaultdict(lambda: [0.0, 0])

@@ -86,6 +86,27 @@ def test_send_recv_edge_cases(pgl):
         g1.send_recv(x.cpu())                                     # no CPU fallback
 
 
+@pytest.mark.parametrize("op", ["sum", "mean", "max"])
+@pytest.mark.parametrize("d", [128, 64, 20])
+def test_split_rows_at_the_fixup_class_boundary(pgl, op, d):
+    """Rows longer than a chunk of 256 edges leave partial sums; the flat kernel files a row with <= 16 further pieces under the
+    one-wave class and a longer one under the 16-wave class, and ONE launch finishes both (agg_fixup_merged_kernel).  Rows whose piece
+    count sits on either side of that boundary, at several alignments to the chunk grid, next to short rows and a 40 000-edge hub."""
+    rng = np.random.default_rng(31 + d)
+    n = 600
+    lens = {3: 4096, 7: 4097, 11: 4352, 12: 4353, 20: 4607, 21: 4608, 22: 4609, 30: 257, 31: 256, 32: 255, 40: 8705, 50: 40000, 599: 4400}
+    dst = np.concatenate([np.full(L, r, np.int64) for r, L in lens.items()] + [rng.integers(60, 590, 5000)])
+    dst = dst[rng.permutation(len(dst))]
+    src = rng.integers(0, n, len(dst))
+    edges = np.stack([src, dst], 1)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    want = R.c_send_u_recv(x, src, dst, op)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    a = g.send_recv(dev(x), op)
+    check_aggregate(host(a), x, src, dst, op, want=want)
+    assert torch.equal(a, g.send_recv(dev(x), op))                # fixed combination order: bit-reproducible
+
+
 def test_send_recv_deterministic_and_matches_atomic_variant(pgl):
     n, e, d = 20000, 400000, 128
     edges, rng = rand_graph(n, e, 9, hub=50000)
