@@ -24,6 +24,14 @@ def _act(activation):
     return activation
 
 
+
+def _head_mean(output):
+    """mean over the head axis of [N, H, D] (pgl/nn/conv.py:343-344, concat=False).  With ONE head -- the classifier layer of
+    examples/gat/train.py -- the mean is the identity: a view instead of a reduction pass over [N, D] and its expand / divide
+    in the backward (0.25 ms of the 12.2 ms GAT training step at C2)."""
+    return output.squeeze(1) if output.shape[1] == 1 else torch.mean(output, dim=1)
+
+
 class _TallLinearFn(torch.autograd.Function):
     """y = x W^T + b for x [N, in] with N in the millions.  The weight gradient g^T x is a [out, N] x [N, in] product with
     a reduction length of N and a tiny output: the stock GEMM picks one 32x32 tile per workgroup and runs the whole
@@ -305,7 +313,7 @@ class GATConv(nn.Module):
             if self.concat:
                 output = output.reshape(-1, self.num_heads * self.hidden_size)
             else:
-                output = torch.mean(output, dim=1)
+                output = _head_mean(output)
             if self.activation is not None:
                 output = self.activation(output)
             return output if output.dtype == store_dtype else output.to(store_dtype)
@@ -319,7 +327,7 @@ class GATConv(nn.Module):
         if self.concat:
             output = output.reshape(-1, self.num_heads * self.hidden_size)
         else:
-            output = torch.mean(output, dim=1)
+            output = _head_mean(output)
         if self.activation is not None:
             output = self.activation(output)
         return output if output.dtype == store_dtype else output.to(store_dtype)

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import functional as GF
-from .conv import _act, _linear
+from .conv import _act, _head_mean, _linear
 
 __all__ = ["GATv2Conv", "APPNP", "GCNII", "TransformerConv", "GINConv", "SGCConv", "LightGCNConv", "PinSageConv", "GPRConv",
            "RGCNConv", "SSGCConv", "NGCFConv", "FAConv"]
@@ -191,7 +191,7 @@ class GATv2Conv(nn.Module):
             if self.attn_drop > 1e-15:
                 alpha = self.attn_dropout(alpha)
             output = graph.send_ue_recv(feature, alpha, "mul", "sum")
-        output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(output, dim=1)
+        output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else _head_mean(output)
         if self.activation is not None:
             output = self.activation(output)
         return output
@@ -267,7 +267,7 @@ class TransformerConv(nn.Module):
             # same arithmetic as send_attention / reduce_attention below, as three fused graph ops: per-edge q.k scores
             # (SDDMM), softmax over each destination's edges, alpha-weighted sum of v -- no [E, H, D] message tensor
             output = _dot_attention(graph, k, q, v, self.attn_dropout if self.attn_drop > 1e-15 else None)
-            output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(output, dim=1)
+            output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else _head_mean(output)
         else:
             msg = graph.send(self.send_attention, src_feat={"k": k, "v": v}, dst_feat={"q": q}, **kw)
             output = graph.recv(reduce_func=self.reduce_attention, msg=msg)
