@@ -151,6 +151,26 @@ def no_reuse_legs(pgl, dev, d, steps=5, warmup=2):
                             "achieved": known / (kms * 1e-3) / 1e9, "frac": known / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     del g, x
     torch.cuda.empty_cache()
+    # --- uniform random sources over a table INSIDE the Infinity Cache (2^18 rows x 512 B = 128 MB: 32 x one XCD's L2, half of the 256 MiB
+    #     Infinity Cache), in-degree 19 over 2^21 output rows.  At most 4 MB / 128 MB = 3 % of the gathers can hit an L2, and after the first
+    #     launch none has to come from DRAM: known bytes / time is what the FABRIC + INFINITY CACHE deliver to this kernel's access pattern
+    #     (random 512-byte rows) -- the ceiling the RMAT launch's L2-miss traffic is read against (profiles/r06/tablesize.txt: the rate is
+    #     flat, 6.8 - 7.0 TB/s of gathered rows, for tables of 64 ... 512 MB and falls only beyond: the memory side, not DRAM, sets it).
+    n_out, R, deg = 1 << 21, 1 << 18, 19
+    e = n_out * deg
+    src = torch.randint(0, R, (e,), generator=gen, device=dev)
+    dst = torch.arange(n_out, device=dev).repeat_interleave(deg)
+    g = pgl.Graph(edges=torch.stack([src, dst], 1), num_nodes=n_out); g.adj_dst_index
+    del src, dst
+    x = torch.randn(n_out, d, generator=gen, device=dev)
+    ms, kms, _, kname = timed_leg(pgl, lambda: g.send_recv(x, "sum"), steps, warmup)
+    l2_bound = 4.0 * 2 ** 20 / (R * d * 4)
+    past_l2 = e * (d * 4) * (1.0 - l2_bound) + e * 8 + n_out * d * 4          # gathered rows that cannot hit an L2 + ids read + rows written
+    out["infinity_cache_table"] = {"table_rows": R, "table_bytes": R * d * 4, "rows": n_out, "edges": e, "l2_hit_bound": l2_bound,
+                                   "bytes_past_l2": past_l2, "kernel_ms": kms, "kernel": kname, "edges_per_s": e / (kms * 1e-3),
+                                   "achieved": past_l2 / (kms * 1e-3) / 1e9}
+    del g, x
+    torch.cuda.empty_cache()
     return out
 
 
@@ -723,8 +743,18 @@ def main():
                 "no_reuse": legs, "frac_permutation": legs["permutation"]["frac"],
                 # the known-bytes leg runs in one of two modes from box to box (profiles/r04/noreuse_slab_allocations_slow_box.txt:
                 # same binary, same counters, 29.7 vs 34.3 ms; it is the node slot, not the allocation): say which one this run saw
+                # the HEADLINE launch against the ceiling that binds it: its L2-miss traffic per second over what the fabric + Infinity
+                # Cache deliver to the same kernel gathering from a 128 MB table (no DRAM, no L2 hits) in this run
+                "fabric_ceiling_GBs": legs["infinity_cache_table"]["achieved"],
                 "slot": "fast" if u["kernel_ms"] < 32.0 else "slow",
                 "slot_note": "known-bytes leg %.2f ms: < 32 ms = the fast node slot (frac ~0.71), otherwise the slow one (~0.61)" % u["kernel_ms"]})
+            hw = rec["roofline"]["headline_workload"]
+            ceil_gbs = legs["infinity_cache_table"]["achieved"]
+            hw["fabric_ceiling_GBs"] = ceil_gbs
+            hw["traffic_frac_of_fabric_ceiling"] = (hw["traffic"] / (hw["kernel_ms"] * 1e-3) / 1e9 / ceil_gbs) if (hw.get("traffic") and hw["kernel_ms"] > 0) else None
+            hw["fabric_ceiling_note"] = ("bytes that leave the L2s per second, measured in this run with the same kernel on uniform sources over a "
+                                         "128 MB table (inside the Infinity Cache, 32 x an L2): the RMAT launch is bound by this memory-side rate, "
+                                         "not by DRAM (tables of 64 .. 512 MB run at the same rate: profiles/r06/tablesize.txt)")
             rec["target_size"] = target_size_leg(pgl, dev, d, args.target_scale, args.target_edges)
         elif world == 1:
             rec["roofline"]["what"] = "--no-extra-legs: the known-bytes leg was skipped, so no physical fraction is reported in this run"

@@ -173,7 +173,7 @@ int32_t pglamd_aggregate(const void* x, int32_t dtype, int64_t n_x_rows, int64_t
  *                   rows and truly empty rows, the boundary launch (accumulate 2) writes the rest -- every output row is
  *                   written exactly once across the two launches.
  *   max_row_edges   longest row of the index, or 0 when unknown.  No row of <= chunk edges is ever split between waves, so a
- *                   launcher that sees max_row_edges <= its chunk skips the counter reset and both fix-up launches
+ *                   launcher that sees max_row_edges <= its chunk skips the counter reset and the fix-up launch
  *                   (pack indices of a halo plan: every row has one edge).
  *   ldx, ldout      row strides in elements of x (and x2) and of out; 0 = dense (dx / dout).  A launch may read and write a
  *                   COLUMN BLOCK of wider matrices: pass the address of the block's first column, its width as dx / dout and

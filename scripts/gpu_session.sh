@@ -111,12 +111,34 @@ PY
         echo "== $L" >> $F; PGLAMD_LIB=$R/$L timeout 300 python scripts/prof.py cold --variant ${COLDARGS:-} 2>&1 | grep -v amdgpu.ids >> $F
       done
       cat $F ;;
+    pmc_tablesize)
+      # the table-size sweep under counters: L2 hits / misses and memory-side read requests per launch and size (3 launches per size)
+      ( cd /tmp && export TMPDIR=/tmp
+        for C in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "FETCH_SIZE"; do
+          N=$(echo $C | tr ' ' '_' | cut -c1-40)
+          rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/tszpmc_$N -o p -- python $R/scripts/prof.py tablesize --pmc ${TSZARGS:-} > $F.$N.log 2>&1 || echo "pass $C failed" >> $F.fail
+        done
+        python - <<PY > $F
+import csv, glob, collections
+print(open(glob.glob("$F.TCC_HIT*.log")[0]).read())
+per = collections.OrderedDict()
+for f in sorted(glob.glob("$O/tszpmc_*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if "agg_flat_kernel<float" not in n: continue
+        per.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+print("per dispatch of agg_flat_kernel<float ...> in dispatch order (3 per table size, in the order of the table above):")
+for d, c in sorted(per.items()):
+    print("  #%-5d %s" % (d, "  ".join("%s=%.6g" % kv for kv in sorted(c.items()))))
+PY
+        cat $F.fail >> $F 2>/dev/null; rm -rf $O/tszpmc_* $F.*.log $F.fail )
+      cut -c1-260 $F | head -70 ;;
     rows_c2p_rows2) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero_nosw)  PGLAMD_XCD_SWIZZLE=0 timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero)  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2_zero)   timeout 600 python scripts/prof.py rows --scale 20 --edges 20000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat20_e20000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p)   timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
-    csr|csrsweep|coo|chains|noreuse|gcn|gat|ops|dtypes|gatsplit|model|hub) timeout 900 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
+    csr|csrsweep|coo|chains|noreuse|gcn|gat|ops|dtypes|gatsplit|model|hub|tablesize) timeout 900 python scripts/prof.py $STEP > $F 2>&1; grep -v amdgpu.ids $F ;;
     edgeops)    timeout 600 python scripts/prof.py edgeops > $F 2>&1; timeout 600 python scripts/prof.py edgeops --sorted >> $F 2>&1; grep -v amdgpu.ids $F ;;
     pmc_edgeops)
       # rows a7 / a8 / a10 in original edge order: fetched / written bytes, L2 hit rate and memory-side request mix per KERNEL

@@ -752,6 +752,40 @@ def cmd_cold(args):
                   % (K, K * 512 / 1e6, share, t1, "identical" if ok else "DIFFERS"), flush=True)
 
 
+def cmd_tablesize(args):
+    """Where is the ceiling of the headline kernel's L2-MISS traffic?  The same kernel (agg_flat_kernel<float, 2, 1, 0, 0>, d = 128 fp32,
+    in-degree 19) gathering UNIFORMLY at random from a source table of R rows: R x 512 B = 4 MB (inside one XCD's L2) ... 128 MB (inside the
+    256 MiB Infinity Cache, 32 x an L2) ... 2 GB (HBM).  Uniform sources => the L2 hit rate is ~ min(1, 4 MB / table), so at 64 - 128 MB
+    nearly every gather leaves the L2 and is served by the Infinity Cache: gathered bytes / time there is what the fabric + Infinity Cache
+    deliver to this access pattern -- the physical ceiling the RMAT launch (7.3 TB/s of L2-miss traffic) has to be read against.
+    --pmc: three launches per size for a counter pass (TCC_HIT / TCC_MISS / TCC_EA0_RDREQ)."""
+    import torch
+    import pgl_amd as pgl
+    dev = torch.device("cuda:0")
+    pgl.ops._HUB_TABLE = False
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    n_out, deg, d = args.rows_out, 19, 128
+    E = n_out * deg
+    dst = torch.arange(n_out, device=dev).repeat_interleave(deg)
+    it, warm = (3, 0) if args.pmc else (10, 3)
+    print("uniform in-degree %d over %d output rows (%d edges), d = %d fp32; source table of R rows, sources uniform at random" % (deg, n_out, E, d))
+    print("%10s %10s %10s %12s %14s %22s" % ("R rows", "table MB", "ms", "G edges/s", "gathered TB/s", "all algorithmic TB/s"), flush=True)
+    for lg in args.log2_rows:
+        R = 1 << lg
+        src = torch.randint(0, R, (E,), generator=gen, device=dev)
+        N = max(R, n_out)
+        g = pgl.Graph(edges=torch.stack([src, dst], 1), num_nodes=N); g.adj_dst_index
+        c = g.adj_dst_index.csr
+        del src
+        x = torch.randn(N, d, generator=gen, device=dev)
+        ms = _t(lambda: pgl.ops.aggregate(x, c, "sum", N), it=it, warm=warm)
+        gathered = E * d * 4
+        alg = E * (d * 4 + 8) + n_out * (d * 4 + 8)
+        print("%10d %10.1f %10.3f %12.2f %14.2f %22.2f" % (R, R * d * 4 / 2 ** 20, ms, E / ms / 1e6, gathered / ms / 1e9, alg / ms / 1e9), flush=True)
+        del g, c, x
+        torch.cuda.empty_cache()
+
+
 def cmd_hub(args):
     """VERDICT r5 item 3b on the headline kernel (C2 / C2', d = 128 fp32): do contiguous HUB rows cut the L2 misses / translation misses?
       (i)  hub table: the top-K out-degree source rows packed into x2, their column ids remapped once per graph, through the
@@ -1486,6 +1520,8 @@ def main():
     sub.add_parser("hotcold")
     hb = sub.add_parser("hub"); hb.add_argument("--scale", type=int, default=20); hb.add_argument("--edges", type=int, default=20_000_000)
     hb.add_argument("--hub-rows", type=int, nargs="*", default=[2048, 8192, 32768, 131072]); hb.add_argument("--pmc", action="store_true")
+    tsz = sub.add_parser("tablesize"); tsz.add_argument("--rows-out", type=int, default=1 << 21); tsz.add_argument("--pmc", action="store_true")
+    tsz.add_argument("--log2-rows", type=int, nargs="*", default=[13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24])
     cd = sub.add_parser("cold"); cd.add_argument("--scale", type=int, default=20); cd.add_argument("--edges", type=int, default=20_000_000)
     cd.add_argument("--hub-rows", type=int, nargs="*", default=[2048, 4096, 8192, 16384, 32768]); cd.add_argument("--pmc", action="store_true")
     cd.add_argument("--variant", action="store_true")
@@ -1534,6 +1570,8 @@ def main():
         cmd_hub(args)
     elif args.cmd == "cold":
         cmd_cold(args)
+    elif args.cmd == "tablesize":
+        cmd_tablesize(args)
     elif args.cmd == "noreuse":
         cmd_noreuse(args)
     elif args.cmd == "gcn":
