@@ -11,9 +11,13 @@ __version__ = "0.1.0"
 
 from . import _ffi
 from . import ops
+from . import graph
+from . import graph_kernel
 from . import math
 from . import message
 from . import nn
+from . import dataset
+from . import utils
 from . import partition
 from . import sampling
 from .graph import Graph
@@ -21,4 +25,5 @@ from .bigraph import BiGraph, HeterGraph
 from .message import Message
 from .distributed import DistGraph, DistGPUGraph
 
-__all__ = ["Graph", "BiGraph", "HeterGraph", "Message", "DistGraph", "DistGPUGraph", "math", "message", "nn", "ops", "partition", "sampling"]
+__all__ = ["Graph", "BiGraph", "HeterGraph", "Message", "DistGraph", "DistGPUGraph", "dataset", "graph", "graph_kernel", "math", "message", "nn", "ops",
+           "partition", "sampling", "utils"]

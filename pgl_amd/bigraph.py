@@ -280,7 +280,7 @@ class HeterGraph(object):
     layer / kernel works per relation (RGCN-style loops, pgl/nn/conv.py:1014-1019).  Same constructor, queries and
     on-disk layout (node_types.npy, edge_types.pkl, one Graph directory per edge type) as the reference."""
 
-    def __init__(self, edges, node_types=None, node_feat=None, edge_feat=None, num_nodes=None, **kwargs):
+    def __init__(self, edges, num_nodes=None, node_types=None, node_feat=None, edge_feat=None, **kwargs):        # (the reference's order: pgl/heter_graph.py:76-82)
         if isinstance(node_types, list):
             node_types = np.array(node_types, dtype=object)[:, 1]
         self._node_types = node_types

@@ -109,8 +109,8 @@ class Graph(object):
             return self
         g = self._rebuild(edges=self._edges.copy(), num_nodes=self._num_nodes, node_feat=dict(self._node_feat),
                            edge_feat=dict(self._edge_feat),
-                           adj_src_index=None if self._adj_src_index is None else self._adj_src_index.tensor(False, device),
-                           adj_dst_index=None if self._adj_dst_index is None else self._adj_dst_index.tensor(False, device),
+                           adj_src_index=None if self._adj_src_index is None else self._adj_src_index.tensor(False, device=device),
+                           adj_dst_index=None if self._adj_dst_index is None else self._adj_dst_index.tensor(False, device=device),
                            _num_graph=self._num_graph, _graph_node_index=self._graph_node_index,
                            _graph_edge_index=self._graph_edge_index)
         if not g._is_tensor:

@@ -252,6 +252,14 @@ class TransformerConv(nn.Module):
         feature = feature.reshape(-1, self.num_heads * self.hidden_size) if self.concat else torch.mean(feature, dim=1)
         return msg.reduce(feature, pool_type="sum")
 
+    def send_recv(self, graph, q, k, v, edge_feat):
+        """pgl/nn/conv.py:832-847: the layer's message passing on its own (q, k, v already projected and shaped [N, H, D]) through
+        the user-function path -- what `forward` takes when it cannot use the fused score / softmax / aggregation ops."""
+        q = q / (self.hidden_size ** 0.5)
+        kw = {} if edge_feat is None else {"edge_feat": {"edge_feat": edge_feat}}
+        msg = graph.send(self.send_attention, src_feat={"k": k, "v": v}, dst_feat={"q": q}, **kw)
+        return graph.recv(reduce_func=self.reduce_attention, msg=msg)
+
     def forward(self, graph, feature, edge_feat=None):
         if self.feat_drop > 1e-5:
             feature = self.feat_dropout(feature)

@@ -11,7 +11,9 @@ from .utils.edge_index import EdgeIndex
 
 
 class NeighborSampler(object):
-    def __init__(self, graph, samples, seed=0):
+    def __init__(self, graph, samples, uva=False, seed=0):
+        # (uva: the reference's third argument -- sample from a graph kept in pinned host memory, pgl/sampling/sage.py:133-137; accepted,
+        #  the index this sampler walks is in HBM)
         if not graph.is_tensor():
             raise ValueError("NeighborSampler needs a tensor-mode graph; call Graph.tensor() first")
         self.graph, self.samples = graph, list(samples)
@@ -36,6 +38,32 @@ class NeighborSampler(object):
             graph_list.append((block, int(nodes.shape[0])))
             nodes = sample_index
         return graph_list[::-1], nodes
+
+
+class HeteroNeighborSampler(object):
+    """pgl/sampling/sage.py:158-162: declared by the reference, not implemented there either."""
+
+    def __init__(self, graph_list, sample_list, uva=False):
+        raise NotImplementedError
+
+
+def traverse(item):
+    """pgl/sampling/sage.py:34-41: every scalar of a nested list / ndarray, depth first."""
+    if isinstance(item, (list, np.ndarray)):
+        for sub in item:
+            yield from traverse(sub)
+    else:
+        yield item
+
+
+def flat_node_and_edge(nodes, eids, weights=None):
+    """pgl/sampling/sage.py:44-50: distinct node ids, all edge ids (and weights) of nested per-node lists."""
+    return list(set(traverse(nodes))), list(traverse(eids)), (None if weights is None else list(traverse(weights)))
+
+
+def edge_hash(src, dst):
+    """pgl/sampling/sage.py:53-56: the key graphsage_sample filters ignore_edges by."""
+    return src * 100000007 + dst
 
 
 def subgraph(graph, nodes, eid=None, edges=None, with_node_feat=True, with_edge_feat=True):
@@ -89,3 +117,11 @@ def graphsage_sample(graph, nodes, samples, ignore_edges=[]):
     return [(subgraph(graph, nodes=all_nodes, eid=np.asarray(layer_eids[i], dtype="int64"),
                       edges=np.asarray(layer_edges[i], dtype="int64").reshape(-1, 2)), sample_index, node_index)
             for i in range(len(samples))]
+
+
+# The reference keeps these functions in two submodules (pgl/sampling/sage.py, pgl/sampling/custom.py) and its programs import from there
+# (`from pgl.sampling.custom import subgraph`: 15 places); both names answer with this module.
+import sys as _sys                                                   # noqa: E402
+custom = sage = _sys.modules[__name__]
+_sys.modules[__name__ + ".custom"] = _sys.modules[__name__ + ".sage"] = custom
+__path__ = []                                                        # (lets `import <alias>.sampling.custom` reach the finders: a module without __path__ is refused as a parent)

@@ -96,3 +96,10 @@ class Dataloader(object):
 
     def __call__(self):
         return self.__iter__()
+
+
+# the reference's submodule names (pgl/utils/data/dataloader.py, dataset.py: a few of its programs import from there) answer with this module
+import sys as _sys                                                   # noqa: E402
+dataloader = dataset = _sys.modules[__name__]
+_sys.modules[__name__ + ".dataloader"] = _sys.modules[__name__ + ".dataset"] = dataloader
+

@@ -138,7 +138,11 @@ class EdgeIndex(object):
         return self._is_tensor
 
     # ---- conversion --------------------------------------------------------------------------
-    def tensor(self, inplace=True, device=None):
+    def tensor(self, inplace=True, uva=False, device=None):
+        """pgl/utils/edge_index.py:139-171.  `uva` is the reference's SECOND positional argument (index kept in pinned host memory,
+        a capacity workaround): accepted, the index goes to HBM either way (Graph.tensor says why)."""
+        if uva and not torch.cuda.is_available():
+            raise ValueError("uva tensor graph should be run under gpu environment!")
         if self._is_tensor:
             return self
         arrs = [to_device_tensor(a, device) for a in

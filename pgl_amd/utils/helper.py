@@ -78,3 +78,21 @@ def scatter(x, index, updates, overwrite=True, name=None):
     out = x.clone()
     out[index] = 0
     return out.index_add(0, index, updates.to(x.dtype))
+
+
+def to_paddle_tensor(data, uva=False):
+    """pgl/utils/helper.py:32-43: a numpy array as a device tensor.  `uva` (pinned host memory mapped into the GPU's address space, the
+    reference's capacity workaround) is accepted and means HBM here; like the reference it refuses uva without a GPU."""
+    if uva and not torch.cuda.is_available():
+        raise ValueError("UVA tensor should be used under GPU environment.")
+    return to_device_tensor(data)
+
+
+def graph_send_recv(x, src_index, dst_index, pool_type="sum"):
+    """pgl/utils/helper.py:163-210 -- the reference's own fallback for `send_recv` on RAW index arrays (an [E, d] gather followed by a
+    scatter-add into zeros([N, d])), kept by it for Paddle versions without `paddle.geometric`.  Here it is the engine's raw-COO entry
+    (`ops.send_u_recv`: the edge-parallel atomic kernel for small fp32 sums, csr_build + the flat kernel otherwise -- DESIGN section 3 K1');
+    no [E, d] message tensor exists.  The reference implements "sum" only and asserts so; the other three pool types work here."""
+    assert pool_type in ("sum", "mean", "max", "min"), "pool_type must be one of 'sum', 'mean', 'max', 'min'"
+    return ops.send_u_recv(x, src_index, dst_index, pool_type)
+

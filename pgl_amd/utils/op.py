@@ -66,12 +66,14 @@ class _AllReduceSum(torch.autograd.Function):
         return g, None
 
 
-def all_reduce_sum_with_grad(tensor, group=None):
+def all_reduce_sum_with_grad(tensor, group=0):
     """pgl/utils/op.py:90-122 (the collective behind the reference's DistGPUGraph): all-reduce(sum) that autograd can
     differentiate.  Out of place; a single process (no initialised group) returns the tensor unchanged.
     `DistGraph` (pgl_amd/distributed.py) does not need it -- its layout has no reduction
     collective -- it is here for code written against the reference's edge-sharded scheme."""
     import torch.distributed as dist
+    if group == 0:                                   # Paddle's ring id 0 = the default group (the reference's default argument)
+        group = None
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return tensor
     return _AllReduceSum.apply(tensor, group)
