@@ -224,6 +224,9 @@ class _SegmentReduce(torch.autograd.Function):
 
 def segment_reduce(data, ids, pool="sum", num_segments=None):
     data = _et.materialize(data)
+    if not isinstance(data, torch.Tensor) or not isinstance(ids, torch.Tensor):
+        raise TypeError("pgl.math.segment_%s takes device tensors (data: %s, segment_ids: %s); there is no host path"
+                        % (pool, type(data).__name__, type(ids).__name__))
     if torch.is_grad_enabled() and data.requires_grad:
         return _SegmentReduce.apply(data, ids, pool, num_segments)
     return ops.segment_reduce(data, ids, pool, num_segments)

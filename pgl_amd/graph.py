@@ -255,7 +255,7 @@ class Graph(object):
         """pgl/graph.py Graph.disjoint: one big graph out of several, node ids offset graph by graph.
         merged_graph_index=True treats the result as ONE graph, False keeps per-graph node/edge ranges
         (graph_node_id / graph_edge_id, used by graph_pool / graph_norm readouts)."""
-        assert len(graph_list) > 0, "The input graph_list of Graph.disjoint has length $d. It should be greater than 0. " % len(graph_list)
+        assert len(graph_list) > 0, "The input graph_list of Graph.disjoint has length %d. It should be greater than 0. " % len(graph_list)
         is_tensor = graph_list[0].is_tensor()
         cat = (lambda xs: torch.cat(xs, 0)) if is_tensor else (lambda xs: np.concatenate(xs, axis=0))
         offs = np.concatenate([[0], np.cumsum([g.num_nodes for g in graph_list])]).astype("int64")
