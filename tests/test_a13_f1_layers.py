@@ -414,7 +414,7 @@ def test_c3_fused_gat_backward_vs_fp64_autograd(pgl, c3):
         assert float(rel) <= 2e-5
 
 
-@pytest.mark.parametrize("d", [128, 64, 100, 7, 256, 1000])
+@pytest.mark.parametrize("d", [128, 64, 100, 7, 256, 1000, 32, 41, 20])
 @pytest.mark.parametrize("act,normalize", [(None, True), ("relu", True), ("relu", False), (None, False)])
 def test_row_epilogue_forward_backward_vs_torch(pgl, d, act, normalize):
     """y = normalize(act(z + bias)) (GraphSageConv / GCNConv epilogue, pgl/nn/conv.py:109-115, 250-254) against the torch
