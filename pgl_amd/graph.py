@@ -578,6 +578,14 @@ class Graph(object):
         ds = None if dst_scale is None else dst_scale.reshape(-1).contiguous()                     #  cheaper than a 4-byte read per edge)
         return ag.aggregate_dense(feature.contiguous(), weight, bias, self._csr_dst(), self._csr_src, act, ds, reduce_op, ss)
 
+    def send_recv_dual_linear(self, feature, w_self, w_neigh, reduce_op="sum"):
+        """feature @ w_self^T + send_recv(feature, reduce_op) @ w_neigh^T as one differentiable op (engine extension for GraphSageConv
+        in full-graph mode, pgl/nn/conv.py:99-109): the gradient of `feature` is written by one GEMM and accumulated into by the
+        transposed aggregation instead of being added up by an extra pass over [N, d].  fp32, sum / mean."""
+        if not self._is_tensor:
+            raise ValueError("You must call Graph.tensor()")
+        return ag.aggregate_dual_linear(feature.contiguous(), w_self, w_neigh, self._csr_dst(), self._csr_src, reduce_op)
+
     def reorder(self, num_clusters=None, rows_per_cluster=4096, seed=0):
         """-> (graph2, order): the same graph with its nodes RENUMBERED cluster by cluster (engine extension, opt-in; the
         reference feeds node ids as they come, pgl/graph.py:859).  order[new_id] = old_id; graph2's node features are

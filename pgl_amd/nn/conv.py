@@ -135,6 +135,15 @@ class GraphSageConv(nn.Module):
     def forward(self, graph, feature, act=None):
         if isinstance(feature, torch.Tensor):
             feature = (feature, feature)
+        if (feature[0] is feature[1] and act in (None, "relu") and self.fused and self.aggr_func in ("sum", "mean")
+                and hasattr(graph, "send_recv_dual_linear") and feature[0].is_cuda and feature[0].dim() == 2
+                and feature[0].dtype == torch.float32 and self.self_linear.weight.dtype == torch.float32
+                and feature[0].requires_grad and torch.is_grad_enabled() and feature[0].shape[0] == graph.num_nodes
+                and ops.row_epilogue_supported(feature[0], self.self_linear.out_features)):
+            # full-graph training on ONE feature tensor: aggregation + both GEMMs as one autograd node, so that the two gradients of
+            # `feature` (through self_linear and through the aggregation) are never added by a separate pass (Graph.send_recv_dual_linear)
+            z = graph.send_recv_dual_linear(feature[0], self.self_linear.weight, self.neigh_linear.weight, self.aggr_func)
+            return ag.row_epilogue(z, self.self_linear.bias + self.neigh_linear.bias, act, self.normalize)
         neigh_feature = graph.send_recv(feature[0], self.aggr_func, out_size=feature[1].shape[0])
         if act in (None, "relu") and ops.row_epilogue_supported(neigh_feature, self.self_linear.out_features) \
                 and feature[1].dtype == torch.float32 and self.self_linear.weight.dtype == torch.float32 \

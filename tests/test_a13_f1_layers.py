@@ -462,8 +462,8 @@ def test_graphsage_fused_epilogue_equals_the_reference_composition(pgl):
     g = pgl.Graph(edges=np.stack([rng.integers(0, n, e), rng.integers(0, n, e)], 1).astype(np.int64), num_nodes=n).tensor()
     x = dev(rng.standard_normal((n, d)).astype(np.float32))
     w = dev(rng.standard_normal((n, 96)).astype(np.float32))
-    for act in (None, "relu"):
-        layer = pgl.nn.GraphSageConv(d, 96, "mean").cuda()
+    for act, aggr in ((None, "mean"), ("relu", "mean"), ("relu", "sum")):
+        layer = pgl.nn.GraphSageConv(d, 96, aggr).cuda()
         torch.nn.init.normal_(layer.self_linear.bias); torch.nn.init.normal_(layer.neigh_linear.bias)
         res = []
         for fused in (True, False):
@@ -471,6 +471,10 @@ def test_graphsage_fused_epilogue_equals_the_reference_composition(pgl):
             layer.zero_grad()
             xs = x.clone().requires_grad_(True)
             out = layer(g, xs, act=act)
+            if fused:
+                # round 6: on ONE feature tensor the aggregation and both GEMMs are one autograd node (the transposed aggregation
+                # accumulates into the GEMM that writes d x: no add pass) -- Graph.send_recv_dual_linear
+                assert any("AggregateDualLinear" in type(f[0]).__name__ for f in out.grad_fn.next_functions if f[0] is not None)
             (out * w).sum().backward()
             res.append((out.detach(), xs.grad, [p.grad.clone() for p in layer.parameters()]))
         (o1, gx1, gp1), (o0, gx0, gp0) = res
