@@ -293,6 +293,45 @@ def gat_attention(feature, attn_src, attn_dst, csr_dst, csr_src_fn, slope=0.2, d
     return ops.gat_aggregate(feature, attn_src, attn_dst, csr_dst, slope, None, False, drop_p, seed)
 
 
+class _GatAttentionProj(torch.autograd.Function):
+    """_GatAttention with the two score projections inside the node: a_src | a_dst = feature2d @ proj (proj [H*D, 2H]: GATConv's
+    block-diagonal form of weight_src / weight_dst, pgl/nn/conv.py:325-330).  As separate nodes `feature` receives two gradients -- from
+    the attention kernels and from the projection GEMM -- which autograd adds with an element pass over [N, H*D] (0.27 ms at N = 2^20,
+    128 columns); here the projection's share is ACCUMULATED into the kernels' output by the GEMM itself (addmm_, beta = 1)."""
+
+    @staticmethod
+    def forward(ctx, feature, proj, csr_dst, csr_src_fn, slope, drop_p, seed):
+        n, h = int(feature.shape[0]), int(feature.shape[1])
+        # (the same GEMM call as the three-node form makes -- linear(x, proj^T) -- so the scores are the same BITS: leaky_relu has a kink at
+        #  0 and an edge whose score lands within rounding of it would otherwise take a different slope in the two forms)
+        att = torch.nn.functional.linear(feature.reshape(n, -1), proj.t().contiguous())
+        a_s, a_d = att[:, :h].contiguous(), att[:, h:].contiguous()
+        out, mx, sm, out_pos, s_pos = ops.gat_aggregate(feature, a_s, a_d, csr_dst, slope, None, True, drop_p, seed)
+        ctx.csr_dst, ctx.csr_src_fn, ctx.slope, ctx.drop_p, ctx.seed = csr_dst, csr_src_fn, slope, drop_p, seed
+        ctx.has_pos = out_pos is not None
+        ctx.save_for_backward(feature, proj, a_s, a_d, out, mx, sm, *((out_pos, s_pos) if ctx.has_pos else ()))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        feature, proj, a_s, a_d, out, mx, sm = ctx.saved_tensors[:7]
+        out_pos, s_pos = ctx.saved_tensors[7:] if ctx.has_pos else (None, None)
+        gf, gs, gd = ops.gat_backward(grad, feature, out, a_s, a_d, mx, sm, ctx.csr_dst, ctx.csr_src_fn(), ctx.slope,
+                                      ctx.drop_p, ctx.seed, out_pos, s_pos)
+        n = int(feature.shape[0])
+        datt = torch.cat([gs, gd], dim=1)
+        gproj = _tall_wgrad(datt, feature.reshape(n, -1)).t() if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[0]:
+            gf.reshape(n, -1).addmm_(datt, proj.t())                 # d feature += d att @ proj^T, inside the GEMM
+        else:
+            gf = None
+        return gf, gproj, None, None, None, None, None
+
+
+def gat_attention_proj(feature, proj, csr_dst, csr_src_fn, slope=0.2, drop_p=0.0, seed=0):
+    return _GatAttentionProj.apply(feature, proj, csr_dst, csr_src_fn, slope, drop_p, seed)
+
+
 class _SDDMM(torch.autograd.Function):
     """out[e, h] = <x[src_e, h, :], y[dst_e, h, :]> in original edge order.  Backward = two edge-weighted aggregations
     (the same flat kernel with an [E,H,1] edge operand): d x[u] = sum_{e: src=u} g_e y[dst_e] over the src-keyed CSR,

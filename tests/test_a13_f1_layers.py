@@ -181,6 +181,43 @@ def test_gat_fused_backward_matches_unfused_autograd(pgl, H, D):
         close_rows(a, b, rtol=2e-4, atol_row=2e-5, what=name, cancel=cancel)
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.4])
+def test_gatconv_training_at_scale_is_one_autograd_node(pgl, monkeypatch, drop):
+    """Round 6: training on >= 65 536 nodes with a head shape the fused kernels take, GATConv computes scores, attention and aggregation
+    as ONE autograd node (Graph.gat_aggregate_proj): the projection's share of d feature is accumulated by its GEMM instead of being added
+    by a pass over [N, H*D].  Same outputs and the same gradients (input, linear weight, both attention vectors) as the three-node form,
+    with and without attention dropout (same seed stream)."""
+    n, e, H, D = 70000, 700000, 8, 16
+    edges, rng = rand_graph(n, e, 4711, hub=9000)
+    g = pgl.Graph(edges=edges, num_nodes=n).tensor()
+    x0 = rng.standard_normal((n, 64)).astype(np.float32)
+    w = dev(rng.standard_normal((n, H * D)).astype(np.float32))
+    torch.manual_seed(3)
+    layer = pgl.nn.GATConv(64, D, feat_drop=0.0, attn_drop=drop, num_heads=H, activation="elu").cuda()
+    layer.train()
+    res = []
+    for one_node in (True, False):
+        if not one_node:
+            monkeypatch.delattr(pgl.Graph, "gat_aggregate_proj")
+        layer.zero_grad()
+        x = dev(x0).requires_grad_(True)
+        torch.manual_seed(11)                                  # the dropout seed is drawn from torch's generator
+        out = layer(g, x)
+        chain, todo = set(), [out.grad_fn]
+        while todo:
+            f = todo.pop()
+            if f is None or f in chain:
+                continue
+            chain.add(f); todo += [nf[0] for nf in f.next_functions]
+        assert any("GatAttentionProj" in type(f).__name__ for f in chain) == one_node
+        (out * w).sum().backward()
+        res.append([host(out.detach()), host(x.grad)] + [host(p_.grad) for p_ in (layer.linear.weight, layer.weight_src, layer.weight_dst)])
+    for a, b, name in zip(res[0], res[1], ("out", "d_x", "d_W", "d_weight_src", "d_weight_dst")):
+        # (the two forms differ by the GEMM that forms the scores and by where the projection's gradient share is added: rounding only.
+        #  Parameter gradients are sums over 70 000 rows of terms of either sign: held to their row's own magnitude)
+        close_rows(a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1), rtol=2e-4, atol_row=2e-4, what=name)
+
+
 def test_gat_fused_dropout_is_consistent_between_forward_and_backward(pgl):
     """With attention dropout the in-kernel mask must be identical in forward and backward: check the
     gradient against finite differences of the (deterministic for a fixed seed) forward."""
