@@ -297,46 +297,39 @@ class _GatAttentionProj(torch.autograd.Function):
     """_GatAttention with the two score projections inside the node: a_src | a_dst = feature2d @ proj (proj [H*D, 2H]: GATConv's
     block-diagonal form of weight_src / weight_dst, pgl/nn/conv.py:325-330).  As separate nodes `feature` receives two gradients -- from
     the attention kernels and from the projection GEMM -- which autograd adds with an element pass over [N, H*D] (0.27 ms at N = 2^20,
-    128 columns); here the projection's share is ACCUMULATED into the kernels' output by the GEMM itself (addmm_, beta = 1).
-    pad_to: a head dimension the kernels do not take (D / vec not a power of two: a classifier layer's D = number of classes) is
-    zero-padded to `pad_to` INSIDE the node -- one copy each way instead of the pad / slice nodes' copy, zero-fill and copy-back."""
+    128 columns); here the projection's share is ACCUMULATED into the kernels' output by the GEMM itself (addmm_, beta = 1)."""
 
     @staticmethod
-    def forward(ctx, feature, proj, csr_dst, csr_src_fn, slope, drop_p, seed, pad_to):
-        n, h, d = (int(v) for v in feature.shape)
+    def forward(ctx, feature, proj, csr_dst, csr_src_fn, slope, drop_p, seed):
+        n, h = int(feature.shape[0]), int(feature.shape[1])
         # (the same GEMM call as the three-node form makes -- linear(x, proj^T) -- so the scores are the same BITS: leaky_relu has a kink at
         #  0 and an edge whose score lands within rounding of it would otherwise take a different slope in the two forms)
         att = torch.nn.functional.linear(feature.reshape(n, -1), proj.t().contiguous())
         a_s, a_d = att[:, :h].contiguous(), att[:, h:].contiguous()
-        padded = pad_to is not None and int(pad_to) != d
-        fk = torch.nn.functional.pad(feature, (0, int(pad_to) - d)) if padded else feature
-        out, mx, sm, out_pos, s_pos = ops.gat_aggregate(fk, a_s, a_d, csr_dst, slope, None, True, drop_p, seed)
+        out, mx, sm, out_pos, s_pos = ops.gat_aggregate(feature, a_s, a_d, csr_dst, slope, None, True, drop_p, seed)
         ctx.csr_dst, ctx.csr_src_fn, ctx.slope, ctx.drop_p, ctx.seed = csr_dst, csr_src_fn, slope, drop_p, seed
-        ctx.has_pos, ctx.padded, ctx.d = out_pos is not None, padded, d
-        ctx.save_for_backward(feature, fk, proj, a_s, a_d, out, mx, sm, *((out_pos, s_pos) if ctx.has_pos else ()))
-        return out[..., :d] if padded else out
+        ctx.has_pos = out_pos is not None
+        ctx.save_for_backward(feature, proj, a_s, a_d, out, mx, sm, *((out_pos, s_pos) if ctx.has_pos else ()))
+        return out
 
     @staticmethod
     def backward(ctx, grad):
-        feature, fk, proj, a_s, a_d, out, mx, sm = ctx.saved_tensors[:8]
-        out_pos, s_pos = ctx.saved_tensors[8:] if ctx.has_pos else (None, None)
-        n, h, d = int(feature.shape[0]), int(feature.shape[1]), ctx.d
-        g = torch.nn.functional.pad(grad, (0, int(fk.shape[2]) - d)) if ctx.padded else grad.contiguous()
-        gf, gs, gd = ops.gat_backward(g, fk, out, a_s, a_d, mx, sm, ctx.csr_dst, ctx.csr_src_fn(), ctx.slope,
+        feature, proj, a_s, a_d, out, mx, sm = ctx.saved_tensors[:7]
+        out_pos, s_pos = ctx.saved_tensors[7:] if ctx.has_pos else (None, None)
+        gf, gs, gd = ops.gat_backward(grad, feature, out, a_s, a_d, mx, sm, ctx.csr_dst, ctx.csr_src_fn(), ctx.slope,
                                       ctx.drop_p, ctx.seed, out_pos, s_pos)
+        n = int(feature.shape[0])
         datt = torch.cat([gs, gd], dim=1)
         gproj = _tall_wgrad(datt, feature.reshape(n, -1)).t() if ctx.needs_input_grad[1] else None
         if ctx.needs_input_grad[0]:
-            gf2 = (gf[..., :d] if ctx.padded else gf).reshape(n, -1)  # (a view for one head or an unpadded shape, a copy otherwise)
-            gf2.addmm_(datt, proj.t())                               # d feature += d att @ proj^T, inside the GEMM
-            gf = gf2.reshape(n, h, d)
+            gf.reshape(n, -1).addmm_(datt, proj.t())                 # d feature += d att @ proj^T, inside the GEMM
         else:
             gf = None
-        return gf, gproj, None, None, None, None, None, None
+        return gf, gproj, None, None, None, None, None
 
 
-def gat_attention_proj(feature, proj, csr_dst, csr_src_fn, slope=0.2, drop_p=0.0, seed=0, pad_to=None):
-    return _GatAttentionProj.apply(feature, proj, csr_dst, csr_src_fn, slope, drop_p, seed, pad_to)
+def gat_attention_proj(feature, proj, csr_dst, csr_src_fn, slope=0.2, drop_p=0.0, seed=0):
+    return _GatAttentionProj.apply(feature, proj, csr_dst, csr_src_fn, slope, drop_p, seed)
 
 
 class _SDDMM(torch.autograd.Function):

@@ -628,14 +628,13 @@ class Graph(object):
             raise ValueError("You must call Graph.tensor()")
         return ag.gat_attention(feature, attn_src, attn_dst, self._csr_dst(), self._csr_src, negative_slope, attn_drop, seed)
 
-    def gat_aggregate_proj(self, feature, proj, negative_slope=0.2, attn_drop=0.0, seed=0, pad_to=None):
+    def gat_aggregate_proj(self, feature, proj, negative_slope=0.2, attn_drop=0.0, seed=0):
         """gat_aggregate with the attention scores computed inside the op: a_src | a_dst = feature.reshape(N, H*D) @ proj (proj
         [H*D, 2H], differentiable).  One autograd node, so the two gradients of `feature` are not added by a separate pass
-        (training; engine extension; fp32).  pad_to: zero-pad the head dimension to this size inside the op (a head dimension the
-        kernels do not take, e.g. the class count of a classifier layer)."""
+        (training; engine extension; fp32)."""
         if not self._is_tensor:
             raise ValueError("You must call Graph.tensor()")
-        return ag.gat_attention_proj(feature, proj, self._csr_dst(), self._csr_src, negative_slope, attn_drop, seed, pad_to)
+        return ag.gat_attention_proj(feature, proj, self._csr_dst(), self._csr_src, negative_slope, attn_drop, seed)
 
     def _aggregate(self, feature, edge_feature, message_op, reduce_op, out_size):
         if isinstance(out_size, torch.Tensor):

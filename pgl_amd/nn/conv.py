@@ -279,20 +279,14 @@ class GATConv(nn.Module):
                               (w_dst.unsqueeze(2) * eye).reshape(-1, self.num_heads)], dim=1)
             feat2d = feature.reshape(-1, self.num_heads * self.hidden_size)
             D_, vec_ = self.hidden_size, (4 if self.hidden_size % 4 == 0 else 2 if self.hidden_size % 2 == 0 else 1)
-            Dk_ = D_
-            if ((D_ // vec_) & (D_ // vec_ - 1)) != 0:         # a head dimension the kernels do not take: padded inside the node
-                Dk_ = 1
-                while Dk_ < D_:
-                    Dk_ *= 2
-                vec_ = 4 if Dk_ % 4 == 0 else 2 if Dk_ % 2 == 0 else 1
             if (torch.is_grad_enabled() and feature.requires_grad and feat2d.shape[0] >= 65536 and self.fused
                     and store_dtype == torch.float32 and hasattr(graph, "gat_aggregate_proj")
-                    and Dk_ <= 256 and self.num_heads * Dk_ <= 64 * vec_):
+                    and self.num_heads * D_ <= 64 * vec_ and ((D_ // vec_) & (D_ // vec_ - 1)) == 0):
                 # training at scale, a shape the fused kernels take in one launch: scores, attention and aggregation as ONE autograd node
                 # (Graph.gat_aggregate_proj) -- the projection's share of d feature is accumulated by its GEMM, not added by a pass over [N, H*D]
                 p = self.attn_drop if (self.training and self.attn_drop > 1e-15) else 0.0
                 seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p > 0 else 0
-                output = graph.gat_aggregate_proj(feature, proj, 0.2, p, seed, None if Dk_ == D_ else Dk_)
+                output = graph.gat_aggregate_proj(feature, proj, 0.2, p, seed)
                 output = output.reshape(-1, self.num_heads * self.hidden_size) if self.concat else _head_mean(output)
                 return output if self.activation is None else self.activation(output)
             # (its weight gradient is again a [H*D, N] x [N, 2H] reduction over N: split-reduction variant)

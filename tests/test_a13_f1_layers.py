@@ -181,19 +181,19 @@ def test_gat_fused_backward_matches_unfused_autograd(pgl, H, D):
         close_rows(a, b, rtol=2e-4, atol_row=2e-5, what=name, cancel=cancel)
 
 
-@pytest.mark.parametrize("drop,H,D,concat", [(0.0, 8, 16, True), (0.4, 8, 16, True), (0.0, 1, 41, False), (0.3, 2, 24, True), (0.0, 3, 7, False)])
-def test_gatconv_training_at_scale_is_one_autograd_node(pgl, monkeypatch, drop, H, D, concat):
+@pytest.mark.parametrize("drop", [0.0, 0.4])
+def test_gatconv_training_at_scale_is_one_autograd_node(pgl, monkeypatch, drop):
     """Round 6: training on >= 65 536 nodes with a head shape the fused kernels take, GATConv computes scores, attention and aggregation
     as ONE autograd node (Graph.gat_aggregate_proj): the projection's share of d feature is accumulated by its GEMM instead of being added
     by a pass over [N, H*D].  Same outputs and the same gradients (input, linear weight, both attention vectors) as the three-node form,
     with and without attention dropout (same seed stream)."""
-    n, e = 70000, 700000                                       # (head dimensions 41, 24 and 7 are zero-padded INSIDE the node)
+    n, e, H, D = 70000, 700000, 8, 16
     edges, rng = rand_graph(n, e, 4711, hub=9000)
     g = pgl.Graph(edges=edges, num_nodes=n).tensor()
     x0 = rng.standard_normal((n, 64)).astype(np.float32)
-    w = dev(rng.standard_normal((n, H * D if concat else D)).astype(np.float32))
+    w = dev(rng.standard_normal((n, H * D)).astype(np.float32))
     torch.manual_seed(3)
-    layer = pgl.nn.GATConv(64, D, feat_drop=0.0, attn_drop=drop, num_heads=H, activation="elu" if concat else None, concat=concat).cuda()
+    layer = pgl.nn.GATConv(64, D, feat_drop=0.0, attn_drop=drop, num_heads=H, activation="elu").cuda()
     layer.train()
     res = []
     for one_node in (True, False):
