@@ -133,6 +133,30 @@ for d, c in sorted(per.items()):
 PY
         cat $F.fail >> $F 2>/dev/null; rm -rf $O/tszpmc_* $F.*.log $F.fail )
       cut -c1-260 $F | head -70 ;;
+    csrlocal)
+      # what a scatter pass costs when its writes are local (prof.py csrlocal): per case, the average duration of every sort kernel
+      ( cd /tmp && export TMPDIR=/tmp
+        rocprofv3 --kernel-trace --output-format csv -d $O/csrlocal_tmp -o t -- python $R/scripts/prof.py csrlocal > $F.run 2>&1
+        python - <<PY > $F
+import csv, glob, collections
+print(open("$F.run").read().strip())
+rows = []
+for f in glob.glob("$O/csrlocal_tmp/**/*kernel_trace.csv", recursive=True):
+    rows += [r for r in csv.DictReader(open(f)) if any(k in r["Kernel_Name"] for k in ("sort_scatter", "sort_hist"))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+per = len(rows) // 3                                                  # three cases, the same launches each
+names = ("random (RMAT destinations)", "low digit sorted, high digit random", "high digit sorted, low digit random")
+for c in range(3):
+    agg = collections.OrderedDict()
+    for r in rows[c * per:(c + 1) * per]:
+        k = r["Kernel_Name"].replace("void ", "").split("(")[0]
+        agg.setdefault(k, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("== %s" % names[c])
+    for k, v in agg.items():
+        print("   %-60s %3d launches  avg %7.1f us" % (k, len(v), sum(v) / len(v)))
+PY
+        rm -rf $O/csrlocal_tmp $F.run )
+      cat $F ;;
     rows_c2p_rows2) timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero_nosw)  PGLAMD_XCD_SWIZZLE=0 timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;
     rows_c2p_zero)  timeout 900 python scripts/prof.py rows --scale 22 --edges 100000000 --parts 8 --flow rows2 --row-order peers --no-chain --partition "$PARTS/rmat22_e100000000_p{P}_kway.npy" > $F 2>&1; tail -12 $F ;;

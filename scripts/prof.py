@@ -583,6 +583,35 @@ def cmd_csr(args):
         del edges, c, u_sorted, v_sorted
 
 
+def cmd_csrlocal(args):
+    """VERDICT r5 item 4 (an MSD-first sort whose SECOND pass stays inside its bucket): what does a scatter pass cost when its writes are
+    local?  Measured with the product's own kernels on crafted keys at C2 size (20 M edges, 20 key bits = two 10-bit passes):
+      random      RMAT destinations (the benchmark): both passes scatter over the whole array;
+      low-sorted  the LOW digit of the keys ascends with the position (high digit random): pass 0 writes every tile's items next to where
+                  they were read -- a pass with perfectly local writes -- and pass 1 is an ordinary scatter;
+      high-sorted the HIGH digit ascends with the position (low digit random): pass 0 ordinary, pass 1 moves items only inside their
+                  bucket's 1 / 1024 of the array -- what the second pass of an MSD-first order would do.
+    Run under `rocprofv3 --kernel-trace` (gpu_session.sh trace:csrlocal): the per-launch times of sort_scatter_kernel tell the passes apart."""
+    import torch
+    import pgl_amd as pgl
+    from pgl_amd.utils.rmat import rmat_edges
+    dev = torch.device("cuda:0")
+    scale, E = 20, 20_000_000
+    N = 1 << scale
+    edges = rmat_edges(scale, E, seed=42, device=dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    pos = torch.arange(E, device=dev)
+    ramp = (pos * 1024 // E)                                       # 0 .. 1023, ascending with the position
+    rnd = torch.randint(0, 1024, (E,), generator=gen, device=dev)
+    cases = (("random (RMAT destinations)", edges[:, 1].contiguous()),
+             ("low digit sorted, high digit random", (rnd << 10) | ramp),
+             ("high digit sorted, low digit random", (ramp << 10) | rnd))
+    v = edges[:, 0].contiguous()
+    for name, u in cases:
+        ms = _t(lambda: pgl.ops.csr_build(u, v, N, want_i64=False, check_range=False), it=5, warm=2)
+        print("%-40s csr_build %.3f ms" % (name, ms), flush=True)
+
+
 def cmd_csrsweep(args):
     """CSR build: the one-sweep passes (pglamd_set_option("csr_onesweep", group)) beside the multi-kernel passes (group 0), same inputs,
     every output array compared bit for bit."""
@@ -1522,6 +1551,7 @@ def main():
     hb.add_argument("--hub-rows", type=int, nargs="*", default=[2048, 8192, 32768, 131072]); hb.add_argument("--pmc", action="store_true")
     tsz = sub.add_parser("tablesize"); tsz.add_argument("--rows-out", type=int, default=1 << 21); tsz.add_argument("--pmc", action="store_true")
     tsz.add_argument("--log2-rows", type=int, nargs="*", default=[13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 24])
+    sub.add_parser("csrlocal")
     cd = sub.add_parser("cold"); cd.add_argument("--scale", type=int, default=20); cd.add_argument("--edges", type=int, default=20_000_000)
     cd.add_argument("--hub-rows", type=int, nargs="*", default=[2048, 4096, 8192, 16384, 32768]); cd.add_argument("--pmc", action="store_true")
     cd.add_argument("--variant", action="store_true")
@@ -1570,6 +1600,8 @@ def main():
         cmd_hub(args)
     elif args.cmd == "cold":
         cmd_cold(args)
+    elif args.cmd == "csrlocal":
+        cmd_csrlocal(args)
     elif args.cmd == "tablesize":
         cmd_tablesize(args)
     elif args.cmd == "noreuse":
